@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def cnn_golden():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "cnn_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def state_dict():
+    from suo_slam_amd import weights
+    return weights.make_random_state_dict(seed=0, logit_gain=8.0)
