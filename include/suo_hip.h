@@ -1,0 +1,94 @@
+/* libsuo_hip.so -- C ABI of the MI355X-native (gfx950) hot path of rpng/suo_slam.
+ *
+ * Drop-in boundary.  Today the reference reaches its native code through
+ * two pybind11 modules imported at /root/reference/lib/object_slam.py:9-10:
+ *     lambdatwist.pnp(xs, ys, threshold)     thirdparty/lambdatwist/pnp_python_binding.cpp:57-62
+ *     g2o.* graph API used by optimize()     lib/object_slam.py:703-903 (python/types/object_slam/types_object_slam.h:17-52)
+ * and runs its network as stock PyTorch ops (PkpNet.forward, lib/models/pkpnet.py:80-119).
+ * This header is what a ctypes / pybind stub binds instead (INTEGRATION.md shows the stubs).
+ *
+ * Conventions: plain C, caller-owned buffers, no exceptions; every function returns 0 on success
+ * or a SUO_ERR_* code (suo_last_error() gives the message).  Pointers named *_dev are device (HBM)
+ * pointers; `stream` is a hipStream_t passed as void* (NULL = internal stream + blocking).
+ * All work is stream-ordered; the library never reads or writes host memory behind *_dev names.
+ */
+#ifndef SUO_HIP_H
+#define SUO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUO_NUM_KP 41     /* lib/labeling/kp_config.py:82-94 */
+#define SUO_HEAT 64       /* heat-map side */
+#define SUO_CROP 256      /* network input side (lib/datasets/bop.py:21) */
+
+const char* suo_last_error(void);
+int suo_version(void);
+/* number of visible HIP devices; <0 on error.  The product path requires one. */
+int suo_device_count(void);
+
+/* ---- keypoint network: replaces PkpNet.forward (lib/models/pkpnet.py:80-119) -------------------- */
+typedef struct suo_net suo_net;
+
+/* Build from a reference-layout state_dict (checkpoint['model'], lib/object_slam.py:92-97):
+ * n float32 host tensors, names[i] the reference key ("backbone.r1.conv1.weight", ...), shapes[i]
+ * its dims.  BatchNorm is folded and weights are packed for MFMA on the host, then uploaded. */
+int suo_net_create(int n, const char* const* names, const float* const* data, const int64_t* const* shapes,
+                   const int* ndims, int max_crops, suo_net** out);
+void suo_net_destroy(suo_net* net);
+int suo_net_set_graph(suo_net* net, int enable);          /* hipGraph replay of the backbone (default on) */
+size_t suo_net_workspace_bytes(const suo_net* net);
+
+/* One frame: image either SUO_IMG_U8_HWC = uint8 [H,W,3] as cv2.imread gives it (scaled by 1/255 on
+ * device: object_slam.py:1092 fused) or SUO_IMG_F32_CHW = float32 [3,H,W] already scaled (the tensor
+ * PkpNet.forward receives); boxes float32 [L,4] xyxy pixels, priors float32 [L,41,256,256] or NULL (= zeros, pkpnet.py:95-97).
+ * Outputs (device): uv [L,41,2], cov [L,41,2,2], kp_mask [L,41] (sigmoid prob), optional
+ * kp_mask_logits [L,41] and prob_logits [L,41,64,64] (NCHW, the reference's ret["prob_logits"]). */
+#define SUO_IMG_U8_HWC 0
+#define SUO_IMG_F32_CHW 1
+int suo_net_forward(suo_net* net, const void* img_dev, int img_format, int H, int W, const float* boxes_dev, int L,
+                    const float* priors_dev, float* uv_dev, float* cov_dev, float* kp_mask_dev,
+                    float* kp_mask_logits_dev, float* prob_logits_dev, void* stream);
+
+/* Backbone only (HourglassNet.forward, lib/models/hg.py:95-119): staged NHWC input [L,256,256,48]
+ * (44 channels zero padded to 48; NULL = re-use the input staged by the previous call) -> logits
+ * [L,41,64,64] NCHW (may be NULL).  Test / profiling entry for the conv stack. */
+int suo_net_backbone(suo_net* net, const float* staged_dev, int L, float* prob_logits_dev, void* stream);
+
+/* ---- stand-alone stages (each is also a parity-test entry point) --------------------------------- */
+/* spatial_softmax + post_process_kp (pkpnet.py:13-63): logits [L,41,64,64] -> uv, cov, mean logit */
+int suo_decode_heatmaps(const float* logits_dev, int L, float* uv_dev, float* cov_dev, float* mean_logit_dev, void* stream);
+/* classifier (pkpnet.py:74-78,116-118): sigmoid(W relu(mean_logit) + b) */
+int suo_classifier(const float* mean_logit_dev, const float* w_dev, const float* b_dev, int L,
+                   float* kp_logit_dev, float* kp_prob_dev, void* stream);
+/* keypoint validity masks (object_slam.py:1100-1115); model_mask may be NULL (= all true) */
+int suo_keypoint_masks(const float* uv_dev, const float* cov_dev, const float* kp_prob_dev, const uint8_t* model_mask_dev,
+                       int L, float bbox_thresh, float kp_var_thresh, uint8_t* mask_dev, void* stream);
+/* roi_align + concat (pkpnet.py:93-101) -> NHWC [L,256,256,48] (44 channels, zero padded to 48) */
+int suo_roi_align_concat(const void* img_dev, int img_format, int H, int W, const float* boxes_dev, int L, const float* priors_dev,
+                         float* out_dev, void* stream);
+
+/* Weight packers (host): GEMM weight W[N][K] -> MFMA B-operand layout [Kp/8][Np/32][64][4];
+ * conv weight W[N][C][KS][KS] -> same with K' = [chunk][ky][kx][kk]. */
+int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* out);
+int suo_pack_conv_weight(const float* w, int N, int C, int KS, int Np, int Cp, int CK, float* out);
+
+/* 1x1 convolution on NHWC pixels: out = epi(pro(A1) W1 + A2 W2 + bias (+R)); see csrc/conv.hip */
+int suo_conv1x1(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev,
+                const float* a2_dev, int lda2, int K2, const float* wp_dev, const float* bias_dev,
+                const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int n_valid, int relu,
+                int nchw_hw, void* stream);
+/* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
+int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
+                 float* out_dev, int N, int relu, void* stream);
+int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
+int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUO_HIP_H */

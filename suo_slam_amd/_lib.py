@@ -1,0 +1,79 @@
+"""ctypes binding of libsuo_hip.so (include/suo_hip.h).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsuo_hip.so")
+
+_lib = None
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+c_i32p = C.POINTER(C.c_int)
+c_i64p = C.POINTER(C.c_int64)
+VP = C.c_void_p
+
+
+class SuoError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/suo_hip.h declares
+SIGNATURES = {
+    "suo_last_error": (C.c_char_p, []),
+    "suo_version": (C.c_int, []),
+    "suo_device_count": (C.c_int, []),
+    "suo_net_create": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(VP), C.POINTER(VP), c_i32p, C.c_int, C.POINTER(VP)]),
+    "suo_net_destroy": (None, [VP]),
+    "suo_net_set_graph": (C.c_int, [VP, C.c_int]),
+    "suo_net_workspace_bytes": (C.c_size_t, [VP]),
+    "suo_net_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_net_backbone": (C.c_int, [VP, VP, C.c_int, VP, VP]),
+    "suo_decode_heatmaps": (C.c_int, [VP, C.c_int, VP, VP, VP, VP]),
+    "suo_classifier": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP]),
+    "suo_keypoint_masks": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_float, C.c_float, VP, VP]),
+    "suo_roi_align_concat": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP]),
+    "suo_pack_gemm_weight": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_pack_conv_weight": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_conv1x1": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_conv_kxk": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP]),
+    "suo_maxpool2": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_upsample2_add": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+}
+
+
+def register(extra):
+    SIGNATURES.update(extra)
+
+
+def lib():
+    """Load the HIP extension; raise if it is missing (the product path has no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SuoError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().suo_last_error().decode("utf-8", "replace")
+        raise SuoError(f"{what} failed (code {rc}): {msg}")
+
+
+def require_gpu():
+    n = lib().suo_device_count()
+    if n <= 0:
+        raise SuoError("no HIP device visible: the suo_slam_amd product path needs an MI355X (no CPU fallback)")
+    return n

@@ -1,0 +1,126 @@
+// extern "C" surface of libsuo_hip.so (declared in include/suo_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/suo_hip.h"
+#include "net.h"
+
+static thread_local char g_err[1024] = "";
+
+void suo_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct suo_net { suo::Net* impl; };
+
+extern "C" {
+
+const char* suo_last_error(void) { return g_err; }
+int suo_version(void) { return 100; }
+
+int suo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int suo_net_create(int n, const char* const* names, const float* const* data, const int64_t* const* shapes,
+                   const int* ndims, int max_crops, suo_net** out) {
+    if (!out || n <= 0 || max_crops <= 0) { suo_set_error("suo_net_create: bad arguments"); return SUO_ERR_ARG; }
+    try {
+        suo_net* h = new suo_net();
+        h->impl = new suo::Net(n, names, data, shapes, ndims, max_crops);
+        *out = h;
+    } catch (const std::exception& e) {
+        suo_set_error("suo_net_create: %s", e.what());
+        return SUO_ERR_MISSING;
+    }
+    return SUO_OK;
+}
+
+void suo_net_destroy(suo_net* net) {
+    if (!net) return;
+    delete net->impl;
+    delete net;
+}
+
+int suo_net_set_graph(suo_net* net, int enable) {
+    if (!net) return SUO_ERR_ARG;
+    net->impl->set_use_graph(enable != 0);
+    return SUO_OK;
+}
+
+size_t suo_net_workspace_bytes(const suo_net* net) { return net ? net->impl->workspace_bytes() : 0; }
+
+int suo_net_forward(suo_net* net, const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors,
+                    float* uv, float* cov, float* kp_mask, float* kp_logits, float* logits, void* stream) {
+    if (!net || !img || !boxes || !uv || !cov || !kp_mask) { suo_set_error("suo_net_forward: null argument"); return SUO_ERR_ARG; }
+    return net->impl->forward(img, img_format, H, W, boxes, L, priors, uv, cov, kp_mask, kp_logits, logits, (hipStream_t)stream);
+}
+
+int suo_net_backbone(suo_net* net, const float* staged, int L, float* logits, void* stream) {
+    if (!net) { suo_set_error("suo_net_backbone: null net"); return SUO_ERR_ARG; }
+    return net->impl->forward_staged(staged, L, logits, (hipStream_t)stream);
+}
+
+int suo_decode_heatmaps(const float* logits, int L, float* uv, float* cov, float* mean_logit, void* stream) {
+    return suo::launch_decode(logits, L, uv, cov, mean_logit, (hipStream_t)stream);
+}
+
+int suo_classifier(const float* mean_logit, const float* w, const float* b, int L, float* kp_logit, float* kp_prob, void* stream) {
+    return suo::launch_classifier(mean_logit, w, b, L, kp_logit, kp_prob, (hipStream_t)stream);
+}
+
+int suo_keypoint_masks(const float* uv, const float* cov, const float* kp_prob, const uint8_t* model_mask, int L,
+                       float bbox_thresh, float kp_var_thresh, uint8_t* mask, void* stream) {
+    return suo::launch_kp_masks(uv, cov, kp_prob, model_mask, L, bbox_thresh, kp_var_thresh, mask, (hipStream_t)stream);
+}
+
+int suo_roi_align_concat(const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors, float* out, void* stream) {
+    return suo::launch_roi_align_concat(img, img_format, H, W, boxes, L, priors, out, (hipStream_t)stream);
+}
+
+int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* out) {
+    if (Np % 32 || Kp % 8 || N > Np || K > Kp) { suo_set_error("suo_pack_gemm_weight: bad padding"); return SUO_ERR_ARG; }
+    suo::pack_gemm_weight(w, N, K, K, Np, Kp, out);
+    return SUO_OK;
+}
+
+int suo_pack_conv_weight(const float* w, int N, int C, int KS, int Np, int Cp, int CK, float* out) {
+    if (Np % 32 || Cp % CK || CK % 8 || N > Np || C > Cp) { suo_set_error("suo_pack_conv_weight: bad padding"); return SUO_ERR_ARG; }
+    suo::pack_conv_weight(w, N, C, KS, Np, Cp, CK, nullptr, out);
+    return SUO_OK;
+}
+
+int suo_conv1x1(const float* a1, int lda1, int K1, const float* pro_scale, const float* pro_shift, const float* a2, int lda2,
+                int K2, const float* wp, const float* bias, const float* r, int ldr, float* out, int ldo, int M, int N,
+                int n_valid, int relu, int nchw_hw, void* stream) {
+    suo::GemmArgs g = {};
+    g.A1 = a1; g.lda1 = lda1; g.K1 = K1; g.pro_scale = pro_scale; g.pro_shift = pro_shift;
+    g.A2 = a2; g.lda2 = lda2; g.K2 = a2 ? K2 : 0; g.Wp = wp; g.bias = bias; g.R = r; g.ldr = ldr;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = n_valid; g.relu = relu; g.nchw_hw = nchw_hw;
+    return suo::launch_gemm1x1(g, (hipStream_t)stream);
+}
+
+int suo_conv_kxk(int KS, const float* in, int L, int H, int W, int C, const float* wp, const float* bias, float* out, int N,
+                 int relu, void* stream) {
+    suo::ConvArgs c = {};
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = C; c.Wp = wp; c.bias = bias; c.out = out; c.N = N; c.relu = relu;
+    if (KS == 3) { c.OH = H; c.OW = W; return suo::launch_conv3x3(c, (hipStream_t)stream); }
+    if (KS == 7) { c.OH = H / 2; c.OW = W / 2; return suo::launch_conv7x7s2(c, (hipStream_t)stream); }
+    suo_set_error("suo_conv_kxk: KS=%d unsupported", KS);
+    return SUO_ERR_ARG;
+}
+
+int suo_maxpool2(const float* in, float* out, int L, int H, int W, int C, void* stream) {
+    return suo::launch_maxpool2(in, out, L, H, W, C, (hipStream_t)stream);
+}
+
+int suo_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, void* stream) {
+    return suo::launch_upsample2_add(up1, low, out, L, H, W, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// HBM-bound kernels of the keypoint-CNN path: RoI crop + prior concat, 2x2 max-pool, nearest 2x
+// up-sample + add, heat-map decode (softmax -> soft-argmax -> 2x2 covariance), validity head and
+// the boolean keypoint masks.  NHWC fp32 activations; 16-byte vector accesses; wave64 reductions.
+//
+// Reference ops replaced:
+//   image prep  img/255, HWC->CHW                 /root/reference/lib/object_slam.py:1092
+//   torchvision.ops.roi_align + torch.cat         /root/reference/lib/models/pkpnet.py:93-101
+//   nn.MaxPool2d(2,2)                             /root/reference/lib/models/hg.py:16,71
+//   F.interpolate(scale_factor=2) + add           /root/reference/lib/models/hg.py:56-58
+//   spatial_softmax / mesh_grid / post_process_kp /root/reference/lib/models/pkpnet.py:13-63
+//   classifier (ReLU, Linear, sigmoid)            /root/reference/lib/models/pkpnet.py:74-78,116-118
+//   keypoint mask logic                           /root/reference/lib/object_slam.py:1100-1115
+#include "suo_internal.h"
+
+namespace suo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 max-pool, NHWC.  One thread per output float4.
+__global__ void maxpool2_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int L, int OH, int OW, int C4) {
+    const size_t total = (size_t)L * OH * OW * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ox = (int)(p % OW); p /= OW;
+        const int oy = (int)(p % OH);
+        const int l = (int)(p / OH);
+        const size_t W = (size_t)OW * 2;
+        const size_t base = (((size_t)l * OH * 2 + oy * 2) * W + ox * 2) * C4 + c;
+        const f32x4 a = in[base], b = in[base + C4], d = in[base + W * C4], e = in[base + W * C4 + C4];
+        f32x4 r;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[t] = fmaxf(fmaxf(a[t], b[t]), fmaxf(d[t], e[t]));
+        out[i] = r;
+    }
+}
+
+int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s) {
+    if ((H | W) & 1 || (C & 3)) { suo_set_error("maxpool2: bad shape"); return SUO_ERR_ARG; }
+    const size_t total = (size_t)L * (H / 2) * (W / 2) * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(blocks), dim3(256), 0, s, (const f32x4*)in, (f32x4*)out, L, H / 2, W / 2, C / 4);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[l,y,x,:] = up1[l,y,x,:] + low[l,y/2,x/2,:]   (nearest 2x up-sample + add), out is [L,H,W,C]
+__global__ void upsample2_add_kernel(const f32x4* __restrict__ up1, const f32x4* __restrict__ low,
+                                     f32x4* __restrict__ out, int L, int H, int W, int C4) {
+    const size_t total = (size_t)L * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int l = (int)(p / H);
+        const size_t li = (((size_t)l * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * C4 + c;
+        out[i] = up1[i] + low[li];
+    }
+}
+
+int launch_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, hipStream_t s) {
+    if ((H | W) & 1 || (C & 3)) { suo_set_error("upsample2_add: bad shape"); return SUO_ERR_ARG; }
+    const size_t total = (size_t)L * H * W * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3(blocks), dim3(256), 0, s, (const f32x4*)up1, (const f32x4*)low,
+                       (f32x4*)out, L, H, W, C / 4);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoIAlign(aligned=False, sampling_ratio=-1, spatial_scale=1) of a uint8 HWC image (values /255)
+// to 256x256, concatenated with the 41 prior heat-maps (NCHW, or NULL = zeros), written NHWC with
+// the 44 channels padded to 48.  One thread per output pixel.
+// FMT 0: uint8 HWC (scaled by 1/255 here = object_slam.py:1092 fused); FMT 1: float32 CHW planar
+template <int FMT>
+__device__ __forceinline__ float pix(const void* __restrict__ img, int H, int W, int y, int x, int c) {
+    if (FMT == 0) return (float)((const uint8_t*)img)[((size_t)y * W + x) * 3 + c] / 255.0f;
+    return ((const float*)img)[((size_t)c * H + y) * W + x];
+}
+
+template <int FMT>
+__device__ __forceinline__ void bilinear3(const void* __restrict__ img, int H, int W, float y, float x, float acc[3]) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return;
+    y = fmaxf(y, 0.f);
+    x = fmaxf(x, 0.f);
+    int y0 = (int)y, x0 = (int)x, y1, x1;
+    if (y0 >= H - 1) { y0 = y1 = H - 1; y = (float)y0; } else y1 = y0 + 1;
+    if (x0 >= W - 1) { x0 = x1 = W - 1; x = (float)x0; } else x1 = x0 + 1;
+    const float ly = y - (float)y0, lx = x - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        // same operation order as the restated torchvision kernel: ((w00*v00 + w01*v01) + w10*v10) + w11*v11
+        const float v00 = pix<FMT>(img, H, W, y0, x0, c), v01 = pix<FMT>(img, H, W, y0, x1, c);
+        const float v10 = pix<FMT>(img, H, W, y1, x0, c), v11 = pix<FMT>(img, H, W, y1, x1, c);
+        acc[c] += __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w00, v00), __fmul_rn(w01, v01)), __fmul_rn(w10, v10)), __fmul_rn(w11, v11));
+    }
+}
+
+template <int FMT>
+__global__ void roi_align_concat_kernel(const void* __restrict__ img, int H, int W, const float* __restrict__ boxes,
+                                        const float* __restrict__ priors, float* __restrict__ out) {
+    const int l = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. 65535
+    const int ph = p >> 8, pw = p & 255;
+    const float x1 = boxes[l * 4 + 0], y1 = boxes[l * 4 + 1], x2 = boxes[l * 4 + 2], y2 = boxes[l * 4 + 3];
+    const float roi_w = fmaxf(x2 - x1, 1.0f), roi_h = fmaxf(y2 - y1, 1.0f);
+    const float bin_h = roi_h / 256.0f, bin_w = roi_w / 256.0f;
+    const int gh = (int)ceilf(roi_h / 256.0f), gw = (int)ceilf(roi_w / 256.0f);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int iy = 0; iy < gh; ++iy) {
+        const float y = __fadd_rn(__fadd_rn(y1, __fmul_rn((float)ph, bin_h)), __fmul_rn((float)iy + 0.5f, bin_h) / (float)gh);
+        for (int ix = 0; ix < gw; ++ix) {
+            const float x = __fadd_rn(__fadd_rn(x1, __fmul_rn((float)pw, bin_w)), __fmul_rn((float)ix + 0.5f, bin_w) / (float)gw);
+            bilinear3<FMT>(img, H, W, y, x, acc);
+        }
+    }
+    const float cnt = (float)(gh * gw);
+    float* o = out + ((size_t)l * CROP * CROP + p) * IN_C;
+    f32x4 v[IN_C / 4];
+#pragma unroll
+    for (int i = 0; i < IN_C / 4; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    v[0][0] = acc[0] / cnt;
+    v[0][1] = acc[1] / cnt;
+    v[0][2] = acc[2] / cnt;
+    if (priors) {
+        const float* pr = priors + (size_t)l * NUM_KP * CROP * CROP + p;
+#pragma unroll
+        for (int k = 0; k < NUM_KP; ++k) v[(3 + k) >> 2][(3 + k) & 3] = pr[(size_t)k * CROP * CROP];
+    }
+#pragma unroll
+    for (int i = 0; i < IN_C / 4; ++i) ((f32x4*)o)[i] = v[i];
+}
+
+int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, int L, const float* priors,
+                            float* out, hipStream_t s) {
+    if (L <= 0 || H <= 1 || W <= 1) { suo_set_error("roi_align: bad shape"); return SUO_ERR_ARG; }
+    if (fmt == 0)
+        hipLaunchKernelGGL(roi_align_concat_kernel<0>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, priors, out);
+    else if (fmt == 1)
+        hipLaunchKernelGGL(roi_align_concat_kernel<1>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, priors, out);
+    else { suo_set_error("roi_align: unknown image format %d", fmt); return SUO_ERR_ARG; }
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Heat-map decode: one wave per (crop, keypoint) 64x64 heat-map held entirely in registers
+// (16 float4 per lane).  Three in-register passes: max; exp / sum / first moments; centred second
+// moments (two-pass covariance exactly like post_process_kp, no E[x^2]-mu^2 cancellation).
+// Axis convention: u = sum p * r[row],  v = sum p * (-r[col]),  r[i] = (i+0.5)/32 - 1.
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ logits, int n_maps, float* __restrict__ uv,
+                                                     float* __restrict__ cov, float* __restrict__ mean_logit) {
+    const int lane = threadIdx.x & 63;
+    const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (map >= n_maps) return;
+    const f32x4* src = (const f32x4*)(logits + (size_t)map * HEAT * HEAT);
+    f32x4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[j * 64 + lane];   // element index e = (j*64+lane)*4 + t
+    float mx = -INFINITY, raw = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { mx = fmaxf(mx, v[j][t]); raw += v[j][t]; }
+    mx = wave_max(mx);
+    raw = wave_sum(raw);
+    // row = e / 64 = j*4 + lane/16 ; col = (lane & 15)*4 + t
+    const float colbase = (float)((lane & 15) * 4);
+    float s0 = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float rx = ((float)(j * 4 + (lane >> 4)) + 0.5f) / 32.0f - 1.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float e = expf(v[j][t] - mx);
+            v[j][t] = e;
+            const float ry = -((colbase + (float)t + 0.5f) / 32.0f - 1.0f);
+            s0 += e;
+            sx = fmaf(e, rx, sx);
+            sy = fmaf(e, ry, sy);
+        }
+    }
+    s0 = wave_sum(s0);
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    const float inv = 1.0f / s0;
+    const float mu_x = sx * inv, mu_y = sy * inv;
+    float cxx = 0.f, cxy = 0.f, cyy = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float dx = (((float)(j * 4 + (lane >> 4)) + 0.5f) / 32.0f - 1.0f) - mu_x;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float dy = -((colbase + (float)t + 0.5f) / 32.0f - 1.0f) - mu_y;
+            const float e = v[j][t];
+            cxx = fmaf(e * dx, dx, cxx);
+            cxy = fmaf(e * dx, dy, cxy);
+            cyy = fmaf(e * dy, dy, cyy);
+        }
+    }
+    cxx = wave_sum(cxx) * inv;
+    cxy = wave_sum(cxy) * inv;
+    cyy = wave_sum(cyy) * inv;
+    if (lane == 0) {
+        uv[map * 2 + 0] = mu_x;
+        uv[map * 2 + 1] = mu_y;
+        cov[map * 4 + 0] = cxx;
+        cov[map * 4 + 1] = cxy;
+        cov[map * 4 + 2] = cxy;
+        cov[map * 4 + 3] = cyy;
+        mean_logit[map] = raw * (1.0f / (HEAT * HEAT));
+    }
+}
+
+int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, hipStream_t s) {
+    if (L <= 0) { suo_set_error("decode: L<=0"); return SUO_ERR_ARG; }
+    const int n_maps = L * NUM_KP;
+    hipLaunchKernelGGL(decode_kernel, dim3((n_maps + 3) / 4), dim3(256), 0, s, logits, n_maps, uv, cov, mean_logit);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// validity head: sigmoid(W * relu(mean_logit) + b); one wave per crop, lane = output keypoint
+__global__ void classifier_kernel(const float* __restrict__ mean_logit, const float* __restrict__ Wc,
+                                  const float* __restrict__ bc, float* __restrict__ kp_logit, float* __restrict__ kp_prob) {
+    const int l = blockIdx.x, k = threadIdx.x;
+    __shared__ float m[NUM_KP];
+    if (k < NUM_KP) m[k] = fmaxf(mean_logit[l * NUM_KP + k], 0.f);
+    __syncthreads();
+    if (k < NUM_KP) {
+        float a = 0.f;
+        for (int j = 0; j < NUM_KP; ++j) a = fmaf(Wc[k * NUM_KP + j], m[j], a);
+        a += bc[k];
+        if (kp_logit) kp_logit[l * NUM_KP + k] = a;
+        kp_prob[l * NUM_KP + k] = 1.0f / (1.0f + expf(-a));
+    }
+}
+
+int launch_classifier(const float* mean_logit, const float* Wc, const float* bc, int L, float* kp_logit, float* kp_prob,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(classifier_kernel, dim3(L), dim3(64), 0, s, mean_logit, Wc, bc, kp_logit, kp_prob);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// object_slam.py:1100-1115 on device: boolean keypoint masks (bit-exact target)
+__global__ void kp_masks_kernel(const float* __restrict__ uv, const float* __restrict__ cov, const float* __restrict__ kp_prob,
+                                const uint8_t* __restrict__ model_mask, int n, float bbox_thresh, float two_var,
+                                uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u = uv[i * 2], v = uv[i * 2 + 1];
+    bool m = (kp_prob[i] > 0.3f) && (model_mask ? model_mask[i] != 0 : true);
+    m = m && (fminf(u, v) > -bbox_thresh) && (fmaxf(u, v) < bbox_thresh);
+    const float sx = sqrtf(cov[i * 4 + 0]), sy = sqrtf(cov[i * 4 + 3]);
+    m = m && (sx < two_var) && (sy < two_var);
+    out[i] = m ? 1 : 0;
+}
+
+int launch_kp_masks(const float* uv, const float* cov, const float* kp_prob, const uint8_t* model_mask, int L,
+                    float bbox_thresh, float kp_var_thresh, uint8_t* out_mask, hipStream_t s) {
+    const int n = L * NUM_KP;
+    hipLaunchKernelGGL(kp_masks_kernel, dim3((n + 255) / 256), dim3(256), 0, s, uv, cov, kp_prob, model_mask, n,
+                       bbox_thresh, 2.0f * kp_var_thresh, out_mask);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+}  // namespace suo

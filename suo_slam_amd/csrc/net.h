@@ -1,0 +1,77 @@
+// Host-side runtime object behind suo_net_* (see include/suo_hip.h).
+#pragma once
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "suo_internal.h"
+
+namespace suo {
+
+struct HostTensor {
+    const float* data = nullptr;
+    std::vector<int64_t> shape;
+    size_t numel = 0;
+};
+
+struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; };
+struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; };
+struct ResidualW {
+    float* pro_scale = nullptr; float* pro_shift = nullptr;
+    GemmW c1; ConvW c2; GemmW c3;
+    int cin = 0, cout = 0; bool has_skip_conv = false;
+};
+struct HourglassW {
+    int n = 0;
+    ResidualW up1[2], low1[2], low2[2], low3[2];
+    std::unique_ptr<HourglassW> inner;
+};
+
+void pack_gemm_weight(const float* W, int N, int K, int ldw, int Np, int Kp, float* out);
+void pack_conv_weight(const float* W, int N, int C, int KS, int Np, int Cp, int CK, const float* out_scale, float* out);
+
+class Net {
+public:
+    Net(int n, const char* const* names, const float* const* data, const int64_t* const* shapes, const int* ndims, int max_crops);
+    ~Net();
+    int forward(const void* img, int fmt, int H, int W, const float* boxes, int L, const float* priors, float* uv, float* cov,
+                float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s);
+    int forward_staged(const float* in0_user, int L, float* logits_out, hipStream_t s);
+    void set_use_graph(bool v) { use_graph_ = v; }
+    int max_crops() const { return max_crops_; }
+    size_t workspace_bytes() const { return ws_floats_ * sizeof(float); }
+    const HostTensor& T(const std::string& name) const;
+
+private:
+    static constexpr int kNumSide = 4, kNumEvents = 32;
+    float* upload(const std::vector<float>& v);
+    void make_gemm(const std::string& conv, const std::string& bn_after, const std::string& conv2, GemmW& g);
+    void make_conv(const std::string& conv, const std::string& bn_after, int CK, ConvW& c);
+    void make_residual(const std::string& p, ResidualW& r);
+    void make_hourglass(const std::string& p, int n, HourglassW& h);
+    float* alloc(size_t floats);
+    int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s);
+    int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx);
+    int backbone(const float* in0, float* logits, int L, hipStream_t s);
+    int run_backbone(float* in0, float* logits, int L, hipStream_t s);
+
+    std::map<std::string, HostTensor> tensors_;
+    std::vector<float*> owned_;
+    ConvW stem_;
+    ResidualW r1_, r4_, r5_, post_[2][2];
+    HourglassW hg_[2];
+    GemmW lin_[2], head_[2], reinject_;
+    float* cls_w_ = nullptr; float* cls_b_ = nullptr;
+    int max_crops_;
+    float* ws_ = nullptr; size_t ws_floats_ = 0, ws_used_ = 0, ws_mark_ = 0;
+    float* d_mean_logit_ = nullptr;
+    hipStream_t side_[kNumSide] = {}; hipStream_t own_stream_ = nullptr;
+    hipEvent_t ev_[kNumEvents] = {}; int ev_next_ = 0;
+    bool use_graph_ = true; bool dry_run_ = false;
+    struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    std::map<int, GraphEntry> graphs_;
+};
+
+}  // namespace suo

@@ -1,0 +1,412 @@
+// Host-side runtime of the keypoint CNN: weight folding/packing, workspace, launch schedule,
+// multi-stream hourglass branches and hipGraph capture of the backbone.
+//
+// Mirrors PkpNet.forward (/root/reference/lib/models/pkpnet.py:80-119) over a state_dict with the
+// reference's key names (backbone.* / classifier.2.*), see suo_slam_amd/weights.py.
+#include "net.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <string>
+
+namespace suo {
+
+static constexpr float BN_EPS = 1e-5f;
+
+// ------------------------------------------------------------------------------------------------
+// weight lookup helpers
+const HostTensor& Net::T(const std::string& name) const {
+    auto it = tensors_.find(name);
+    if (it == tensors_.end()) throw std::runtime_error("missing tensor: " + name);
+    return it->second;
+}
+
+// BN(eval) as y = x*scale + shift
+static void bn_affine(const Net& net, const std::string& p, std::vector<float>& scale, std::vector<float>& shift) {
+    const HostTensor& g = net.T(p + ".weight");
+    const HostTensor& b = net.T(p + ".bias");
+    const HostTensor& m = net.T(p + ".running_mean");
+    const HostTensor& v = net.T(p + ".running_var");
+    const size_t c = g.numel;
+    scale.resize(c);
+    shift.resize(c);
+    for (size_t i = 0; i < c; ++i) {
+        const float s = g.data[i] / sqrtf(v.data[i] + BN_EPS);
+        scale[i] = s;
+        shift[i] = b.data[i] - m.data[i] * s;
+    }
+}
+
+// Pack W[n][k] (n < N, k < K; zero beyond) into the MFMA B-operand layout [Kp/8][Np/32][64][4].
+void pack_gemm_weight(const float* W, int N, int K, int ldw, int Np, int Kp, float* out) {
+    const int NB = Np / 32;
+    for (int kb = 0; kb < Kp / 8; ++kb)
+        for (int nb = 0; nb < NB; ++nb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t) {
+                    const int n = nb * 32 + (lane & 31), k = kb * 8 + (lane >> 5) * 4 + t;
+                    out[(((size_t)kb * NB + nb) * 64 + lane) * 4 + t] = (n < N && k < K) ? W[(size_t)n * ldw + k] : 0.f;
+                }
+}
+
+// Conv weight W[n][c][ky][kx] -> GEMM weight with K' = [chunk][ky][kx][kk] (kk < CK), then packed.
+void pack_conv_weight(const float* W, int N, int C, int KS, int Np, int Cp, int CK, const float* out_scale, float* out) {
+    const int nch = Cp / CK, Kp = nch * KS * KS * CK;
+    std::vector<float> g((size_t)Np * Kp, 0.f);
+    for (int n = 0; n < N; ++n)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int ky = 0; ky < KS; ++ky)
+                for (int kx = 0; kx < KS; ++kx)
+                    for (int kk = 0; kk < CK; ++kk) {
+                        const int c = ch * CK + kk;
+                        if (c >= C) continue;
+                        const float s = out_scale ? out_scale[n] : 1.f;
+                        g[(size_t)n * Kp + ((ch * KS + ky) * KS + kx) * CK + kk] = W[(((size_t)n * C + c) * KS + ky) * KS + kx] * s;
+                    }
+    pack_gemm_weight(g.data(), Np, Kp, Kp, Np, Kp, out);
+}
+
+float* Net::upload(const std::vector<float>& v) {
+    float* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(float)) != hipSuccess) throw std::runtime_error("hipMalloc(weights) failed");
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("hipMemcpy(weights) failed");
+    owned_.push_back(d);
+    return d;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// 1x1 conv W[N][K] with optional per-output scale (BN folded) -> device packed weight + bias
+void Net::make_gemm(const std::string& conv, const std::string& bn_after, const std::string& conv2, GemmW& g) {
+    const HostTensor& w = T(conv + ".weight");
+    const HostTensor& b = T(conv + ".bias");
+    const int N = (int)w.shape[0], K1 = (int)w.shape[1];
+    const int Np = round_up(N, 64), K1p = round_up(K1, 32);
+    int K2 = 0, K2p = 0;
+    if (!conv2.empty()) { K2 = (int)T(conv2 + ".weight").shape[1]; K2p = round_up(K2, 32); }
+    std::vector<float> scale, shift;
+    if (!bn_after.empty()) bn_affine(*this, bn_after, scale, shift);
+    const int Kp = K1p + K2p;
+    std::vector<float> full((size_t)Np * Kp, 0.f), bias(Np, 0.f);
+    for (int n = 0; n < N; ++n) {
+        const float s = scale.empty() ? 1.f : scale[n];
+        for (int k = 0; k < K1; ++k) full[(size_t)n * Kp + k] = w.data[(size_t)n * K1 + k] * s;
+        bias[n] = scale.empty() ? b.data[n] : b.data[n] * s + shift[n];
+    }
+    if (K2) {
+        const HostTensor& w2 = T(conv2 + ".weight");
+        const HostTensor& b2 = T(conv2 + ".bias");
+        for (int n = 0; n < N; ++n) {
+            for (int k = 0; k < K2; ++k) full[(size_t)n * Kp + K1p + k] = w2.data[(size_t)n * K2 + k];
+            bias[n] += b2.data[n];
+        }
+    }
+    std::vector<float> packed((size_t)Np * Kp);
+    pack_gemm_weight(full.data(), Np, Kp, Kp, Np, Kp, packed.data());
+    g.Wp = upload(packed);
+    g.bias = upload(bias);
+    g.N = Np; g.n_valid = N; g.K1 = K1p; g.K2 = K2p;
+}
+
+void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK, ConvW& c) {
+    const HostTensor& w = T(conv + ".weight");
+    const HostTensor& b = T(conv + ".bias");
+    const int N = (int)w.shape[0], C = (int)w.shape[1], KS = (int)w.shape[2];
+    const int Np = round_up(N, 64), Cp = round_up(C, CK);
+    std::vector<float> scale, shift;
+    if (!bn_after.empty()) bn_affine(*this, bn_after, scale, shift);
+    std::vector<float> packed((size_t)Np * Cp * KS * KS), bias(Np, 0.f);
+    pack_conv_weight(w.data, N, C, KS, Np, Cp, CK, scale.empty() ? nullptr : scale.data(), packed.data());
+    for (int n = 0; n < N; ++n) bias[n] = scale.empty() ? b.data[n] : b.data[n] * scale[n] + shift[n];
+    c.Wp = upload(packed);
+    c.bias = upload(bias);
+    c.N = Np; c.C = Cp; c.KS = KS;
+}
+
+void Net::make_residual(const std::string& p, ResidualW& r) {
+    std::vector<float> sc, sh;
+    bn_affine(*this, p + ".bn", sc, sh);
+    r.cin = (int)sc.size();
+    r.pro_scale = upload(sc);
+    r.pro_shift = upload(sh);
+    make_gemm(p + ".conv1", p + ".bn1", "", r.c1);
+    make_conv(p + ".conv2", p + ".bn2", 32, r.c2);
+    r.has_skip_conv = tensors_.count(p + ".conv4.weight") > 0;
+    // conv3 (+ conv4 on the raw input as a second K segment: out = W3*mid + W4*x + b3 + b4)
+    make_gemm(p + ".conv3", "", r.has_skip_conv ? p + ".conv4" : "", r.c3);
+    r.cout = r.c3.n_valid;
+}
+
+void Net::make_hourglass(const std::string& p, int n, HourglassW& h) {
+    h.n = n;
+    for (int j = 0; j < 2; ++j) {
+        make_residual(p + ".up1_." + std::to_string(j), h.up1[j]);
+        make_residual(p + ".low1_." + std::to_string(j), h.low1[j]);
+        make_residual(p + ".low3_." + std::to_string(j), h.low3[j]);
+    }
+    if (n > 1) {
+        h.inner.reset(new HourglassW());
+        make_hourglass(p + ".low2", n - 1, *h.inner);
+    } else {
+        for (int j = 0; j < 2; ++j) make_residual(p + ".low2_." + std::to_string(j), h.low2[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+Net::Net(int n, const char* const* names, const float* const* data, const int64_t* const* shapes, const int* ndims, int max_crops)
+    : max_crops_(max_crops) {
+    for (int i = 0; i < n; ++i) {
+        HostTensor t;
+        t.data = data[i];
+        t.numel = 1;
+        for (int d = 0; d < ndims[i]; ++d) { t.shape.push_back(shapes[i][d]); t.numel *= (size_t)shapes[i][d]; }
+        tensors_[names[i]] = t;
+    }
+    const std::string b = "backbone";
+    make_conv(b + ".conv1_", b + ".bn1", 16, stem_);
+    make_residual(b + ".r1", r1_);
+    make_residual(b + ".r4", r4_);
+    make_residual(b + ".r5", r5_);
+    for (int i = 0; i < 2; ++i) {
+        make_hourglass(b + ".hourglass." + std::to_string(i), 4, hg_[i]);
+        for (int j = 0; j < 2; ++j) make_residual(b + ".Residual." + std::to_string(i * 2 + j), post_[i][j]);
+        make_gemm(b + ".lin_." + std::to_string(i) + ".0", b + ".lin_." + std::to_string(i) + ".1", "", lin_[i]);
+        make_gemm(b + ".tmpOut." + std::to_string(i), "", "", head_[i]);
+    }
+    // inter-stack re-injection: x + ll_(ll) + tmpOut_(tmpOut)  ==  one dual-operand GEMM + residual
+    make_gemm(b + ".ll_.0", "", b + ".tmpOut_.0", reinject_);
+    {
+        const HostTensor& w = T("classifier.2.weight");
+        const HostTensor& bb = T("classifier.2.bias");
+        cls_w_ = upload(std::vector<float>(w.data, w.data + w.numel));
+        cls_b_ = upload(std::vector<float>(bb.data, bb.data + bb.numel));
+    }
+    tensors_.clear();   // host pointers are not retained past construction
+
+    // ---- workspace: every intermediate gets its own slab (288 GB of HBM: no aliasing games).
+    // Size it with a dry run of the launch schedule at max_crops.
+    dry_run_ = true;
+    ws_floats_ = (size_t)-1 / sizeof(float) / 2;
+    ws_used_ = 0;
+    (void)alloc((size_t)max_crops_ * CROP * CROP * IN_C);
+    (void)alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+    ws_mark_ = ws_used_;
+    if (backbone(nullptr, nullptr, max_crops_, nullptr) != SUO_OK) throw std::runtime_error("dry run failed");
+    ws_floats_ = ws_used_;
+    dry_run_ = false;
+    if (hipMalloc(&ws_, ws_floats_ * sizeof(float)) != hipSuccess) throw std::runtime_error("hipMalloc(workspace) failed");
+    if (hipMalloc(&d_mean_logit_, (size_t)max_crops_ * NUM_KP * sizeof(float)) != hipSuccess)
+        throw std::runtime_error("hipMalloc failed");
+    if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
+    for (int i = 0; i < kNumSide; ++i) {
+        if (hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("hipStreamCreate failed");
+    }
+    for (int i = 0; i < kNumEvents; ++i)
+        if (hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) != hipSuccess) throw std::runtime_error("hipEventCreate failed");
+}
+
+Net::~Net() {
+    for (auto& kv : graphs_) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+    for (float* p : owned_) (void)hipFree(p);
+    if (ws_) (void)hipFree(ws_);
+    if (d_mean_logit_) (void)hipFree(d_mean_logit_);
+    for (int i = 0; i < kNumSide; ++i) if (side_[i]) (void)hipStreamDestroy(side_[i]);
+    if (own_stream_) (void)hipStreamDestroy(own_stream_);
+    for (int i = 0; i < kNumEvents; ++i) if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+}
+
+float* Net::alloc(size_t floats) {
+    floats = (floats + 63) & ~(size_t)63;
+    if (ws_used_ + floats > ws_floats_) throw std::runtime_error("workspace exhausted");
+    float* p = ws_ + ws_used_;
+    ws_used_ += floats;
+    return p;
+}
+
+#define SUO_TRY(x) do { int _r = (x); if (_r != SUO_OK) return _r; } while (0)
+#define SUO_LAUNCH(x) do { if (!dry_run_) { int _r = (x); if (_r != SUO_OK) return _r; } } while (0)
+#define SUO_HIP_LIVE(x) do { if (!dry_run_) SUO_HIP_CHECK(x); } while (0)
+
+// Residual.forward: three fused launches
+int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s) {
+    const int M = L * H * W;
+    float* mid1 = alloc((size_t)M * r.c1.N);
+    float* mid2 = alloc((size_t)M * r.c2.N);
+    GemmArgs g1 = {};
+    g1.A1 = x; g1.lda1 = r.cin; g1.K1 = r.c1.K1; g1.pro_scale = r.pro_scale; g1.pro_shift = r.pro_shift;
+    g1.Wp = r.c1.Wp; g1.bias = r.c1.bias; g1.out = mid1; g1.ldo = r.c1.N; g1.M = M; g1.N = r.c1.N; g1.n_valid = r.c1.n_valid; g1.relu = 1;
+    SUO_LAUNCH(launch_gemm1x1(g1, s));
+    ConvArgs c2 = {};
+    c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
+    c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
+    SUO_LAUNCH(launch_conv3x3(c2, s));
+    GemmArgs g3 = {};
+    g3.A1 = mid2; g3.lda1 = r.c2.N; g3.K1 = r.c3.K1;
+    if (r.has_skip_conv) { g3.A2 = x; g3.lda2 = r.cin; g3.K2 = r.c3.K2; }
+    else { g3.R = x; g3.ldr = r.cin; }
+    g3.Wp = r.c3.Wp; g3.bias = r.c3.bias; g3.out = out; g3.ldo = r.cout; g3.M = M; g3.N = r.c3.N; g3.n_valid = r.c3.n_valid;
+    SUO_LAUNCH(launch_gemm1x1(g3, s));
+    return SUO_OK;
+}
+
+// Hourglass.forward (hg.py:37-58).  The up1 branch is independent of the low branch until the
+// final add: it runs on a side stream (fork/join with events) so the small, latency-bound low
+// levels overlap with the large up1 kernels.
+int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx) {
+    const int C = 256;
+    const size_t n_hi = (size_t)L * H * W * C, n_lo = n_hi / 4;
+    hipStream_t side = side_[depth_idx % kNumSide];
+    hipEvent_t ev_fork = ev_[(ev_next_++) % kNumEvents], ev_join = ev_[(ev_next_++) % kNumEvents];
+    float* up_a = alloc(n_hi);
+    float* up_b = alloc(n_hi);
+    SUO_HIP_LIVE(hipEventRecord(ev_fork, s));
+    SUO_HIP_LIVE(hipStreamWaitEvent(side, ev_fork, 0));
+    SUO_TRY(residual(h.up1[0], x, up_a, L, H, W, side));
+    SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
+    SUO_HIP_LIVE(hipEventRecord(ev_join, side));
+
+    float* pooled = alloc(n_lo);
+    float* lo_a = alloc(n_lo);
+    float* lo_b = alloc(n_lo);
+    SUO_LAUNCH(launch_maxpool2(x, pooled, L, H, W, C, s));
+    SUO_TRY(residual(h.low1[0], pooled, lo_a, L, H / 2, W / 2, s));
+    SUO_TRY(residual(h.low1[1], lo_a, lo_b, L, H / 2, W / 2, s));
+    float* low2 = alloc(n_lo);
+    if (h.n > 1) {
+        SUO_TRY(hourglass(*h.inner, lo_b, low2, L, H / 2, W / 2, s, depth_idx + 1));
+    } else {
+        float* t = alloc(n_lo);
+        SUO_TRY(residual(h.low2[0], lo_b, t, L, H / 2, W / 2, s));
+        SUO_TRY(residual(h.low2[1], t, low2, L, H / 2, W / 2, s));
+    }
+    float* l3a = alloc(n_lo);
+    float* l3b = alloc(n_lo);
+    SUO_TRY(residual(h.low3[0], low2, l3a, L, H / 2, W / 2, s));
+    SUO_TRY(residual(h.low3[1], l3a, l3b, L, H / 2, W / 2, s));
+    SUO_HIP_LIVE(hipStreamWaitEvent(s, ev_join, 0));
+    SUO_LAUNCH(launch_upsample2_add(up_b, l3b, out, L, H, W, C, s));
+    return SUO_OK;
+}
+
+// HourglassNet.forward (hg.py:95-119) from the staged NHWC input to NCHW logits
+int Net::backbone(const float* in0, float* logits, int L, hipStream_t s) {
+    ws_used_ = ws_mark_;
+    ev_next_ = 0;
+    float* stem = alloc((size_t)L * 128 * 128 * 64);
+    ConvArgs c = {};
+    c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = IN_C; c.Wp = stem_.Wp; c.bias = stem_.bias;
+    c.out = stem; c.OH = 128; c.OW = 128; c.N = 64; c.relu = 1;
+    SUO_LAUNCH(launch_conv7x7s2(c, s));
+    float* r1o = alloc((size_t)L * 128 * 128 * 128);
+    SUO_TRY(residual(r1_, stem, r1o, L, 128, 128, s));
+    float* p1 = alloc((size_t)L * 64 * 64 * 128);
+    SUO_LAUNCH(launch_maxpool2(r1o, p1, L, 128, 128, 128, s));
+    float* r4o = alloc((size_t)L * 64 * 64 * 128);
+    SUO_TRY(residual(r4_, p1, r4o, L, 64, 64, s));
+    float* x = alloc((size_t)L * 64 * 64 * 256);
+    SUO_TRY(residual(r5_, r4o, x, L, 64, 64, s));
+    const int M = L * 64 * 64;
+    for (int i = 0; i < 2; ++i) {
+        float* hg = alloc((size_t)M * 256);
+        SUO_TRY(hourglass(hg_[i], x, hg, L, 64, 64, s, 0));
+        float* ra = alloc((size_t)M * 256);
+        float* rb = alloc((size_t)M * 256);
+        SUO_TRY(residual(post_[i][0], hg, ra, L, 64, 64, s));
+        SUO_TRY(residual(post_[i][1], ra, rb, L, 64, 64, s));
+        float* ll = alloc((size_t)M * 256);
+        GemmArgs gl = {};
+        gl.A1 = rb; gl.lda1 = 256; gl.K1 = 256; gl.Wp = lin_[i].Wp; gl.bias = lin_[i].bias; gl.out = ll; gl.ldo = 256;
+        gl.M = M; gl.N = 256; gl.n_valid = 256; gl.relu = 1;
+        SUO_LAUNCH(launch_gemm1x1(gl, s));
+        GemmArgs gh = {};
+        gh.A1 = ll; gh.lda1 = 256; gh.K1 = 256; gh.Wp = head_[i].Wp; gh.bias = head_[i].bias; gh.M = M; gh.N = 64;
+        if (i == 0) {
+            // stack-0 head feeds tmpOut_: keep it NHWC, 41 channels padded to 64 (pad columns are exact zeros)
+            float* t0 = alloc((size_t)M * 64);
+            gh.out = t0; gh.ldo = 64; gh.n_valid = 64;
+            SUO_LAUNCH(launch_gemm1x1(gh, s));
+            float* xn = alloc((size_t)M * 256);
+            GemmArgs gr = {};
+            gr.A1 = ll; gr.lda1 = 256; gr.K1 = 256; gr.A2 = t0; gr.lda2 = 64; gr.K2 = reinject_.K2;
+            gr.Wp = reinject_.Wp; gr.bias = reinject_.bias; gr.R = x; gr.ldr = 256; gr.out = xn; gr.ldo = 256;
+            gr.M = M; gr.N = 256; gr.n_valid = 256;
+            SUO_LAUNCH(launch_gemm1x1(gr, s));
+            x = xn;
+        } else {
+            gh.out = logits; gh.n_valid = NUM_KP; gh.nchw_hw = HEAT * HEAT;
+            SUO_LAUNCH(launch_gemm1x1(gh, s));
+        }
+    }
+    return SUO_OK;
+}
+
+int Net::run_backbone(float* in0, float* logits, int L, hipStream_t s) {
+    if (use_graph_) {
+        auto it = graphs_.find(L);
+        if (it == graphs_.end()) {
+            GraphEntry ge;
+            SUO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            int r = backbone(in0, logits, L, s);
+            hipError_t e = hipStreamEndCapture(s, &ge.graph);
+            if (r != SUO_OK) return r;
+            SUO_HIP_CHECK(e);
+            SUO_HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+            it = graphs_.emplace(L, ge).first;
+        }
+        SUO_HIP_CHECK(hipGraphLaunch(it->second.exec, s));
+        return SUO_OK;
+    }
+    return backbone(in0, logits, L, s);
+}
+
+// Backbone only, from an already staged NHWC [L,256,256,48] input (test / profiling entry).
+int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStream_t s) {
+    if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_backbone: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
+    const bool own = (s == nullptr);
+    if (own) s = own_stream_;
+    try {
+        ws_used_ = 0;
+        float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
+        float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+        ws_mark_ = ws_used_;
+        if (in0_user)
+            SUO_HIP_CHECK(hipMemcpyAsync(in0, in0_user, (size_t)L * CROP * CROP * IN_C * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SUO_TRY(run_backbone(in0, logits, L, s));
+        if (logits_out)
+            SUO_HIP_CHECK(hipMemcpyAsync(logits_out, logits, (size_t)L * NUM_KP * HEAT * HEAT * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } catch (const std::exception& e) {
+        suo_set_error("suo_net_backbone: %s", e.what());
+        return SUO_ERR_ARG;
+    }
+    if (own) SUO_HIP_CHECK(hipStreamSynchronize(s));
+    return SUO_OK;
+}
+
+int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, int L, const float* priors, float* uv, float* cov,
+                 float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s) {
+    if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_forward: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
+    const bool own = (s == nullptr);
+    if (own) s = own_stream_;   // the legacy NULL stream cannot be captured: run on an internal stream and block
+    try {
+        // persistent slabs at the bottom of the workspace: staged input + logits
+        ws_used_ = 0;
+        float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
+        float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+        ws_mark_ = ws_used_;
+        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, L, priors, in0, s));
+        SUO_TRY(run_backbone(in0, logits, L, s));
+        SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, s));
+        SUO_LAUNCH(launch_classifier(d_mean_logit_, cls_w_, cls_b_, L, kp_logit, kp_prob, s));
+        if (logits_out)
+            SUO_HIP_CHECK(hipMemcpyAsync(logits_out, logits, (size_t)L * NUM_KP * HEAT * HEAT * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } catch (const std::exception& e) {
+        suo_set_error("suo_net_forward: %s", e.what());
+        return SUO_ERR_ARG;
+    }
+    if (own) SUO_HIP_CHECK(hipStreamSynchronize(s));
+    return SUO_OK;
+}
+
+}  // namespace suo

@@ -1,0 +1,69 @@
+// Internal declarations shared by the HIP translation units of libsuo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define SUO_OK 0
+#define SUO_ERR_ARG 1
+#define SUO_ERR_HIP 2
+#define SUO_ERR_MISSING 3
+
+#define SUO_HIP_CHECK(expr)                                                            \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            suo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return SUO_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+void suo_set_error(const char* fmt, ...);
+
+namespace suo {
+
+constexpr int NUM_KP = 41;
+constexpr int HEAT = 64;          // heat-map side
+constexpr int CROP = 256;         // network input side
+constexpr int IN_C = 48;          // 3 + 41 = 44 input channels, padded to 48 in the NHWC staging buffer
+
+// ---- packed-weight geometry (B operand of v_mfma_f32_32x32x2_f32) -------------------------------
+// A GEMM weight W[N][K] (row = output channel) is stored as  Wp[K/8][N/32][64 lanes][4]  with
+//   Wp[kb][nb][lane][t] = W[nb*32 + (lane&31)][kb*8 + (lane>>5)*4 + t]
+// so one wave reads its four next MFMA B operands with ONE coalesced 16-byte-per-lane load.
+size_t packed_weight_floats(int n_pad, int k_pad);
+
+// 1x1 convolution (= GEMM over NHWC pixels) with fused prologue / epilogue.
+struct GemmArgs {
+    const float* A1; int lda1; int K1;                   // [M, K1] activations, row stride lda1
+    const float* pro_scale; const float* pro_shift;      // optional: A1 <- relu(A1*scale[k]+shift[k])
+    const float* A2; int lda2; int K2;                   // optional second operand (skip conv4 / tmpOut_)
+    const float* Wp;                                     // packed [(K1+K2)/8][N/32][64][4]
+    const float* bias;                                   // [N] (padded)
+    const float* R; int ldr;                             // optional residual [M, n_valid]
+    float* out; int ldo;                                 // [M, ldo]   (NHWC)   or NCHW when nchw_hw>0
+    int M; int N; int n_valid; int relu; int nchw_hw;    // nchw_hw = H*W of one crop for NCHW output
+};
+int launch_gemm1x1(const GemmArgs& a, hipStream_t s);
+
+// KxK convolution (3x3 s1 p1 or 7x7 s2 p3), NHWC, input already activated, zero padding.
+struct ConvArgs {
+    const float* in; int L, H, W, C;                     // [L,H,W,C]
+    const float* Wp;                                     // packed with K' = [chunk][ky][kx][kk]
+    const float* bias; float* out; int OH, OW, N;        // out [L,OH,OW,N]
+    int relu;
+};
+int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+int launch_conv7x7s2(const ConvArgs& a, hipStream_t s);
+
+int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);
+int launch_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, hipStream_t s);
+int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, int L,
+                            const float* priors, float* out, hipStream_t s);
+int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, hipStream_t s);
+int launch_classifier(const float* mean_logit, const float* Wc, const float* bc, int L,
+                      float* kp_logit, float* kp_prob, hipStream_t s);
+int launch_kp_masks(const float* uv, const float* cov, const float* kp_prob, const uint8_t* model_mask,
+                    int L, float bbox_thresh, float kp_var_thresh, uint8_t* out_mask, hipStream_t s);
+
+}  // namespace suo

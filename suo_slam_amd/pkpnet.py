@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference's ``PkpNet`` (/root/reference/lib/models/pkpnet.py:65-119).
+
+Same constructor / ``forward(images, boxes, prior_kp)`` / ``load_state_dict`` surface, but every
+operator runs in libsuo_hip.so (hand-written gfx950 kernels).  PyTorch is used only to own device
+memory and the current HIP stream.  There is no CPU fallback: a missing extension or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import NUM_KP
+
+HEAT = 64
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PkpNet:
+    """Keypoint / uncertainty network (eval mode only)."""
+
+    def __init__(self, input_res=(256, 256), calc_cov=True, state_dict=None, max_crops=16, device="cuda:0"):
+        assert tuple(input_res) == (256, 256), "the HIP path is built for 256x256 crops (lib/datasets/bop.py:21)"
+        assert calc_cov, "covariance is always computed on the HIP path"
+        self.input_res = tuple(input_res)
+        self.calc_cov = True
+        self.num_kp = NUM_KP
+        self.max_crops = int(max_crops)
+        self.device = torch.device(device)
+        self._h = None
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # -- reference surface -------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts ``checkpoint['model']`` of the reference (torch tensors or numpy arrays)."""
+        lib = _lib.lib()
+        _lib.require_gpu()
+        torch.cuda.set_device(self.device)
+        arrs = {}
+        for k, v in state_dict.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            arrs[k] = np.ascontiguousarray(a, dtype=np.float32)
+        n = len(arrs)
+        names = (C.c_char_p * n)(*[k.encode() for k in arrs])
+        data = (C.c_void_p * n)(*[a.ctypes.data for a in arrs.values()])
+        shapes_keep = [(C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,))) for a in arrs.values()]
+        shapes = (C.c_void_p * n)(*[C.cast(s, C.c_void_p).value for s in shapes_keep])
+        ndims = (C.c_int * n)(*[max(a.ndim, 1) for a in arrs.values()])
+        h = C.c_void_p()
+        _lib.check(lib.suo_net_create(n, names, data, shapes, ndims, self.max_crops, C.byref(h)), "suo_net_create")
+        self.close()
+        self._h = h
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().suo_net_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_graph(self, enable: bool):
+        _lib.check(_lib.lib().suo_net_set_graph(self._h, int(enable)), "suo_net_set_graph")
+
+    def workspace_bytes(self):
+        return int(_lib.lib().suo_net_workspace_bytes(self._h))
+
+    def forward(self, images, boxes, prior_kp=None, want_prob=False):
+        """images: uint8 [H,W,3] (cv2 layout) or float32 [1,3,H,W] device/host tensor; boxes: list with
+        one Tensor[L,4] (xyxy); prior_kp: list with one Tensor[L,41,256,256] or None.
+        Returns the reference's dict: uv, cov, prob_logits, kp_mask_logits, kp_mask (+ prob if asked)."""
+        assert self._h is not None, "load_state_dict first"
+        assert isinstance(boxes, (list, tuple)) and len(boxes) == 1, "one image per call (lib/object_slam.py:1092-1099)"
+        dev = self.device
+        if isinstance(images, np.ndarray):
+            images = torch.from_numpy(images)
+        if images.dtype == torch.uint8:
+            assert images.dim() == 3 and images.shape[2] == 3
+            fmt, H, W = 0, int(images.shape[0]), int(images.shape[1])
+        else:
+            assert images.dim() == 4 and images.shape[0] == 1 and images.shape[1] == 3
+            images = images.to(torch.float32)
+            fmt, H, W = 1, int(images.shape[2]), int(images.shape[3])
+        img = images.to(dev).contiguous()
+        bx = torch.as_tensor(boxes[0], dtype=torch.float32).to(dev).contiguous()
+        L = int(bx.shape[0])
+        pr = None
+        if prior_kp is not None:
+            pr = torch.cat([torch.as_tensor(p, dtype=torch.float32) for p in prior_kp]).to(dev).contiguous()
+            assert tuple(pr.shape) == (L, NUM_KP, 256, 256)
+        uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
+        cov = torch.empty((L, NUM_KP, 2, 2), dtype=torch.float32, device=dev)
+        kpm = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+        kpl = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+        logits = torch.empty((L, NUM_KP, HEAT, HEAT), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().suo_net_forward(self._h, _ptr(img), fmt, H, W, _ptr(bx), L, _ptr(pr), _ptr(uv), _ptr(cov),
+                                              _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward")
+        ret = {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
+        if want_prob:
+            ret["prob"] = torch.softmax(logits.reshape(L, NUM_KP, -1), -1).reshape(logits.shape)
+        return ret
+
+    __call__ = forward
+
+
+def keypoint_masks(uv, cov, kp_mask, model_kps_masks, bbox_thresh=0.9, kp_var_thresh=0.2):
+    """Device version of the mask logic at lib/object_slam.py:1100-1115 -> uint8 [L,41]."""
+    L = int(uv.shape[0])
+    mm = None
+    if model_kps_masks is not None:
+        mm = torch.as_tensor(np.asarray(model_kps_masks, dtype=np.uint8)).to(uv.device).contiguous()
+    out = torch.empty((L, NUM_KP), dtype=torch.uint8, device=uv.device)
+    _lib.check(_lib.lib().suo_keypoint_masks(_ptr(uv), _ptr(cov), _ptr(kp_mask), _ptr(mm), L, float(bbox_thresh),
+                                             float(kp_var_thresh), _ptr(out), _stream()), "suo_keypoint_masks")
+    return out

@@ -1,0 +1,87 @@
+"""Thin test helpers that call the per-stage C-ABI entry points of libsuo_hip.so on torch CUDA tensors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from suo_slam_amd import _lib
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).cuda().contiguous()
+
+
+def nhwc(x):  # [L,C,H,W] numpy/torch -> NHWC cuda
+    return dev(np.ascontiguousarray(np.asarray(x).transpose(0, 2, 3, 1)))
+
+
+def nchw(t):  # NHWC cuda -> numpy [L,C,H,W]
+    return t.cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def pack_gemm(w, Np, Kp):
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty(Np * Kp, np.float32)
+    _lib.check(_lib.lib().suo_pack_gemm_weight(w.ctypes.data, w.shape[0], w.shape[1], Np, Kp, out.ctypes.data), "pack_gemm")
+    return out
+
+
+def pack_conv(w, Np, Cp, CK):
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty(Np * Cp * w.shape[2] * w.shape[3], np.float32)
+    _lib.check(_lib.lib().suo_pack_conv_weight(w.ctypes.data, w.shape[0], w.shape[1], w.shape[2], Np, Cp, CK, out.ctypes.data), "pack_conv")
+    return out
+
+
+def conv1x1(a1, w1, bias, pro=None, a2=None, w2=None, res=None, relu=False, nchw_hw=0):
+    """a1 [M,K1] cuda, w1 [N,K1] numpy, bias [N]; optional pro=(scale,shift), a2 [M,K2]/w2 [N,K2], res [M,N]."""
+    M, K1 = a1.shape
+    N = w1.shape[0]
+    Np = (N + 63) // 64 * 64
+    K2 = a2.shape[1] if a2 is not None else 0
+    full = np.zeros((Np, K1 + K2), np.float32)
+    full[:N, :K1] = w1
+    if a2 is not None:
+        full[:N, K1:] = w2
+    wp = dev(pack_gemm(full, Np, K1 + K2))
+    b = np.zeros(Np, np.float32)
+    b[:N] = bias
+    b = dev(b)
+    if nchw_hw:
+        out = torch.empty((M // nchw_hw, N, nchw_hw), device="cuda")
+        ldo = 0
+    else:
+        out = torch.empty((M, N), device="cuda")
+        ldo = N
+    ps = dev(pro[0]) if pro is not None else None
+    pt = dev(pro[1]) if pro is not None else None
+    _lib.check(_lib.lib().suo_conv1x1(P(a1), a1.stride(0), K1, P(ps), P(pt), P(a2), a2.stride(0) if a2 is not None else 0, K2,
+                                      P(wp), P(b), P(res), res.stride(0) if res is not None else 0, P(out), ldo, M, Np, N,
+                                      int(relu), nchw_hw, S()), "suo_conv1x1")
+    torch.cuda.synchronize()
+    return out
+
+
+def conv_kxk(x_nhwc, w, bias, relu=False):
+    L, H, W, C = x_nhwc.shape
+    N, Cw, KS, _ = w.shape
+    CK = 32 if KS == 3 else 16
+    Np = (N + 63) // 64 * 64
+    assert C % CK == 0 and Cw <= C
+    wp = dev(pack_conv(w, Np, C, CK))
+    b = np.zeros(Np, np.float32)
+    b[:N] = bias
+    b = dev(b)
+    OH, OW = (H, W) if KS == 3 else (H // 2, W // 2)
+    out = torch.empty((L, OH, OW, Np), device="cuda")
+    _lib.check(_lib.lib().suo_conv_kxk(KS, P(x_nhwc), L, H, W, C, P(wp), P(b), P(out), Np, int(relu), S()), "suo_conv_kxk")
+    torch.cuda.synchronize()
+    return out[..., :N]
