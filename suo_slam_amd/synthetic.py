@@ -1,0 +1,126 @@
+"""Synthetic YCB-V-shaped inputs: 640x480 frames, L objects per frame with known poses,
+per-class keypoint subsets of the 41-channel vocabulary, bounding boxes, and keypoint measurements
+generated like the reference's --debug_gt_kp mode (projected GT keypoints + N(0, 0.01^2) NDC noise,
+/root/reference/lib/object_slam.py:1129-1131).  No dataset or network is involved."""
+from __future__ import annotations
+
+import numpy as np
+
+from .geometry import fix_K_for_bbox_ndc, project_ndc
+
+NUM_KP = 41
+# channel groups of the keypoint vocabulary (lib/labeling/kp_config.py:7-72): box 8, cylinder 10, tool 6,
+# grip 4, spout 1, brand 4, nutrition 4, barcode 4
+GROUPS = {"box_like": (0, 8), "cylinder_like": (8, 18), "hand_tool": (18, 24), "grip": (24, 28), "spout": (28, 29),
+          "brand_name": (29, 33), "nutrition_facts": (33, 37), "bar_code": (37, 41)}
+# (class, has_grip, has_spout, has_brand, has_nutrition, has_barcode) rows shaped like kp_configs/ycbv_kp_config.csv:2-22
+YCBV_LIKE = [("cylinder_like", 0, 0, 1, 0, 1), ("box_like", 0, 0, 1, 1, 1), ("box_like", 0, 0, 1, 1, 1),
+             ("cylinder_like", 0, 0, 1, 1, 1), ("cylinder_like", 0, 0, 1, 1, 1), ("cylinder_like", 0, 0, 1, 1, 1),
+             ("box_like", 0, 0, 1, 1, 1), ("box_like", 0, 0, 1, 1, 1), ("box_like", 0, 0, 1, 0, 1), ("hand_tool", 0, 0, 0, 0, 0),
+             ("cylinder_like", 1, 1, 1, 0, 0), ("cylinder_like", 0, 0, 1, 0, 0), ("cylinder_like", 0, 0, 0, 0, 0),
+             ("cylinder_like", 1, 0, 0, 0, 0), ("hand_tool", 1, 0, 0, 0, 0), ("box_like", 0, 0, 0, 0, 0),
+             ("hand_tool", 1, 0, 0, 0, 0), ("hand_tool", 0, 0, 0, 0, 0), ("hand_tool", 1, 0, 0, 0, 0),
+             ("hand_tool", 1, 0, 0, 0, 0), ("box_like", 0, 0, 0, 0, 0)]
+
+K_YCBV = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]])
+
+
+def class_mask(obj_class_idx):
+    cls, grip, spout, brand, nutr, bar = YCBV_LIKE[obj_class_idx % len(YCBV_LIKE)]
+    m = np.zeros(NUM_KP, bool)
+    m[GROUPS[cls][0]:GROUPS[cls][1]] = True
+    for flag, name in ((grip, "grip"), (spout, "spout"), (brand, "brand_name"), (nutr, "nutrition_facts"), (bar, "bar_code")):
+        if flag:
+            m[GROUPS[name][0]:GROUPS[name][1]] = True
+    return m
+
+
+def random_rotation(rng):
+    A = rng.standard_normal((3, 3))
+    Q, R = np.linalg.qr(A)
+    Q = Q @ np.diag(np.sign(np.diag(R)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    return Q
+
+
+def make_texture(rng, H=480, W=640):
+    """Smooth random uint8 image (low-pass filtered noise) so bilinear sampling is non-trivial."""
+    img = rng.uniform(0, 1, (H // 8 + 2, W // 8 + 2, 3))
+    img = np.kron(img, np.ones((8, 8, 1)))[:H, :W]
+    k = np.ones(5) / 5
+    for ax in (0, 1):
+        img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, img)
+    img += rng.normal(0, 0.02, img.shape)
+    return (np.clip(img, 0, 1) * 255).astype(np.uint8)
+
+
+def make_frame(rng, n_obj=8, K=K_YCBV, H=480, W=640, noise=0.01, outlier_frac=0.0, with_image=True):
+    """One synthetic single-view frame.  Returns a dict with image, K, per-object class masks, model
+    keypoints [L,41,3] (mm), GT poses T_OtoC [L,4,4], boxes [L,4] xyxy, K_bbox [L,3,3], measured uv
+    [L,41,2] (NDC, float32), cov [L,41,2,2] (float32), visibility/validity masks [L,41] and diameters."""
+    model_kps = np.zeros((n_obj, NUM_KP, 3), np.float32)
+    masks = np.zeros((n_obj, NUM_KP), bool)
+    poses = np.zeros((n_obj, 4, 4))
+    boxes = np.zeros((n_obj, 4), np.float32)
+    K_bbox = np.zeros((n_obj, 3, 3))
+    uv = np.zeros((n_obj, NUM_KP, 2), np.float32)
+    cov = np.zeros((n_obj, NUM_KP, 2, 2), np.float32)
+    diam = np.zeros(n_obj)
+    for o in range(n_obj):
+        masks[o] = class_mask(int(rng.integers(0, len(YCBV_LIKE))))
+        ext = rng.uniform(40, 100, 3)
+        model_kps[o] = (rng.uniform(-1, 1, (NUM_KP, 3)) * ext).astype(np.float32)
+        diam[o] = 2 * np.linalg.norm(ext)
+        for _ in range(100):
+            T = np.eye(4)
+            T[:3, :3] = random_rotation(rng)
+            z = rng.uniform(600, 1200)
+            T[:3, 3] = [rng.uniform(-0.25, 0.25) * z, rng.uniform(-0.18, 0.18) * z, z]
+            pts = model_kps[o].astype(np.float64)
+            pc = pts @ T[:3, :3].T + T[:3, 3]
+            px = pc @ K.T
+            px = px[:, :2] / px[:, 2:3]
+            x1, y1 = px.min(0) - rng.uniform(5, 15, 2)
+            x2, y2 = px.max(0) + rng.uniform(5, 15, 2)
+            if x1 >= 0 and y1 >= 0 and x2 <= W - 1 and y2 <= H - 1 and x2 - x1 >= 40 and y2 - y1 >= 40:
+                break
+        poses[o] = T
+        boxes[o] = [x1, y1, x2, y2]
+        K_bbox[o] = fix_K_for_bbox_ndc(K, boxes[o].astype(np.float64))
+        uv_gt, _ = project_ndc(K_bbox[o], T, model_kps[o].astype(np.float64))
+        uv_o = uv_gt + rng.normal(0, noise, uv_gt.shape)
+        if outlier_frac > 0:
+            out = rng.random(NUM_KP) < outlier_frac
+            uv_o[out] = rng.uniform(-0.8, 0.8, (int(out.sum()), 2))
+        uv[o] = uv_o.astype(np.float32)
+        s = max(noise, 1e-3)
+        A = rng.normal(0, 0.3, (NUM_KP, 2, 2)) + np.eye(2)
+        cov[o] = ((A @ A.transpose(0, 2, 1)) * s * s).astype(np.float32)
+    frame = {"K": K.copy(), "model_kps": model_kps, "model_kps_masks": masks, "T_OtoC": poses, "boxes": boxes,
+             "K_bbox": K_bbox, "uv": uv, "cov": cov, "diameter": diam, "obj_ids": list(range(1, n_obj + 1))}
+    if with_image:
+        frame["image"] = make_texture(rng, H, W)
+    return frame
+
+
+def frame_to_ba_problem(frame, init_poses, use_cov=True):
+    """Flat SoA of ObjectSLAM.optimize's single-view graph (object_slam.py:746-839): one fixed camera at
+    identity, one free vertex per object, one edge per valid keypoint."""
+    L = len(frame["boxes"])
+    e_cam, e_obj, e_k, e_p, e_uv, e_info = [], [], [], [], [], []
+    for o in range(L):
+        Kb = frame["K_bbox"][o]
+        for k in np.nonzero(frame["model_kps_masks"][o])[0]:
+            e_cam.append(0)
+            e_obj.append(o)
+            e_k.append([Kb[0, 0], Kb[1, 1], Kb[0, 2], Kb[1, 2]])
+            e_p.append(frame["model_kps"][o, k].astype(np.float64))
+            e_uv.append(frame["uv"][o, k].astype(np.float64))
+            Om = np.linalg.inv(frame["cov"][o, k].astype(np.float64)) if use_cov else np.eye(2)
+            e_info.append([Om[0, 0], Om[0, 1], Om[1, 1]])
+    return {"cam_T": np.eye(4)[None, :3, :], "cam_fixed": np.array([1], np.uint8),
+            "obj_T": np.asarray(init_poses, np.float64)[:, :3, :], "obj_fixed": np.zeros(L, np.uint8),
+            "edge_cam": np.array(e_cam, np.int32), "edge_obj": np.array(e_obj, np.int32), "edge_camk": np.array(e_k),
+            "edge_p": np.array(e_p), "edge_uv": np.array(e_uv), "edge_info": np.array(e_info),
+            "edge_inlier": np.ones(len(e_cam), np.uint8)}

@@ -107,7 +107,8 @@ def test_pool_and_upsample(ops):
     assert np.array_equal(ops.nchw(out), F.max_pool2d(torch.from_numpy(x), 2, 2).numpy())
     low = rng.standard_normal((2, 64, 8, 8)).astype(np.float32)
     o2 = torch.empty((2, 16, 16, 64), device="cuda")
-    _lib.check(_lib.lib().suo_upsample2_add(ops.P(xd), ops.P(ops.nhwc(low)), ops.P(o2), 2, 16, 16, 64, ops.S()))
+    lowd = ops.nhwc(low)
+    _lib.check(_lib.lib().suo_upsample2_add(ops.P(xd), ops.P(lowd), ops.P(o2), 2, 16, 16, 64, ops.S()))
     torch.cuda.synchronize()
     ref = torch.from_numpy(x) + F.interpolate(torch.from_numpy(low), scale_factor=2)
     assert np.array_equal(ops.nchw(o2), ref.numpy())
@@ -125,7 +126,8 @@ def test_roi_align_concat_matches_oracle(ops):
     for fmt, src in ((0, ops.dev(img, torch.uint8)), (1, ops.dev(O.image_to_chw(img)))):
         for priors in (None, ops.dev(pri)):
             out = torch.full((len(boxes), 256, 256, 48), 7.0, device="cuda")
-            _lib.check(_lib.lib().suo_roi_align_concat(ops.P(src), fmt, 480, 640, ops.P(ops.dev(boxes)), len(boxes), ops.P(priors),
+            bx = ops.dev(boxes)
+            _lib.check(_lib.lib().suo_roi_align_concat(ops.P(src), fmt, 480, 640, ops.P(bx), len(boxes), ops.P(priors),
                                                        ops.P(out), ops.S()))
             torch.cuda.synchronize()
             o = out.cpu().numpy()
@@ -150,8 +152,8 @@ def test_decode_golden_and_masks(ops, cnn_golden, state_dict):
         _lib.check(lib.suo_decode_heatmaps(ops.P(ld), L, ops.P(uv), ops.P(cov), ops.P(ml), ops.S()))
         kl = torch.empty((L, 41), device="cuda")
         kp = torch.empty((L, 41), device="cuda")
-        _lib.check(lib.suo_classifier(ops.P(ml), ops.P(ops.dev(state_dict["classifier.2.weight"])),
-                                      ops.P(ops.dev(state_dict["classifier.2.bias"])), L, ops.P(kl), ops.P(kp), ops.S()))
+        wc, bc = ops.dev(state_dict["classifier.2.weight"]), ops.dev(state_dict["classifier.2.bias"])   # keep alive
+        _lib.check(lib.suo_classifier(ops.P(ml), ops.P(wc), ops.P(bc), L, ops.P(kl), ops.P(kp), ops.S()))
         torch.cuda.synchronize()
         # tolerance: abs 1e-5 (fp32 reduction-order noise over 4096 terms), SURVEY.md 7.2
         np.testing.assert_allclose(uv.cpu().numpy(), cnn_golden[key + "_uv"], atol=1e-5, rtol=0)
