@@ -88,6 +88,49 @@ int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const 
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 
+/* ---- PnP: replaces lambdatwist.pnp (thirdparty/lambdatwist/pnp_python_binding.cpp:32-62) ---------- */
+/* One call per object in the reference (lib/object_slam.py:1144); here all objects of a frame go in one
+ * launch (one wavefront each).  Host buffers: n_pts[n_obj]; xs [sum n_pts][3] model points; ys
+ * [sum n_pts][2] NORMALISED image points (object_slam.py:34-36); threshold as PnpParams (1e-3).
+ * T_out [n_obj][16] row-major 4x4.  status[o] = 1 <=> identity pose = total failure, the reference's
+ * error convention (pnp_ransac.cpp:231, object_slam.py:38).  Objects with n_pts < 4 return identity.
+ * seed keys the counter-based sampler (object o uses seed + o * 0x9E3779B97F4A7C15).  Never throws. */
+int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, uint64_t seed,
+                  int do_refine, double* T_out, int* status, int* best_inliers, int* iterations);
+/* exact legacy signature: pnp(xs[N,3], ys[N,2], threshold) -> 4x4 */
+int suo_pnp(const double* xs, const double* ys, int n, double threshold, double* T_out);
+
+/* ---- pose refinement / bundle adjustment: replaces the g2o calls of ObjectSLAM.optimize -------------
+ * (lib/object_slam.py:703-903; g2o surface listed in SURVEY.md 8b).  A problem is the flat SoA of the graph
+ * the reference builds edge by edge (:746-839): vertices = cameras (T_GtoC) and objects (T_OtoG) as
+ * row-major 3x4; one edge per keypoint measurement with cam_k = [fx,fy,cx,cy] of K_bbox, model point,
+ * measured uv (NDC) and information (xx,xy,yy).  obj_fixed all 1 reproduces curr_only mode
+ * (EdgeSE3ProjectFromFixedObject); cam_fixed[0]=1 the global / single-view gauge (:774).
+ * Runs the robust rounds of :842-896 (its[], chi2 gate, Huber drop at round max(1,n_rounds/2)) on-device. */
+typedef struct suo_ba_problem {
+    int n_cam, n_obj, n_edge;
+    double* cam_T;                 /* [n_cam][12] in/out */
+    const uint8_t* cam_fixed;      /* [n_cam] */
+    double* obj_T;                 /* [n_obj][12] in/out */
+    const uint8_t* obj_fixed;      /* [n_obj] */
+    const int32_t* edge_cam;       /* [n_edge] */
+    const int32_t* edge_obj;       /* [n_edge] */
+    const double* edge_camk;       /* [n_edge][4] */
+    const double* edge_p;          /* [n_edge][3] */
+    const double* edge_uv;         /* [n_edge][2] */
+    const double* edge_info;       /* [n_edge][3] = (xx, xy, yy) */
+    uint8_t* edge_inlier;          /* [n_edge] in/out (detections[...]["inliers"]) */
+    double* edge_chi2;             /* [n_edge] out, may be NULL */
+    int its[8]; int n_rounds;      /* e.g. {10,10,40,40}, 4 */
+    int init_with_outliers;        /* opt_init_with_outliers and curr_only (:848-852) */
+    double chi2_thr;               /* 5.991 */
+    double huber_delta;            /* sqrt(5.991) */
+    int stats[4];                  /* out: rounds, LM iterations, LM trials, final num_good */
+} suo_ba_problem;
+int suo_optimize(suo_ba_problem* problem);
+/* many independent problems (frames) in one launch, one workgroup each */
+int suo_optimize_batch(suo_ba_problem* problems, int n_problems);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,21 @@ SIGNATURES = {
     "suo_conv_kxk": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP]),
     "suo_maxpool2": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_upsample2_add": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_pnp_batch": (C.c_int, [C.c_int, VP, VP, VP, C.c_double, C.c_uint64, C.c_int, VP, VP, VP, VP]),
+    "suo_pnp": (C.c_int, [VP, VP, C.c_int, C.c_double, VP]),
+    "suo_optimize": (C.c_int, [VP]),
+    "suo_optimize_batch": (C.c_int, [VP, C.c_int]),
 }
+
+
+class BaProblem(C.Structure):
+    """ctypes mirror of suo_ba_problem (include/suo_hip.h)."""
+    _fields_ = [("n_cam", C.c_int), ("n_obj", C.c_int), ("n_edge", C.c_int),
+                ("cam_T", VP), ("cam_fixed", VP), ("obj_T", VP), ("obj_fixed", VP),
+                ("edge_cam", VP), ("edge_obj", VP), ("edge_camk", VP), ("edge_p", VP), ("edge_uv", VP), ("edge_info", VP),
+                ("edge_inlier", VP), ("edge_chi2", VP),
+                ("its", C.c_int * 8), ("n_rounds", C.c_int), ("init_with_outliers", C.c_int),
+                ("chi2_thr", C.c_double), ("huber_delta", C.c_double), ("stats", C.c_int * 4)]
 
 
 def register(extra):

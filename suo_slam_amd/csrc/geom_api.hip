@@ -1,0 +1,301 @@
+// Host-buffer entry points for the geometry kernels (what the reference's FFI would bind):
+//   suo_pnp / suo_pnp_batch        <- lambdatwist.pnp      (thirdparty/lambdatwist/pnp_python_binding.cpp:57-62)
+//   suo_optimize / suo_optimize_batch <- the g2o calls of ObjectSLAM.optimize (lib/object_slam.py:703-903)
+// They stage the caller's host arrays into one device arena (one H2D), launch, and copy results back
+// (one D2H).  Everything between the two copies runs on the GPU.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "../../include/suo_hip.h"
+#include "suo_internal.h"
+
+namespace suo {
+int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, uint64_t seed,
+                     const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
+                     int* iters_out, hipStream_t s);
+int launch_lm(const void* problems_dev, int n_problems, hipStream_t s);
+size_t lm_problem_struct_size();
+
+// PnpParams::get_iterations (thirdparty/lambdatwist/parameters.h:76-102), evaluated on the host so the
+// kernel's adaptive iteration count uses the same libm as the reference would.
+static int get_iterations(double estimated_inliers) {
+    const double p_meets = 0.9, min_probability = 0.99999;
+    const unsigned max_iterations = 1000, min_iterations = 100;
+    double p_inlier = std::min(0.9, estimated_inliers * p_meets);
+    p_inlier = std::min(std::max(p_inlier, 1e-2), 1 - 1e-8);
+    if (p_inlier < 0.01) return (int)max_iterations;
+    const double p_failure = std::min(std::max(1.0 - min_probability, 1e-8), 0.01);
+    const double p_good = pow(p_inlier, 4);
+    const double iterations = ceil(log(p_failure) / log(1.0 - p_good)) + 50;
+    if (iterations < min_iterations) return (int)min_iterations;
+    if (iterations > max_iterations) return (int)max_iterations;
+    return (int)iterations;
+}
+
+// grow-only device arena + pinned host mirror, one per process (guarded: the reference is single-threaded)
+struct Arena {
+    char* dev = nullptr; char* host = nullptr; size_t cap = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    int ensure(size_t bytes) {
+        if (!stream) SUO_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (bytes <= cap) return SUO_OK;
+        size_t ncap = std::max(bytes, cap * 2);
+        ncap = (ncap + 4095) & ~(size_t)4095;
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+        dev = nullptr; host = nullptr; cap = 0;
+        SUO_HIP_CHECK(hipMalloc((void**)&dev, ncap));
+        SUO_HIP_CHECK(hipHostMalloc((void**)&host, ncap, hipHostMallocDefault));
+        cap = ncap;
+        return SUO_OK;
+    }
+};
+static Arena g_arena;
+
+struct Layout {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return o; }
+};
+
+// mirror of the device-side LmProblem (csrc/lm.hip) -- keep field order identical
+struct LmProblemHost {
+    int n_cam, n_obj, n_edge, n_pair;
+    double* cam_T; double* obj_T;
+    const uint8_t* cam_fixed; const uint8_t* obj_fixed;
+    const int* edge_pair;
+    const double* edge_k; const double* edge_p; const double* edge_uv; const double* edge_info;
+    uint8_t* edge_inlier; double* edge_chi2;
+    const int* pair_cam; const int* pair_obj; const int* pair_start;
+    const int* cam_pair_ptr; const int* cam_pair_idx;
+    const int* obj_pair_ptr; const int* obj_pair_idx;
+    int its[8]; int n_rounds; int init_with_outliers; double chi2_thr; double huber_delta;
+    void* cam; void* obj; void* cam_bak; void* obj_bak;
+    double* err; uint8_t* level; double* pair_part;
+    double* Hcc; double* bc; double* Hoo; double* bo; double* Hcc_inv; double* Y; double* yc; double* xc; double* xo;
+    int* obj_slot; int* stats;
+};
+
+}  // namespace suo
+
+using namespace suo;
+
+extern "C" {
+
+int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, uint64_t seed,
+                  int do_refine, double* T_out, int* status, int* best_inliers, int* iterations) {
+    if (n_obj <= 0) return SUO_OK;
+    if (!n_pts || !xs || !ys || !T_out) { suo_set_error("suo_pnp_batch: null argument"); return SUO_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    std::vector<int> offsets(n_obj + 1, 0), tab_off(n_obj, 0);
+    std::vector<int> tab;
+    for (int o = 0; o < n_obj; ++o) {
+        if (n_pts[o] < 0) { suo_set_error("suo_pnp_batch: negative point count"); return SUO_ERR_ARG; }
+        offsets[o + 1] = offsets[o] + n_pts[o];
+        tab_off[o] = (int)tab.size();
+        for (int b = 0; b <= n_pts[o]; ++b) tab.push_back(get_iterations(n_pts[o] > 0 ? b / (double)n_pts[o] : 0.0));
+    }
+    const int total = offsets[n_obj];
+    Layout L;
+    const size_t o_off = L.take(sizeof(int) * (n_obj + 1)), o_toff = L.take(sizeof(int) * n_obj), o_tab = L.take(sizeof(int) * tab.size());
+    const size_t o_xs = L.take(sizeof(double) * 3 * (size_t)total), o_ys = L.take(sizeof(double) * 2 * (size_t)total);
+    const size_t in_bytes = L.off;
+    const size_t o_T = L.take(sizeof(double) * 16 * (size_t)n_obj), o_st = L.take(sizeof(int) * n_obj), o_best = L.take(sizeof(int) * n_obj),
+                 o_it = L.take(sizeof(int) * n_obj);
+    int rc = g_arena.ensure(L.off);
+    if (rc != SUO_OK) return rc;
+    char* h = g_arena.host;
+    char* d = g_arena.dev;
+    memcpy(h + o_off, offsets.data(), sizeof(int) * (n_obj + 1));
+    memcpy(h + o_toff, tab_off.data(), sizeof(int) * n_obj);
+    memcpy(h + o_tab, tab.data(), sizeof(int) * tab.size());
+    memcpy(h + o_xs, xs, sizeof(double) * 3 * (size_t)total);
+    memcpy(h + o_ys, ys, sizeof(double) * 2 * (size_t)total);
+    hipStream_t s = g_arena.stream;
+    SUO_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    rc = launch_pnp_batch(n_obj, (const int*)(d + o_off), (const double*)(d + o_xs), (const double*)(d + o_ys), threshold, seed,
+                          (const int*)(d + o_tab), (const int*)(d + o_toff), do_refine, (double*)(d + o_T), (int*)(d + o_st),
+                          (int*)(d + o_best), (int*)(d + o_it), s);
+    if (rc != SUO_OK) return rc;
+    SUO_HIP_CHECK(hipMemcpyAsync(h + o_T, d + o_T, L.off - o_T, hipMemcpyDeviceToHost, s));
+    SUO_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(T_out, h + o_T, sizeof(double) * 16 * (size_t)n_obj);
+    if (status) memcpy(status, h + o_st, sizeof(int) * n_obj);
+    if (best_inliers) memcpy(best_inliers, h + o_best, sizeof(int) * n_obj);
+    if (iterations) memcpy(iterations, h + o_it, sizeof(int) * n_obj);
+    return SUO_OK;
+}
+
+int suo_pnp(const double* xs, const double* ys, int n, double threshold, double* T_out) {
+    int st = 0;
+    return suo_pnp_batch(1, &n, xs, ys, threshold, 0, 1, T_out, &st, nullptr, nullptr);
+}
+
+int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
+    if (n_prob <= 0) return SUO_OK;
+    if (!probs) { suo_set_error("suo_optimize_batch: null argument"); return SUO_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    struct Prep {
+        std::vector<int> order, edge_pair, pair_cam, pair_obj, pair_start, cam_ptr, cam_idx, obj_ptr, obj_idx;
+        size_t o[40];
+    };
+    std::vector<Prep> prep(n_prob);
+    Layout L;
+    const size_t o_structs = L.take(sizeof(LmProblemHost) * (size_t)n_prob);
+    if (sizeof(LmProblemHost) != lm_problem_struct_size()) { suo_set_error("LmProblem layout mismatch"); return SUO_ERR_ARG; }
+    size_t in_end = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        suo_ba_problem& q = probs[i];
+        Prep& P = prep[i];
+        if (q.n_cam < 0 || q.n_obj < 0 || q.n_edge < 0 || q.n_rounds < 0 || q.n_rounds > 8) { suo_set_error("suo_optimize: bad sizes"); return SUO_ERR_ARG; }
+        // sort edges by (cam, obj) pair, stable, so each pair is one contiguous segment
+        P.order.resize(q.n_edge);
+        for (int e = 0; e < q.n_edge; ++e) {
+            if (q.edge_cam[e] < 0 || q.edge_cam[e] >= q.n_cam || q.edge_obj[e] < 0 || q.edge_obj[e] >= q.n_obj) {
+                suo_set_error("suo_optimize: edge %d references a missing vertex", e);
+                return SUO_ERR_ARG;
+            }
+            P.order[e] = e;
+        }
+        std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) {
+            if (q.edge_cam[a] != q.edge_cam[b]) return q.edge_cam[a] < q.edge_cam[b];
+            return q.edge_obj[a] < q.edge_obj[b];
+        });
+        P.edge_pair.resize(q.n_edge);
+        for (int k = 0; k < q.n_edge; ++k) {
+            const int e = P.order[k];
+            if (k == 0 || q.edge_cam[e] != q.edge_cam[P.order[k - 1]] || q.edge_obj[e] != q.edge_obj[P.order[k - 1]]) {
+                P.pair_cam.push_back(q.edge_cam[e]);
+                P.pair_obj.push_back(q.edge_obj[e]);
+                P.pair_start.push_back(k);
+            }
+            P.edge_pair[k] = (int)P.pair_cam.size() - 1;
+        }
+        P.pair_start.push_back(q.n_edge);
+        const int np = (int)P.pair_cam.size();
+        P.cam_ptr.assign(q.n_cam + 1, 0);
+        P.obj_ptr.assign(q.n_obj + 1, 0);
+        for (int p = 0; p < np; ++p) { P.cam_ptr[P.pair_cam[p] + 1]++; P.obj_ptr[P.pair_obj[p] + 1]++; }
+        for (int c = 0; c < q.n_cam; ++c) P.cam_ptr[c + 1] += P.cam_ptr[c];
+        for (int o = 0; o < q.n_obj; ++o) P.obj_ptr[o + 1] += P.obj_ptr[o];
+        P.cam_idx.resize(np);
+        P.obj_idx.resize(np);
+        { std::vector<int> cc(P.cam_ptr.begin(), P.cam_ptr.end() - 1), oo(P.obj_ptr.begin(), P.obj_ptr.end() - 1);
+          for (int p = 0; p < np; ++p) { P.cam_idx[cc[P.pair_cam[p]]++] = p; P.obj_idx[oo[P.pair_obj[p]]++] = p; } }
+        const size_t E = q.n_edge, C = q.n_cam, O = q.n_obj, NP = np;
+        size_t* o = P.o;
+        o[0] = L.take(sizeof(double) * 12 * C); o[1] = L.take(sizeof(double) * 12 * O);           // cam_T, obj_T
+        o[2] = L.take(C); o[3] = L.take(O);                                                      // fixed flags
+        o[4] = L.take(sizeof(int) * E);                                                          // edge_pair
+        o[5] = L.take(sizeof(double) * 4 * E); o[6] = L.take(sizeof(double) * 3 * E);
+        o[7] = L.take(sizeof(double) * 2 * E); o[8] = L.take(sizeof(double) * 3 * E);
+        o[9] = L.take(E);                                                                        // edge_inlier
+        o[10] = L.take(sizeof(int) * NP); o[11] = L.take(sizeof(int) * NP); o[12] = L.take(sizeof(int) * (NP + 1));
+        o[13] = L.take(sizeof(int) * (C + 1)); o[14] = L.take(sizeof(int) * NP);
+        o[15] = L.take(sizeof(int) * (O + 1)); o[16] = L.take(sizeof(int) * NP);
+    }
+    in_end = L.off;
+    // outputs + scratch (device only, but laid out in the same arena; outputs first for one D2H)
+    const size_t out_begin = L.off;
+    for (int i = 0; i < n_prob; ++i) {
+        suo_ba_problem& q = probs[i];
+        size_t* o = prep[i].o;
+        o[17] = L.take(sizeof(double) * q.n_edge);     // edge_chi2
+        o[18] = L.take(sizeof(int) * 4);               // stats
+    }
+    const size_t out_end = L.off;
+    for (int i = 0; i < n_prob; ++i) {
+        suo_ba_problem& q = probs[i];
+        size_t* o = prep[i].o;
+        const size_t E = q.n_edge, C = q.n_cam, O = q.n_obj, NP = prep[i].pair_cam.size();
+        o[19] = L.take(56 * C); o[20] = L.take(56 * O); o[21] = L.take(56 * C); o[22] = L.take(56 * O);   // Pose = 7 doubles
+        o[23] = L.take(sizeof(double) * 2 * E); o[24] = L.take(E); o[25] = L.take(sizeof(double) * 90 * NP);
+        o[26] = L.take(sizeof(double) * 36 * C); o[27] = L.take(sizeof(double) * 6 * C);
+        o[28] = L.take(sizeof(double) * 36 * O); o[29] = L.take(sizeof(double) * 6 * O);
+        o[30] = L.take(sizeof(double) * 36 * C); o[31] = L.take(sizeof(double) * 36 * NP); o[32] = L.take(sizeof(double) * 6 * C);
+        o[33] = L.take(sizeof(double) * 6 * C); o[34] = L.take(sizeof(double) * 6 * O); o[35] = L.take(sizeof(int) * O);
+    }
+    int rc = g_arena.ensure(L.off);
+    if (rc != SUO_OK) return rc;
+    char* h = g_arena.host;
+    char* d = g_arena.dev;
+    LmProblemHost* hs = (LmProblemHost*)(h + o_structs);
+    for (int i = 0; i < n_prob; ++i) {
+        suo_ba_problem& q = probs[i];
+        Prep& P = prep[i];
+        size_t* o = P.o;
+        const int E = q.n_edge, np = (int)P.pair_cam.size();
+        memcpy(h + o[0], q.cam_T, sizeof(double) * 12 * q.n_cam);
+        memcpy(h + o[1], q.obj_T, sizeof(double) * 12 * q.n_obj);
+        memcpy(h + o[2], q.cam_fixed, q.n_cam);
+        memcpy(h + o[3], q.obj_fixed, q.n_obj);
+        memcpy(h + o[4], P.edge_pair.data(), sizeof(int) * E);
+        for (int k = 0; k < E; ++k) {
+            const int e = P.order[k];
+            memcpy(h + o[5] + sizeof(double) * 4 * k, q.edge_camk + 4 * e, sizeof(double) * 4);
+            memcpy(h + o[6] + sizeof(double) * 3 * k, q.edge_p + 3 * e, sizeof(double) * 3);
+            memcpy(h + o[7] + sizeof(double) * 2 * k, q.edge_uv + 2 * e, sizeof(double) * 2);
+            memcpy(h + o[8] + sizeof(double) * 3 * k, q.edge_info + 3 * e, sizeof(double) * 3);
+            ((uint8_t*)(h + o[9]))[k] = q.edge_inlier[e];
+        }
+        memcpy(h + o[10], P.pair_cam.data(), sizeof(int) * np);
+        memcpy(h + o[11], P.pair_obj.data(), sizeof(int) * np);
+        memcpy(h + o[12], P.pair_start.data(), sizeof(int) * (np + 1));
+        memcpy(h + o[13], P.cam_ptr.data(), sizeof(int) * (q.n_cam + 1));
+        memcpy(h + o[14], P.cam_idx.data(), sizeof(int) * np);
+        memcpy(h + o[15], P.obj_ptr.data(), sizeof(int) * (q.n_obj + 1));
+        memcpy(h + o[16], P.obj_idx.data(), sizeof(int) * np);
+        LmProblemHost& S = hs[i];
+        memset(&S, 0, sizeof(S));
+        S.n_cam = q.n_cam; S.n_obj = q.n_obj; S.n_edge = E; S.n_pair = np;
+        S.cam_T = (double*)(d + o[0]); S.obj_T = (double*)(d + o[1]);
+        S.cam_fixed = (const uint8_t*)(d + o[2]); S.obj_fixed = (const uint8_t*)(d + o[3]);
+        S.edge_pair = (const int*)(d + o[4]);
+        S.edge_k = (const double*)(d + o[5]); S.edge_p = (const double*)(d + o[6]); S.edge_uv = (const double*)(d + o[7]);
+        S.edge_info = (const double*)(d + o[8]); S.edge_inlier = (uint8_t*)(d + o[9]); S.edge_chi2 = (double*)(d + o[17]);
+        S.pair_cam = (const int*)(d + o[10]); S.pair_obj = (const int*)(d + o[11]); S.pair_start = (const int*)(d + o[12]);
+        S.cam_pair_ptr = (const int*)(d + o[13]); S.cam_pair_idx = (const int*)(d + o[14]);
+        S.obj_pair_ptr = (const int*)(d + o[15]); S.obj_pair_idx = (const int*)(d + o[16]);
+        for (int k = 0; k < 8; ++k) S.its[k] = k < q.n_rounds ? q.its[k] : 0;
+        S.n_rounds = q.n_rounds; S.init_with_outliers = q.init_with_outliers; S.chi2_thr = q.chi2_thr; S.huber_delta = q.huber_delta;
+        S.cam = d + o[19]; S.obj = d + o[20]; S.cam_bak = d + o[21]; S.obj_bak = d + o[22];
+        S.err = (double*)(d + o[23]); S.level = (uint8_t*)(d + o[24]); S.pair_part = (double*)(d + o[25]);
+        S.Hcc = (double*)(d + o[26]); S.bc = (double*)(d + o[27]); S.Hoo = (double*)(d + o[28]); S.bo = (double*)(d + o[29]);
+        S.Hcc_inv = (double*)(d + o[30]); S.Y = (double*)(d + o[31]); S.yc = (double*)(d + o[32]);
+        S.xc = (double*)(d + o[33]); S.xo = (double*)(d + o[34]); S.obj_slot = (int*)(d + o[35]); S.stats = (int*)(d + o[18]);
+    }
+    hipStream_t s = g_arena.stream;
+    SUO_HIP_CHECK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, s));
+    rc = launch_lm(d + o_structs, n_prob, s);
+    if (rc != SUO_OK) return rc;
+    // poses + inlier flags live in the input region, chi2 + stats in the output region
+    SUO_HIP_CHECK(hipMemcpyAsync(h, d, out_end, hipMemcpyDeviceToHost, s));
+    SUO_HIP_CHECK(hipStreamSynchronize(s));
+    (void)out_begin;
+    for (int i = 0; i < n_prob; ++i) {
+        suo_ba_problem& q = probs[i];
+        Prep& P = prep[i];
+        size_t* o = P.o;
+        memcpy(q.cam_T, h + o[0], sizeof(double) * 12 * q.n_cam);
+        memcpy(q.obj_T, h + o[1], sizeof(double) * 12 * q.n_obj);
+        for (int k = 0; k < q.n_edge; ++k) {
+            const int e = P.order[k];
+            q.edge_inlier[e] = ((uint8_t*)(h + o[9]))[k];
+            if (q.edge_chi2) q.edge_chi2[e] = ((double*)(h + o[17]))[k];
+        }
+        memcpy(q.stats, h + o[18], sizeof(int) * 4);
+        if (q.stats[0] < 0) {
+            suo_set_error("suo_optimize: %d free objects with free cameras exceeds the Schur limit of 16", q.n_obj);
+            return SUO_ERR_ARG;
+        }
+    }
+    return SUO_OK;
+}
+
+int suo_optimize(suo_ba_problem* problem) { return suo_optimize_batch(problem, 1); }
+
+}  // extern "C"

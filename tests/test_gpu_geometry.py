@@ -1,0 +1,223 @@
+"""GPU parity tests of the geometry path (HIP PnP + LM/BA through the C ABI) against the C oracle on
+identical seeded inputs.  fp64 on both sides; tolerances written per test."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import geometry as G  # noqa: E402
+from suo_slam_amd import geometry as geo  # noqa: E402
+from suo_slam_amd import synthetic as S  # noqa: E402
+
+SEED_STRIDE = 0x9E3779B97F4A7C15
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "pnp_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def lt():
+    from suo_slam_amd import _lib, lambdatwist
+    _lib.require_gpu()
+    return lambdatwist
+
+
+@pytest.fixture(scope="module")
+def ba():
+    from suo_slam_amd import _lib, ba
+    _lib.require_gpu()
+    return ba
+
+
+def _pose_close(A, B, rtol_R=1e-9, tol_t=1e-7):
+    return np.linalg.norm(A[:3, :3] - B[:3, :3]) < rtol_R and np.linalg.norm(A[:3, 3] - B[:3, 3]) < tol_t * max(1.0, np.linalg.norm(B[:3, 3]))
+
+
+def test_pnp_known_answer_vector(lt):
+    T = lt.pnp(GOLD["kat_xs"], GOLD["kat_ys"])
+    assert T.shape == (4, 4) and np.abs(T - GOLD["kat_pose"]).max() < 1e-4
+    To, best, its = G.pnp(GOLD["kat_xs"], GOLD["kat_ys"], 1e-3, seed=0)
+    assert np.abs(T - To).max() < 1e-10
+
+
+def test_pnp_four_point_problems_match_reference_p4p_vectors(lt):
+    """With exactly 4 points every hypothesis is p4p(0,1,2,3): the no-refine RANSAC result must equal the
+    reference's own p4p output (golden vectors from its compiled p4p.cpp) whenever it has >0 inliers."""
+    xs = [GOLD["xs"][i] for i in range(100)]
+    ys = [GOLD["ys"][i] for i in range(100)]
+    T, status, info = lt.pnp_batch(xs, ys, 1e-3, seed=7, refine=False, return_info=True)
+    n_checked = 0
+    for i in range(100):
+        if info["best_inliers"][i] > 0:
+            assert np.abs(T[i] - GOLD["p4p_T"][i]).max() < 1e-12, i
+            n_checked += 1
+        else:
+            assert status[i] == 1 and np.array_equal(T[i], np.eye(4))
+    assert n_checked > 60
+
+
+@pytest.mark.parametrize("noise,outliers", [(0.0, 0.0), (0.002, 0.0), (0.002, 0.2), (0.01, 0.1)])
+def test_pnp_batch_matches_oracle(lt, noise, outliers):
+    rng = np.random.default_rng(int(noise * 1e4) + int(outliers * 100))
+    xs, ys = [], []
+    for f in range(6):
+        fr = S.make_frame(rng, 8, noise=noise, outlier_frac=outliers, with_image=False)
+        for o in range(8):
+            m = fr["model_kps_masks"][o]
+            xs.append(fr["model_kps"][o][m].astype(np.float64))
+            ys.append(geo.normalize_uv(fr["uv"][o][m].astype(np.float64), fr["K_bbox"][o]))
+    seed = 1234
+    T, status, info = lt.pnp_batch(xs, ys, 1e-3, seed=seed, return_info=True)
+    for o in range(len(xs)):
+        To, best, its = G.pnp(xs[o], ys[o], 1e-3, seed=(seed + o * SEED_STRIDE) % 2**64)
+        assert info["best_inliers"][o] == best and info["iterations"][o] == its, o     # integer outputs: exact
+        assert _pose_close(T[o], To), (o, np.abs(T[o] - To).max())
+        assert status[o] == int(np.array_equal(To, np.eye(4)))
+
+
+def test_pnp_edge_cases(lt):
+    rng = np.random.default_rng(5)
+    fr = S.make_frame(rng, 3, noise=0.0, with_image=False)
+    xs, ys = [], []
+    for o in range(3):
+        m = fr["model_kps_masks"][o]
+        xs.append(fr["model_kps"][o][m].astype(np.float64))
+        ys.append(geo.normalize_uv(fr["uv"][o][m].astype(np.float64), fr["K_bbox"][o]))
+    xs.append(xs[0][:3]); ys.append(ys[0][:3])                 # < 4 points -> identity (object_slam.py:31)
+    xs.append(np.zeros((0, 3))); ys.append(np.zeros((0, 2)))   # empty
+    xs.append(np.tile(xs[0][:1], (6, 1))); ys.append(ys[0][:6])  # degenerate: coincident points
+    T, status = lt.pnp_batch(xs, ys)
+    assert list(status) == [0, 0, 0, 1, 1, 1]
+    for o in (3, 4, 5):
+        assert np.array_equal(T[o], np.eye(4))
+    for o in range(3):
+        assert np.linalg.norm(T[o][:3, 3] - fr["T_OtoC"][o][:3, 3]) < 1e-2
+    # large N (strided lanes): 250 points, half outliers (thirdparty/lambdatwist/test_pnp.cpp:68-147)
+    Q = S.random_rotation(rng)
+    t = np.array([0.3, -0.2, 6.0])
+    X = rng.uniform(-2, 2, (250, 3))
+    P = X @ Q.T + t
+    y = P[:, :2] / P[:, 2:3]
+    y[::2] = rng.uniform(-0.5, 0.5, (125, 2))
+    T1, st = lt.pnp_batch([X], [y], 1e-3, seed=3)
+    To, best, its = G.pnp(X, y, 1e-3, seed=3)
+    assert _pose_close(T1[0], To) and np.linalg.norm(T1[0][:3, 3] - t) < 1e-6
+
+
+def _perturb(T, rng, rot, trans):
+    t = np.ascontiguousarray(np.asarray(T)[:3, :].ravel().copy())
+    G.lib().orc_pose_oplus(t, np.r_[rng.normal(0, rot, 3), rng.normal(0, trans, 3)])
+    return t.reshape(3, 4)
+
+
+def _compare_ba(ba, P, **kw):
+    args = [P[k] for k in ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv",
+                           "edge_info", "edge_inlier")]
+    ref = G.optimize(*args, **kw)
+    got = ba.optimize(*args, **kw)
+    assert np.array_equal(got[2], ref[2]), "inlier flags differ"            # boolean output: bit-exact
+    assert list(got[4]) == list(ref[4]), (got[4], ref[4])                     # rounds / iterations / trials / num_good
+    for a, b in zip(got[0], ref[0]):
+        assert _pose_close(a, b, 1e-8, 1e-8), np.abs(a - b).max()
+    for a, b in zip(got[1], ref[1]):
+        assert _pose_close(a, b, 1e-8, 1e-8), np.abs(a - b).max()
+    np.testing.assert_allclose(got[3], ref[3], rtol=1e-6, atol=1e-9)
+    return got, ref
+
+
+@pytest.mark.parametrize("noise,outliers,n_obj", [(0.0, 0.0, 8), (0.002, 0.15, 8), (0.01, 0.1, 16), (0.002, 0.0, 1)])
+def test_single_view_refinement_matches_oracle(ba, noise, outliers, n_obj):
+    rng = np.random.default_rng(100 + n_obj + int(noise * 1e4))
+    fr = S.make_frame(rng, n_obj, noise=noise, outlier_frac=outliers, with_image=False)
+    init = np.stack([_perturb(T, rng, 2e-4, 0.1) for T in fr["T_OtoC"]])
+    P = S.frame_to_ba_problem(fr, init)
+    got, ref = _compare_ba(ba, P)
+    assert got[4][0] == 4                     # all four robust rounds ran
+    assert np.array_equal(got[0][0], np.eye(4)[:3])
+
+
+def test_curr_only_camera_tracking_matches_oracle(ba):
+    """SLAM curr_only mode: objects fixed (unary edges), one free camera, its=[10]*4 (object_slam.py:846)."""
+    rng = np.random.default_rng(11)
+    fr = S.make_frame(rng, 6, noise=0.003, outlier_frac=0.1, with_image=False)
+    P = S.frame_to_ba_problem(fr, fr["T_OtoC"])
+    P["cam_T"] = _perturb(np.eye(4), rng, 1e-4, 0.05)[None]
+    P["cam_fixed"] = np.array([0], np.uint8)
+    P["obj_fixed"] = np.ones(6, np.uint8)
+    for iwo in (False, True):
+        _compare_ba(ba, P, its=(10, 10, 10, 10), init_with_outliers=iwo)
+
+
+def _multi_view_scene(rng, n_cam, n_obj, noise_px=0.5):
+    k = np.array([600.0, 600.0, 320.0, 240.0])
+    cam_gt = np.zeros((n_cam, 3, 4))
+    for c in range(n_cam):
+        ang = 0.5 * (c / max(n_cam - 1, 1) - 0.5)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        cam_gt[c, :, :3] = R
+        cam_gt[c, :, 3] = [-300 * (c / max(n_cam - 1, 1) - 0.5), rng.uniform(-20, 20), rng.uniform(-20, 20)]
+    obj_gt = np.zeros((n_obj, 3, 4))
+    pts = rng.uniform(-60, 60, (n_obj, 10, 3))
+    for o in range(n_obj):
+        obj_gt[o, :, :3] = S.random_rotation(rng)
+        obj_gt[o, :, 3] = [rng.uniform(-250, 250), rng.uniform(-150, 150), rng.uniform(800, 1100)]
+    e_cam, e_obj, e_p, e_uv = [], [], [], []
+    for c in range(n_cam):
+        for o in range(n_obj):
+            if rng.random() < 0.15:
+                continue                                      # object not detected in this view
+            pw = pts[o] @ obj_gt[o, :, :3].T + obj_gt[o, :, 3]
+            pc = pw @ cam_gt[c, :, :3].T + cam_gt[c, :, 3]
+            uv = np.c_[k[0] * pc[:, 0] / pc[:, 2] + k[2], k[1] * pc[:, 1] / pc[:, 2] + k[3]] + rng.normal(0, noise_px, (10, 2))
+            for j in range(10):
+                if rng.random() < 0.05:
+                    uv[j] = rng.uniform(0, 480, 2)
+                e_cam.append(c); e_obj.append(o); e_p.append(pts[o, j]); e_uv.append(uv[j])
+    E = len(e_cam)
+    info = np.tile([1.0 / noise_px ** 2, 0, 1.0 / noise_px ** 2], (E, 1))
+    cam_fixed = np.zeros(n_cam, np.uint8)
+    cam_fixed[0] = 1
+    cam_init = cam_gt.copy()
+    for c in range(1, n_cam):
+        cam_init[c] = _perturb(np.vstack([cam_gt[c], [0, 0, 0, 1]]), rng, 5e-4, 0.3)
+    obj_init = np.stack([_perturb(np.vstack([T, [0, 0, 0, 1]]), rng, 5e-4, 0.3) for T in obj_gt])
+    return {"cam_T": cam_init, "cam_fixed": cam_fixed, "obj_T": obj_init, "obj_fixed": np.zeros(n_obj, np.uint8),
+            "edge_cam": np.array(e_cam, np.int32), "edge_obj": np.array(e_obj, np.int32), "edge_camk": np.tile(k, (E, 1)),
+            "edge_p": np.array(e_p), "edge_uv": np.array(e_uv), "edge_info": info, "edge_inlier": np.ones(E, np.uint8)}, obj_gt
+
+
+@pytest.mark.parametrize("n_cam,n_obj", [(3, 2), (12, 6), (30, 8)])
+def test_global_bundle_adjustment_matches_oracle(ba, n_cam, n_obj):
+    """Global mode: first camera fixed, all other cameras and all objects free (object_slam.py:746-778).
+    HIP eliminates cameras by Schur complement; the oracle solves the full dense system."""
+    rng = np.random.default_rng(n_cam * 7 + n_obj)
+    P, obj_gt = _multi_view_scene(rng, n_cam, n_obj)
+    got, ref = _compare_ba(ba, P)
+    err = max(np.linalg.norm(got[1][o][:, 3] - obj_gt[o][:, 3]) for o in range(n_obj))
+    assert err < 5.0
+
+
+def test_batch_of_frames_equals_individual_calls(ba):
+    rng = np.random.default_rng(42)
+    probs, singles = [], []
+    for f in range(5):
+        fr = S.make_frame(rng, 8, noise=0.004, outlier_frac=0.1, with_image=False)
+        init = np.stack([_perturb(T, rng, 2e-4, 0.1) for T in fr["T_OtoC"]])
+        P = S.frame_to_ba_problem(fr, init)
+        args = [P[k] for k in ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv",
+                               "edge_info", "edge_inlier")]
+        probs.append(ba.Problem(*args))
+        singles.append(ba.optimize(*args))
+    ba.optimize_batch(probs)
+    for p, s in zip(probs, singles):
+        assert np.array_equal(p.obj_T.reshape(-1, 3, 4), s[1]) and np.array_equal(p.inlier, s[2])
+
+
+def test_too_few_edges_is_a_noop(ba):
+    rng = np.random.default_rng(9)
+    fr = S.make_frame(rng, 1, noise=0.0, with_image=False)
+    P = S.frame_to_ba_problem(fr, fr["T_OtoC"])
+    for k in ("edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier"):
+        P[k] = P[k][:3]
+    got, ref = _compare_ba(ba, P)
+    assert got[4][0] == 0
