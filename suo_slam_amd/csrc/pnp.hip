@@ -523,12 +523,12 @@ __global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ o
                 if (base + j >= iters) break;
                 const unsigned cj = __shfl(cnt, j, 64);
                 if (cj > best) { best = cj; win = j; iters = (unsigned)tab[best]; }
+                i_done = base + j + 1;           // total_iters of PNP::compute = loop counter at exit
             }
             if (win >= 0) {
                 for (int k = 0; k < 4; ++k) bq[k] = bcast_d(q[k], win);
                 for (int k = 0; k < 3; ++k) bt[k] = bcast_d(t[k], win);
             }
-            i_done = (base + 64 < iters) ? base + 64 : iters;
         }
         if (best > 3 && do_refine) {
             int m = 0, deltas = 0;
