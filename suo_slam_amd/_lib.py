@@ -71,6 +71,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SuoError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64; load it FIRST so that this library binds to the same HIP
+        # runtime (two runtimes in one process cannot share the device: torch would then see "No HIP GPUs").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol

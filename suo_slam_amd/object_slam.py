@@ -1,0 +1,570 @@
+"""Host-side mirror of the reference's ``ObjectSLAM`` driver (/root/reference/lib/object_slam.py:51-1167)
+for the hot path: same public methods, argument order and state dictionaries (``detections``,
+``cam_poses``, ``obj_poses``), so an ``evaluate.py``-shaped harness can call it unchanged:
+
+    ObjectSLAM(chkpt_path, mesh_db, ...)                 object_slam.py:52-57
+    reset()                                              :125-153
+    process_view(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt, cam_pose)  :327-451
+    collect_results(last_only, no_viz, final)            :175-225 (visualisation is out of scope: no_viz only)
+    optimize(curr_only)                                  :703-930
+    pnp(points_3d, points_2d, camera_matrix)             :25-41
+
+What differs is where the work runs: the network, the keypoint masks, PnP for all objects of the frame
+and every LM round execute in libsuo_hip.so (HIP, gfx950); this file only keeps the reference's
+bookkeeping (thresholds, acceptance / removal / re-initialisation rules).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from time import time
+
+import numpy as np
+
+from . import ba as _ba
+from . import lambdatwist as _lt
+from .geometry import fix_K_for_bbox_ndc, invert_SE3, normalize_uv, to4x4
+from .weights import NUM_KP
+
+CHI2_2DOF_95 = 5.991
+
+
+class AverageMeter:
+    """lib/utils/eval_meter.py:47-63."""
+
+    def __init__(self):
+        self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.sum += float(val) * n
+        self.count += n
+
+    def average(self):
+        return self.sum / self.count if self.count > 0 else 0.0
+
+
+def pnp(points_3d, points_2d, camera_matrix):
+    """object_slam.py:25-41: PnP pose [3,4] + all-true inlier mask, or None (needs >= 4 points; the
+    identity pose is the native failure code)."""
+    assert points_3d.shape[0] == points_2d.shape[0], "points 3D and points 2D must have same number of rows"
+    assert camera_matrix.shape == (3, 3), "Camera matrix must be of shape (3,3)"
+    n = points_3d.shape[0]
+    if n < 4:
+        return None
+    res = _lt.pnp(np.asarray(points_3d, np.float64), normalize_uv(np.asarray(points_2d, np.float64), camera_matrix))
+    if np.allclose(res, np.eye(4)):
+        return None
+    return res[:3, :], np.ones(n, dtype=bool)
+
+
+# ---- prior heat-maps (lib/utils/utils.py:356-411) ------------------------------------------------
+def _gaussian_patch(size=91):
+    """gaussian_2d(): a unit impulse blurred by cv2.GaussianBlur(ksize=size, sigma=0) and divided by its
+    max.  OpenCV derives sigma = 0.3*((size-1)*0.5-1)+0.8 (= 14.0 for 91) and reflects at the border
+    (BORDER_REFLECT_101), which doubles the outermost ring of the impulse response."""
+    sigma = 0.3 * ((size - 1) * 0.5 - 1) + 0.8
+    i = np.arange(size, dtype=np.float64) - (size - 1) / 2
+    k = np.exp(-(i * i) / (2 * sigma * sigma))
+    k /= k.sum()
+    k[0] *= 2
+    k[-1] *= 2
+    g = np.outer(k, k)
+    return (g / g.max()).astype(np.float32)
+
+
+_PATCH = None
+
+
+def draw_gaussian_2d(img, pt, sigma=15):
+    """utils.py:364-385: paste (assign) the 91x91 patch around pt=(x,y); window [pt-45, pt+45)."""
+    global _PATCH
+    tmp = int(np.ceil(3 * sigma))
+    ul = [int(np.floor(pt[0] - tmp)), int(np.floor(pt[1] - tmp))]
+    br = [int(np.floor(pt[0] + tmp)), int(np.floor(pt[1] + tmp))]
+    H, W = img.shape
+    if ul[0] > W or ul[1] > H or br[0] < 1 or br[1] < 1:
+        return img
+    if _PATCH is None or _PATCH.shape[0] != 2 * tmp + 1:
+        _PATCH = _gaussian_patch(2 * tmp + 1)
+    gx = [max(0, -ul[0]), min(br[0], W) - max(0, ul[0]) + max(0, -ul[0])]
+    gy = [max(0, -ul[1]), min(br[1], H) - max(0, ul[1]) + max(0, -ul[1])]
+    ix = [max(0, ul[0]), min(br[0], W)]
+    iy = [max(0, ul[1]), min(br[1], H)]
+    img[iy[0]:iy[1], ix[0]:ix[1]] = _PATCH[gy[0]:gy[1], gx[0]:gx[1]]
+    return img
+
+
+def make_prior_kp_input(kp_uv, kp_uv_mask, img_shape, ndc=True):
+    """utils.py:398-411: one Gaussian stamp per valid keypoint channel."""
+    n = kp_uv.shape[0]
+    vh, vw = img_shape
+    x = np.zeros((n, vh, vw), dtype=np.float32)
+    for i in range(n):
+        if kp_uv_mask[i] and np.all(np.isfinite(kp_uv[i, :2])):
+            u, v = float(kp_uv[i, 0]), float(kp_uv[i, 1])
+            if ndc:
+                u = (min(max(u, -1), 1) * vw / 2 + vw / 2) - 0.5
+                v = vh - 0.5 - (min(max(v, -1), 1) * vh / 2 + vh / 2)
+            draw_gaussian_2d(x[i], (int(round(u)), int(round(v))))
+    return x
+
+
+def _chi2_inliers(T_OtoC, det, use_inlier_subset, manual_kp_std):
+    """Shared scoring of __estimate_camera_pose (:1032-1066) and __maybe_reinit_objects (:648-681):
+    number of keypoints whose re-projection has chi2 <= 5.991 under the detection's covariance."""
+    sel = det["inliers"] if use_inlier_subset else np.ones(len(det["model_kp"]), bool)
+    pts = det["model_kp"][sel]
+    if pts.shape[0] == 0:
+        return 0
+    p = pts @ T_OtoC[:3, :3].T + T_OtoC[:3, 3]
+    uvw = p @ det["K"].T
+    pos = uvw[:, 2] > 0
+    if not np.any(pos):
+        return 0
+    uv_proj = (uvw[:, :2] / uvw[:, 2:3])[pos]
+    res = det["uv_pred"][sel][pos] - uv_proj
+    cov = det["cov_pred"]
+    if cov is not None:
+        cov = np.array(cov[sel][pos], dtype=np.float64)
+        cov[:, [0, 1], [0, 1]] = np.maximum(cov[:, [0, 1], [0, 1]], 1e-4)      # ensure invertible (:669,:1054)
+        inf = np.linalg.inv(cov)
+        assert not np.any(np.isnan(inf)), "NaN in information matrix"
+    else:
+        inf = np.zeros((res.shape[0], 2, 2))
+        inf[:, [0, 1], [0, 1]] = 1.0 / manual_kp_std ** 2
+    chi2 = np.einsum("ni,nij,nj->n", res, inf, res)
+    return int(np.count_nonzero(chi2 <= CHI2_2DOF_95))
+
+
+class ObjectSLAM:
+    def __init__(self, chkpt_path, mesh_db, no_network_cov=False, no_prior_det=False, pred_res=(256, 256),
+                 debug_gt_kp=False, sfm_mode=False, single_view_mode=False, viz_cov=False, do_viz_extra=False,
+                 global_opt_every=10, kp_var_thresh=0.2, bbox_thresh=0.9, bbox_inflate=0.0, manual_kp_std=0.005,
+                 opt_init_with_outliers=False, give_all_prior=False, state_dict=None, max_crops=16, seed=0, verbose=False):
+        """Same keyword surface as the reference.  ``chkpt_path`` is a torch checkpoint whose ``['model']`` is the
+        PkpNet state_dict (object_slam.py:92-97); ``state_dict`` may be given directly instead."""
+        self.mesh_db = mesh_db
+        self.no_network_cov = no_network_cov or debug_gt_kp
+        self.no_prior_det = no_prior_det
+        self.pred_res = list(pred_res)
+        self.debug_gt_kp = debug_gt_kp
+        self.sfm_mode = sfm_mode
+        self.single_view_mode = single_view_mode
+        self.slam_mode = not (sfm_mode or single_view_mode)
+        self.global_opt_every = global_opt_every
+        self.kp_var_thresh = kp_var_thresh
+        self.bbox_thresh = bbox_thresh
+        self.bbox_inflate = bbox_inflate
+        self.manual_kp_std = manual_kp_std
+        self.opt_init_with_outliers = opt_init_with_outliers
+        self.give_all_prior = give_all_prior
+        self.verbose = verbose
+        self._rng = np.random.default_rng(seed)
+        self._pnp_seed = int(seed)
+        self.reset()
+        self.model = None
+        self.model_epoch = -1
+        if not debug_gt_kp:
+            from .pkpnet import PkpNet
+            if state_dict is None:
+                import torch
+                ck = torch.load(chkpt_path, map_location="cpu")
+                state_dict = ck["model"]
+                self.model_epoch = ck.get("epoch", -1)
+            self.model = PkpNet(calc_cov=True, state_dict=state_dict, max_crops=max_crops)
+        self.avg_std_meter = AverageMeter()
+        self.track_time_meter = AverageMeter()
+        self.opt_time_meter = AverageMeter()
+        self.all_time_num_views = 0
+
+    def _log(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def reset(self):
+        self.detections = {}
+        self.cam_poses = {}
+        self.view_ids = []
+        self.cam_K = {}
+        self.images = {}
+        self.obj_poses = {}
+        self.obj_num_dets = defaultdict(int)
+        self.obj_num_det_kps = defaultdict(int)
+        self.remove_penalty = defaultdict(int)
+        self.needs_opt = False
+
+    def num_views_processed(self):
+        return len(self.cam_poses)
+
+    def obj_num_inliers(self, obj_id):
+        n = 0
+        for det in self.detections.values():
+            n += int(np.count_nonzero(det.get(obj_id, {}).get("inliers", np.array([]))))
+        return n
+
+    def remove_obj(self, obj_id):
+        self.obj_poses.pop(obj_id)
+
+    def get_tracking_strtime(self, tt0=np.nan, tt1=np.nan):
+        avg = self.track_time_meter.average()
+        return f"TIMING: Tracking time: {1000 * (tt1 - tt0):.3f} ms ({1000 * avg:.3f} avg) ({'inf' if avg < 1e-12 else 1 / avg} Hz)"
+
+    def get_global_opt_strtime(self, t0=np.nan, t1=np.nan):
+        avg = self.opt_time_meter.average()
+        return f"TIMING: Global opt time: {1000 * (t1 - t0)} ms ({1000 * avg} avg) ({'inf' if avg < 1e-12 else 1 / avg} Hz)"
+
+    # ---------------------------------------------------------------------------------------------
+    def collect_results(self, last_only=False, no_viz=True, final=False):
+        """object_slam.py:175-225: T_OtoC = T_GtoC @ T_OtoG per view; score = 1 + total inliers."""
+        if self.slam_mode and self.needs_opt and final:
+            t0 = time()
+            self.optimize()
+            self.opt_time_meter.update(time() - t0)
+        results = {}
+        assert len(self.view_ids) == len(self.cam_poses)
+        for view_id in ([self.view_ids[-1]] if last_only else self.view_ids):
+            T_GtoC = to4x4(self.cam_poses[view_id])
+            detection = self.detections[view_id]
+            results[view_id] = {"poses": {}}
+            for obj_id in set(list(self.obj_poses.keys()) + list(detection.keys())):
+                T_OtoC = None
+                if obj_id in self.obj_poses:
+                    T_OtoC = T_GtoC @ to4x4(self.obj_poses[obj_id])
+                results[view_id]["poses"][obj_id] = {"T_OtoC": T_OtoC, "score": 1 + self.obj_num_inliers(obj_id)}
+        return results
+
+    # ---------------------------------------------------------------------------------------------
+    def process_view(self, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt=None, cam_pose=None):
+        """object_slam.py:327-451."""
+        assert view_id not in self.cam_poses, f"Repeat view_id {view_id}"
+        import torch
+        if self.model is not None:
+            torch.cuda.synchronize()
+        tt0 = time()
+        obj_ids = np.asarray(obj_ids)
+        bboxes = np.array(bboxes, dtype=np.float64)
+        model_kps = np.asarray(model_kps)
+        model_kps_masks = np.asarray(model_kps_masks, dtype=bool)
+        kp_masks = np.asarray(kp_masks, dtype=bool)
+        self.cam_K[view_id] = K
+        self.images[view_id] = img
+        self.all_time_num_views += 1
+        if not self.no_prior_det:
+            is_sym = np.array([bool(self.mesh_db[o]["is_symmetric"]) for o in obj_ids], dtype=bool)
+        else:
+            is_sym = np.zeros(len(obj_ids), dtype=bool)
+        if cam_pose is not None:
+            self.cam_poses[view_id] = cam_pose
+            self.view_ids.append(view_id)
+            is_sym = np.ones(len(obj_ids), dtype=bool)
+        if self.give_all_prior:
+            is_sym = np.ones(len(obj_ids), dtype=bool)
+        if self.single_view_mode:
+            is_sym = np.zeros(len(obj_ids), dtype=bool)
+        is_non_sym = ~is_sym
+        n_sym, n_non_sym = int(is_sym.sum()), int(is_non_sym.sum())
+        if cam_pose is None and not self.single_view_mode and len(self.view_ids) > 0 and n_non_sym == 0:
+            self._backup_estimate_camera_pose(view_id, obj_ids, bboxes)
+        self.needs_opt = True
+        bboxes[:, [0, 1]] *= 1.0 - self.bbox_inflate
+        bboxes[:, [2, 3]] *= 1.0 + self.bbox_inflate
+
+        def sub(mask):
+            return (obj_ids[mask], bboxes[mask], model_kps[mask], model_kps_masks[mask], kp_masks[mask],
+                    uv_gt[mask] if uv_gt is not None else None)
+        if n_non_sym > 0:
+            self._process_objects(False, view_id, img, K, *sub(is_non_sym))
+        if view_id not in self.cam_poses:
+            if len(self.view_ids) == 0:
+                self.view_ids.append(view_id)
+                self.cam_poses[view_id] = np.eye(4)[:3, :]
+            else:
+                self._backup_estimate_camera_pose(view_id, obj_ids, bboxes)
+        if n_sym > 0 and ((view_id in self.cam_poses) or self.no_prior_det):
+            self._process_objects(True, view_id, img, K, *sub(is_sym))
+        if not self.single_view_mode:
+            self._maybe_reinit_objects(view_id, len(self.view_ids) if self.sfm_mode else 15)
+            self.optimize(curr_only=True)
+        if self.model is not None:
+            torch.cuda.synchronize()
+        tt1 = time()
+        if self.all_time_num_views > 5:            # warm-up views are not timed (:425)
+            self.track_time_meter.update(tt1 - tt0)
+        if self.sfm_mode or self.single_view_mode or (len(self.view_ids) > 1 and len(self.view_ids) % self.global_opt_every == 0):
+            t0 = time()
+            self.optimize()
+            self.opt_time_meter.update(time() - t0)
+            self.needs_opt = False
+
+    # ---------------------------------------------------------------------------------------------
+    def _process_objects(self, is_sym, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt=None):
+        """object_slam.py:464-593."""
+        if len(obj_ids) == 0:
+            return
+        prior_dets = prior_det_uv = None
+        if is_sym and (not self.no_prior_det) and (view_id in self.cam_poses):
+            prior_dets, prior_det_uv = {}, {}
+            T_GtoC = to4x4(self.cam_poses[view_id])
+            for k, obj_id in enumerate(obj_ids):
+                if obj_id not in self.obj_poses:
+                    continue
+                m = model_kps_masks[k]
+                T_OtoC = T_GtoC @ to4x4(self.obj_poses[obj_id])
+                kps_in_C = model_kps[k][m] @ T_OtoC[:3, :3].T + T_OtoC[:3, 3]
+                uvd = kps_in_C @ fix_K_for_bbox_ndc(K, bboxes[k]).T
+                if np.all(uvd[:, 2] > 0):
+                    full = np.zeros((m.shape[0], 2), dtype=np.float32)
+                    full[m] = uvd[:, :2] / uvd[:, 2:3]
+                    prior_det_uv[obj_id] = full
+                    prior_dets[obj_id] = make_prior_kp_input(full, m, self.pred_res, ndc=True)
+        kp_det = self._run_kp_model(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt, prior_dets)
+        if not self.no_network_cov:
+            for det in kp_det:
+                if det["cov_pred"] is not None and det["cov_pred"].size > 0:
+                    std = np.sqrt(det["cov_pred"][..., [0, 1], [0, 1]])
+                    self.avg_std_meter.update(std.mean(), std.size)
+        detection = {}
+        for k, obj_id in enumerate(obj_ids):
+            detection[obj_id] = {"bbox": bboxes[k], "model_kp_mask": model_kps_masks[k],
+                                 "prior_uv": prior_det_uv.get(obj_id) if prior_det_uv is not None else None}
+            detection[obj_id].update(kp_det[k])
+            if self.num_views_processed() == 0:
+                assert obj_id not in self.obj_poses, f"Object {obj_id} is in detections twice! obj_id must be an instance label."
+                if detection[obj_id]["pose"] is not None:
+                    T_OtoC = detection[obj_id]["pose"]
+                    self.obj_poses[obj_id] = (invert_SE3(to4x4(self.cam_poses[view_id])) @ T_OtoC) if view_id in self.cam_poses else T_OtoC
+        if view_id in self.detections:
+            for obj_id in obj_ids:
+                assert obj_id not in self.detections[view_id], "Object has already been processed for this view"
+                self.detections[view_id][obj_id] = detection[obj_id]
+        else:
+            self.detections[view_id] = detection
+        if view_id not in self.cam_poses:
+            if self.num_views_processed() == 0:
+                self.cam_poses[view_id] = np.eye(4)[:3, :]
+            else:
+                cam_pose = self._estimate_camera_pose(view_id)
+                if cam_pose is None:
+                    return
+                self.cam_poses[view_id] = cam_pose
+            self.view_ids.append(view_id)
+        for obj_id in obj_ids:
+            if obj_id not in self.obj_poses and detection[obj_id]["pose"] is not None:
+                self.obj_poses[obj_id] = invert_SE3(to4x4(self.cam_poses[view_id])) @ detection[obj_id]["pose"]
+
+    # ---------------------------------------------------------------------------------------------
+    def _run_kp_model(self, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks_gt=None, uv_gt=None, prior_dets=None):
+        """object_slam.py:1077-1167.  Network + masks on the GPU, then ONE batched PnP launch for all
+        objects of the frame (the reference loops lambdatwist.pnp per object)."""
+        L = len(obj_ids)
+        K_bbox = np.zeros((L, 3, 3), dtype=np.float32)            # float32 container as in the reference (:1082)
+        for k in range(L):
+            K_bbox[k] = fix_K_for_bbox_ndc(K, bboxes[k])
+        cov_uv = None
+        if not self.debug_gt_kp:
+            import torch
+            from .pkpnet import keypoint_masks
+            priors = None
+            if prior_dets:
+                priors_np = np.zeros([L, NUM_KP] + self.pred_res, dtype=np.float32)
+                for k, obj_id in enumerate(obj_ids):
+                    if obj_id in prior_dets:
+                        priors_np[k] = prior_dets[obj_id]
+                priors = [torch.from_numpy(priors_np)]
+            pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], priors)
+            if self.no_network_cov:
+                bt, vt = self.bbox_thresh, 1e30
+            else:
+                bt, vt = self.bbox_thresh, self.kp_var_thresh
+            masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, bt, vt)
+            exp_uv = pred["uv"].cpu().numpy()
+            kp_masks = masks_dev.cpu().numpy().astype(bool)
+            if not self.no_network_cov:
+                cov_uv = pred["cov"].cpu().numpy()
+        else:
+            assert kp_masks_gt is not None and uv_gt is not None
+            kp_masks = np.asarray(kp_masks_gt, dtype=bool)
+        per_obj = []
+        for k in range(L):
+            m = kp_masks[k]
+            if not self.debug_gt_kp:
+                uv_pred = exp_uv[k][m].astype(np.float64)
+            else:
+                uv_pred = uv_gt[k][m].astype(np.float64)
+                uv_pred = uv_pred + self._rng.normal(scale=0.01, size=uv_pred.shape)       # :1129-1131
+            per_obj.append((uv_pred, cov_uv[k][m] if cov_uv is not None else None, model_kps[k][m].astype(np.float64),
+                            K_bbox[k].astype(np.float64)))
+        # batched PnP: objects with < 4 points are failures by definition (:31)
+        idx = [k for k in range(L) if per_obj[k][0].shape[0] >= 4]
+        poses = {}
+        if idx:
+            T, status = _lt.pnp_batch([per_obj[k][2] for k in idx], [normalize_uv(per_obj[k][0], per_obj[k][3]) for k in idx],
+                                      0.001, seed=self._pnp_seed)
+            self._pnp_seed += len(idx)
+            for j, k in enumerate(idx):
+                if not np.allclose(T[j], np.eye(4)):
+                    poses[k] = T[j]
+        ret = []
+        for k, obj_id in enumerate(obj_ids):
+            uv_pred, cov_pred, kp_model, K_kp = per_obj[k]
+            inliers = np.ones(uv_pred.shape[0], dtype=bool)
+            pose = None
+            if k in poses and poses[k][2, 3] > 0.5 * self.mesh_db[obj_id]["diameter"] and inliers.sum() >= 4:      # :1147-1148
+                pose = poses[k]
+            self.obj_num_dets[obj_id] += 1
+            self.obj_num_det_kps[obj_id] += uv_pred.shape[0]
+            ret.append({"pose": pose, "inliers": inliers, "kp_mask": kp_masks[k], "model_kp": kp_model, "uv_gt": uv_gt,
+                        "uv_pred": uv_pred, "cov_pred": cov_pred, "K": K_kp,
+                        "score": 0.0 if inliers.size == 0 else float(inliers.astype(np.float32).mean())})
+        return ret
+
+    # ---------------------------------------------------------------------------------------------
+    def _estimate_camera_pose(self, view_id, min_num_inliers=4):
+        """object_slam.py:975-1072: hypotheses T_GtoC = T_OtoC(pnp) @ T_GtoO per object, scored by chi2 inliers."""
+        curr = self.detections[view_id]
+        obj_ids = [o for o in curr if curr[o].get("pose") is not None and o in self.obj_poses]
+        if not obj_ids:
+            return None
+        best, best_n = None, -1
+        for i in obj_ids:
+            T_GtoC = curr[i]["pose"] @ invert_SE3(to4x4(self.obj_poses[i]))
+            n = 0
+            for j in obj_ids:
+                if np.count_nonzero(curr[j]["inliers"]) > 0:
+                    T_OtoC = T_GtoC @ to4x4(self.obj_poses[j]).astype(np.float32).astype(np.float64)   # float32 container (:1004)
+                    n += _chi2_inliers(T_OtoC, curr[j], True, self.manual_kp_std)
+            if n >= min_num_inliers and n > best_n:
+                best, best_n = T_GtoC, n
+        return best
+
+    def _maybe_reinit_objects(self, view_id, check_n_views=15):
+        """object_slam.py:595-697: re-initialise an object from its current PnP pose when that explains
+        >= 3 and more than 3x as many keypoints (over the last views) as the map pose."""
+        if self.num_views_processed() < 2 or view_id not in self.cam_poses:
+            return
+        check_n_views = min(len(self.view_ids), check_n_views)
+        curr = self.detections[view_id]
+        obj_ids = [o for o in self.obj_poses if curr.get(o, {}).get("pose") is not None]
+        if not obj_ids:
+            return
+        T_CtoG = invert_SE3(to4x4(self.cam_poses[view_id]))
+        views = [self.view_ids[-(i + 1)] for i in range(check_n_views)]
+        for o in obj_ids:
+            T_pnp = T_CtoG @ curr[o]["pose"]
+            T_est = to4x4(self.obj_poses[o]).astype(np.float32).astype(np.float64)       # float32 containers (:619,:631)
+            n = {"estim": 0, "pnp": 0}
+            for v in views:
+                if o in self.detections[v]:
+                    T_GtoCi = to4x4(self.cam_poses[v]).astype(np.float32).astype(np.float64)
+                    n["pnp"] += _chi2_inliers(T_GtoCi @ T_pnp, self.detections[v][o], False, self.manual_kp_std)
+                    n["estim"] += _chi2_inliers(T_GtoCi @ T_est, self.detections[v][o], False, self.manual_kp_std)
+            if n["pnp"] >= 3 and n["pnp"] > 3 * n["estim"]:
+                self.obj_poses[o] = T_pnp
+
+    def _backup_estimate_camera_pose(self, view_id, obj_ids_, bboxes):
+        """object_slam.py:933-973: bbox-centroid PnP, else constant velocity, else copy the last pose."""
+        assert len(self.view_ids) > 0 and view_id not in self.view_ids and view_id not in self.cam_poses
+        cents, centers = [], []
+        for i, o in enumerate(obj_ids_):
+            if o in self.obj_poses:
+                cents.append(0.5 * (bboxes[i, :2] + bboxes[i, 2:]))
+                centers.append(self.obj_poses[o][:3, 3])
+        ret = pnp(np.stack(centers), np.stack(cents), self.cam_K[view_id]) if cents else None
+        if ret is not None:
+            self.cam_poses[view_id] = ret[0]
+        elif len(self.view_ids) > 1:
+            T1, T2 = to4x4(self.cam_poses[self.view_ids[-2]]), to4x4(self.cam_poses[self.view_ids[-1]])
+            self.cam_poses[view_id] = (T2 @ invert_SE3(T1)) @ T2
+        else:
+            self.cam_poses[view_id] = self.cam_poses[self.view_ids[-1]]
+        self.view_ids.append(view_id)
+
+    # ---------------------------------------------------------------------------------------------
+    def build_problem(self, curr_only=False):
+        """Graph construction of optimize() (object_slam.py:713-839) as a flat SoA for suo_optimize.
+        Returns (problem, bookkeeping) or None when the reference would return early."""
+        if len(self.view_ids) == 0:
+            return None
+        num_cam_edges, num_obj_edges = defaultdict(int), defaultdict(int)
+        obj_ids = list(self.obj_poses.keys())
+        view_curr = self.view_ids[-1]
+        if curr_only:
+            if view_curr not in self.cam_poses:
+                return None
+            dets = {view_curr: self.detections[view_curr]}
+        else:
+            dets = self.detections
+        for v, det in dets.items():
+            if v in self.cam_poses:
+                for o, d in det.items():
+                    if o in obj_ids:
+                        n = int(np.count_nonzero(d["inliers"]))
+                        num_cam_edges[v] += n
+                        num_obj_edges[o] += n
+        if curr_only and num_cam_edges[view_curr] < 3:
+            return None
+        obj_index = {o: j for j, o in enumerate(o for o in obj_ids if num_obj_edges[o] > 0)}
+        cam_views = [view_curr] if curr_only else list(self.cam_poses.keys())
+        cam_index, cam_fixed = {}, []
+        for i, v in enumerate(cam_views):
+            if num_cam_edges[v] > 0:
+                cam_index[v] = len(cam_index)
+                cam_fixed.append(0 if curr_only else int(i == 0))          # gauge: enumeration index 0 only (:774, R11)
+        if not cam_index or not obj_index:
+            return None
+        e_cam, e_obj, e_k, e_p, e_uv, e_info, e_inl, e_ref = [], [], [], [], [], [], [], []
+        for v, det in dets.items():
+            for o, d in det.items():
+                if v in cam_index and o in obj_index:
+                    Kd = d["K"]
+                    assert np.allclose(Kd[[0, 1, 2, 2, 2], [1, 0, 0, 1, 2]], [0, 0, 0, 0, 1]), f"K matrix has off-diagonals!\n\n{Kd}"
+                    camk = [Kd[0, 0], Kd[1, 1], Kd[0, 2], Kd[1, 2]]
+                    for k in range(d["uv_pred"].shape[0]):
+                        e_cam.append(cam_index[v]); e_obj.append(obj_index[o]); e_k.append(camk)
+                        e_p.append(d["model_kp"][k]); e_uv.append(d["uv_pred"][k])
+                        Om = np.linalg.inv(np.asarray(d["cov_pred"][k], np.float64)) if d["cov_pred"] is not None else np.eye(2)
+                        e_info.append([Om[0, 0], Om[0, 1], Om[1, 1]])
+                        e_inl.append(bool(d["inliers"][k])); e_ref.append((v, o, k))
+        E = len(e_cam)
+        if self.sfm_mode or (self.slam_mode and not curr_only):
+            its = (10, 10, 40, 40)
+        else:
+            its = (10, 10, 10, 10)
+        prob = _ba.Problem(np.stack([to4x4(self.cam_poses[v])[:3] for v in cam_index]), np.array(cam_fixed, np.uint8),
+                           np.stack([to4x4(self.obj_poses[o])[:3] for o in obj_index]),
+                           np.full(len(obj_index), 1 if curr_only else 0, np.uint8),
+                           np.array(e_cam, np.int32), np.array(e_obj, np.int32), np.array(e_k, np.float64).reshape(E, 4),
+                           np.array(e_p, np.float64).reshape(E, 3), np.array(e_uv, np.float64).reshape(E, 2),
+                           np.array(e_info, np.float64).reshape(E, 3), np.array(e_inl, np.uint8), its=its,
+                           init_with_outliers=bool(self.opt_init_with_outliers and curr_only))
+        return prob, (cam_index, obj_index, e_ref, curr_only, view_curr)
+
+    def apply_problem(self, prob, book):
+        """Read-back + culling of optimize() (object_slam.py:898-930)."""
+        cam_index, obj_index, e_ref, curr_only, view_curr = book
+        for (v, o, k), inl in zip(e_ref, prob.inlier):
+            self.detections[v][o]["inliers"][k] = bool(inl)
+        cam_T = prob.cam_T.reshape(-1, 3, 4)
+        obj_T = prob.obj_T.reshape(-1, 3, 4)
+        for v, i in cam_index.items():
+            self.cam_poses[v] = cam_T[i].copy()
+        if not curr_only:
+            for o, j in obj_index.items():
+                self.obj_poses[o] = obj_T[j].copy()
+                if view_curr in self.cam_poses:
+                    p = self.cam_poses[view_curr][:3, :3] @ self.obj_poses[o][:3, 3] + self.cam_poses[view_curr][:3, 3]
+                    if p[2] < 0.5 * self.mesh_db[o]["diameter"]:
+                        self.remove_obj(o)
+        for o in list(self.obj_poses.keys()):
+            need = 3 if self.obj_num_dets[o] < 3 else 6
+            if self.obj_num_inliers(o) < need:
+                self.remove_obj(o)
+
+    def optimize(self, curr_only=False):
+        """object_slam.py:703-930 with the g2o graph replaced by one suo_optimize call."""
+        built = self.build_problem(curr_only)
+        if built is None:
+            return
+        prob, book = built
+        _ba.optimize_batch([prob])
+        self.apply_problem(prob, book)
