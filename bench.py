@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the suo_slam hot path on MI355X (contract: see the task statement).
+
+One "step" = one synthetic YCB-V-shaped frame (640x480 uint8, 8 object boxes) through the whole per-frame
+path of BASELINE.json configs[1] (single-view eval, no SLAM):
+    RoI crop + prior concat -> stacked-hourglass keypoint CNN (fp32 MFMA) -> heat-map decode -> validity masks
+    -> batched P3P-RANSAC PnP (8 objects) -> uncertainty-weighted LM refinement, rounds [10,10,40,40].
+The network has random weights (no checkpoint ships), so -- exactly like the reference's --debug_gt_kp mode
+(lib/object_slam.py:1129-1131) -- PnP / LM are driven by projected ground-truth keypoints + N(0, 0.01^2) noise
+with random SPD covariances, while the CNN runs on the frame's pixels; nothing is skipped or cached.
+Inputs (image, boxes) are resident in HBM before the timed region; PnP / LM take the small host arrays the
+reference's FFI hands over (their H2D/D2H is inside the timed region).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_CROP = 31.495          # conv FLOPs, hook-counted on the reference module
+FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+N_OBJ = 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--objects", type=int, default=N_OBJ)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pool", type=int, default=16, help="number of distinct synthetic frames cycled through")
+    ap.add_argument("--only", choices=["all", "cnn", "geometry"], default="all", help="diagnostic: run only one half of the step")
+    return ap.parse_args()
+
+
+def make_pool(rng, n, L):
+    from suo_slam_amd import geometry as geo
+    from suo_slam_amd import synthetic as S
+    pool = []
+    for _ in range(n):
+        fr = S.make_frame(rng, L, noise=0.01, outlier_frac=0.05)
+        xs, ys = [], []
+        for o in range(L):
+            m = fr["model_kps_masks"][o]
+            xs.append(fr["model_kps"][o][m].astype(np.float64))
+            ys.append(geo.normalize_uv(fr["uv"][o][m].astype(np.float64), fr["K_bbox"][o].astype(np.float32).astype(np.float64)))
+        fr["pnp_xs"], fr["pnp_ys"] = xs, ys
+        fr["ba"] = S.frame_to_ba_problem(fr, np.tile(np.eye(4)[None], (L, 1, 1)))
+        pool.append(fr)
+    return pool
+
+
+class FramePipeline:
+    """The per-frame product path, called through the C ABI with pre-allocated device buffers."""
+
+    def __init__(self, L, pool, use_graph=True, only="all"):
+        self.only = only
+        import torch
+        from suo_slam_amd import _lib, ba, lambdatwist, weights
+        from suo_slam_amd.pkpnet import PkpNet
+        self.torch, self.lib, self._lib, self.ba, self.lt = torch, _lib.lib(), _lib, ba, lambdatwist
+        self.L = L
+        self.net = PkpNet(state_dict=weights.make_random_state_dict(0, 8.0), max_crops=L)
+        self.net.set_graph(use_graph)
+        dev = "cuda"
+        self.pool = pool
+        self.img = [torch.from_numpy(fr["image"]).to(dev) for fr in pool]
+        self.boxes = [torch.from_numpy(fr["boxes"]).to(dev) for fr in pool]
+        self.mm = [torch.from_numpy(fr["model_kps_masks"].astype(np.uint8)).to(dev) for fr in pool]
+        self.uv = torch.empty((L, 41, 2), device=dev)
+        self.cov = torch.empty((L, 41, 2, 2), device=dev)
+        self.kp = torch.empty((L, 41), device=dev)
+        self.mask = torch.empty((L, 41), dtype=torch.uint8, device=dev)
+        # a real (non-NULL) stream: the network then runs fully asynchronously (hipGraph replay) while the host thread
+        # drives the geometry kernels of the same frame on the library's own high-priority stream
+        self.tstream = torch.cuda.Stream()
+        self.stream = C.c_void_p(self.tstream.cuda_stream)
+        self.pose_err = 0.0
+        self.n_pose = 0
+        self.n_inl = 0
+
+    def step(self, i):
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        k = i % len(self.pool)
+        fr = self.pool[k]
+        L = self.L
+        # network + decode + masks: asynchronous on the torch stream
+        if self.only != "geometry":
+          self._lib.check(self.lib.suo_net_forward(self.net._h, P(self.img[k]), 0, 480, 640, P(self.boxes[k]), L, None, P(self.uv),
+                                                 P(self.cov), P(self.kp), None, None, self.stream), "suo_net_forward")
+          self._lib.check(self.lib.suo_keypoint_masks(P(self.uv), P(self.cov), P(self.kp), P(self.mm[k]), L, 0.9, 0.2, P(self.mask),
+                                                      self.stream), "suo_keypoint_masks")
+        if self.only == "cnn":
+            return
+        # geometry: one PnP launch for the 8 objects, then the LM rounds (overlaps with the network above)
+        T, status = self.lt.pnp_batch(fr["pnp_xs"], fr["pnp_ys"], 1e-3, seed=i)
+        B = fr["ba"]
+        prob = self.ba.Problem(B["cam_T"], B["cam_fixed"], T[:, :3, :], B["obj_fixed"], B["edge_cam"], B["edge_obj"], B["edge_camk"],
+                               B["edge_p"], B["edge_uv"], B["edge_info"], B["edge_inlier"], its=(10, 10, 40, 40))
+        self.ba.optimize_batch([prob])
+        obj = prob.obj_T.reshape(-1, 3, 4)
+        d = np.linalg.norm(obj[:, :, 3] - fr["T_OtoC"][:, :3, 3], axis=1) / fr["T_OtoC"][:, 2, 3]
+        ok = status == 0
+        self.pose_err += float(d[ok].sum())
+        self.n_pose += int(ok.sum())
+        self.n_inl += int(prob.inlier.sum())
+
+
+def conv_roofline(L, iters=30):
+    """Live HIP-event timing of the dominant kernel: 3x3 conv 128->128 @ 64x64 (34.5 % of all MACs), L crops."""
+    import torch
+    from suo_slam_amd import _lib
+    from tests import hipops
+    rng = np.random.default_rng(0)
+    x = torch.rand((L, 64, 64, 128), device="cuda") - 0.5
+    w = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
+    wp = hipops.dev(hipops.pack_conv(w, 128, 128, 32))
+    b = torch.zeros(128, device="cuda")
+    out = torch.empty((L, 64, 64, 128), device="cuda")
+    st = torch.cuda.current_stream()
+    s = C.c_void_p(st.cuda_stream)
+    lib = _lib.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for _ in range(5):
+        lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp), P(b), P(out), 128, 1, s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp), P(b), P(out), 128, 1, s)
+    e1.record(st)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flop = 2.0 * L * 64 * 64 * 128 * 128 * 9
+    ach = flop / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "convk_kernel<3,1,32,...> 3x3 128->128 @64x64", "achieved": round(ach, 2),
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+            "avg_launch_us": round(us, 2), "flop_per_launch": flop}
+
+
+def cpu_baseline(pool, L):
+    """The oracle (CPU restatement) timed on this box's host cores on a bounded sample of the same workload."""
+    import torch
+    from oracle import cnn_oracle as O
+    from oracle import geometry as G
+    from suo_slam_amd import weights
+    n = min(len(os.sched_getaffinity(0)), 64)
+    torch.set_num_threads(n)
+    sd = weights.make_random_state_dict(0, 8.0)
+    Pw = O.to_torch(sd)
+    t0 = time.perf_counter()
+    n_cnn = 0
+    while n_cnn < 1 or (time.perf_counter() - t0 < 10.0 and n_cnn < 8):
+        fr = pool[n_cnn % len(pool)]
+        O.pkpnet_forward(fr["image"], fr["boxes"], None, sd, Pw)
+        n_cnn += 1
+    t_cnn = (time.perf_counter() - t0) / n_cnn
+    t0 = time.perf_counter()
+    n_geo = 0
+    for rep in range(3):
+        for fr in pool:
+            init = []
+            for o in range(L):
+                T, _, _ = G.pnp(fr["pnp_xs"][o], fr["pnp_ys"][o], 1e-3, seed=o)
+                init.append(T[:3])
+            B = fr["ba"]
+            G.optimize(B["cam_T"], B["cam_fixed"], np.array(init), B["obj_fixed"], B["edge_cam"], B["edge_obj"], B["edge_camk"], B["edge_p"],
+                       B["edge_uv"], B["edge_info"], B["edge_inlier"])
+            n_geo += 1
+    t_geo = (time.perf_counter() - t0) / n_geo
+    return {"value": round(1.0 / (t_cnn + t_geo), 4), "unit": "frames/s", "cores": n, "kind": "port",
+            "sample": f"{n_cnn} frames x {L} crops through the torch-CPU CNN oracle ({n} threads, {t_cnn * 1e3:.0f} ms/frame) + "
+                      f"{n_geo} frames through the C PnP/LM oracle (1 thread, {t_geo * 1e3:.2f} ms/frame)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    L = args.objects
+    # frames shard embarrassingly: rank r processes its own stream (weak scaling: K frames per GPU)
+    pool = make_pool(np.random.default_rng(1000 + rank), args.pool, L)
+    pipe = FramePipeline(L, pool, use_graph=not args.no_graph, only=args.only)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        pipe.step(i)
+    pipe.pose_err, pipe.n_pose, pipe.n_inl = 0.0, 0, 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pipe.step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    acc = torch.tensor([dt, pipe.pose_err, float(pipe.n_pose), float(pipe.n_inl)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = acc[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)               # max over ranks
+        dist.all_reduce(acc[1:], op=dist.ReduceOp.SUM)            # the only collective: metric accumulators (RCCL)
+        dt = float(tmax.item())
+    pose_err, n_pose, n_inl = float(acc[1]), float(acc[2]), float(acc[3])
+    if rank == 0:
+        fps = world * args.steps / dt
+        line = {
+            "metric": "frames/sec (obj-crops/sec) YCB-V 640x480 8-obj; ADD(-S) vs ref",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> RoI crop, hourglass keypoint "
+                                   "CNN fp32, decode, masks, batched PnP, LM rounds [10,10,40,40]" % L,
+                       "objects_per_frame": L, "crops_per_s": round(fps * L, 2), "frames_per_gpu": args.steps,
+                       "geometry_inputs": "projected GT keypoints + N(0,0.01^2) NDC noise, 5% outliers (debug_gt_kp mode)",
+                       "parallelism": f"frame-sharded x{world}, no data-path collective"},
+            "cnn_tflops": round(fps * L * GFLOP_PER_CROP / 1e3, 2),
+            "cnn_frac_of_fp32_mfma_peak": round(fps / world * L * GFLOP_PER_CROP / 1e3 / FP32_MFMA_PEAK_TF, 4),
+            "pose_check": {"mean_rel_translation_err": round(pose_err / max(n_pose, 1), 5), "poses": int(n_pose), "inlier_edges": int(n_inl)},
+        }
+        if world == 1:
+            line["roofline"] = conv_roofline(L)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(pool, L)
+        else:
+            line["roofline"] = conv_roofline(L)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

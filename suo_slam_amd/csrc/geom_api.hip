@@ -42,7 +42,13 @@ struct Arena {
     hipStream_t stream = nullptr;
     std::mutex mu;
     int ensure(size_t bytes) {
-        if (!stream) SUO_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (!stream) {
+            // highest priority: the geometry kernels are tiny (8 waves / 1 workgroup) and latency-bound; on its own
+            // priority level the stream also gets its own hardware queue instead of sharing one with the CNN's streams.
+            int lo = 0, hi = 0;
+            SUO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            SUO_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+        }
         if (bytes <= cap) return SUO_OK;
         size_t ncap = std::max(bytes, cap * 2);
         ncap = (ncap + 4095) & ~(size_t)4095;
@@ -75,7 +81,7 @@ struct LmProblemHost {
     const int* obj_pair_ptr; const int* obj_pair_idx;
     int its[8]; int n_rounds; int init_with_outliers; double chi2_thr; double huber_delta;
     void* cam; void* obj; void* cam_bak; void* obj_bak;
-    double* err; uint8_t* level; double* pair_part;
+    double* err; double* jac; uint8_t* level; double* pair_part;
     double* Hcc; double* bc; double* Hoo; double* bo; double* Hcc_inv; double* Y; double* yc; double* xc; double* xo;
     int* obj_slot; int* stats;
 };
@@ -218,6 +224,7 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         o[28] = L.take(sizeof(double) * 36 * O); o[29] = L.take(sizeof(double) * 6 * O);
         o[30] = L.take(sizeof(double) * 36 * C); o[31] = L.take(sizeof(double) * 36 * NP); o[32] = L.take(sizeof(double) * 6 * C);
         o[33] = L.take(sizeof(double) * 6 * C); o[34] = L.take(sizeof(double) * 6 * O); o[35] = L.take(sizeof(int) * O);
+        o[36] = L.take(sizeof(double) * 29 * E);
     }
     int rc = g_arena.ensure(L.off);
     if (rc != SUO_OK) return rc;
@@ -263,6 +270,7 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         for (int k = 0; k < 8; ++k) S.its[k] = k < q.n_rounds ? q.its[k] : 0;
         S.n_rounds = q.n_rounds; S.init_with_outliers = q.init_with_outliers; S.chi2_thr = q.chi2_thr; S.huber_delta = q.huber_delta;
         S.cam = d + o[19]; S.obj = d + o[20]; S.cam_bak = d + o[21]; S.obj_bak = d + o[22];
+        S.jac = (double*)(d + o[36]);
         S.err = (double*)(d + o[23]); S.level = (uint8_t*)(d + o[24]); S.pair_part = (double*)(d + o[25]);
         S.Hcc = (double*)(d + o[26]); S.bc = (double*)(d + o[27]); S.Hoo = (double*)(d + o[28]); S.bo = (double*)(d + o[29]);
         S.Hcc_inv = (double*)(d + o[30]); S.Y = (double*)(d + o[31]); S.yc = (double*)(d + o[32]);

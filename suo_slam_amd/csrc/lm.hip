@@ -17,6 +17,8 @@
 //     camera (single-view mode) the system is block diagonal and each object is solved by one thread;
 //   * g2o's lambda schedule (tau = 1e-5, rho-gain update, nu doubling, <= 10 trials) runs on-device.
 // Many problems (frames) run concurrently as independent workgroups.
+#include <type_traits>
+
 #include "suo_internal.h"
 
 namespace suo {
@@ -189,6 +191,7 @@ struct LmProblem {
     // scratch (device)
     Pose* cam; Pose* obj; Pose* cam_bak; Pose* obj_bak;
     double* err;                 // [n_edge][2]
+    double* jac;                 // [n_edge][29]: Jc(12) Jo(12) rho'*Omega (xx,xy,yy) omega_r(2)
     uint8_t* level;              // [n_edge]
     double* pair_part;           // [n_pair][90]: Hcc(21) Hoo(21) Hco(36) bc(6) bo(6)
     double* Hcc; double* bc;     // [n_cam][36], [n_cam][6]
@@ -226,83 +229,82 @@ DEV double edge_chi2(const LmProblem& P, int e, const double* err) {
     return err[0] * (I[0] * err[0] + I[1] * err[1]) + err[1] * (I[1] * err[0] + I[2] * err[1]);
 }
 
-// computeActiveErrors + activeRobustChi2
-DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, double* red) {
+// computeActiveErrors + activeRobustChi2; with_jac also stores the edge Jacobians (linearizeOplus) and the
+// Huber-weighted information / gradient factors used by constructQuadraticForm.  Threads over edges.
+DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, bool with_jac, double* red) {
     double c = 0;
     for (int e = threadIdx.x; e < P.n_edge; e += LM_THREADS) {
-        if (edge_active(P, e)) {
-            double er[2];
-            edge_error(P, e, er, nullptr, nullptr);
-            P.err[2 * e] = er[0];
-            P.err[2 * e + 1] = er[1];
-            const double c2 = edge_chi2(P, e, er);
-            double r1;
-            c += robust_on ? huber_rho(c2, P.huber_delta, r1) : c2;
+        if (!edge_active(P, e)) continue;
+        double er[2], pw[3], pc[3];
+        edge_error(P, e, er, pw, pc);
+        P.err[2 * e] = er[0];
+        P.err[2 * e + 1] = er[1];
+        const double c2 = edge_chi2(P, e, er);
+        double w = 1.0;
+        c += robust_on ? huber_rho(c2, P.huber_delta, w) : c2;
+        if (with_jac) {
+            double Rc[9];
+            q_to_R(P.cam[P.pair_cam[P.edge_pair[e]]].q, Rc);
+            const double* k = P.edge_k + 4 * e;
+            const double PJ[6] = {-(k[0] / pc[2]), 0, k[0] * pc[0] / (pc[2] * pc[2]), 0, -(k[1] / pc[2]), k[1] * pc[1] / (pc[2] * pc[2])};
+            double PR[6];
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 3; ++cc) PR[3 * r + cc] = PJ[3 * r] * Rc[cc] + PJ[3 * r + 1] * Rc[3 + cc] + PJ[3 * r + 2] * Rc[6 + cc];
+            const double Dw[18] = {0, pw[2], -pw[1], 1, 0, 0, -pw[2], 0, pw[0], 0, 1, 0, pw[1], -pw[0], 0, 0, 0, 1};
+            const double Dc[18] = {0, pc[2], -pc[1], 1, 0, 0, -pc[2], 0, pc[0], 0, 1, 0, pc[1], -pc[0], 0, 0, 0, 1};
+            double* J = P.jac + 29 * (size_t)e;
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 6; ++cc) {
+                    J[6 * r + cc] = PJ[3 * r] * Dc[cc] + PJ[3 * r + 1] * Dc[6 + cc] + PJ[3 * r + 2] * Dc[12 + cc];            // Jc
+                    J[12 + 6 * r + cc] = PR[3 * r] * Dw[cc] + PR[3 * r + 1] * Dw[6 + cc] + PR[3 * r + 2] * Dw[12 + cc];       // Jo
+                }
+            const double* I = P.edge_info + 3 * e;
+            J[24] = w * I[0]; J[25] = w * I[1]; J[26] = w * I[2];
+            J[27] = -(I[0] * er[0] + I[1] * er[1]) * w;
+            J[28] = -(I[1] * er[0] + I[2] * er[1]) * w;
         }
     }
     return block_sum(c, red);
 }
 
-// one wavefront linearises one (camera, object) pair
-DEV void linearise_pair(const LmProblem& P, int p, bool robust_on, int lane) {
-    const int c = P.pair_cam[p], o = P.pair_obj[p];
-    const bool cfree = !P.cam_fixed[c], ofree = !P.obj_fixed[o];
-    double acc[90];
-#pragma unroll
-    for (int i = 0; i < 90; ++i) acc[i] = 0;
-    double Rc[9];
-    q_to_R(P.cam[c].q, Rc);
-    for (int e = P.pair_start[p] + lane; e < P.pair_start[p + 1]; e += 64) {
-        if (P.level[e] != 0 || !(cfree || ofree)) continue;
-        double pw[3], pc[3], er[2];
-        edge_error(P, e, er, pw, pc);      // errors at the current estimate (== P.err)
-        const double* k = P.edge_k + 4 * e;
-        const double PJ[6] = {-(k[0] / pc[2]), 0, k[0] * pc[0] / (pc[2] * pc[2]), 0, -(k[1] / pc[2]), k[1] * pc[1] / (pc[2] * pc[2])};
-        double PR[6];
-        for (int r = 0; r < 2; ++r)
-            for (int cc = 0; cc < 3; ++cc) PR[3 * r + cc] = PJ[3 * r] * Rc[cc] + PJ[3 * r + 1] * Rc[3 + cc] + PJ[3 * r + 2] * Rc[6 + cc];
-        const double Dw[18] = {0, pw[2], -pw[1], 1, 0, 0, -pw[2], 0, pw[0], 0, 1, 0, pw[1], -pw[0], 0, 0, 0, 1};
-        const double Dc[18] = {0, pc[2], -pc[1], 1, 0, 0, -pc[2], 0, pc[0], 0, 1, 0, pc[1], -pc[0], 0, 0, 0, 1};
-        double Jo[12], Jc[12];
-        for (int r = 0; r < 2; ++r)
-            for (int cc = 0; cc < 6; ++cc) {
-                Jo[6 * r + cc] = PR[3 * r] * Dw[cc] + PR[3 * r + 1] * Dw[6 + cc] + PR[3 * r + 2] * Dw[12 + cc];
-                Jc[6 * r + cc] = PJ[3 * r] * Dc[cc] + PJ[3 * r + 1] * Dc[6 + cc] + PJ[3 * r + 2] * Dc[12 + cc];
-            }
-        const double* I = P.edge_info + 3 * e;
-        double w = 1.0;
-        if (robust_on) huber_rho(edge_chi2(P, e, er), P.huber_delta, w);
-        const double O[4] = {w * I[0], w * I[1], w * I[1], w * I[2]};
-        const double orr[2] = {-(I[0] * er[0] + I[1] * er[1]) * w, -(I[1] * er[0] + I[2] * er[1]) * w};
-        double JcO[12], JoO[12];           // (J^T Omega) rows
-        for (int r = 0; r < 6; ++r) {
-            JcO[2 * r] = Jc[r] * O[0] + Jc[6 + r] * O[2]; JcO[2 * r + 1] = Jc[r] * O[1] + Jc[6 + r] * O[3];
-            JoO[2 * r] = Jo[r] * O[0] + Jo[6 + r] * O[2]; JoO[2 * r + 1] = Jo[r] * O[1] + Jo[6 + r] * O[3];
+// One thread per (pair, entry): entry k of [Hcc(21) | Hoo(21) | Hco(36) | bc(6) | bo(6)] summed over the pair's
+// active edges in edge order (deterministic, no cross-lane reduction).
+DEV void accumulate_pairs(const LmProblem& P) {
+    for (int idx = threadIdx.x; idx < P.n_pair * 90; idx += LM_THREADS) {
+        const int p = idx / 90, k = idx - p * 90;
+        const bool cfree = !P.cam_fixed[P.pair_cam[p]], ofree = !P.obj_fixed[P.pair_obj[p]];
+        int a_off, b_off, r, c, kind;      // kind 0: A^T O B block entry (r,c); 1: gradient entry r
+        if (k < 21) { if (!cfree) continue; kind = 0; a_off = 0; b_off = 0; int u = k; r = 0; while (u >= 6 - r) { u -= 6 - r; ++r; } c = r + u; }
+        else if (k < 42) { if (!ofree) continue; kind = 0; a_off = 12; b_off = 12; int u = k - 21; r = 0; while (u >= 6 - r) { u -= 6 - r; ++r; } c = r + u; }
+        else if (k < 78) { if (!(cfree && ofree)) continue; kind = 0; a_off = 0; b_off = 12; r = (k - 42) / 6; c = (k - 42) - r * 6; }
+        else if (k < 84) { if (!cfree) continue; kind = 1; a_off = 0; b_off = 0; r = k - 78; c = 0; }
+        else { if (!ofree) continue; kind = 1; a_off = 12; b_off = 0; r = k - 84; c = 0; }
+        double s = 0;
+        for (int e = P.pair_start[p]; e < P.pair_start[p + 1]; ++e) {
+            if (P.level[e] != 0) continue;
+            const double* J = P.jac + 29 * (size_t)e;
+            const double a0 = J[a_off + r], a1 = J[a_off + 6 + r];
+            if (kind == 0) s += (a0 * J[24] + a1 * J[25]) * J[b_off + c] + (a0 * J[25] + a1 * J[26]) * J[b_off + 6 + c];
+            else s += a0 * J[27] + a1 * J[28];
         }
-        int u = 0;
-        if (cfree) {
-            for (int r = 0; r < 6; ++r)
-                for (int cc = r; cc < 6; ++cc) acc[u++] += JcO[2 * r] * Jc[cc] + JcO[2 * r + 1] * Jc[6 + cc];
-        }
-        u = 21;
-        if (ofree) {
-            for (int r = 0; r < 6; ++r)
-                for (int cc = r; cc < 6; ++cc) acc[u++] += JoO[2 * r] * Jo[cc] + JoO[2 * r + 1] * Jo[6 + cc];
-        }
-        u = 42;
-        if (cfree && ofree) {
-            for (int r = 0; r < 6; ++r)
-                for (int cc = 0; cc < 6; ++cc) acc[u++] += JcO[2 * r] * Jo[cc] + JcO[2 * r + 1] * Jo[6 + cc];
-        }
-        if (cfree) for (int r = 0; r < 6; ++r) acc[78 + r] += Jc[r] * orr[0] + Jc[6 + r] * orr[1];
-        if (ofree) for (int r = 0; r < 6; ++r) acc[84 + r] += Jo[r] * orr[0] + Jo[6 + r] * orr[1];
+        P.pair_part[idx] = s;
     }
-    double* out = P.pair_part + 90 * (size_t)p;
-#pragma unroll
-    for (int i = 0; i < 90; ++i) {
-        const double v = wsum(acc[i]);
-        if (lane == 0) out[i] = v;
-    }
+}
+
+// solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if not PD
+__device__ bool spd_solve6(const double* A, const double* b, double* x) {
+    double L[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (!(s > 0) || !isfinite(s)) return false; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+    return true;
 }
 
 DEV void unpack_sym21(const double* s, double* A) {
@@ -311,23 +313,35 @@ DEV void unpack_sym21(const double* s, double* A) {
         for (int c = r; c < 6; ++c) { A[r * 6 + c] = s[u]; A[c * 6 + r] = s[u]; ++u; }
 }
 
-__global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restrict__ problems) {
-    const LmProblem& P = problems[blockIdx.x];
-    __shared__ double red[LM_THREADS / 64];
-    __shared__ double S[LM_NS * LM_NS];     // reduced (object) system / its Cholesky factor
-    __shared__ double rhs[LM_NS], colbuf[LM_NS];
-    __shared__ double sh_lambda, sh_ni, sh_rho, sh_cur;
-    __shared__ int sh_flag, sh_ok, sh_good;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = LM_THREADS / 64;
+constexpr int LM_LDS_BYTES = 150 * 1024;     // dynamic LDS per workgroup (160 KiB per CU on gfx950)
 
-    // ---- load poses, count free vertices ----------------------------------------------------
-    for (int c = tid; c < P.n_cam; c += LM_THREADS) pose_from_T(P.cam_T + 12 * c, P.cam[c]);
-    for (int o = tid; o < P.n_obj; o += LM_THREADS) pose_from_T(P.obj_T + 12 * o, P.obj[o]);
+// Move one array of the problem into LDS when it still fits (flat pointers address LDS transparently): the
+// working set of a single-view frame (poses, 6x6 blocks, ~100 edges and their Jacobians) then never leaves
+// the CU during the ~80 LM trials.  Larger problems keep whatever does not fit in HBM/L2.
+template <typename T>
+DEV void lds_relocate(T*& ptr, size_t count, unsigned char* lds, size_t& off, bool copy_in) {
+    const size_t bytes = (count * sizeof(T) + 15) & ~(size_t)15;
+    if (count == 0 || off + bytes > (size_t)LM_LDS_BYTES) return;
+    typedef typename std::remove_const<T>::type U;
+    U* dst = (U*)(lds + off);
+    if (copy_in)
+        for (size_t i = threadIdx.x; i < count; i += LM_THREADS) dst[i] = ptr[i];
+    ptr = dst;
+    off += bytes;
+}
+
+__global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restrict__ problems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lm_lds[];
+    const LmProblem& G = problems[blockIdx.x];      // the problem as laid out in HBM
+    LmProblem P = G;                                // working copy whose pointers may be redirected to LDS
+    __shared__ double red[LM_THREADS / 64];
+    __shared__ int sh_flag, sh_ok, sh_good;
+    const int tid = threadIdx.x;
+
     if (tid == 0) {
         int ns = 0, nfc = 0;
-        for (int o = 0; o < P.n_obj; ++o) P.obj_slot[o] = P.obj_fixed[o] ? -1 : ns++;
-        for (int c = 0; c < P.n_cam; ++c) nfc += P.cam_fixed[c] ? 0 : 1;
+        for (int o = 0; o < G.n_obj; ++o) G.obj_slot[o] = G.obj_fixed[o] ? -1 : ns++;
+        for (int c = 0; c < G.n_cam; ++c) nfc += G.cam_fixed[c] ? 0 : 1;
         sh_flag = ns | (nfc << 16);
     }
     __syncthreads();
@@ -336,9 +350,60 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
     const int ns = 6 * n_free_obj;
     __syncthreads();
     if (schur && n_free_obj > LM_MAX_SCHUR_OBJ) {       // unsupported size: report and leave poses untouched
-        if (tid == 0) { P.stats[0] = -1; P.stats[1] = P.stats[2] = P.stats[3] = 0; }
+        if (tid == 0) { G.stats[0] = -1; G.stats[1] = G.stats[2] = G.stats[3] = 0; }
         return;
     }
+    // ---- LDS carve-up: reduced system first (Schur only), then the problem's arrays by access frequency ---
+    size_t off = 0;
+    double* S = (double*)lm_lds;            // reduced (object) system / its Cholesky factor, ns x ns
+    double* rhs = S;
+    double* colbuf = S;
+    if (schur) {
+        off = ((size_t)ns * ns * sizeof(double) + 15) & ~(size_t)15;
+        rhs = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
+        colbuf = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
+    }
+    {
+        const size_t C = P.n_cam, O = P.n_obj, E = P.n_edge, NP = P.n_pair;
+        lds_relocate(P.cam, C, lm_lds, off, false);
+        lds_relocate(P.obj, O, lm_lds, off, false);
+        lds_relocate(P.cam_bak, C, lm_lds, off, false);
+        lds_relocate(P.obj_bak, O, lm_lds, off, false);
+        lds_relocate(P.cam_fixed, C, lm_lds, off, true);
+        lds_relocate(P.obj_fixed, O, lm_lds, off, true);
+        lds_relocate(P.obj_slot, O, lm_lds, off, true);
+        lds_relocate(P.Hoo, 36 * O, lm_lds, off, false);
+        lds_relocate(P.bo, 6 * O, lm_lds, off, false);
+        lds_relocate(P.xo, 6 * O, lm_lds, off, false);
+        lds_relocate(P.Hcc, 36 * C, lm_lds, off, false);
+        lds_relocate(P.bc, 6 * C, lm_lds, off, false);
+        lds_relocate(P.xc, 6 * C, lm_lds, off, false);
+        lds_relocate(P.yc, 6 * C, lm_lds, off, false);
+        lds_relocate(P.pair_cam, NP, lm_lds, off, true);
+        lds_relocate(P.pair_obj, NP, lm_lds, off, true);
+        lds_relocate(P.pair_start, NP + 1, lm_lds, off, true);
+        lds_relocate(P.cam_pair_ptr, C + 1, lm_lds, off, true);
+        lds_relocate(P.cam_pair_idx, NP, lm_lds, off, true);
+        lds_relocate(P.obj_pair_ptr, O + 1, lm_lds, off, true);
+        lds_relocate(P.obj_pair_idx, NP, lm_lds, off, true);
+        lds_relocate(P.edge_pair, E, lm_lds, off, true);
+        lds_relocate(P.level, E, lm_lds, off, false);
+        lds_relocate(P.edge_k, 4 * E, lm_lds, off, true);
+        lds_relocate(P.edge_p, 3 * E, lm_lds, off, true);
+        lds_relocate(P.edge_uv, 2 * E, lm_lds, off, true);
+        lds_relocate(P.edge_info, 3 * E, lm_lds, off, true);
+        lds_relocate(P.err, 2 * E, lm_lds, off, false);
+        lds_relocate(P.pair_part, 90 * NP, lm_lds, off, false);
+        lds_relocate(P.jac, 29 * E, lm_lds, off, false);
+        lds_relocate(P.Hcc_inv, 36 * C, lm_lds, off, false);
+        lds_relocate(P.Y, 36 * NP, lm_lds, off, false);
+    }
+    __syncthreads();
+
+    // ---- load poses ---------------------------------------------------------------------------
+    for (int c = tid; c < P.n_cam; c += LM_THREADS) pose_from_T(P.cam_T + 12 * c, P.cam[c]);
+    for (int o = tid; o < P.n_obj; o += LM_THREADS) pose_from_T(P.obj_T + 12 * o, P.obj[o]);
+    __syncthreads();
 
     // ---- initial classification (object_slam.py:848-866) --------------------------------------
     for (int e = tid; e < P.n_edge; e += LM_THREADS) P.level[e] = 0;
@@ -376,8 +441,8 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
         double lambda = -1, ni = 2;
         for (int it = 0; it < iterations; ++it) {
             // ---- errors, chi2, linearisation ---------------------------------------------------
-            double currentChi = active_errors_and_chi2(P, robust_on, red);
-            for (int p = wave; p < P.n_pair; p += NW) linearise_pair(P, p, robust_on, lane);
+            double currentChi = active_errors_and_chi2(P, robust_on, true, red);
+            accumulate_pairs(P);
             __syncthreads();
             // ---- gather the diagonal blocks (fixed summation order) ----------------------------
             for (int idx = tid; idx < P.n_cam * 27; idx += LM_THREADS) {
@@ -419,18 +484,25 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                 for (int o = tid; o < P.n_obj; o += LM_THREADS) P.obj_bak[o] = P.obj[o];
                 if (tid == 0) sh_ok = 1;
                 __syncthreads();
-                // (Hcc + lambda I)^-1, y_c = Hcc^-1 b_c
+                // cameras: (Hcc + lambda I)^-1 and y_c = Hcc^-1 b_c (the inverse is only needed for the Schur complement)
                 for (int c = tid; c < P.n_cam; c += LM_THREADS) {
                     if (P.cam_fixed[c]) continue;
-                    double A[36], Ai[36];
+                    double A[36];
                     unpack_sym21(P.Hcc + 36 * c, A);
                     for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
-                    if (!spd_inverse6(A, Ai)) { sh_ok = 0; for (int i = 0; i < 36; ++i) Ai[i] = 0; }
-                    for (int i = 0; i < 36; ++i) P.Hcc_inv[36 * c + i] = Ai[i];
-                    for (int r = 0; r < 6; ++r) {
-                        double s = 0;
-                        for (int k = 0; k < 6; ++k) s += Ai[r * 6 + k] * P.bc[6 * c + k];
-                        P.yc[6 * c + r] = s;
+                    if (schur) {
+                        double Ai[36];
+                        if (!spd_inverse6(A, Ai)) { sh_ok = 0; for (int i = 0; i < 36; ++i) Ai[i] = 0; }
+                        for (int i = 0; i < 36; ++i) P.Hcc_inv[36 * c + i] = Ai[i];
+                        for (int r = 0; r < 6; ++r) {
+                            double sacc = 0;
+                            for (int k = 0; k < 6; ++k) sacc += Ai[r * 6 + k] * P.bc[6 * c + k];
+                            P.yc[6 * c + r] = sacc;
+                        }
+                    } else {
+                        double x[6] = {0, 0, 0, 0, 0, 0};
+                        if (!spd_solve6(A, P.bc + 6 * c, x)) sh_ok = 0;
+                        for (int r = 0; r < 6; ++r) P.yc[6 * c + r] = x[r];
                     }
                 }
                 __syncthreads();
@@ -438,15 +510,11 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     // block-diagonal: one thread per free object / camera
                     for (int o = tid; o < P.n_obj; o += LM_THREADS) {
                         if (P.obj_fixed[o]) continue;
-                        double A[36], Ai[36];
+                        double A[36], x[6] = {0, 0, 0, 0, 0, 0};
                         unpack_sym21(P.Hoo + 36 * o, A);
                         for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
-                        if (!spd_inverse6(A, Ai)) { sh_ok = 0; for (int i = 0; i < 36; ++i) Ai[i] = 0; }
-                        for (int r = 0; r < 6; ++r) {
-                            double s = 0;
-                            for (int k = 0; k < 6; ++k) s += Ai[r * 6 + k] * P.bo[6 * o + k];
-                            P.xo[6 * o + r] = s;
-                        }
+                        if (!spd_solve6(A, P.bo + 6 * o, x)) sh_ok = 0;
+                        for (int r = 0; r < 6; ++r) P.xo[6 * o + r] = x[r];
                     }
                     for (int idx = tid; idx < P.n_cam * 6; idx += LM_THREADS) P.xc[idx] = P.cam_fixed[idx / 6] ? 0.0 : P.yc[idx];
                     __syncthreads();
@@ -569,7 +637,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     for (int o = tid; o < P.n_obj; o += LM_THREADS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
                 }
                 __syncthreads();
-                double tempChi = active_errors_and_chi2(P, robust_on, red);
+                double tempChi = active_errors_and_chi2(P, robust_on, false, red);
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 // computeScale: sum x (lambda x + b)
                 double sc = 0;
@@ -624,7 +692,12 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
 
 int launch_lm(const void* problems_dev, int n_problems, hipStream_t s) {
     if (n_problems <= 0) return SUO_OK;
-    hipLaunchKernelGGL(lm_kernel, dim3(n_problems), dim3(LM_THREADS), 0, s, (const LmProblem*)problems_dev);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SUO_HIP_CHECK(hipFuncSetAttribute((const void*)lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lm_kernel, dim3(n_problems), dim3(LM_THREADS), LM_LDS_BYTES, s, (const LmProblem*)problems_dev);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
