@@ -213,13 +213,9 @@ def main():
         pipe.step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    acc = torch.tensor([dt, pipe.pose_err, float(pipe.n_pose), float(pipe.n_inl)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = acc[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)               # max over ranks
-        dist.all_reduce(acc[1:], op=dist.ReduceOp.SUM)            # the only collective: metric accumulators (RCCL)
-        dt = float(tmax.item())
-    pose_err, n_pose, n_inl = float(acc[1]), float(acc[2]), float(acc[3])
+    # max-over-ranks time + the only collective of the path: metric accumulators (RCCL all-reduce over xGMI)
+    from suo_slam_amd import sharding
+    dt, (pose_err, n_pose, n_inl) = sharding.reduce_metrics(dt, [pipe.pose_err, pipe.n_pose, pipe.n_inl], device="cuda")
     if rank == 0:
         fps = world * args.steps / dt
         line = {
