@@ -17,6 +17,8 @@
 //    chunk's MFMAs and written to the other LDS buffer afterwards (one barrier per chunk);
 //  * epilogue fuses bias (BN folded on the host), residual add, ReLU, and for the final head the
 //    NCHW transpose (operands swapped so the wave's 32 columns are 32 consecutive pixels).
+#include <type_traits>
+
 #include "suo_internal.h"
 
 namespace suo {
@@ -107,13 +109,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm1x1_kernel(const GemmArgs a
     sstore(0, 0);
     __syncthreads();
 
-    for (int kc = 0; kc < nch; ++kc) {
+    // One K-chunk: prefetch chunk kc+1 (A into registers, B into the OTHER weight buffer), then 16*TM*TN MFMAs from
+    // LDS buffer kc&1 and weight buffer `b`.  The two weight buffers swap roles every chunk (static ring: no
+    // register copies, so hipcc keeps the loads a full chunk ahead of their first use).
+    auto chunk = [&](int kc, const f32x4(&b)[4][TN], f32x4(&bn)[4][TN]) {
         const int buf = kc & 1;
         const bool more = kc + 1 < nch;
-        if (more) {
-            gload(kc + 1);
-            bload(kc + 1, bnxt);
-        }
+        if (more) gload(kc + 1);
+        bload(more ? kc + 1 : kc, bn);
+        __builtin_amdgcn_sched_barrier(0);
         const float* as = &As[buf][((wm * TM * 32) + (lane & 31)) * PK + (lane >> 5) * 4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -126,18 +130,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm1x1_kernel(const GemmArgs a
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (NCHW) acc[i][j] = mfma32(bcur[s][j][t], af[i][t], acc[i][j]);
-                        else acc[i][j] = mfma32(af[i][t], bcur[s][j][t], acc[i][j]);
+                        if (NCHW) acc[i][j] = mfma32(b[s][j][t], af[i][t], acc[i][j]);
+                        else acc[i][j] = mfma32(af[i][t], b[s][j][t], acc[i][j]);
                     }
         }
         if (more) sstore(kc + 1, buf ^ 1);
         __syncthreads();
-        if (more) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bcur[s][j] = bnxt[s][j];
-        }
+    };
+    for (int kc = 0; kc < nch; kc += 2) {
+        chunk(kc, bcur, bnxt);
+        if (kc + 1 < nch) chunk(kc + 1, bnxt, bcur);
     }
 
     // ---- epilogue --------------------------------------------------------------------------
@@ -285,36 +287,51 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
     sstore(0);
     __syncthreads();
 
+    // One tap = S k-groups of 8 channels: ds_read_b128 A fragments + 4*S*TM*TN MFMAs against B registers `b`.
+    auto tap = [&](const float* as, const f32x4(&b)[S][TN], int toff) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x4 af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + abase[i] + toff + s * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][t], b[s][j][t], acc[i][j]);
+        }
+    };
+    // All KS*KS taps of one channel chunk, fully unrolled, with a STATIC two-buffer register ring for the weights
+    // (bcur / bnxt swap roles every tap; PAR = which buffer holds tap 0).  The next tap's weights are requested
+    // before this tap's MFMAs and first touched one tap later -- no register copies for hipcc to coalesce away.
+    auto chunk = [&](int c, const float* as, auto par) {
+        constexpr int PAR = decltype(par)::value;
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            const int q = c * KS * KS + t;
+            const int qn = q + 1 < qtot ? q + 1 : q;
+            const int toff = ((t / KS) * IW + (t % KS)) * PK;
+            if (((t + PAR) & 1) == 0) {
+                bload(qn, bnxt);
+                __builtin_amdgcn_sched_barrier(0);
+                tap(as, bcur, toff);
+            } else {
+                bload(qn, bcur);
+                __builtin_amdgcn_sched_barrier(0);
+                tap(as, bnxt, toff);
+            }
+        }
+    };
+
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
         const bool more = c + 1 < nch;
         if (more) gload(c + 1);
-        const float* as = &As[buf][0];
-#pragma unroll 1
-        for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const int q = (c * KS + ky) * KS + kx;
-                if (q + 1 < qtot) bload(q + 1, bnxt);
-                const int toff = (ky * IW + kx) * PK;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    f32x4 af[TM];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + abase[i] + toff + s * 8);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][t], bcur[s][j][t], acc[i][j]);
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bcur[s][j] = bnxt[s][j];
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        // KS*KS is odd, so the ring parity flips every chunk
+        if (((c * KS * KS) & 1) == 0) chunk(c, &As[buf][0], std::integral_constant<int, 0>());
+        else chunk(c, &As[buf][0], std::integral_constant<int, 1>());
         if (more) sstore(buf ^ 1);
         __syncthreads();
     }
