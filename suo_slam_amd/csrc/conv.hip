@@ -148,18 +148,34 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm1x1_kernel(const GemmArgs a
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (!NCHW) {
-                const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                const float bv = a.bias[col];
+                // transpose the 32x32 accumulator tile through a wave-private LDS patch (the A buffers are free after
+                // the last barrier) so every lane owns 4 consecutive channels of one pixel: 16-byte residual loads and
+                // stores, 8 full 128-byte lines per instruction, all residual loads in flight before the first store
+                float* T = &As[0][0] + w * (32 * PK);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
-                    if (row < a.M && col < a.n_valid) {
-                        float v = acc[i][j][r] + bv;
-                        if (a.R) v += a.R[(size_t)row * a.ldr + col];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.out[(size_t)row * a.ldo + col] = v;
-                    }
+                for (int r = 0; r < 16; ++r) T[acc_row(r, lane) * PK + (lane & 31)] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                const int col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+                const f32x4 bv = *(const f32x4*)(a.bias + col);
+                f32x4 v[4], rv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
+                    rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.R && row < a.M && col < a.n_valid) rv[k] = *(const f32x4*)(a.R + (size_t)row * a.ldr + col);
+                    v[k] = *(const f32x4*)&T[((lane >> 3) + 8 * k) * PK + (lane & 7) * 4];
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
+                    f32x4 o = v[k] + bv + rv[k];
+                    if (a.relu) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+                    }
+                    if (row < a.M && col < a.n_valid) *(f32x4*)(a.out + (size_t)row * a.ldo + col) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
             } else {
                 const int m = m0 + (wm * TM + i) * 32 + (lane & 31);
                 const int crop = m / a.nchw_hw, pix = m - crop * a.nchw_hw;
@@ -340,19 +356,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-            const float bv = a.bias[col];
+            // LDS transpose of the accumulator tile (wave-private patch of the free A buffers) -> 16-byte stores
+            static_assert(2 * NPIX * PK >= WGM * WGN * 32 * 36, "epilogue patch must fit the A buffers");
+            float* T = &As[0][0] + w * (32 * 36);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = (wm * TM + i) * 32 + acc_row(r, lane);
+            for (int r = 0; r < 16; ++r) T[acc_row(r, lane) * 36 + (lane & 31)] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+            const f32x4 bv = *(const f32x4*)(a.bias + col);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pr = (lane >> 3) + 8 * k;
+                const int p = (wm * TM + i) * 32 + pr;
                 const int py = p / TW, px = p - py * TW;
                 const int oy = oy0 + py, ox = ox0 + px;
-                if (oy < a.OH && ox < a.OW) {
-                    float v = acc[i][j][r] + bv;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.out[(((size_t)l * a.OH + oy) * a.OW + ox) * a.N + col] = v;
+                f32x4 o = *(const f32x4*)&T[pr * 36 + (lane & 7) * 4] + bv;
+                if (a.relu) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
                 }
+                if (oy < a.OH && ox < a.OW) *(f32x4*)(a.out + (((size_t)l * a.OH + oy) * a.OW + ox) * a.N + col) = o;
             }
+            __builtin_amdgcn_wave_barrier();
         }
 }
 
