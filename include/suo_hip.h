@@ -72,8 +72,9 @@ int suo_keypoint_masks(const float* uv_dev, const float* cov_dev, const float* k
 int suo_roi_align_concat(const void* img_dev, int img_format, int H, int W, const float* boxes_dev, int L, const float* priors_dev,
                          float* out_dev, void* stream);
 
-/* Weight packers (host): GEMM weight W[N][K] -> MFMA B-operand layout [Kp/8][Np/32][64][4];
- * conv weight W[N][C][KS][KS] -> same with K' = [chunk][ky][kx][kk]. */
+/* Weight packers (host): GEMM weight W[N][K] -> the two MFMA B-operand layouts back to back, `out` holds
+ * 2*Np*Kp floats: [Kp/8][Np/32][64][4] for v_mfma_f32_32x32x2 and [Kp/16][Np/16][64][4] for v_mfma_f32_16x16x4
+ * (small feature maps); conv weight W[N][C][KS][KS] -> same with K' = [chunk][ky][kx][kk]. */
 int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* out);
 int suo_pack_conv_weight(const float* w, int N, int C, int KS, int Np, int Cp, int CK, float* out);
 

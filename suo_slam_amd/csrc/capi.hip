@@ -84,7 +84,7 @@ int suo_roi_align_concat(const void* img, int img_format, int H, int W, const fl
 }
 
 int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* out) {
-    if (Np % 32 || Kp % 8 || N > Np || K > Kp) { suo_set_error("suo_pack_gemm_weight: bad padding"); return SUO_ERR_ARG; }
+    if (Np % 32 || Kp % 16 || N > Np || K > Kp) { suo_set_error("suo_pack_gemm_weight: bad padding"); return SUO_ERR_ARG; }
     suo::pack_gemm_weight(w, N, K, K, Np, Kp, out);
     return SUO_OK;
 }

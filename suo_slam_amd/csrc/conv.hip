@@ -208,6 +208,8 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     if (a.nchw_hw > 0) return launch_gemm_cfg<1, 1, 2, 2, true>(a, s);
+    // small feature maps are latency problems: 16x16 tiles + split-K (csrc/conv_small.hip)
+    if (a.M <= 4096 && ((a.K1 | a.K2) & 15) == 0 && (a.K1 + a.K2) <= 640) return launch_gemm_small(a, s);
     // tile choice: keep >= ~2 workgroups per CU where the problem allows it
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128 > 0 ? a.N / 128 : 1);
     if ((a.N % 128) == 0 && tiles128 >= 512) return launch_gemm_cfg<2, 2, 2, 2, false>(a, s);
@@ -398,6 +400,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const long px = (long)a.L * a.OH * a.OW;
+    if (px <= 4096 && (a.C == 128 || a.C == 64 || a.C == 32)) return launch_conv3x3_small(a, s);
     const long t128 = ((px + 127) / 128) * (a.N / 64);
     if (a.OH >= 8 && a.OW >= 16 && t128 >= 384) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 1, 2, 2>(a, s);
     const long t64 = ((px + 63) / 64) * (a.N / 64);

@@ -38,8 +38,21 @@ static void bn_affine(const Net& net, const std::string& p, std::vector<float>& 
     }
 }
 
-// Pack W[n][k] (n < N, k < K; zero beyond) into the MFMA B-operand layout [Kp/8][Np/32][64][4].
+// Pack W[n][k] (n < N, k < K; zero beyond) into the MFMA B-operand layouts.  `out` holds 2*Np*Kp floats:
+//   [0, Np*Kp)        32x32x2 form  [Kp/8][Np/32][64][4]:  W[nb*32+(lane&31)][kb*8 +(lane>>5)*4+t]
+//   [Np*Kp, 2*Np*Kp)  16x16x4 form  [Kp/16][Np/16][64][4]: W[nb*16+(lane&15)][kg*16+(lane>>4)*4+t]   (small-map kernels)
 void pack_gemm_weight(const float* W, int N, int K, int ldw, int Np, int Kp, float* out) {
+    {
+        float* o16 = out + (size_t)Np * Kp;
+        const int NB16 = Np / 16;
+        for (int kg = 0; kg < Kp / 16; ++kg)
+            for (int nb = 0; nb < NB16; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 4; ++t) {
+                        const int n = nb * 16 + (lane & 15), k = kg * 16 + (lane >> 4) * 4 + t;
+                        o16[(((size_t)kg * NB16 + nb) * 64 + lane) * 4 + t] = (n < N && k < K) ? W[(size_t)n * ldw + k] : 0.f;
+                    }
+    }
     const int NB = Np / 32;
     for (int kb = 0; kb < Kp / 8; ++kb)
         for (int nb = 0; nb < NB; ++nb)
@@ -103,7 +116,7 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
             bias[n] += b2.data[n];
         }
     }
-    std::vector<float> packed((size_t)Np * Kp);
+    std::vector<float> packed(2 * (size_t)Np * Kp);
     pack_gemm_weight(full.data(), Np, Kp, Kp, Np, Kp, packed.data());
     g.Wp = upload(packed);
     g.bias = upload(bias);
@@ -117,7 +130,7 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
     const int Np = round_up(N, 64), Cp = round_up(C, CK);
     std::vector<float> scale, shift;
     if (!bn_after.empty()) bn_affine(*this, bn_after, scale, shift);
-    std::vector<float> packed((size_t)Np * Cp * KS * KS), bias(Np, 0.f);
+    std::vector<float> packed(2 * (size_t)Np * Cp * KS * KS), bias(Np, 0.f);
     pack_conv_weight(w.data, N, C, KS, Np, Cp, CK, scale.empty() ? nullptr : scale.data(), packed.data());
     for (int n = 0; n < N; ++n) bias[n] = scale.empty() ? b.data[n] : b.data[n] * scale[n] + shift[n];
     c.Wp = upload(packed);

@@ -29,14 +29,14 @@ def nchw(t):  # NHWC cuda -> numpy [L,C,H,W]
 
 def pack_gemm(w, Np, Kp):
     w = np.ascontiguousarray(w, np.float32)
-    out = np.empty(Np * Kp, np.float32)
+    out = np.empty(2 * Np * Kp, np.float32)
     _lib.check(_lib.lib().suo_pack_gemm_weight(w.ctypes.data, w.shape[0], w.shape[1], Np, Kp, out.ctypes.data), "pack_gemm")
     return out
 
 
 def pack_conv(w, Np, Cp, CK):
     w = np.ascontiguousarray(w, np.float32)
-    out = np.empty(Np * Cp * w.shape[2] * w.shape[3], np.float32)
+    out = np.empty(2 * Np * Cp * w.shape[2] * w.shape[3], np.float32)
     _lib.check(_lib.lib().suo_pack_conv_weight(w.ctypes.data, w.shape[0], w.shape[1], w.shape[2], Np, Cp, CK, out.ctypes.data), "pack_conv")
     return out
 

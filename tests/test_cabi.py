@@ -45,12 +45,12 @@ def test_host_packers_roundtrip(built):
     from tests import hipops
     rng = np.random.default_rng(0)
     w = rng.standard_normal((70, 40)).astype(np.float32)
-    p = hipops.pack_gemm(w, 96, 64).reshape(64 // 8, 96 // 32, 64, 4)
+    p = hipops.pack_gemm(w, 96, 64)[:96 * 64].reshape(64 // 8, 96 // 32, 64, 4)      # first half: 32x32x2 form
     for (n, k) in ((0, 0), (69, 39), (33, 17), (5, 36)):
         assert p[k // 8, n // 32, (n % 32) + 32 * ((k % 8) // 4), k % 4] == w[n, k]
     assert p[7, 2, 40, 0] == 0  # padding
     wc = rng.standard_normal((64, 44, 7, 7)).astype(np.float32)
-    pc = hipops.pack_conv(wc, 64, 48, 16).reshape(-1, 2, 64, 4)
+    pc = hipops.pack_conv(wc, 64, 48, 16)[:64 * 48 * 49].reshape(-1, 2, 64, 4)
     n, c, ky, kx = 37, 20, 3, 5
     kprime = ((c // 16) * 49 + ky * 7 + kx) * 16 + c % 16
     assert pc[kprime // 8, n // 32, (n % 32) + 32 * ((kprime % 8) // 4), kprime % 4] == wc[n, c, ky, kx]
