@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pool", type=int, default=16, help="number of distinct synthetic frames cycled through")
+    ap.add_argument("--depth", type=int, default=2, help="frames in flight (independent network instances / streams)")
+    ap.add_argument("--geom-batch", type=int, default=8, help="frames whose PnP / LM problems share one launch")
     ap.add_argument("--only", choices=["all", "cnn", "geometry"], default="all", help="diagnostic: run only one half of the step")
     return ap.parse_args()
 
@@ -61,30 +63,37 @@ def make_pool(rng, n, L):
 
 
 class FramePipeline:
-    """The per-frame product path, called through the C ABI with pre-allocated device buffers."""
+    """The per-frame product path, called through the C ABI with pre-allocated device buffers.
 
-    def __init__(self, L, pool, use_graph=True, only="all"):
-        self.only = only
+    `depth` frames are in flight at once: frame i runs on network instance i % depth (own workspace, own
+    hipGraph, own stream).  Frames of the single-view stream are independent (evaluate.py resets the SLAM state
+    for every frame, :345-346), and one frame alone cannot fill 256 CUs during the low-resolution hourglass
+    levels, so the next frame's kernels fill the gaps.  Every frame still executes the complete path."""
+
+    def __init__(self, L, pool, use_graph=True, only="all", depth=2, geom_batch=8):
         import torch
         from suo_slam_amd import _lib, ba, lambdatwist, weights
         from suo_slam_amd.pkpnet import PkpNet
+        self.only = only
         self.torch, self.lib, self._lib, self.ba, self.lt = torch, _lib.lib(), _lib, ba, lambdatwist
         self.L = L
-        self.net = PkpNet(state_dict=weights.make_random_state_dict(0, 8.0), max_crops=L)
-        self.net.set_graph(use_graph)
+        self.depth = depth
+        self.geom_batch = geom_batch
+        self.pending = []
+        sd = weights.make_random_state_dict(0, 8.0)
         dev = "cuda"
         self.pool = pool
         self.img = [torch.from_numpy(fr["image"]).to(dev) for fr in pool]
         self.boxes = [torch.from_numpy(fr["boxes"]).to(dev) for fr in pool]
         self.mm = [torch.from_numpy(fr["model_kps_masks"].astype(np.uint8)).to(dev) for fr in pool]
-        self.uv = torch.empty((L, 41, 2), device=dev)
-        self.cov = torch.empty((L, 41, 2, 2), device=dev)
-        self.kp = torch.empty((L, 41), device=dev)
-        self.mask = torch.empty((L, 41), dtype=torch.uint8, device=dev)
-        # a real (non-NULL) stream: the network then runs fully asynchronously (hipGraph replay) while the host thread
-        # drives the geometry kernels of the same frame on the library's own high-priority stream
-        self.tstream = torch.cuda.Stream()
-        self.stream = C.c_void_p(self.tstream.cuda_stream)
+        self.slots = []
+        for _ in range(depth):
+            net = PkpNet(state_dict=sd, max_crops=L)
+            net.set_graph(use_graph)
+            ts = torch.cuda.Stream()      # a real (non-NULL) stream: hipGraph replay is then fully asynchronous
+            self.slots.append({"net": net, "tstream": ts, "stream": C.c_void_p(ts.cuda_stream),
+                               "uv": torch.empty((L, 41, 2), device=dev), "cov": torch.empty((L, 41, 2, 2), device=dev),
+                               "kp": torch.empty((L, 41), device=dev), "mask": torch.empty((L, 41), dtype=torch.uint8, device=dev)})
         self.pose_err = 0.0
         self.n_pose = 0
         self.n_inl = 0
@@ -94,26 +103,44 @@ class FramePipeline:
         k = i % len(self.pool)
         fr = self.pool[k]
         L = self.L
-        # network + decode + masks: asynchronous on the torch stream
+        S = self.slots[i % self.depth]
+        # network + decode + masks: asynchronous on this slot's stream
         if self.only != "geometry":
-          self._lib.check(self.lib.suo_net_forward(self.net._h, P(self.img[k]), 0, 480, 640, P(self.boxes[k]), L, None, P(self.uv),
-                                                 P(self.cov), P(self.kp), None, None, self.stream), "suo_net_forward")
-          self._lib.check(self.lib.suo_keypoint_masks(P(self.uv), P(self.cov), P(self.kp), P(self.mm[k]), L, 0.9, 0.2, P(self.mask),
-                                                      self.stream), "suo_keypoint_masks")
+            self._lib.check(self.lib.suo_net_forward(S["net"]._h, P(self.img[k]), 0, 480, 640, P(self.boxes[k]), L, None, P(S["uv"]),
+                                                     P(S["cov"]), P(S["kp"]), None, None, S["stream"]), "suo_net_forward")
+            self._lib.check(self.lib.suo_keypoint_masks(P(S["uv"]), P(S["cov"]), P(S["kp"]), P(self.mm[k]), L, 0.9, 0.2, P(S["mask"]),
+                                                        S["stream"]), "suo_keypoint_masks")
         if self.only == "cnn":
             return
-        # geometry: one PnP launch for the 8 objects, then the LM rounds (overlaps with the network above)
-        T, status = self.lt.pnp_batch(fr["pnp_xs"], fr["pnp_ys"], 1e-3, seed=i)
-        B = fr["ba"]
-        prob = self.ba.Problem(B["cam_T"], B["cam_fixed"], T[:, :3, :], B["obj_fixed"], B["edge_cam"], B["edge_obj"], B["edge_camk"],
-                               B["edge_p"], B["edge_uv"], B["edge_info"], B["edge_inlier"], its=(10, 10, 40, 40))
-        self.ba.optimize_batch([prob])
-        obj = prob.obj_T.reshape(-1, 3, 4)
-        d = np.linalg.norm(obj[:, :, 3] - fr["T_OtoC"][:, :3, 3], axis=1) / fr["T_OtoC"][:, 2, 3]
-        ok = status == 0
-        self.pose_err += float(d[ok].sum())
-        self.n_pose += int(ok.sum())
-        self.n_inl += int(prob.inlier.sum())
+        self.pending.append(i)
+        if len(self.pending) >= self.geom_batch:
+            self.flush()
+
+    def flush(self):
+        """Geometry for the pending frames: ONE PnP launch (a wave per object) and ONE LM launch (a workgroup per
+        frame) for the whole group -- frames are independent, so their problems batch like their crops do."""
+        if not self.pending:
+            return
+        frames = [self.pool[i % len(self.pool)] for i in self.pending]
+        xs = [x for fr in frames for x in fr["pnp_xs"]]
+        ys = [y for fr in frames for y in fr["pnp_ys"]]
+        T, status = self.lt.pnp_batch(xs, ys, 1e-3, seed=self.pending[0])
+        L = self.L
+        probs = []
+        for j, fr in enumerate(frames):
+            B = fr["ba"]
+            probs.append(self.ba.Problem(B["cam_T"], B["cam_fixed"], T[j * L:(j + 1) * L, :3, :], B["obj_fixed"], B["edge_cam"],
+                                         B["edge_obj"], B["edge_camk"], B["edge_p"], B["edge_uv"], B["edge_info"], B["edge_inlier"],
+                                         its=(10, 10, 40, 40)))
+        self.ba.optimize_batch(probs)
+        for j, (fr, prob) in enumerate(zip(frames, probs)):
+            obj = prob.obj_T.reshape(-1, 3, 4)
+            d = np.linalg.norm(obj[:, :, 3] - fr["T_OtoC"][:, :3, 3], axis=1) / fr["T_OtoC"][:, 2, 3]
+            ok = status[j * L:(j + 1) * L] == 0
+            self.pose_err += float(d[ok].sum())
+            self.n_pose += int(ok.sum())
+            self.n_inl += int(prob.inlier.sum())
+        self.pending = []
 
 
 def conv_roofline(L, iters=30):
@@ -196,7 +223,7 @@ def main():
     L = args.objects
     # frames shard embarrassingly: rank r processes its own stream (weak scaling: K frames per GPU)
     pool = make_pool(np.random.default_rng(1000 + rank), args.pool, L)
-    pipe = FramePipeline(L, pool, use_graph=not args.no_graph, only=args.only)
+    pipe = FramePipeline(L, pool, use_graph=not args.no_graph, only=args.only, depth=args.depth, geom_batch=args.geom_batch)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,11 +233,13 @@ def main():
 
     for i in range(args.warmup):
         pipe.step(i)
+    pipe.flush()
     pipe.pose_err, pipe.n_pose, pipe.n_inl = 0.0, 0, 0
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         pipe.step(args.warmup + i)
+    pipe.flush()                  # every timed frame's geometry completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     # max-over-ranks time + the only collective of the path: metric accumulators (RCCL all-reduce over xGMI)
@@ -225,7 +254,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> RoI crop, hourglass keypoint "
                                    "CNN fp32, decode, masks, batched PnP, LM rounds [10,10,40,40]" % L,
-                       "objects_per_frame": L, "crops_per_s": round(fps * L, 2), "frames_per_gpu": args.steps,
+                       "objects_per_frame": L, "crops_per_s": round(fps * L, 2), "frames_per_gpu": args.steps, "frames_in_flight": args.depth, "geometry_frames_per_launch": args.geom_batch,
                        "geometry_inputs": "projected GT keypoints + N(0,0.01^2) NDC noise, 5% outliers (debug_gt_kp mode)",
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "cnn_tflops": round(fps * L * GFLOP_PER_CROP / 1e3, 2),

@@ -17,7 +17,8 @@ namespace suo {
 int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, uint64_t seed,
                      const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                      int* iters_out, hipStream_t s);
-int launch_lm(const void* problems_dev, int n_problems, hipStream_t s);
+int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
+int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
 
 // PnpParams::get_iterations (thirdparty/lambdatwist/parameters.h:76-102), evaluated on the host so the
@@ -278,7 +279,15 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     }
     hipStream_t s = g_arena.stream;
     SUO_HIP_CHECK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, s));
-    rc = launch_lm(d + o_structs, n_prob, s);
+    int lds_need = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const suo_ba_problem& q = probs[i];
+        int nfo = 0, nfc = 0;
+        for (int o = 0; o < q.n_obj; ++o) nfo += q.obj_fixed[o] ? 0 : 1;
+        for (int c = 0; c < q.n_cam; ++c) nfc += q.cam_fixed[c] ? 0 : 1;
+        lds_need = std::max(lds_need, lm_lds_bytes(q.n_cam, q.n_obj, q.n_edge, (int)prep[i].pair_cam.size(), (nfo > 0 && nfc > 0) ? nfo : 0));
+    }
+    rc = launch_lm(d + o_structs, n_prob, lds_need, s);
     if (rc != SUO_OK) return rc;
     // poses + inlier flags live in the input region, chi2 + stats in the output region
     SUO_HIP_CHECK(hipMemcpyAsync(h, d, out_end, hipMemcpyDeviceToHost, s));

@@ -319,9 +319,9 @@ constexpr int LM_LDS_BYTES = 150 * 1024;     // dynamic LDS per workgroup (160 K
 // working set of a single-view frame (poses, 6x6 blocks, ~100 edges and their Jacobians) then never leaves
 // the CU during the ~80 LM trials.  Larger problems keep whatever does not fit in HBM/L2.
 template <typename T>
-DEV void lds_relocate(T*& ptr, size_t count, unsigned char* lds, size_t& off, bool copy_in) {
+DEV void lds_relocate(T*& ptr, size_t count, unsigned char* lds, size_t& off, size_t cap, bool copy_in) {
     const size_t bytes = (count * sizeof(T) + 15) & ~(size_t)15;
-    if (count == 0 || off + bytes > (size_t)LM_LDS_BYTES) return;
+    if (count == 0 || off + bytes > cap) return;
     typedef typename std::remove_const<T>::type U;
     U* dst = (U*)(lds + off);
     if (copy_in)
@@ -330,7 +330,7 @@ DEV void lds_relocate(T*& ptr, size_t count, unsigned char* lds, size_t& off, bo
     off += bytes;
 }
 
-__global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restrict__ problems) {
+__global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restrict__ problems, int lds_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_lds[];
     const LmProblem& G = problems[blockIdx.x];      // the problem as laid out in HBM
     LmProblem P = G;                                // working copy whose pointers may be redirected to LDS
@@ -364,39 +364,39 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
         colbuf = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
     }
     {
-        const size_t C = P.n_cam, O = P.n_obj, E = P.n_edge, NP = P.n_pair;
-        lds_relocate(P.cam, C, lm_lds, off, false);
-        lds_relocate(P.obj, O, lm_lds, off, false);
-        lds_relocate(P.cam_bak, C, lm_lds, off, false);
-        lds_relocate(P.obj_bak, O, lm_lds, off, false);
-        lds_relocate(P.cam_fixed, C, lm_lds, off, true);
-        lds_relocate(P.obj_fixed, O, lm_lds, off, true);
-        lds_relocate(P.obj_slot, O, lm_lds, off, true);
-        lds_relocate(P.Hoo, 36 * O, lm_lds, off, false);
-        lds_relocate(P.bo, 6 * O, lm_lds, off, false);
-        lds_relocate(P.xo, 6 * O, lm_lds, off, false);
-        lds_relocate(P.Hcc, 36 * C, lm_lds, off, false);
-        lds_relocate(P.bc, 6 * C, lm_lds, off, false);
-        lds_relocate(P.xc, 6 * C, lm_lds, off, false);
-        lds_relocate(P.yc, 6 * C, lm_lds, off, false);
-        lds_relocate(P.pair_cam, NP, lm_lds, off, true);
-        lds_relocate(P.pair_obj, NP, lm_lds, off, true);
-        lds_relocate(P.pair_start, NP + 1, lm_lds, off, true);
-        lds_relocate(P.cam_pair_ptr, C + 1, lm_lds, off, true);
-        lds_relocate(P.cam_pair_idx, NP, lm_lds, off, true);
-        lds_relocate(P.obj_pair_ptr, O + 1, lm_lds, off, true);
-        lds_relocate(P.obj_pair_idx, NP, lm_lds, off, true);
-        lds_relocate(P.edge_pair, E, lm_lds, off, true);
-        lds_relocate(P.level, E, lm_lds, off, false);
-        lds_relocate(P.edge_k, 4 * E, lm_lds, off, true);
-        lds_relocate(P.edge_p, 3 * E, lm_lds, off, true);
-        lds_relocate(P.edge_uv, 2 * E, lm_lds, off, true);
-        lds_relocate(P.edge_info, 3 * E, lm_lds, off, true);
-        lds_relocate(P.err, 2 * E, lm_lds, off, false);
-        lds_relocate(P.pair_part, 90 * NP, lm_lds, off, false);
-        lds_relocate(P.jac, 29 * E, lm_lds, off, false);
-        lds_relocate(P.Hcc_inv, 36 * C, lm_lds, off, false);
-        lds_relocate(P.Y, 36 * NP, lm_lds, off, false);
+        const size_t C = P.n_cam, O = P.n_obj, E = P.n_edge, NP = P.n_pair, cap = (size_t)lds_bytes;
+        lds_relocate(P.cam, C, lm_lds, off, cap, false);
+        lds_relocate(P.obj, O, lm_lds, off, cap, false);
+        lds_relocate(P.cam_bak, C, lm_lds, off, cap, false);
+        lds_relocate(P.obj_bak, O, lm_lds, off, cap, false);
+        lds_relocate(P.cam_fixed, C, lm_lds, off, cap, true);
+        lds_relocate(P.obj_fixed, O, lm_lds, off, cap, true);
+        lds_relocate(P.obj_slot, O, lm_lds, off, cap, true);
+        lds_relocate(P.Hoo, 36 * O, lm_lds, off, cap, false);
+        lds_relocate(P.bo, 6 * O, lm_lds, off, cap, false);
+        lds_relocate(P.xo, 6 * O, lm_lds, off, cap, false);
+        lds_relocate(P.Hcc, 36 * C, lm_lds, off, cap, false);
+        lds_relocate(P.bc, 6 * C, lm_lds, off, cap, false);
+        lds_relocate(P.xc, 6 * C, lm_lds, off, cap, false);
+        lds_relocate(P.yc, 6 * C, lm_lds, off, cap, false);
+        lds_relocate(P.pair_cam, NP, lm_lds, off, cap, true);
+        lds_relocate(P.pair_obj, NP, lm_lds, off, cap, true);
+        lds_relocate(P.pair_start, NP + 1, lm_lds, off, cap, true);
+        lds_relocate(P.cam_pair_ptr, C + 1, lm_lds, off, cap, true);
+        lds_relocate(P.cam_pair_idx, NP, lm_lds, off, cap, true);
+        lds_relocate(P.obj_pair_ptr, O + 1, lm_lds, off, cap, true);
+        lds_relocate(P.obj_pair_idx, NP, lm_lds, off, cap, true);
+        lds_relocate(P.edge_pair, E, lm_lds, off, cap, true);
+        lds_relocate(P.level, E, lm_lds, off, cap, false);
+        lds_relocate(P.edge_k, 4 * E, lm_lds, off, cap, true);
+        lds_relocate(P.edge_p, 3 * E, lm_lds, off, cap, true);
+        lds_relocate(P.edge_uv, 2 * E, lm_lds, off, cap, true);
+        lds_relocate(P.edge_info, 3 * E, lm_lds, off, cap, true);
+        lds_relocate(P.err, 2 * E, lm_lds, off, cap, false);
+        lds_relocate(P.pair_part, 90 * NP, lm_lds, off, cap, false);
+        lds_relocate(P.jac, 29 * E, lm_lds, off, cap, false);
+        lds_relocate(P.Hcc_inv, 36 * C, lm_lds, off, cap, false);
+        lds_relocate(P.Y, 36 * NP, lm_lds, off, cap, false);
     }
     __syncthreads();
 
@@ -690,14 +690,30 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
     if (tid == 0) { P.stats[0] = rounds; P.stats[1] = lm_its; P.stats[2] = lm_trials; P.stats[3] = num_good; }
 }
 
-int launch_lm(const void* problems_dev, int n_problems, hipStream_t s) {
+// Dynamic LDS a problem of this size wants (everything resident), capped at LM_LDS_BYTES.  Small problems ask
+// for little, so their workgroup can share a CU with the CNN's workgroups instead of waiting for an empty one.
+int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur) {
+    size_t b = 0;
+    const size_t ns = 6 * (size_t)n_free_obj_schur;
+    b += 8 * (ns * ns + 2 * ns) + 48;
+    b += 4 * 56 * (size_t)(C + O) / 2 * 2 + 2 * (size_t)(C + O) + 4 * (size_t)O;
+    b += 8 * 48 * (size_t)O + 8 * 54 * (size_t)C;
+    b += 4 * (3 * (size_t)NP + 1) + 4 * ((size_t)C + 1 + NP) + 4 * ((size_t)O + 1 + NP);
+    b += (4 + 1 + 8 * 12 + 16) * (size_t)E + 720 * (size_t)NP + 232 * (size_t)E + 288 * (size_t)C + 288 * (size_t)NP;
+    b += 16 * 40;                                    // per-array alignment slack
+    b = (b + 1023) & ~(size_t)1023;
+    return (int)(b > (size_t)LM_LDS_BYTES ? (size_t)LM_LDS_BYTES : b);
+}
+
+int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s) {
     if (n_problems <= 0) return SUO_OK;
+    if (lds_bytes <= 0 || lds_bytes > LM_LDS_BYTES) lds_bytes = LM_LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         SUO_HIP_CHECK(hipFuncSetAttribute((const void*)lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(lm_kernel, dim3(n_problems), dim3(LM_THREADS), LM_LDS_BYTES, s, (const LmProblem*)problems_dev);
+    hipLaunchKernelGGL(lm_kernel, dim3(n_problems), dim3(LM_THREADS), lds_bytes, s, (const LmProblem*)problems_dev, lds_bytes);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
