@@ -34,12 +34,13 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--objects", type=int, default=N_OBJ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pool", type=int, default=16, help="number of distinct synthetic frames cycled through")
     ap.add_argument("--depth", type=int, default=2, help="frames in flight (independent network instances / streams)")
+    ap.add_argument("--frames-per-forward", type=int, default=4, help="consecutive frames batched into one network call (8 crops each)")
     ap.add_argument("--geom-batch", type=int, default=8, help="frames whose PnP / LM problems share one launch")
     ap.add_argument("--only", choices=["all", "cnn", "geometry"], default="all", help="diagnostic: run only one half of the step")
     return ap.parse_args()
@@ -70,7 +71,7 @@ class FramePipeline:
     for every frame, :345-346), and one frame alone cannot fill 256 CUs during the low-resolution hourglass
     levels, so the next frame's kernels fill the gaps.  Every frame still executes the complete path."""
 
-    def __init__(self, L, pool, use_graph=True, only="all", depth=2, geom_batch=8):
+    def __init__(self, L, pool, use_graph=True, only="all", depth=2, geom_batch=8, frames_per_forward=4):
         import torch
         from suo_slam_amd import _lib, ba, lambdatwist, weights
         from suo_slam_amd.pkpnet import PkpNet
@@ -83,17 +84,27 @@ class FramePipeline:
         sd = weights.make_random_state_dict(0, 8.0)
         dev = "cuda"
         self.pool = pool
-        self.img = [torch.from_numpy(fr["image"]).to(dev) for fr in pool]
-        self.boxes = [torch.from_numpy(fr["boxes"]).to(dev) for fr in pool]
-        self.mm = [torch.from_numpy(fr["model_kps_masks"].astype(np.uint8)).to(dev) for fr in pool]
+        F = self.F = frames_per_forward
+        assert len(pool) % F == 0, "--pool must be a multiple of --frames-per-forward"
+        # the frame stream is resident in HBM as one stack; a forward call takes F consecutive frames (8F crops)
+        self.imgs = torch.from_numpy(np.stack([fr["image"] for fr in pool])).to(dev)
+        self.g_boxes, self.g_img, self.g_mm = [], [], []
+        for g in range(len(pool) // F):
+            ks = range(g * F, (g + 1) * F)
+            self.g_boxes.append(torch.from_numpy(np.concatenate([pool[k]["boxes"] for k in ks])).to(dev))
+            self.g_img.append(torch.from_numpy(np.repeat(np.array(list(ks), np.int32), L)).to(dev))
+            self.g_mm.append(torch.from_numpy(np.concatenate([pool[k]["model_kps_masks"] for k in ks]).astype(np.uint8)).to(dev))
+        self.fwd_pending = 0
+        self.n_forward = 0
+        LF = L * F
         self.slots = []
         for _ in range(depth):
-            net = PkpNet(state_dict=sd, max_crops=L)
+            net = PkpNet(state_dict=sd, max_crops=LF)
             net.set_graph(use_graph)
             ts = torch.cuda.Stream()      # a real (non-NULL) stream: hipGraph replay is then fully asynchronous
             self.slots.append({"net": net, "tstream": ts, "stream": C.c_void_p(ts.cuda_stream),
-                               "uv": torch.empty((L, 41, 2), device=dev), "cov": torch.empty((L, 41, 2, 2), device=dev),
-                               "kp": torch.empty((L, 41), device=dev), "mask": torch.empty((L, 41), dtype=torch.uint8, device=dev)})
+                               "uv": torch.empty((LF, 41, 2), device=dev), "cov": torch.empty((LF, 41, 2, 2), device=dev),
+                               "kp": torch.empty((LF, 41), device=dev), "mask": torch.empty((LF, 41), dtype=torch.uint8, device=dev)})
         self.pose_err = 0.0
         self.n_pose = 0
         self.n_inl = 0
@@ -103,22 +114,34 @@ class FramePipeline:
         k = i % len(self.pool)
         fr = self.pool[k]
         L = self.L
-        S = self.slots[i % self.depth]
-        # network + decode + masks: asynchronous on this slot's stream
+        # network + decode + masks for F consecutive frames in ONE forward (8F crops), asynchronous on a slot's stream
         if self.only != "geometry":
-            self._lib.check(self.lib.suo_net_forward(S["net"]._h, P(self.img[k]), 0, 480, 640, P(self.boxes[k]), L, None, P(S["uv"]),
-                                                     P(S["cov"]), P(S["kp"]), None, None, S["stream"]), "suo_net_forward")
-            self._lib.check(self.lib.suo_keypoint_masks(P(S["uv"]), P(S["cov"]), P(S["kp"]), P(self.mm[k]), L, 0.9, 0.2, P(S["mask"]),
-                                                        S["stream"]), "suo_keypoint_masks")
+            self.fwd_pending += 1
+            self.last_k = k
+            if self.fwd_pending == self.F:
+                self.forward_group(k // self.F)
         if self.only == "cnn":
             return
         self.pending.append(i)
         if len(self.pending) >= self.geom_batch:
             self.flush()
 
+    def forward_group(self, g):
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        S = self.slots[self.n_forward % self.depth]
+        self.n_forward += 1
+        LF = self.L * self.F
+        self._lib.check(self.lib.suo_net_forward_frames(S["net"]._h, P(self.imgs), 0, 480, 640, P(self.g_boxes[g]), P(self.g_img[g]), LF, None,
+                                                        P(S["uv"]), P(S["cov"]), P(S["kp"]), None, None, S["stream"]), "suo_net_forward_frames")
+        self._lib.check(self.lib.suo_keypoint_masks(P(S["uv"]), P(S["cov"]), P(S["kp"]), P(self.g_mm[g]), LF, 0.9, 0.2, P(S["mask"]),
+                                                    S["stream"]), "suo_keypoint_masks")
+        self.fwd_pending = 0
+
     def flush(self):
         """Geometry for the pending frames: ONE PnP launch (a wave per object) and ONE LM launch (a workgroup per
         frame) for the whole group -- frames are independent, so their problems batch like their crops do."""
+        if self.fwd_pending > 0:             # tail of the stream: a last (partially filled) network call
+            self.forward_group(self.last_k // self.F)
         if not self.pending:
             return
         frames = [self.pool[i % len(self.pool)] for i in self.pending]
@@ -223,7 +246,7 @@ def main():
     L = args.objects
     # frames shard embarrassingly: rank r processes its own stream (weak scaling: K frames per GPU)
     pool = make_pool(np.random.default_rng(1000 + rank), args.pool, L)
-    pipe = FramePipeline(L, pool, use_graph=not args.no_graph, only=args.only, depth=args.depth, geom_batch=args.geom_batch)
+    pipe = FramePipeline(L, pool, use_graph=not args.no_graph, only=args.only, depth=args.depth, geom_batch=args.geom_batch, frames_per_forward=args.frames_per_forward)
 
     def barrier():
         torch.cuda.synchronize()
@@ -254,7 +277,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> RoI crop, hourglass keypoint "
                                    "CNN fp32, decode, masks, batched PnP, LM rounds [10,10,40,40]" % L,
-                       "objects_per_frame": L, "crops_per_s": round(fps * L, 2), "frames_per_gpu": args.steps, "frames_in_flight": args.depth, "geometry_frames_per_launch": args.geom_batch,
+                       "objects_per_frame": L, "crops_per_s": round(fps * L, 2), "frames_per_gpu": args.steps, "frames_per_forward": args.frames_per_forward, "forwards_in_flight": args.depth, "geometry_frames_per_launch": args.geom_batch,
                        "geometry_inputs": "projected GT keypoints + N(0,0.01^2) NDC noise, 5% outliers (debug_gt_kp mode)",
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "cnn_tflops": round(fps * L * GFLOP_PER_CROP / 1e3, 2),

@@ -54,6 +54,12 @@ int suo_net_forward(suo_net* net, const void* img_dev, int img_format, int H, in
                     const float* priors_dev, float* uv_dev, float* cov_dev, float* kp_mask_dev,
                     float* kp_mask_logits_dev, float* prob_logits_dev, void* stream);
 
+/* Several independent frames in one call (they batch like crops do): imgs_dev is a contiguous stack of frames
+ * [B,H,W,3] uint8 (or [B,3,H,W] float32), box_img_dev[l] the frame index of crop l; everything else as above. */
+int suo_net_forward_frames(suo_net* net, const void* imgs_dev, int img_format, int H, int W, const float* boxes_dev,
+                           const int* box_img_dev, int L, const float* priors_dev, float* uv_dev, float* cov_dev,
+                           float* kp_mask_dev, float* kp_mask_logits_dev, float* prob_logits_dev, void* stream);
+
 /* Backbone only (HourglassNet.forward, lib/models/hg.py:95-119): staged NHWC input [L,256,256,48]
  * (44 channels zero padded to 48; NULL = re-use the input staged by the previous call) -> logits
  * [L,41,64,64] NCHW (may be NULL).  Test / profiling entry for the conv stack. */

@@ -402,6 +402,10 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
     const long px = (long)a.L * a.OH * a.OW;
     if (px <= 4096 && (a.C == 128 || a.C == 64 || a.C == 32)) return launch_conv3x3_small(a, s);
     const long t128 = ((px + 127) / 128) * (a.N / 64);
+    static const int force = getenv("SUO_CONV3_CFG") ? atoi(getenv("SUO_CONV3_CFG")) : 0;     // tuning aid only
+    if (force == 1) return launch_conv_cfg<3, 1, 32, 8, 8, 1, 1, 2, 2>(a, s);
+    if (force == 2 && (a.N % 128) == 0) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 2, 2, 2>(a, s);
+    if (force == 3) return launch_conv_cfg<3, 1, 32, 8, 16, 1, 1, 4, 2>(a, s);
     if (a.OH >= 8 && a.OW >= 16 && t128 >= 384) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 1, 2, 2>(a, s);
     const long t64 = ((px + 63) / 64) * (a.N / 64);
     if (a.OH >= 8 && a.OW >= 8 && t64 >= 256) return launch_conv_cfg<3, 1, 32, 8, 8, 1, 1, 2, 2>(a, s);

@@ -113,9 +113,13 @@ __device__ __forceinline__ void bilinear3(const void* __restrict__ img, int H, i
 }
 
 template <int FMT>
-__global__ void roi_align_concat_kernel(const void* __restrict__ img, int H, int W, const float* __restrict__ boxes,
-                                        const float* __restrict__ priors, float* __restrict__ out) {
+__global__ void roi_align_concat_kernel(const void* __restrict__ img0, int H, int W, const float* __restrict__ boxes,
+                                        const int* __restrict__ box_img, const float* __restrict__ priors, float* __restrict__ out) {
     const int l = blockIdx.y;
+    // several frames per launch: crop l samples image box_img[l] of a contiguous [B,H,W,3] (or [B,3,H,W]) stack
+    const size_t img_elems = (size_t)H * W * 3;
+    const void* img = box_img ? (FMT == 0 ? (const void*)((const uint8_t*)img0 + box_img[l] * img_elems)
+                                          : (const void*)((const float*)img0 + box_img[l] * img_elems)) : img0;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. 65535
     const int ph = p >> 8, pw = p & 255;
     const float x1 = boxes[l * 4 + 0], y1 = boxes[l * 4 + 1], x2 = boxes[l * 4 + 2], y2 = boxes[l * 4 + 3];
@@ -147,13 +151,13 @@ __global__ void roi_align_concat_kernel(const void* __restrict__ img, int H, int
     for (int i = 0; i < IN_C / 4; ++i) ((f32x4*)o)[i] = v[i];
 }
 
-int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, int L, const float* priors,
-                            float* out, hipStream_t s) {
+int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L,
+                            const float* priors, float* out, hipStream_t s) {
     if (L <= 0 || H <= 1 || W <= 1) { suo_set_error("roi_align: bad shape"); return SUO_ERR_ARG; }
     if (fmt == 0)
-        hipLaunchKernelGGL(roi_align_concat_kernel<0>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, priors, out);
+        hipLaunchKernelGGL(roi_align_concat_kernel<0>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, box_img, priors, out);
     else if (fmt == 1)
-        hipLaunchKernelGGL(roi_align_concat_kernel<1>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, priors, out);
+        hipLaunchKernelGGL(roi_align_concat_kernel<1>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, box_img, priors, out);
     else { suo_set_error("roi_align: unknown image format %d", fmt); return SUO_ERR_ARG; }
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;

@@ -397,7 +397,7 @@ int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStre
     return SUO_OK;
 }
 
-int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, int L, const float* priors, float* uv, float* cov,
+int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const float* priors, float* uv, float* cov,
                  float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s) {
     if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_forward: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
     const bool own = (s == nullptr);
@@ -408,7 +408,7 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, int
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
         ws_mark_ = ws_used_;
-        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, L, priors, in0, s));
+        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, priors, in0, s));
         SUO_TRY(run_backbone(in0, logits, L, s));
         SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, s));
         SUO_LAUNCH(launch_classifier(d_mean_logit_, cls_w_, cls_b_, L, kp_logit, kp_prob, s));

@@ -124,6 +124,26 @@ class PkpNet:
 
     __call__ = forward
 
+    def forward_frames(self, images, boxes_per_frame):
+        """Several independent frames in one call: images uint8 [B,H,W,3], boxes_per_frame list of B arrays [L_b,4].
+        Returns the same dict with the crops of all frames concatenated in frame order."""
+        assert self._h is not None, "load_state_dict first"
+        dev = self.device
+        imgs = torch.as_tensor(images).to(dev).contiguous()
+        assert imgs.dtype == torch.uint8 and imgs.dim() == 4 and imgs.shape[3] == 3 and imgs.shape[0] == len(boxes_per_frame)
+        bx = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in boxes_per_frame]).to(dev).contiguous()
+        idx = torch.cat([torch.full((len(b),), i, dtype=torch.int32) for i, b in enumerate(boxes_per_frame)]).to(dev).contiguous()
+        L = int(bx.shape[0])
+        uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
+        cov = torch.empty((L, NUM_KP, 2, 2), dtype=torch.float32, device=dev)
+        kpm = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+        kpl = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+        logits = torch.empty((L, NUM_KP, HEAT, HEAT), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().suo_net_forward_frames(self._h, _ptr(imgs), 0, int(imgs.shape[1]), int(imgs.shape[2]), _ptr(bx), _ptr(idx), L,
+                                                     None, _ptr(uv), _ptr(cov), _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()),
+                   "suo_net_forward_frames")
+        return {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
+
 
 def keypoint_masks(uv, cov, kp_mask, model_kps_masks, bbox_thresh=0.9, kp_var_thresh=0.2):
     """Device version of the mask logic at lib/object_slam.py:1100-1115 -> uint8 [L,41]."""

@@ -193,6 +193,26 @@ def test_full_network_golden(ops, cnn_golden, state_dict):
         assert rel < 2e-4, rel   # 186 fp32 conv layers deep; observed ~1e-5
 
 
+def test_forward_frames_equals_per_frame_calls(ops, state_dict):
+    """Two frames in one call (crops of both frames batched) == two single-frame calls.  Not bit for bit: the
+    tile / split-K configuration is chosen from the number of pixels in the launch, so accumulation order differs."""
+    from suo_slam_amd.pkpnet import PkpNet
+    rng = np.random.default_rng(33)
+    imgs = (rng.uniform(0, 1, (2, 480, 640, 3)) * 255).astype(np.uint8)
+    boxes = [np.array([[100, 80, 300, 290], [350.5, 100.25, 600, 400]], np.float32), np.array([[10, 200, 130, 330]], np.float32)]
+    net = PkpNet(state_dict=state_dict, max_crops=4)
+    both = net.forward_frames(imgs, boxes)
+    off = 0
+    for f in range(2):
+        one = net(imgs[f], [torch.from_numpy(boxes[f])], None)
+        n = len(boxes[f])
+        lg = one["prob_logits"]
+        assert float((both["prob_logits"][off:off + n] - lg).abs().max() / lg.abs().max()) < 1e-4
+        for key in ("uv", "cov", "kp_mask"):
+            assert float((both[key][off:off + n] - one[key]).abs().max()) < 1e-4, (f, key)
+        off += n
+
+
 def test_forward_matches_oracle_end_to_end(ops, state_dict):
     """uint8 frame + boxes -> uv/cov/kp_mask: HIP vs the CPU oracle on the same seeded inputs."""
     from oracle import cnn_oracle as O
