@@ -192,9 +192,17 @@ def conv_roofline(L, iters=30):
     us = e0.elapsed_time(e1) * 1e3 / iters
     flop = 2.0 * L * 64 * 64 * 128 * 128 * 9
     ach = flop / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": "convk_kernel<3,1,32,...> 3x3 128->128 @64x64", "achieved": round(ach, 2),
-            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
-            "avg_launch_us": round(us, 2), "flop_per_launch": flop}
+    # HBM traffic per launch: rocprofv3 --pmc passes of this same kernel / launch shape (FETCH_SIZE doubled as the
+    # microarch guide prescribes for gfx950, WRITE_SIZE as reported), stored by tools/collect_pmc.sh under profiles/
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_conv.json")
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        if rec.get("crops_per_launch") == L:
+            traffic = rec.get("hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": "convk_kernel<3,1,32,8,16,2,2,2,2> 3x3 128->128 @64x64, %d crops/launch" % L,
+            "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4),
+            "traffic": traffic, "avg_launch_us": round(us, 2), "flop_per_launch": flop}
 
 
 def cpu_baseline(pool, L):
@@ -285,11 +293,11 @@ def main():
             "pose_check": {"mean_rel_translation_err": round(pose_err / max(n_pose, 1), 5), "poses": int(n_pose), "inlier_edges": int(n_inl)},
         }
         if world == 1:
-            line["roofline"] = conv_roofline(L)
+            line["roofline"] = conv_roofline(L * args.frames_per_forward)      # the launch shape of the timed region
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(pool, L)
         else:
-            line["roofline"] = conv_roofline(L)
+            line["roofline"] = conv_roofline(L * args.frames_per_forward)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

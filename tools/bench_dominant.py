@@ -6,5 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-r = bench.conv_roofline(8, iters=n)
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+r = bench.conv_roofline(L, iters=n)
 print(r)
