@@ -157,3 +157,37 @@ def test_network_path_runs_and_masks_match_oracle(state_dict):
     near = (np.abs(kp - 0.3) < 1e-3) | (np.abs(np.abs(uv).max(-1) - 1.0) < 1e-3) | (np.abs(np.sqrt(cov[..., [0, 1], [0, 1]]) - 1.0).min(-1) < 1e-3)
     assert np.array_equal(got[~near], ref_mask[~near])
     assert set(slam.collect_results()[0]["poses"].keys()) == set(fr["obj_ids"])
+
+
+def test_symmetric_objects_get_prior_heatmaps_through_the_network(state_dict):
+    """SLAM pass B (object_slam.py:486-519): a symmetric object with a map pose gets a rendered prior that is fed
+    to the network as the 41 extra input channels.  Random weights: only the plumbing and the effect of the prior
+    on the logits are checked (prior given != prior omitted; zero prior == omitted)."""
+    import torch
+    from suo_slam_amd.object_slam import ObjectSLAM, make_prior_kp_input
+    from suo_slam_amd.pkpnet import PkpNet
+    rng = np.random.default_rng(12)
+    fr = S.make_frame(rng, 2, noise=0.0)
+    mesh_db = {o: {"diameter": float(fr["diameter"][i]), "is_symmetric": True} for i, o in enumerate(fr["obj_ids"])}
+    slam = ObjectSLAM(None, mesh_db, state_dict=state_dict, max_crops=4, kp_var_thresh=0.5, bbox_thresh=1.0)
+    # seed the map as if a first view had initialised the objects
+    slam.cam_poses[0] = np.eye(4)[:3]
+    slam.view_ids.append(0)
+    slam.detections[0] = {}
+    for k, o in enumerate(fr["obj_ids"]):
+        slam.obj_poses[o] = fr["T_OtoC"][k].copy()
+    slam.process_view(1, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"],
+                      fr["model_kps_masks"], fr["model_kps_masks"], cam_pose=np.eye(4)[:3])
+    for k, o in enumerate(fr["obj_ids"]):
+        pu = slam.detections[1][o]["prior_uv"]
+        assert pu is not None
+        gt_uv = geo.project_ndc(fr["K_bbox"][k], fr["T_OtoC"][k], fr["model_kps"][k].astype(np.float64))[0]
+        m = fr["model_kps_masks"][k]
+        np.testing.assert_allclose(pu[m], gt_uv[m], atol=1e-5)        # projected map pose == GT projection here
+    net = PkpNet(state_dict=state_dict, max_crops=2)
+    pri = np.stack([make_prior_kp_input(slam.detections[1][o]["prior_uv"], fr["model_kps_masks"][k], (256, 256)) for k, o in enumerate(fr["obj_ids"])])
+    bx = [torch.from_numpy(fr["boxes"])]
+    a = net(fr["image"], bx, [torch.from_numpy(pri)])["prob_logits"]
+    b = net(fr["image"], bx, None)["prob_logits"]
+    c = net(fr["image"], bx, [torch.zeros(2, 41, 256, 256)])["prob_logits"]
+    assert torch.equal(b, c) and float((a - b).abs().max()) > 1e-3
