@@ -138,6 +138,25 @@ int suo_optimize(suo_ba_problem* problem);
 /* many independent problems (frames) in one launch, one workgroup each */
 int suo_optimize_batch(suo_ba_problem* problems, int n_problems);
 
+/* ---- phase-wise bundle adjustment for the multi-GPU global pose graph ------------------------
+ * Cameras are partitioned across GPUs; each rank builds a context over ITS cameras' edges and ALL objects, and
+ * a host driver (suo_slam_amd/ba_dist.py) runs g2o's LM schedule with two all-reduces per trial (RCCL):
+ *   suo_ba_linearize   -> [chi2_local | (Hoo 21 + bo 6) per object | max diag Hcc]         (sum / max over ranks)
+ *   suo_ba_schur       -> [S_g (ns x ns) | r_g (ns) | ok]   S_g = sum_c Hco^T (Hcc + lambda I)^-1 Hco  (sum)
+ *   suo_ba_solve_update(in = [Hoo+bo totals | S_total | r_total]) -> [chi2_local | scale_cams | scale_objs | ok]
+ *   suo_ba_restore      = pop() after a rejected trial;  suo_ba_classify = chi2 re-classification of own edges.
+ * ns = 6 * (#free objects) <= 96. */
+typedef struct suo_ba_ctx suo_ba_ctx;
+int suo_ba_ctx_create(suo_ba_problem* local_problem, suo_ba_ctx** out);
+void suo_ba_ctx_destroy(suo_ba_ctx* ctx);
+int suo_ba_ctx_ns(const suo_ba_ctx* ctx);
+int suo_ba_classify(suo_ba_ctx* ctx, int keep_all, double* num_good_local);
+int suo_ba_linearize(suo_ba_ctx* ctx, int robust_on, double* out);
+int suo_ba_schur(suo_ba_ctx* ctx, double lambda, double* out);
+int suo_ba_solve_update(suo_ba_ctx* ctx, double lambda, int robust_on, const double* in, double* out);
+int suo_ba_restore(suo_ba_ctx* ctx);
+int suo_ba_ctx_download(suo_ba_ctx* ctx, suo_ba_problem* local_problem);
+
 #ifdef __cplusplus
 }
 #endif

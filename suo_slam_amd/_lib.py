@@ -48,6 +48,15 @@ SIGNATURES = {
     "suo_pnp": (C.c_int, [VP, VP, C.c_int, C.c_double, VP]),
     "suo_optimize": (C.c_int, [VP]),
     "suo_optimize_batch": (C.c_int, [VP, C.c_int]),
+    "suo_ba_ctx_create": (C.c_int, [VP, C.POINTER(VP)]),
+    "suo_ba_ctx_destroy": (None, [VP]),
+    "suo_ba_ctx_ns": (C.c_int, [VP]),
+    "suo_ba_classify": (C.c_int, [VP, C.c_int, VP]),
+    "suo_ba_linearize": (C.c_int, [VP, C.c_int, VP]),
+    "suo_ba_schur": (C.c_int, [VP, C.c_double, VP]),
+    "suo_ba_solve_update": (C.c_int, [VP, C.c_double, C.c_int, VP, VP]),
+    "suo_ba_restore": (C.c_int, [VP]),
+    "suo_ba_ctx_download": (C.c_int, [VP, VP]),
 }
 
 

@@ -20,6 +20,13 @@ int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const doub
 int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
+int launch_ba_init(const void* P, hipStream_t s);
+int launch_ba_classify(const void* P, int keep_all, double* out, hipStream_t s);
+int launch_ba_linearize(const void* P, int robust_on, double* out, hipStream_t s);
+int launch_ba_schur(const void* P, double lambda, int ns, double* out, hipStream_t s);
+int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, hipStream_t s);
+int launch_ba_restore(const void* P, hipStream_t s);
+int launch_ba_finalize(const void* P, hipStream_t s);
 
 // PnpParams::get_iterations (thirdparty/lambdatwist/parameters.h:76-102), evaluated on the host so the
 // kernel's adaptive iteration count uses the same libm as the reference would.
@@ -87,6 +94,16 @@ struct LmProblemHost {
     int* obj_slot; int* stats;
 };
 
+struct Prep {
+    std::vector<int> order, edge_pair, pair_cam, pair_obj, pair_start, cam_ptr, cam_idx, obj_ptr, obj_idx;
+    size_t o[40];
+};
+struct Staged {
+    std::vector<Prep> prep;
+    size_t o_structs = 0, in_end = 0, out_end = 0;
+    int lds_need = 0;
+};
+
 }  // namespace suo
 
 using namespace suo;
@@ -142,17 +159,13 @@ int suo_pnp(const double* xs, const double* ys, int n, double threshold, double*
     return suo_pnp_batch(1, &n, xs, ys, threshold, 0, 1, T_out, &st, nullptr, nullptr);
 }
 
-int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
-    if (n_prob <= 0) return SUO_OK;
-    if (!probs) { suo_set_error("suo_optimize_batch: null argument"); return SUO_ERR_ARG; }
-    std::lock_guard<std::mutex> lock(g_arena.mu);
-    struct Prep {
-        std::vector<int> order, edge_pair, pair_cam, pair_obj, pair_start, cam_ptr, cam_idx, obj_ptr, obj_idx;
-        size_t o[40];
-    };
-    std::vector<Prep> prep(n_prob);
+// host prep (sort edges by (camera, object) pair, CSR) + arena layout + H2D of one batch of problems
+static int stage_problems(suo_ba_problem* probs, int n_prob, Arena& A, Staged& st) {
+    st.prep.assign(n_prob, Prep());
+    std::vector<Prep>& prep = st.prep;
     Layout L;
     const size_t o_structs = L.take(sizeof(LmProblemHost) * (size_t)n_prob);
+    st.o_structs = o_structs;
     if (sizeof(LmProblemHost) != lm_problem_struct_size()) { suo_set_error("LmProblem layout mismatch"); return SUO_ERR_ARG; }
     size_t in_end = 0;
     for (int i = 0; i < n_prob; ++i) {
@@ -227,10 +240,12 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         o[33] = L.take(sizeof(double) * 6 * C); o[34] = L.take(sizeof(double) * 6 * O); o[35] = L.take(sizeof(int) * O);
         o[36] = L.take(sizeof(double) * 29 * E);
     }
-    int rc = g_arena.ensure(L.off);
+    st.in_end = in_end;
+    st.out_end = out_end;
+    int rc = A.ensure(L.off);
     if (rc != SUO_OK) return rc;
-    char* h = g_arena.host;
-    char* d = g_arena.dev;
+    char* h = A.host;
+    char* d = A.dev;
     LmProblemHost* hs = (LmProblemHost*)(h + o_structs);
     for (int i = 0; i < n_prob; ++i) {
         suo_ba_problem& q = probs[i];
@@ -277,22 +292,25 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         S.Hcc_inv = (double*)(d + o[30]); S.Y = (double*)(d + o[31]); S.yc = (double*)(d + o[32]);
         S.xc = (double*)(d + o[33]); S.xo = (double*)(d + o[34]); S.obj_slot = (int*)(d + o[35]); S.stats = (int*)(d + o[18]);
     }
-    hipStream_t s = g_arena.stream;
-    SUO_HIP_CHECK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, s));
-    int lds_need = 0;
+    SUO_HIP_CHECK(hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, A.stream));
+    st.lds_need = 0;
     for (int i = 0; i < n_prob; ++i) {
         const suo_ba_problem& q = probs[i];
         int nfo = 0, nfc = 0;
         for (int o = 0; o < q.n_obj; ++o) nfo += q.obj_fixed[o] ? 0 : 1;
         for (int c = 0; c < q.n_cam; ++c) nfc += q.cam_fixed[c] ? 0 : 1;
-        lds_need = std::max(lds_need, lm_lds_bytes(q.n_cam, q.n_obj, q.n_edge, (int)prep[i].pair_cam.size(), (nfo > 0 && nfc > 0) ? nfo : 0));
+        st.lds_need = std::max(st.lds_need, lm_lds_bytes(q.n_cam, q.n_obj, q.n_edge, (int)prep[i].pair_cam.size(), (nfo > 0 && nfc > 0) ? nfo : 0));
     }
-    rc = launch_lm(d + o_structs, n_prob, lds_need, s);
-    if (rc != SUO_OK) return rc;
-    // poses + inlier flags live in the input region, chi2 + stats in the output region
-    SUO_HIP_CHECK(hipMemcpyAsync(h, d, out_end, hipMemcpyDeviceToHost, s));
-    SUO_HIP_CHECK(hipStreamSynchronize(s));
-    (void)out_begin;
+    return SUO_OK;
+}
+
+// D2H of poses / inlier flags / chi2 / stats and un-sorting into the caller's arrays
+static int fetch_results(suo_ba_problem* probs, int n_prob, Arena& A, Staged& st) {
+    char* h = A.host;
+    char* d = A.dev;
+    std::vector<Prep>& prep = st.prep;
+    SUO_HIP_CHECK(hipMemcpyAsync(h, d, st.out_end, hipMemcpyDeviceToHost, A.stream));
+    SUO_HIP_CHECK(hipStreamSynchronize(A.stream));
     for (int i = 0; i < n_prob; ++i) {
         suo_ba_problem& q = probs[i];
         Prep& P = prep[i];
@@ -313,6 +331,106 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     return SUO_OK;
 }
 
+int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
+    if (n_prob <= 0) return SUO_OK;
+    if (!probs) { suo_set_error("suo_optimize_batch: null argument"); return SUO_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    Staged st;
+    int rc = stage_problems(probs, n_prob, g_arena, st);
+    if (rc != SUO_OK) return rc;
+    rc = launch_lm(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
+    if (rc != SUO_OK) return rc;
+    return fetch_results(probs, n_prob, g_arena, st);
+}
+
 int suo_optimize(suo_ba_problem* problem) { return suo_optimize_batch(problem, 1); }
+
+// ---- phase-wise bundle adjustment context (multi-GPU global BA; driver: suo_slam_amd/ba_dist.py) ------------
+struct suo_ba_ctx {
+    Arena arena;            // the device-resident problem (private: lives across calls)
+    Staged st;
+    int n_cam = 0, n_obj = 0, ns = 0;
+    double* d_io = nullptr; double* h_io = nullptr; size_t io_doubles = 0;
+    const void* dev_problem() const { return arena.dev + st.o_structs; }
+};
+
+int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
+    if (!p || !out) { suo_set_error("suo_ba_ctx_create: null argument"); return SUO_ERR_ARG; }
+    suo_ba_ctx* c = new suo_ba_ctx();
+    int rc = stage_problems(p, 1, c->arena, c->st);
+    if (rc != SUO_OK) { delete c; return rc; }
+    c->n_cam = p->n_cam; c->n_obj = p->n_obj;
+    int nfo = 0;
+    for (int o = 0; o < p->n_obj; ++o) nfo += p->obj_fixed[o] ? 0 : 1;
+    c->ns = 6 * nfo;
+    if (nfo > 16) { suo_set_error("suo_ba_ctx_create: %d free objects exceed the reduced-system limit of 16", nfo); delete c; return SUO_ERR_ARG; }
+    c->io_doubles = 2 * ((size_t)c->ns * c->ns + c->ns + 27 * (size_t)p->n_obj + 16);
+    if (hipMalloc((void**)&c->d_io, c->io_doubles * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_io, c->io_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        suo_set_error("suo_ba_ctx_create: allocation failed"); delete c; return SUO_ERR_HIP;
+    }
+    rc = launch_ba_init(c->dev_problem(), c->arena.stream);
+    if (rc != SUO_OK) { delete c; return rc; }
+    SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
+    *out = c;
+    return SUO_OK;
+}
+
+void suo_ba_ctx_destroy(suo_ba_ctx* c) {
+    if (!c) return;
+    if (c->d_io) (void)hipFree(c->d_io);
+    if (c->h_io) (void)hipHostFree(c->h_io);
+    if (c->arena.dev) (void)hipFree(c->arena.dev);
+    if (c->arena.host) (void)hipHostFree(c->arena.host);
+    if (c->arena.stream) (void)hipStreamDestroy(c->arena.stream);
+    delete c;
+}
+
+int suo_ba_ctx_ns(const suo_ba_ctx* c) { return c ? c->ns : -1; }
+
+static int ba_fetch(suo_ba_ctx* c, double* out, size_t n) {
+    SUO_HIP_CHECK(hipMemcpyAsync(c->h_io, c->d_io, n * sizeof(double), hipMemcpyDeviceToHost, c->arena.stream));
+    SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
+    memcpy(out, c->h_io, n * sizeof(double));
+    return SUO_OK;
+}
+
+int suo_ba_classify(suo_ba_ctx* c, int keep_all, double* num_good_local) {
+    int rc = launch_ba_classify(c->dev_problem(), keep_all, c->d_io, c->arena.stream);
+    return rc != SUO_OK ? rc : ba_fetch(c, num_good_local, 1);
+}
+
+int suo_ba_linearize(suo_ba_ctx* c, int robust_on, double* out) {
+    int rc = launch_ba_linearize(c->dev_problem(), robust_on, c->d_io, c->arena.stream);
+    return rc != SUO_OK ? rc : ba_fetch(c, out, 2 + 27 * (size_t)c->n_obj);
+}
+
+int suo_ba_schur(suo_ba_ctx* c, double lambda, double* out) {
+    int rc = launch_ba_schur(c->dev_problem(), lambda, c->ns, c->d_io, c->arena.stream);
+    return rc != SUO_OK ? rc : ba_fetch(c, out, (size_t)c->ns * c->ns + c->ns + 1);
+}
+
+int suo_ba_solve_update(suo_ba_ctx* c, double lambda, int robust_on, const double* in, double* out) {
+    const size_t n_in = 27 * (size_t)c->n_obj + (size_t)c->ns * c->ns + c->ns;
+    double* h_in = c->h_io + c->io_doubles / 2;
+    double* d_in = c->d_io + c->io_doubles / 2;
+    memcpy(h_in, in, n_in * sizeof(double));
+    SUO_HIP_CHECK(hipMemcpyAsync(d_in, h_in, n_in * sizeof(double), hipMemcpyHostToDevice, c->arena.stream));
+    int rc = launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, d_in, c->d_io, c->arena.stream);
+    return rc != SUO_OK ? rc : ba_fetch(c, out, 4);
+}
+
+int suo_ba_restore(suo_ba_ctx* c) {
+    int rc = launch_ba_restore(c->dev_problem(), c->arena.stream);
+    if (rc != SUO_OK) return rc;
+    SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
+    return SUO_OK;
+}
+
+int suo_ba_ctx_download(suo_ba_ctx* c, suo_ba_problem* p) {
+    int rc = launch_ba_finalize(c->dev_problem(), c->arena.stream);
+    if (rc != SUO_OK) return rc;
+    return fetch_results(p, 1, c->arena, c->st);
+}
 
 }  // extern "C"

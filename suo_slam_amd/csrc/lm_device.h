@@ -1,0 +1,300 @@
+// Device-side building blocks of the LM / bundle-adjustment kernels (shared by csrc/lm.hip and csrc/lm_dist.hip).
+// See csrc/lm.hip for the reference citations.
+#pragma once
+#include <type_traits>
+
+#include "suo_internal.h"
+
+namespace suo {
+
+#define DEV __device__ __forceinline__
+
+constexpr int LM_THREADS = 256;
+constexpr int LM_MAX_SCHUR_OBJ = 16;                 // reduced system <= 96 x 96 doubles in LDS
+constexpr int LM_NS = 6 * LM_MAX_SCHUR_OBJ;
+
+struct Pose { double q[4]; double t[3]; };
+
+DEV void q_to_R(const double* q, double* R) {
+    const double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];
+    const double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0];
+    const double txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+    const double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+DEV void R_to_q(const double* R, double* q) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+    }
+    if (q[0] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+DEV void q_mul(const double* a, const double* b, double* o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+    o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+}
+
+DEV void pose_from_T(const double* T, Pose& p) {
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    R_to_q(R, p.q);
+    p.t[0] = T[3]; p.t[1] = T[7]; p.t[2] = T[11];
+}
+DEV void pose_to_T(const Pose& p, double* T) {
+    double R[9];
+    q_to_R(p.q, R);
+    for (int r = 0; r < 3; ++r) { T[4 * r] = R[3 * r]; T[4 * r + 1] = R[3 * r + 1]; T[4 * r + 2] = R[3 * r + 2]; T[4 * r + 3] = p.t[r]; }
+}
+
+// T <- exp([omega, upsilon]) * T
+DEV void pose_oplus(Pose& p, const double* u) {
+    const double* w = u;
+    const double* ups = u + 3;
+    const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double Om[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double Om2[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Om2[3 * r + c] = Om[3 * r] * Om[c] + Om[3 * r + 1] * Om[3 + c] + Om[3 * r + 2] * Om[6 + c];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
+        for (int i = 0; i < 9; ++i) {
+            R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+            V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
+        }
+    }
+    double eq[4], et[3];
+    R_to_q(R, eq);
+    for (int r = 0; r < 3; ++r) et[r] = V[3 * r] * ups[0] + V[3 * r + 1] * ups[1] + V[3 * r + 2] * ups[2];
+    double Re[9], nt[3], nq[4];
+    q_to_R(eq, Re);
+    for (int r = 0; r < 3; ++r) nt[r] = et[r] + Re[3 * r] * p.t[0] + Re[3 * r + 1] * p.t[1] + Re[3 * r + 2] * p.t[2];
+    q_mul(eq, p.q, nq);
+    if (nq[0] < 0) { nq[0] = -nq[0]; nq[1] = -nq[1]; nq[2] = -nq[2]; nq[3] = -nq[3]; }
+    const double n = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    for (int k = 0; k < 4; ++k) p.q[k] = nq[k] / n;
+    for (int k = 0; k < 3; ++k) p.t[k] = nt[k];
+}
+
+DEV double huber_rho(double e2, double delta, double& rho1) {
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { rho1 = 1.0; return e2; }
+    const double sq = sqrt(e2);
+    rho1 = delta / sq;
+    return 2 * sq * delta - dsqr;
+}
+
+DEV double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// deterministic workgroup sum / max (fixed order); `red` = LM_THREADS/64 doubles of LDS
+DEV double block_sum(double v, double* red) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < LM_THREADS / 64; ++i) s += red[i];
+    return s;
+}
+DEV double block_max(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int i = 1; i < LM_THREADS / 64; ++i) s = fmax(s, red[i]);
+    return s;
+}
+
+// in-place inverse of a symmetric positive definite 6x6 by Cholesky; false if not PD
+__device__ bool spd_inverse6(const double* A, double* Ainv) {
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (!(s > 0) || !isfinite(s)) return false; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    for (int c = 0; c < 6; ++c) {          // solve A x = e_c
+        double y[6], x[6];
+        for (int i = 0; i < 6; ++i) { double s = (i == c) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+        for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+        for (int i = 0; i < 6; ++i) Ainv[i * 6 + c] = x[i];
+    }
+    return true;
+}
+
+struct LmProblem {
+    // sizes
+    int n_cam, n_obj, n_edge, n_pair;
+    // poses (row-major 3x4), in/out
+    double* cam_T; double* obj_T;
+    const uint8_t* cam_fixed; const uint8_t* obj_fixed;
+    // edges, sorted by pair
+    const int* edge_pair;                    // [n_edge]
+    const double* edge_k; const double* edge_p; const double* edge_uv; const double* edge_info;
+    uint8_t* edge_inlier; double* edge_chi2; // in/out, out
+    // pairs
+    const int* pair_cam; const int* pair_obj; const int* pair_start;   // pair_start [n_pair+1]
+    const int* cam_pair_ptr; const int* cam_pair_idx;                  // CSR camera -> pairs
+    const int* obj_pair_ptr; const int* obj_pair_idx;                  // CSR object -> pairs
+    // parameters
+    int its[8]; int n_rounds; int init_with_outliers; double chi2_thr; double huber_delta;
+    // scratch (device)
+    Pose* cam; Pose* obj; Pose* cam_bak; Pose* obj_bak;
+    double* err;                 // [n_edge][2]
+    double* jac;                 // [n_edge][29]: Jc(12) Jo(12) rho'*Omega (xx,xy,yy) omega_r(2)
+    uint8_t* level;              // [n_edge]
+    double* pair_part;           // [n_pair][90]: Hcc(21) Hoo(21) Hco(36) bc(6) bo(6)
+    double* Hcc; double* bc;     // [n_cam][36], [n_cam][6]
+    double* Hoo; double* bo;     // [n_obj][36], [n_obj][6]
+    double* Hcc_inv;             // [n_cam][36]
+    double* Y;                   // [n_pair][36]  = Hcc_inv * Hco
+    double* yc;                  // [n_cam][6]    = Hcc_inv * bc
+    double* xc; double* xo;      // [n_cam][6], [n_obj][6]
+    int* obj_slot;               // [n_obj] position in the reduced system (free objects only) or -1
+    int* stats;                  // [4] rounds, LM iterations, LM trials, num_good
+};
+
+DEV bool edge_active(const LmProblem& P, int e) {
+    const int p = P.edge_pair[e];
+    return P.level[e] == 0 && !(P.cam_fixed[P.pair_cam[p]] && P.obj_fixed[P.pair_obj[p]]);
+}
+
+DEV void edge_error(const LmProblem& P, int e, double* err, double* pw_out, double* pc_out) {
+    const int p = P.edge_pair[e];
+    const Pose& cam = P.cam[P.pair_cam[p]];
+    const Pose& obj = P.obj[P.pair_obj[p]];
+    double Ro[9], Rc[9], pw[3], pc[3];
+    q_to_R(obj.q, Ro);
+    q_to_R(cam.q, Rc);
+    const double* x = P.edge_p + 3 * e;
+    for (int r = 0; r < 3; ++r) pw[r] = Ro[3 * r] * x[0] + Ro[3 * r + 1] * x[1] + Ro[3 * r + 2] * x[2] + obj.t[r];
+    for (int r = 0; r < 3; ++r) pc[r] = Rc[3 * r] * pw[0] + Rc[3 * r + 1] * pw[1] + Rc[3 * r + 2] * pw[2] + cam.t[r];
+    const double* k = P.edge_k + 4 * e;
+    err[0] = P.edge_uv[2 * e] - (k[0] * pc[0] / pc[2] + k[2]);
+    err[1] = P.edge_uv[2 * e + 1] - (k[1] * pc[1] / pc[2] + k[3]);
+    if (pw_out) { for (int r = 0; r < 3; ++r) { pw_out[r] = pw[r]; pc_out[r] = pc[r]; } }
+}
+DEV double edge_chi2(const LmProblem& P, int e, const double* err) {
+    const double* I = P.edge_info + 3 * e;
+    return err[0] * (I[0] * err[0] + I[1] * err[1]) + err[1] * (I[1] * err[0] + I[2] * err[1]);
+}
+
+// computeActiveErrors + activeRobustChi2; with_jac also stores the edge Jacobians (linearizeOplus) and the
+// Huber-weighted information / gradient factors used by constructQuadraticForm.  Threads over edges.
+DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, bool with_jac, double* red) {
+    double c = 0;
+    for (int e = threadIdx.x; e < P.n_edge; e += LM_THREADS) {
+        if (!edge_active(P, e)) continue;
+        double er[2], pw[3], pc[3];
+        edge_error(P, e, er, pw, pc);
+        P.err[2 * e] = er[0];
+        P.err[2 * e + 1] = er[1];
+        const double c2 = edge_chi2(P, e, er);
+        double w = 1.0;
+        c += robust_on ? huber_rho(c2, P.huber_delta, w) : c2;
+        if (with_jac) {
+            double Rc[9];
+            q_to_R(P.cam[P.pair_cam[P.edge_pair[e]]].q, Rc);
+            const double* k = P.edge_k + 4 * e;
+            const double PJ[6] = {-(k[0] / pc[2]), 0, k[0] * pc[0] / (pc[2] * pc[2]), 0, -(k[1] / pc[2]), k[1] * pc[1] / (pc[2] * pc[2])};
+            double PR[6];
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 3; ++cc) PR[3 * r + cc] = PJ[3 * r] * Rc[cc] + PJ[3 * r + 1] * Rc[3 + cc] + PJ[3 * r + 2] * Rc[6 + cc];
+            const double Dw[18] = {0, pw[2], -pw[1], 1, 0, 0, -pw[2], 0, pw[0], 0, 1, 0, pw[1], -pw[0], 0, 0, 0, 1};
+            const double Dc[18] = {0, pc[2], -pc[1], 1, 0, 0, -pc[2], 0, pc[0], 0, 1, 0, pc[1], -pc[0], 0, 0, 0, 1};
+            double* J = P.jac + 29 * (size_t)e;
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 6; ++cc) {
+                    J[6 * r + cc] = PJ[3 * r] * Dc[cc] + PJ[3 * r + 1] * Dc[6 + cc] + PJ[3 * r + 2] * Dc[12 + cc];            // Jc
+                    J[12 + 6 * r + cc] = PR[3 * r] * Dw[cc] + PR[3 * r + 1] * Dw[6 + cc] + PR[3 * r + 2] * Dw[12 + cc];       // Jo
+                }
+            const double* I = P.edge_info + 3 * e;
+            J[24] = w * I[0]; J[25] = w * I[1]; J[26] = w * I[2];
+            J[27] = -(I[0] * er[0] + I[1] * er[1]) * w;
+            J[28] = -(I[1] * er[0] + I[2] * er[1]) * w;
+        }
+    }
+    return block_sum(c, red);
+}
+
+// One thread per (pair, entry): entry k of [Hcc(21) | Hoo(21) | Hco(36) | bc(6) | bo(6)] summed over the pair's
+// active edges in edge order (deterministic, no cross-lane reduction).
+DEV void accumulate_pairs(const LmProblem& P) {
+    for (int idx = threadIdx.x; idx < P.n_pair * 90; idx += LM_THREADS) {
+        const int p = idx / 90, k = idx - p * 90;
+        const bool cfree = !P.cam_fixed[P.pair_cam[p]], ofree = !P.obj_fixed[P.pair_obj[p]];
+        int a_off, b_off, r, c, kind;      // kind 0: A^T O B block entry (r,c); 1: gradient entry r
+        if (k < 21) { if (!cfree) continue; kind = 0; a_off = 0; b_off = 0; int u = k; r = 0; while (u >= 6 - r) { u -= 6 - r; ++r; } c = r + u; }
+        else if (k < 42) { if (!ofree) continue; kind = 0; a_off = 12; b_off = 12; int u = k - 21; r = 0; while (u >= 6 - r) { u -= 6 - r; ++r; } c = r + u; }
+        else if (k < 78) { if (!(cfree && ofree)) continue; kind = 0; a_off = 0; b_off = 12; r = (k - 42) / 6; c = (k - 42) - r * 6; }
+        else if (k < 84) { if (!cfree) continue; kind = 1; a_off = 0; b_off = 0; r = k - 78; c = 0; }
+        else { if (!ofree) continue; kind = 1; a_off = 12; b_off = 0; r = k - 84; c = 0; }
+        double s = 0;
+        for (int e = P.pair_start[p]; e < P.pair_start[p + 1]; ++e) {
+            if (P.level[e] != 0) continue;
+            const double* J = P.jac + 29 * (size_t)e;
+            const double a0 = J[a_off + r], a1 = J[a_off + 6 + r];
+            if (kind == 0) s += (a0 * J[24] + a1 * J[25]) * J[b_off + c] + (a0 * J[25] + a1 * J[26]) * J[b_off + 6 + c];
+            else s += a0 * J[27] + a1 * J[28];
+        }
+        P.pair_part[idx] = s;
+    }
+}
+
+// solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if not PD
+__device__ bool spd_solve6(const double* A, const double* b, double* x) {
+    double L[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (!(s > 0) || !isfinite(s)) return false; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+    return true;
+}
+
+DEV void unpack_sym21(const double* s, double* A) {
+    int u = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) { A[r * 6 + c] = s[u]; A[c * 6 + r] = s[u]; ++u; }
+}
+
+}  // namespace suo

@@ -225,3 +225,25 @@ def test_too_few_edges_is_a_noop(ba):
         P[k] = P[k][:3]
     got, ref = _compare_ba(ba, P)
     assert got[4][0] == 0
+
+
+@pytest.mark.parametrize("n_cam,n_obj", [(5, 2), (12, 6)])
+def test_phase_wise_global_ba_matches_oracle_and_single_kernel(ba, n_cam, n_obj):
+    """The multi-GPU path's phase kernels (csrc/lm_dist.hip) under the host LM schedule (suo_slam_amd/ba_dist.py),
+    here with one rank: must agree with the dense oracle and with the single-kernel path (csrc/lm.hip).  The
+    2-rank exchange itself is covered on CPU with gloo (tests/test_ba_dist_gloo.py)."""
+    from suo_slam_amd import ba_dist
+    rng = np.random.default_rng(n_cam * 31 + n_obj)
+    P, obj_gt = _multi_view_scene(rng, n_cam, n_obj)
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    args = [P[k] for k in keys]
+    ref = G.optimize(*args)
+    single = ba.optimize(*args)
+    full = ba.Problem(*args)
+    ba_dist.optimize_distributed(full)
+    assert np.array_equal(full.inlier, ref[2]) and np.array_equal(full.inlier, single[2])
+    assert full.stats[0] == ref[4][0] and full.stats[3] == ref[4][3]
+    for got, want in ((full.cam_T.reshape(-1, 3, 4), ref[0]), (full.obj_T.reshape(-1, 3, 4), ref[1])):
+        for a, b in zip(got, want):
+            assert _pose_close(a, b, 1e-6, 1e-6), np.abs(a - b).max()
+    np.testing.assert_allclose(full.chi2, ref[3], rtol=1e-4, atol=1e-7)
