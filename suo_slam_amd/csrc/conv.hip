@@ -234,7 +234,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WGN, wn = w % WGN;
     const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; used for speed only), so give each
+    // XCD a contiguous run of tiles -- neighbouring tiles share halo rows / columns and then hit the same L2
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int l = bid / (tiles_x * tiles_y);
     bid -= l * tiles_x * tiles_y;
     const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
