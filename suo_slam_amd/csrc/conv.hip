@@ -47,7 +47,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm1x1_kernel(const GemmArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WGN, wn = w % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // 1-D grid, XCD-aware order (workgroup b runs on XCD b % 8): each XCD gets a contiguous run of tiles with the
+    // N-tiles of one pixel tile adjacent, so the A tile they share is fetched from HBM once and re-read from that L2
+    const int ntn = a.N / BN;
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     const int nch1 = a.K1 >> 5, nch = nch1 + (a.K2 >> 5);
     const int NB = a.N >> 5;
     const int c4 = tid & 7, r0 = tid >> 3;
@@ -196,7 +201,7 @@ template <int TM, int TN, int WGM, int WGN, bool NCHW>
 static int launch_gemm_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN;
     if (a.N % BN) { suo_set_error("gemm1x1: N=%d not a multiple of %d", a.N, BN); return SUO_ERR_ARG; }
-    dim3 grid((a.M + BM - 1) / BM, a.N / BN);
+    dim3 grid(((a.M + BM - 1) / BM) * (a.N / BN));
     hipLaunchKernelGGL((gemm1x1_kernel<TM, TN, WGM, WGN, NCHW>), grid, dim3(WGM * WGN * 64), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
