@@ -157,6 +157,17 @@ int suo_ba_solve_update(suo_ba_ctx* ctx, double lambda, int robust_on, const dou
 int suo_ba_restore(suo_ba_ctx* ctx);
 int suo_ba_ctx_download(suo_ba_ctx* ctx, suo_ba_problem* local_problem);
 
+/* ---- evaluation meter: ADD / ADD-S pose errors ------------------------------------
+ * Replaces the distance part of EvalMeter.update (lib/utils/eval_meter.py:126-155,233-242):
+ *   ADD = mean_i |T_gt p_i - T_pred p_i|,  ADD-S = mean_i min_j |T_gt p_i - T_pred p_j|   (fp32, mesh units = mm).
+ * suo_mesh_db_create uploads the model point clouds once (mesh_db[obj]["points"], lib/utils/mesh_database.py:31-40):
+ * n_pts[n_models], pts = the clouds concatenated, [sum(n_pts)][3] floats, host memory.
+ * suo_pose_errors evaluates n (model, pose pair) items in one launch set: model_index[n] into the database,
+ * T_pred / T_gt [n][12] = row-major 3x4 [R|t] (host), results add[n], adds[n] (host).  Blocking. */
+int suo_mesh_db_create(int n_models, const int* n_pts, const float* pts, void** mesh_db_out);
+void suo_mesh_db_destroy(void* mesh_db);
+int suo_pose_errors(void* mesh_db, int n, const int* model_index, const float* T_pred, const float* T_gt, float* add, float* adds);
+
 #ifdef __cplusplus
 }
 #endif
