@@ -8,6 +8,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 
 namespace suo {
@@ -20,6 +21,24 @@ const HostTensor& Net::T(const std::string& name) const {
     auto it = tensors_.find(name);
     if (it == tensors_.end()) throw std::runtime_error("missing tensor: " + name);
     return it->second;
+}
+
+// A checkpoint tensor must have exactly the shape the architecture (lib/models/hg.py:61-93, layers/Residual.py:7-18)
+// gives it: anything else would be read out of bounds or silently zero-padded.
+static void expect_shape(const Net& net, const std::string& name, std::initializer_list<int64_t> dims) {
+    const HostTensor& t = net.T(name);
+    if (t.shape.size() == dims.size() && std::equal(dims.begin(), dims.end(), t.shape.begin())) return;
+    std::string got, want;
+    for (int64_t d : t.shape) got += (got.empty() ? "" : ",") + std::to_string(d);
+    for (int64_t d : dims) want += (want.empty() ? "" : ",") + std::to_string(d);
+    throw std::runtime_error("tensor " + name + " has shape [" + got + "], expected [" + want + "]");
+}
+static void expect_bn(const Net& net, const std::string& p, int64_t c) {
+    for (const char* f : {".weight", ".bias", ".running_mean", ".running_var"}) expect_shape(net, p + f, {c});
+}
+static void expect_conv(const Net& net, const std::string& p, int64_t cout, int64_t cin, int64_t k) {
+    expect_shape(net, p + ".weight", {cout, cin, k, k});
+    expect_shape(net, p + ".bias", {cout});
 }
 
 // BN(eval) as y = x*scale + shift
@@ -139,6 +158,18 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
 }
 
 void Net::make_residual(const std::string& p, ResidualW& r) {
+    {   // Residual(cin, cout): bn[cin] conv1[cout/2,cin,1] bn1 conv2[cout/2,cout/2,3] bn2 conv3[cout,cout/2,1] (+conv4[cout,cin,1] iff cin != cout)
+        const int64_t cin = (int64_t)T(p + ".bn.weight").numel, cout = T(p + ".conv3.weight").shape.empty() ? 0 : T(p + ".conv3.weight").shape[0];
+        const int64_t h = cout / 2;
+        expect_bn(*this, p + ".bn", cin);
+        expect_conv(*this, p + ".conv1", h, cin, 1);
+        expect_bn(*this, p + ".bn1", h);
+        expect_conv(*this, p + ".conv2", h, h, 3);
+        expect_bn(*this, p + ".bn2", h);
+        expect_conv(*this, p + ".conv3", cout, h, 1);
+        if (tensors_.count(p + ".conv4.weight")) expect_conv(*this, p + ".conv4", cout, cin, 1);
+        else if (cin != cout) throw std::runtime_error("residual " + p + ": " + std::to_string(cin) + " -> " + std::to_string(cout) + " channels needs conv4");
+    }
     std::vector<float> sc, sh;
     bn_affine(*this, p + ".bn", sc, sh);
     r.cin = (int)sc.size();
@@ -154,10 +185,14 @@ void Net::make_residual(const std::string& p, ResidualW& r) {
 
 void Net::make_hourglass(const std::string& p, int n, HourglassW& h) {
     h.n = n;
+    auto check256 = [&](const ResidualW& r, const std::string& name) {
+        if (r.cin != 256 || r.cout != 256) throw std::runtime_error("residual " + name + " must be 256 -> 256 channels");
+    };
     for (int j = 0; j < 2; ++j) {
         make_residual(p + ".up1_." + std::to_string(j), h.up1[j]);
         make_residual(p + ".low1_." + std::to_string(j), h.low1[j]);
         make_residual(p + ".low3_." + std::to_string(j), h.low3[j]);
+        check256(h.up1[j], p + ".up1_"); check256(h.low1[j], p + ".low1_"); check256(h.low3[j], p + ".low3_");
     }
     if (n > 1) {
         h.inner.reset(new HourglassW());
@@ -178,6 +213,25 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
         tensors_[names[i]] = t;
     }
     const std::string b = "backbone";
+    auto expect_io = [&](const std::string& p, int cin, int cout) {
+        expect_shape(*this, p + ".bn.weight", {cin});
+        expect_shape(*this, p + ".conv3.bias", {cout});
+    };
+    expect_conv(*this, b + ".conv1_", 64, 3 + NUM_KP, 7);
+    expect_bn(*this, b + ".bn1", 64);
+    expect_io(b + ".r1", 64, 128);
+    expect_io(b + ".r4", 128, 128);
+    expect_io(b + ".r5", 128, 256);
+    for (int i = 0; i < 2; ++i) {
+        const std::string si = std::to_string(i);
+        expect_conv(*this, b + ".lin_." + si + ".0", 256, 256, 1);
+        expect_bn(*this, b + ".lin_." + si + ".1", 256);
+        expect_conv(*this, b + ".tmpOut." + si, NUM_KP, 256, 1);
+    }
+    expect_conv(*this, b + ".ll_.0", 256, 256, 1);
+    expect_conv(*this, b + ".tmpOut_.0", 256, NUM_KP, 1);
+    expect_shape(*this, "classifier.2.weight", {NUM_KP, NUM_KP});
+    expect_shape(*this, "classifier.2.bias", {NUM_KP});
     make_conv(b + ".conv1_", b + ".bn1", 16, stem_);
     make_residual(b + ".r1", r1_);
     make_residual(b + ".r4", r4_);
