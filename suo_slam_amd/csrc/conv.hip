@@ -217,9 +217,13 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 4096 && ((a.K1 | a.K2) & 15) == 0 && (a.K1 + a.K2) <= 640) return launch_gemm_small(a, s);
     // tile choice: keep >= ~2 workgroups per CU where the problem allows it
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128 > 0 ? a.N / 128 : 1);
-    if ((a.N % 128) == 0 && tiles128 >= 512) return launch_gemm_cfg<2, 2, 2, 2, false>(a, s);
     const long tiles12864 = (long)((a.M + 127) / 128) * (a.N / 64);
-    if (tiles12864 >= 384) return launch_gemm_cfg<2, 1, 2, 2, false>(a, s);
+    const int cfg = ((a.N % 128) == 0 && tiles128 >= 512) ? 1 : (tiles12864 >= 384 ? 2 : 3);      // 128x128 | 128x64 | 64x64
+    // whole tiles (every shape of this network): the persistent, branch-free kernel of csrc/gemm_persist.hip
+    static const int persist = getenv("SUO_GEMM_PERSIST") ? atoi(getenv("SUO_GEMM_PERSIST")) : 1;     // 0: A/B against the one-tile kernel
+    if (persist && a.n_valid == a.N && a.M % (cfg == 3 ? 64 : 128) == 0) return launch_gemm_persist(a, cfg, s);
+    if (cfg == 1) return launch_gemm_cfg<2, 2, 2, 2, false>(a, s);
+    if (cfg == 2) return launch_gemm_cfg<2, 1, 2, 2, false>(a, s);
     return launch_gemm_cfg<1, 1, 2, 2, false>(a, s);
 }
 

@@ -324,7 +324,8 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
 int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx) {
     const int C = 256;
     const size_t n_hi = (size_t)L * H * W * C, n_lo = n_hi / 4;
-    hipStream_t side = side_[depth_idx % kNumSide];
+    static const bool serial = getenv("SUO_SERIAL") != nullptr;     // profiling aid: one stream, kernels back to back
+    hipStream_t side = serial ? s : side_[depth_idx % kNumSide];
     hipEvent_t ev_fork = ev_[(ev_next_++) % kNumEvents], ev_join = ev_[(ev_next_++) % kNumEvents];
     float* up_a = alloc(n_hi);
     float* up_b = alloc(n_hi);

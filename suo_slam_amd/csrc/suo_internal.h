@@ -56,6 +56,7 @@ struct ConvArgs {
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_small(const ConvArgs& a, hipStream_t s);
 int launch_gemm_small(const GemmArgs& a, hipStream_t s);
+int launch_gemm_persist(const GemmArgs& a, int cfg, hipStream_t s);    // cfg 1: 128x128, 2: 128x64, 3: 64x64 tiles
 int launch_conv7x7s2(const ConvArgs& a, hipStream_t s);
 
 int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);

@@ -61,6 +61,49 @@ def test_conv1x1_fused_prologue_dual_residual_relu(ops):
     assert _rel(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("M,K1,K2,N,pro,res,relu", [
+    (131072, 128, 0, 256, False, True, False),     # 128x128 tiles, 2048 tiles over 512 persistent workgroups (4 each)
+    (66048, 256, 0, 128, True, False, True),       # 128x128 tiles, 516 tiles over 512 workgroups: uneven lists, no XCD split
+    (65536, 256, 64, 256, False, True, False),     # dual operand with a 2-chunk tail (re-injection shape)
+    (65536, 64, 64, 128, False, False, False),     # 2 + 2 chunks per tile
+    (32768, 256, 0, 128, True, False, True),       # 128x64 tiles, one tile per workgroup
+    (33152, 128, 0, 128, False, True, False),      # 128x64 tiles, 518 tiles (not a multiple of 8)
+    (8192, 256, 0, 128, True, False, True),        # 64x64 tiles
+    (8256, 32, 0, 64, False, True, True),          # single-chunk tiles: every step is a tile boundary; 129 tiles
+    (4160, 64, 0, 64, False, False, False),        # 65 tiles: odd count, fewer than the resident workgroups
+])
+def test_conv1x1_persistent_tile_walk(ops, M, K1, K2, N, pro, res, relu):
+    """Whole-tile shapes take the persistent kernel (csrc/gemm_persist.hip): tile lists per workgroup, the two-step
+    prefetch across tile boundaries and the parked fetch cursor at the tail must not change a single output."""
+    rng = np.random.default_rng(M % 1000 + K1 + N)
+    a1 = rng.standard_normal((M, K1)).astype(np.float32)
+    w1 = (rng.standard_normal((N, K1)) / np.sqrt(K1 + K2)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    kw, ref = {}, None
+    act = a1.astype(np.float64)
+    if pro:
+        sc, sh = rng.uniform(0.5, 1.5, K1).astype(np.float32), rng.standard_normal(K1).astype(np.float32)
+        kw["pro"] = (sc, sh)
+        act = np.maximum(act * sc + sh, 0)
+    ref = act @ w1.T.astype(np.float64) + b
+    if K2:
+        a2 = rng.standard_normal((M, K2)).astype(np.float32)
+        w2 = (rng.standard_normal((N, K2)) / np.sqrt(K1 + K2)).astype(np.float32)
+        kw.update(a2=ops.dev(a2), w2=w2)
+        ref += a2.astype(np.float64) @ w2.T
+    if res:
+        r = rng.standard_normal((M, N)).astype(np.float32)
+        kw["res"] = ops.dev(r)
+        ref += r
+    if relu:
+        ref = np.maximum(ref, 0)
+    out = ops.conv1x1(ops.dev(a1), w1, b, relu=relu, **kw).cpu().numpy()
+    assert _rel(out, ref) < 5e-6
+    # per-row check as well: a mis-assigned tile would hide in a global norm only if it were tiny, never in a row max
+    bad = np.abs(out - ref).max(1) > 1e-3 * (1 + np.abs(ref).max())
+    assert not bad.any(), np.flatnonzero(bad)[:8]
+
+
 def test_conv1x1_nchw_head(ops):
     rng = np.random.default_rng(8)
     L, hw, K, N = 2, 4096, 256, 41
