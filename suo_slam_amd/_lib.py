@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsuo_hip.so")
+LIB_PATH = os.environ.get("SUO_HIP_LIB") or os.path.join(HERE, "libsuo_hip.so")      # SUO_HIP_LIB: kernel-tuning variants only
 
 _lib = None
 

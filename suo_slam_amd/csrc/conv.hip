@@ -21,6 +21,13 @@
 
 #include "suo_internal.h"
 
+#ifndef SUO_CONV_SCALAR_WAVE
+#define SUO_CONV_SCALAR_WAVE 1
+#endif
+#ifndef SUO_GEMM_SCALAR_WAVE
+#define SUO_GEMM_SCALAR_WAVE 1
+#endif
+
 namespace suo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +52,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm1x1_kernel(const GemmArgs a
     static_assert(BM * 8 % NT == 0, "staging must divide evenly");
     __shared__ __attribute__((aligned(16))) float As[2][BM * PK];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = SUO_GEMM_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);     // wave index as an SGPR
     const int wm = w / WGN, wn = w % WGN;
     // 1-D grid, XCD-aware order (workgroup b runs on XCD b % 8): each XCD gets a contiguous run of tiles with the
     // N-tiles of one pixel tile adjacent, so the A tile they share is fetched from HBM once and re-read from that L2
@@ -240,7 +248,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
     constexpr int NF4 = NPIX * C4, NLD = (NF4 + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float As[2][NPIX * PK];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // Wave index as an SGPR: the weight addresses and tile offsets derived from it become scalar, which frees 50-70
+    // VGPRs (120 + 16 instead of 192).  Not for the 2x2-tile configuration: there the scalarised addresses let hipcc
+    // hoist more loads and the allocation jumps from 136 + 64 to 248 + 64 registers, i.e. one wave per SIMD.
+    const int w = SUO_CONV_SCALAR_WAVE && TM * TN < 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int wm = w / WGN, wn = w % WGN;
     const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; used for speed only), so give each
@@ -331,6 +343,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][t], b[s][j][t], acc[i][j]);
         }
+        // (Tried and measured, not kept: sched_group_barrier hints that request group s+1's fragments right after the
+        // first two MFMAs of group s.  hipcc then pipelines the LDS reads a full group ahead, but the 2x2 configuration
+        // grows to 256 + 68 registers = one wave per SIMD and lands on the same 113 TFLOP/s; the smaller tiles gain
+        // < 1 %.  DESIGN.md section 4.)
     };
     // All KS*KS taps of one channel chunk, fully unrolled, with a STATIC two-buffer register ring for the weights
     // (bcur / bnxt swap roles every tap; PAR = which buffer holds tap 0).  The next tap's weights are requested

@@ -31,7 +31,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
     __shared__ __attribute__((aligned(16))) float As[2][BM * PK];
     __shared__ __attribute__((aligned(16))) float Tp[WGM * WGN][32 * PK];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifndef SUO_GEMM_SCALAR_WAVE
+#define SUO_GEMM_SCALAR_WAVE 1
+#endif
+    const int w = SUO_GEMM_SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);     // wave index as an SGPR
     const int wm = w / WGN, wn = w % WGN;
     const int ntn = a.N / BN;
     const int nch1 = a.K1 >> 5, nch = nch1 + (a.K2 >> 5);
