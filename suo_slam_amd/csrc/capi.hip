@@ -86,7 +86,7 @@ int suo_keypoint_masks(const float* uv, const float* cov, const float* kp_prob, 
 }
 
 int suo_roi_align_concat(const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors, float* out, void* stream) {
-    return suo::launch_roi_align_concat(img, img_format, H, W, boxes, nullptr, L, priors, out, (hipStream_t)stream);
+    return suo::launch_roi_align_concat(img, img_format, H, W, boxes, nullptr, L, suo::IN_C, priors, out, (hipStream_t)stream);
 }
 
 int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* out) {

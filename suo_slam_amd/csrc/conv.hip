@@ -445,10 +445,12 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv7x7s2(const ConvArgs& a, hipStream_t s) {
-    if (a.OH * 2 != a.H || a.OW * 2 != a.W || (a.C & 15) || (a.N & 63)) {
+    if (a.OH * 2 != a.H || a.OW * 2 != a.W || (a.C & 7) || (a.N & 63)) {
         suo_set_error("conv7x7s2: bad shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;
     }
+    if (a.C == 8) return launch_conv_cfg<7, 2, 8, 8, 8, 1, 1, 2, 2>(a, s);       // image-only stem: 3 channels in one 8-wide chunk
+    if (a.C & 15) { suo_set_error("conv7x7s2: C=%d must be 8 or a multiple of 16", a.C); return SUO_ERR_ARG; }
     return launch_conv_cfg<7, 2, 16, 8, 8, 1, 1, 2, 2>(a, s);
 }
 

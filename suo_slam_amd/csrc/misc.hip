@@ -112,7 +112,7 @@ __device__ __forceinline__ void bilinear3(const void* __restrict__ img, int H, i
     }
 }
 
-template <int FMT>
+template <int FMT, int OUT_C>
 __global__ void roi_align_concat_kernel(const void* __restrict__ img0, int H, int W, const float* __restrict__ boxes,
                                         const int* __restrict__ box_img, const float* __restrict__ priors, float* __restrict__ out) {
     const int l = blockIdx.y;
@@ -135,29 +135,33 @@ __global__ void roi_align_concat_kernel(const void* __restrict__ img0, int H, in
         }
     }
     const float cnt = (float)(gh * gw);
-    float* o = out + ((size_t)l * CROP * CROP + p) * IN_C;
-    f32x4 v[IN_C / 4];
+    float* o = out + ((size_t)l * CROP * CROP + p) * OUT_C;
+    f32x4 v[OUT_C / 4];
 #pragma unroll
-    for (int i = 0; i < IN_C / 4; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < OUT_C / 4; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     v[0][0] = acc[0] / cnt;
     v[0][1] = acc[1] / cnt;
     v[0][2] = acc[2] / cnt;
-    if (priors) {
+    if (OUT_C >= 3 + NUM_KP && priors) {
         const float* pr = priors + (size_t)l * NUM_KP * CROP * CROP + p;
 #pragma unroll
         for (int k = 0; k < NUM_KP; ++k) v[(3 + k) >> 2][(3 + k) & 3] = pr[(size_t)k * CROP * CROP];
     }
 #pragma unroll
-    for (int i = 0; i < IN_C / 4; ++i) ((f32x4*)o)[i] = v[i];
+    for (int i = 0; i < OUT_C / 4; ++i) ((f32x4*)o)[i] = v[i];
 }
 
-int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L,
+// out_c = IN_C: [L,256,256,48] = image + priors (zeros when priors == NULL) + pad;  out_c = IMG_C: [L,256,256,16] = image + pad,
+// for the prior-less single-view pass whose 41 prior channels are structural zeros (lib/object_slam.py:1094-1097)
+int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, int out_c,
                             const float* priors, float* out, hipStream_t s) {
     if (L <= 0 || H <= 1 || W <= 1) { suo_set_error("roi_align: bad shape"); return SUO_ERR_ARG; }
-    if (fmt == 0)
-        hipLaunchKernelGGL(roi_align_concat_kernel<0>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, box_img, priors, out);
-    else if (fmt == 1)
-        hipLaunchKernelGGL(roi_align_concat_kernel<1>, dim3(CROP * CROP / 256, L), dim3(256), 0, s, img, H, W, boxes, box_img, priors, out);
+    if ((out_c != IN_C && out_c != IMG_C) || (out_c == IMG_C && priors)) { suo_set_error("roi_align: bad channel count %d", out_c); return SUO_ERR_ARG; }
+    const dim3 grid(CROP * CROP / 256, L), block(256);
+    if (fmt == 0 && out_c == IN_C) hipLaunchKernelGGL((roi_align_concat_kernel<0, IN_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
+    else if (fmt == 0) hipLaunchKernelGGL((roi_align_concat_kernel<0, IMG_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
+    else if (fmt == 1 && out_c == IN_C) hipLaunchKernelGGL((roi_align_concat_kernel<1, IN_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
+    else if (fmt == 1) hipLaunchKernelGGL((roi_align_concat_kernel<1, IMG_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
     else { suo_set_error("roi_align: unknown image format %d", fmt); return SUO_ERR_ARG; }
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;

@@ -48,18 +48,18 @@ private:
     static constexpr int kNumSide = 4, kNumEvents = 32;
     float* upload(const std::vector<float>& v);
     void make_gemm(const std::string& conv, const std::string& bn_after, const std::string& conv2, GemmW& g);
-    void make_conv(const std::string& conv, const std::string& bn_after, int CK, ConvW& c);
+    void make_conv(const std::string& conv, const std::string& bn_after, int CK, ConvW& c, int c_used = 0);
     void make_residual(const std::string& p, ResidualW& r);
     void make_hourglass(const std::string& p, int n, HourglassW& h);
     float* alloc(size_t floats);
     int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s);
     int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx);
-    int backbone(const float* in0, float* logits, int L, hipStream_t s);
-    int run_backbone(float* in0, float* logits, int L, hipStream_t s);
+    int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s);
+    int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s);
 
     std::map<std::string, HostTensor> tensors_;
     std::vector<float*> owned_;
-    ConvW stem_;
+    ConvW stem_, stem_img_;      // all 44 input channels | the 3 image channels only (no priors: SLAM_C = 16)
     ResidualW r1_, r4_, r5_, post_[2][2];
     HourglassW hg_[2];
     GemmW lin_[2], head_[2], reinject_;

@@ -142,15 +142,25 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
     g.N = Np; g.n_valid = N; g.K1 = K1p; g.K2 = K2p;
 }
 
-void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK, ConvW& c) {
+// c_used > 0: keep only the first c_used input channels of the filter (the others multiply structural zeros)
+void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK, ConvW& c, int c_used) {
     const HostTensor& w = T(conv + ".weight");
     const HostTensor& b = T(conv + ".bias");
-    const int N = (int)w.shape[0], C = (int)w.shape[1], KS = (int)w.shape[2];
+    const int N = (int)w.shape[0], Cw = (int)w.shape[1], KS = (int)w.shape[2];
+    const int C = c_used > 0 ? c_used : Cw;
     const int Np = round_up(N, 64), Cp = round_up(C, CK);
     std::vector<float> scale, shift;
     if (!bn_after.empty()) bn_affine(*this, bn_after, scale, shift);
     std::vector<float> packed(2 * (size_t)Np * Cp * KS * KS), bias(Np, 0.f);
-    pack_conv_weight(w.data, N, C, KS, Np, Cp, CK, scale.empty() ? nullptr : scale.data(), packed.data());
+    std::vector<float> sliced;
+    const float* wdata = w.data;
+    if (C != Cw) {
+        sliced.resize((size_t)N * C * KS * KS);
+        for (int n = 0; n < N; ++n)
+            memcpy(&sliced[(size_t)n * C * KS * KS], w.data + (size_t)n * Cw * KS * KS, (size_t)C * KS * KS * sizeof(float));
+        wdata = sliced.data();
+    }
+    pack_conv_weight(wdata, N, C, KS, Np, Cp, CK, scale.empty() ? nullptr : scale.data(), packed.data());
     for (int n = 0; n < N; ++n) bias[n] = scale.empty() ? b.data[n] : b.data[n] * scale[n] + shift[n];
     c.Wp = upload(packed);
     c.bias = upload(bias);
@@ -233,6 +243,10 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
     expect_shape(*this, "classifier.2.weight", {NUM_KP, NUM_KP});
     expect_shape(*this, "classifier.2.bias", {NUM_KP});
     make_conv(b + ".conv1_", b + ".bn1", 16, stem_);
+    // Without priors (every single-view pass and the first SLAM pass, lib/object_slam.py:1094-1097) the 41 prior
+    // channels are zeros: multiply only the 3 image channels.  Same taps, same order, so the result is bit-identical
+    // to feeding zero priors through the full filter; 13 % of the network's MACs (41/44 of the stem) are never issued.
+    make_conv(b + ".conv1_", b + ".bn1", IMG_C, stem_img_, 3);
     make_residual(b + ".r1", r1_);
     make_residual(b + ".r4", r4_);
     make_residual(b + ".r5", r5_);
@@ -260,7 +274,7 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
     (void)alloc((size_t)max_crops_ * CROP * CROP * IN_C);
     (void)alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
     ws_mark_ = ws_used_;
-    if (backbone(nullptr, nullptr, max_crops_, nullptr) != SUO_OK) throw std::runtime_error("dry run failed");
+    if (backbone(nullptr, IN_C, nullptr, max_crops_, nullptr) != SUO_OK) throw std::runtime_error("dry run failed");
     ws_floats_ = ws_used_;
     dry_run_ = false;
     if (hipMalloc(&ws_, ws_floats_ * sizeof(float)) != hipSuccess) throw std::runtime_error("hipMalloc(workspace) failed");
@@ -359,12 +373,13 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
 }
 
 // HourglassNet.forward (hg.py:95-119) from the staged NHWC input to NCHW logits
-int Net::backbone(const float* in0, float* logits, int L, hipStream_t s) {
+int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s) {
     ws_used_ = ws_mark_;
     ev_next_ = 0;
     float* stem = alloc((size_t)L * 128 * 128 * 64);
     ConvArgs c = {};
-    c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = IN_C; c.Wp = stem_.Wp; c.bias = stem_.bias;
+    const ConvW& sw = in_c == IMG_C ? stem_img_ : stem_;
+    c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = in_c; c.Wp = sw.Wp; c.bias = sw.bias;
     c.out = stem; c.OH = 128; c.OW = 128; c.N = 64; c.relu = 1;
     SUO_LAUNCH(launch_conv7x7s2(c, s));
     float* r1o = alloc((size_t)L * 128 * 128 * 128);
@@ -410,23 +425,24 @@ int Net::backbone(const float* in0, float* logits, int L, hipStream_t s) {
     return SUO_OK;
 }
 
-int Net::run_backbone(float* in0, float* logits, int L, hipStream_t s) {
+int Net::run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s) {
     if (use_graph_) {
-        auto it = graphs_.find(L);
+        const int key = L * 2 + (in_c == IMG_C ? 1 : 0);          // one captured graph per (crop count, staging layout)
+        auto it = graphs_.find(key);
         if (it == graphs_.end()) {
             GraphEntry ge;
             SUO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            int r = backbone(in0, logits, L, s);
+            int r = backbone(in0, in_c, logits, L, s);
             hipError_t e = hipStreamEndCapture(s, &ge.graph);
             if (r != SUO_OK) return r;
             SUO_HIP_CHECK(e);
             SUO_HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
-            it = graphs_.emplace(L, ge).first;
+            it = graphs_.emplace(key, ge).first;
         }
         SUO_HIP_CHECK(hipGraphLaunch(it->second.exec, s));
         return SUO_OK;
     }
-    return backbone(in0, logits, L, s);
+    return backbone(in0, in_c, logits, L, s);
 }
 
 // Backbone only, from an already staged NHWC [L,256,256,48] input (test / profiling entry).
@@ -441,7 +457,7 @@ int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStre
         ws_mark_ = ws_used_;
         if (in0_user)
             SUO_HIP_CHECK(hipMemcpyAsync(in0, in0_user, (size_t)L * CROP * CROP * IN_C * sizeof(float), hipMemcpyDeviceToDevice, s));
-        SUO_TRY(run_backbone(in0, logits, L, s));
+        SUO_TRY(run_backbone(in0, IN_C, logits, L, s));
         if (logits_out)
             SUO_HIP_CHECK(hipMemcpyAsync(logits_out, logits, (size_t)L * NUM_KP * HEAT * HEAT * sizeof(float), hipMemcpyDeviceToDevice, s));
     } catch (const std::exception& e) {
@@ -463,8 +479,9 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
         ws_mark_ = ws_used_;
-        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, priors, in0, s));
-        SUO_TRY(run_backbone(in0, logits, L, s));
+        const int in_c = priors ? IN_C : IMG_C;     // the slab is sized for IN_C; the prior-less layout uses a third of it
+        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, in_c, priors, in0, s));
+        SUO_TRY(run_backbone(in0, in_c, logits, L, s));
         SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, s));
         SUO_LAUNCH(launch_classifier(d_mean_logit_, cls_w_, cls_b_, L, kp_logit, kp_prob, s));
         if (logits_out)

@@ -26,6 +26,7 @@ constexpr int NUM_KP = 41;
 constexpr int HEAT = 64;          // heat-map side
 constexpr int CROP = 256;         // network input side
 constexpr int IN_C = 48;          // 3 + 41 = 44 input channels, padded to 48 in the NHWC staging buffer
+constexpr int IMG_C = 8;          // staging without priors: 3 image channels padded to one 8-channel conv chunk
 
 // ---- packed-weight geometry (B operand of v_mfma_f32_32x32x2_f32) -------------------------------
 // A GEMM weight W[N][K] (row = output channel) is stored as  Wp[K/8][N/32][64 lanes][4]  with
@@ -61,7 +62,7 @@ int launch_conv7x7s2(const ConvArgs& a, hipStream_t s);
 
 int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);
 int launch_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, hipStream_t s);
-int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L,
+int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, int out_c,
                             const float* priors, float* out, hipStream_t s);
 int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, hipStream_t s);
 int launch_classifier(const float* mean_logit, const float* Wc, const float* bc, int L,
