@@ -196,7 +196,7 @@ def conv_roofline(L, iters=30):
     flop = 2.0 * L * 64 * 64 * 128 * 128 * 9
     ach = flop / (us * 1e-6) / 1e12
     # HBM traffic per launch: rocprofv3 --pmc passes of this same kernel / launch shape (FETCH_SIZE doubled as the
-    # microarch guide prescribes for gfx950, WRITE_SIZE as reported), stored by tools/collect_pmc.sh under profiles/
+    # microarch guide prescribes for gfx950, WRITE_SIZE as reported), collected by tools/profile_round.sh, stored under profiles/
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_dominant_conv.json")
     if os.path.exists(pmc):

@@ -1,4 +1,4 @@
-"""gpurun_out/pmc/*.db (tools/collect_pmc.sh) -> profiles/pmc_dominant_conv.{json,txt}"""
+"""gpurun_out/pmc/*.db (tools/profile_round.sh) -> profiles/pmc_dominant_conv.{json,txt}"""
 import json
 import os
 import sqlite3
