@@ -60,6 +60,18 @@ int suo_net_forward_frames(suo_net* net, const void* imgs_dev, int img_format, i
                            const int* box_img_dev, int L, const float* priors_dev, float* uv_dev, float* cov_dev,
                            float* kp_mask_dev, float* kp_mask_logits_dev, float* prob_logits_dev, void* stream);
 
+/* The SLAM pass with priors (lib/object_slam.py:486-519 -> __run_kp_model): instead of the dense prior tensor that the
+ * reference renders on the host with make_prior_kp_input (lib/utils/utils.py:356-411) and uploads -- 10.7 MB per crop --
+ * pass the projected keypoints themselves: prior_uv_dev float32 [L,41,2] NDC, prior_mask_dev uint8 [L,41] (0 = channel
+ * stays zero; non-finite keypoints are skipped like utils.py:402).  The 91x91 Gaussian stamps are evaluated while the
+ * crop is staged.  box_img_dev may be NULL (all crops from frame 0).  Everything else as suo_net_forward_frames. */
+int suo_net_forward_prior_kp(suo_net* net, const void* imgs_dev, int img_format, int H, int W, const float* boxes_dev,
+                             const int* box_img_dev, int L, const float* prior_uv_dev, const uint8_t* prior_mask_dev,
+                             float* uv_dev, float* cov_dev, float* kp_mask_dev, float* kp_mask_logits_dev,
+                             float* prob_logits_dev, void* stream);
+/* make_prior_kp_input on the device: the dense [L,41,256,256] tensor the reference builds (parity / interoperability) */
+int suo_render_priors(const float* prior_uv_dev, const uint8_t* prior_mask_dev, int L, float* out_dev, void* stream);
+
 /* Backbone only (HourglassNet.forward, lib/models/hg.py:95-119): staged NHWC input [L,256,256,48]
  * (44 channels zero padded to 48; NULL = re-use the input staged by the previous call) -> logits
  * [L,41,64,64] NCHW (may be NULL).  Test / profiling entry for the conv stack. */

@@ -32,6 +32,8 @@ SIGNATURES = {
     "suo_net_workspace_bytes": (C.c_size_t, [VP]),
     "suo_net_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_net_forward_frames": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_net_forward_prior_kp": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_render_priors": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "suo_net_backbone": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "suo_decode_heatmaps": (C.c_int, [VP, C.c_int, VP, VP, VP, VP]),
     "suo_classifier": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP]),

@@ -58,13 +58,24 @@ size_t suo_net_workspace_bytes(const suo_net* net) { return net ? net->impl->wor
 int suo_net_forward(suo_net* net, const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors,
                     float* uv, float* cov, float* kp_mask, float* kp_logits, float* logits, void* stream) {
     if (!net || !img || !boxes || !uv || !cov || !kp_mask) { suo_set_error("suo_net_forward: null argument"); return SUO_ERR_ARG; }
-    return net->impl->forward(img, img_format, H, W, boxes, nullptr, L, priors, uv, cov, kp_mask, kp_logits, logits, (hipStream_t)stream);
+    return net->impl->forward(img, img_format, H, W, boxes, nullptr, L, priors, nullptr, nullptr, uv, cov, kp_mask, kp_logits, logits, (hipStream_t)stream);
 }
 
 int suo_net_forward_frames(suo_net* net, const void* imgs, int img_format, int H, int W, const float* boxes, const int* box_img, int L,
                            const float* priors, float* uv, float* cov, float* kp_mask, float* kp_logits, float* logits, void* stream) {
     if (!net || !imgs || !boxes || !box_img || !uv || !cov || !kp_mask) { suo_set_error("suo_net_forward_frames: null argument"); return SUO_ERR_ARG; }
-    return net->impl->forward(imgs, img_format, H, W, boxes, box_img, L, priors, uv, cov, kp_mask, kp_logits, logits, (hipStream_t)stream);
+    return net->impl->forward(imgs, img_format, H, W, boxes, box_img, L, priors, nullptr, nullptr, uv, cov, kp_mask, kp_logits, logits, (hipStream_t)stream);
+}
+
+int suo_net_forward_prior_kp(suo_net* net, const void* imgs, int img_format, int H, int W, const float* boxes, const int* box_img, int L,
+                             const float* prior_uv, const uint8_t* prior_mask, float* uv, float* cov, float* kp_mask, float* kp_logits,
+                             float* logits, void* stream) {
+    if (!net || !imgs || !boxes || !prior_uv || !prior_mask || !uv || !cov || !kp_mask) { suo_set_error("suo_net_forward_prior_kp: null argument"); return SUO_ERR_ARG; }
+    return net->impl->forward(imgs, img_format, H, W, boxes, box_img, L, nullptr, prior_uv, prior_mask, uv, cov, kp_mask, kp_logits, logits, (hipStream_t)stream);
+}
+
+int suo_render_priors(const float* prior_uv, const uint8_t* prior_mask, int L, float* out, void* stream) {
+    return suo::launch_render_priors(prior_uv, prior_mask, L, out, (hipStream_t)stream);
 }
 
 int suo_net_backbone(suo_net* net, const float* staged, int L, float* logits, void* stream) {
@@ -86,7 +97,7 @@ int suo_keypoint_masks(const float* uv, const float* cov, const float* kp_prob, 
 }
 
 int suo_roi_align_concat(const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors, float* out, void* stream) {
-    return suo::launch_roi_align_concat(img, img_format, H, W, boxes, nullptr, L, suo::IN_C, priors, out, (hipStream_t)stream);
+    return suo::launch_roi_align_concat(img, img_format, H, W, boxes, nullptr, L, suo::IN_C, priors, nullptr, nullptr, out, (hipStream_t)stream);
 }
 
 int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* out) {

@@ -10,6 +10,10 @@
 //   spatial_softmax / mesh_grid / post_process_kp /root/reference/lib/models/pkpnet.py:13-63
 //   classifier (ReLU, Linear, sigmoid)            /root/reference/lib/models/pkpnet.py:74-78,116-118
 //   keypoint mask logic                           /root/reference/lib/object_slam.py:1100-1115
+#include <math.h>
+
+#include <mutex>
+
 #include "suo_internal.h"
 
 namespace suo {
@@ -112,10 +116,81 @@ __device__ __forceinline__ void bilinear3(const void* __restrict__ img, int H, i
     }
 }
 
+// ---- prior heat-maps rendered on the device ------------------------------------------------------------------------
+// make_prior_kp_input / draw_gaussian_2d / gaussian_2d (/root/reference/lib/utils/utils.py:356-411): per valid keypoint a
+// 91 x 91 max-normalised Gaussian (cv2.GaussianBlur of an impulse: sigma = 0.3*((91-1)*0.5-1)+0.8 = 14, BORDER_REFLECT_101
+// doubles the outermost ring) is PASTED (assigned) with its upper-left corner at pt - 45, pt = round-half-even of the
+// keypoint's pixel position; the paste window is [pt-45, pt+45) clipped to the image, i.e. the last row / column of the
+// patch is never used.  patch[i][j] = w[i]*w[j] with w[i] = exp(-(i-45)^2 / (2 sigma^2)) * (i == 0 || i == 90 ? 2 : 1).
+// The reference renders on the host and uploads 41*256*256 floats per crop (10.7 MB); here the stamp is evaluated while
+// the crop is staged and the dense tensor never exists.
+constexpr int PRIOR_HALF = 45, PRIOR_SIZE = 2 * PRIOR_HALF + 1;
+__constant__ double c_prior_w[PRIOR_SIZE];
+
+static int ensure_prior_table() {
+    static int rc = -1;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        double w[PRIOR_SIZE];
+        const double sigma = 0.3 * ((PRIOR_SIZE - 1) * 0.5 - 1) + 0.8;
+        for (int i = 0; i < PRIOR_SIZE; ++i) {
+            const double d = (double)i - (PRIOR_SIZE - 1) / 2;
+            w[i] = exp(-(d * d) / (2 * sigma * sigma)) * ((i == 0 || i == PRIOR_SIZE - 1) ? 2.0 : 1.0);
+        }
+        rc = hipMemcpyToSymbol(HIP_SYMBOL(c_prior_w), w, sizeof(w)) == hipSuccess ? SUO_OK : SUO_ERR_HIP;
+    });
+    return rc;
+}
+
+// upper-left corner of the paste window of keypoint (u, v) in NDC on an S x S map; false if the channel stays zero
+__device__ __forceinline__ bool prior_corner(float uf, float vf, bool on, int S, int& ulx, int& uly) {
+    if (!on || !isfinite(uf) || !isfinite(vf)) return false;
+    const double u = fmin(fmax((double)uf, -1.0), 1.0) * S / 2 + S / 2 - 0.5;
+    const double v = S - 0.5 - (fmin(fmax((double)vf, -1.0), 1.0) * S / 2 + S / 2);
+    ulx = (int)rint(u) - PRIOR_HALF;           // rint: round half to even, like Python's round()
+    uly = (int)rint(v) - PRIOR_HALF;
+    return true;
+}
+__device__ __forceinline__ float prior_value(int x, int y, int ulx, int uly) {
+    const int dx = x - ulx, dy = y - uly;
+    if (dx < 0 || dy < 0 || dx >= 2 * PRIOR_HALF || dy >= 2 * PRIOR_HALF) return 0.f;
+    return (float)(c_prior_w[dy] * c_prior_w[dx]);
+}
+
+// dense [L,41,256,256] rendering (the tensor the reference builds) -- parity / interoperability entry point
+__global__ __launch_bounds__(256) void render_priors_kernel(const float* __restrict__ uv, const uint8_t* __restrict__ mask, float* __restrict__ out) {
+    const int lk = blockIdx.y;                                   // crop * 41 + keypoint
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int ulx = 0, uly = 0;
+    const bool on = prior_corner(uv[lk * 2], uv[lk * 2 + 1], mask[lk] != 0, CROP, ulx, uly);
+    out[(size_t)lk * CROP * CROP + p] = on ? prior_value(p & (CROP - 1), p >> 8, ulx, uly) : 0.f;
+}
+
+int launch_render_priors(const float* uv, const uint8_t* mask, int L, float* out, hipStream_t s) {
+    if (L <= 0 || !uv || !mask || !out) { suo_set_error("render_priors: bad argument"); return SUO_ERR_ARG; }
+    int rc = ensure_prior_table();
+    if (rc) { suo_set_error("render_priors: table upload failed"); return rc; }
+    hipLaunchKernelGGL(render_priors_kernel, dim3(CROP * CROP / 256, L * NUM_KP), dim3(256), 0, s, uv, mask, out);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
 template <int FMT, int OUT_C>
 __global__ void roi_align_concat_kernel(const void* __restrict__ img0, int H, int W, const float* __restrict__ boxes,
-                                        const int* __restrict__ box_img, const float* __restrict__ priors, float* __restrict__ out) {
+                                        const int* __restrict__ box_img, const float* __restrict__ priors,
+                                        const float* __restrict__ prior_uv, const uint8_t* __restrict__ prior_mask, float* __restrict__ out) {
     const int l = blockIdx.y;
+    __shared__ int s_ul[NUM_KP][2];
+    __shared__ unsigned char s_on[NUM_KP];
+    if (OUT_C >= 3 + NUM_KP && prior_uv) {                       // block-uniform: the 41 paste windows of this crop
+        if (threadIdx.x < NUM_KP) {
+            const int k = threadIdx.x, lk = l * NUM_KP + k;
+            int ulx = 0, uly = 0;
+            s_on[k] = prior_corner(prior_uv[lk * 2], prior_uv[lk * 2 + 1], prior_mask[lk] != 0, CROP, ulx, uly) ? 1 : 0;
+            s_ul[k][0] = ulx; s_ul[k][1] = uly;
+        }
+        __syncthreads();
+    }
     // several frames per launch: crop l samples image box_img[l] of a contiguous [B,H,W,3] (or [B,3,H,W]) stack
     const size_t img_elems = (size_t)H * W * 3;
     const void* img = box_img ? (FMT == 0 ? (const void*)((const uint8_t*)img0 + box_img[l] * img_elems)
@@ -146,6 +221,10 @@ __global__ void roi_align_concat_kernel(const void* __restrict__ img0, int H, in
         const float* pr = priors + (size_t)l * NUM_KP * CROP * CROP + p;
 #pragma unroll
         for (int k = 0; k < NUM_KP; ++k) v[(3 + k) >> 2][(3 + k) & 3] = pr[(size_t)k * CROP * CROP];
+    } else if (OUT_C >= 3 + NUM_KP && prior_uv) {
+#pragma unroll
+        for (int k = 0; k < NUM_KP; ++k)
+            v[(3 + k) >> 2][(3 + k) & 3] = s_on[k] ? prior_value(pw, ph, s_ul[k][0], s_ul[k][1]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < OUT_C / 4; ++i) ((f32x4*)o)[i] = v[i];
@@ -153,15 +232,18 @@ __global__ void roi_align_concat_kernel(const void* __restrict__ img0, int H, in
 
 // out_c = IN_C: [L,256,256,48] = image + priors (zeros when priors == NULL) + pad;  out_c = IMG_C: [L,256,256,16] = image + pad,
 // for the prior-less single-view pass whose 41 prior channels are structural zeros (lib/object_slam.py:1094-1097)
+// priors: dense [L,41,256,256] heat-maps, OR prior_uv [L,41,2] + prior_mask [L,41]: keypoints whose heat-maps are rendered here
 int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, int out_c,
-                            const float* priors, float* out, hipStream_t s) {
+                            const float* priors, const float* prior_uv, const uint8_t* prior_mask, float* out, hipStream_t s) {
     if (L <= 0 || H <= 1 || W <= 1) { suo_set_error("roi_align: bad shape"); return SUO_ERR_ARG; }
-    if ((out_c != IN_C && out_c != IMG_C) || (out_c == IMG_C && priors)) { suo_set_error("roi_align: bad channel count %d", out_c); return SUO_ERR_ARG; }
+    if ((out_c != IN_C && out_c != IMG_C) || (out_c == IMG_C && (priors || prior_uv))) { suo_set_error("roi_align: bad channel count %d", out_c); return SUO_ERR_ARG; }
+    if ((priors && prior_uv) || (prior_uv && !prior_mask)) { suo_set_error("roi_align: give dense priors OR prior keypoints + mask"); return SUO_ERR_ARG; }
+    if (prior_uv) { int rc = ensure_prior_table(); if (rc) { suo_set_error("roi_align: prior table upload failed"); return rc; } }
     const dim3 grid(CROP * CROP / 256, L), block(256);
-    if (fmt == 0 && out_c == IN_C) hipLaunchKernelGGL((roi_align_concat_kernel<0, IN_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
-    else if (fmt == 0) hipLaunchKernelGGL((roi_align_concat_kernel<0, IMG_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
-    else if (fmt == 1 && out_c == IN_C) hipLaunchKernelGGL((roi_align_concat_kernel<1, IN_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
-    else if (fmt == 1) hipLaunchKernelGGL((roi_align_concat_kernel<1, IMG_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, out);
+    if (fmt == 0 && out_c == IN_C) hipLaunchKernelGGL((roi_align_concat_kernel<0, IN_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, prior_uv, prior_mask, out);
+    else if (fmt == 0) hipLaunchKernelGGL((roi_align_concat_kernel<0, IMG_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, prior_uv, prior_mask, out);
+    else if (fmt == 1 && out_c == IN_C) hipLaunchKernelGGL((roi_align_concat_kernel<1, IN_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, prior_uv, prior_mask, out);
+    else if (fmt == 1) hipLaunchKernelGGL((roi_align_concat_kernel<1, IMG_C>), grid, block, 0, s, img, H, W, boxes, box_img, priors, prior_uv, prior_mask, out);
     else { suo_set_error("roi_align: unknown image format %d", fmt); return SUO_ERR_ARG; }
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;

@@ -36,7 +36,8 @@ class Net {
 public:
     Net(int n, const char* const* names, const float* const* data, const int64_t* const* shapes, const int* ndims, int max_crops);
     ~Net();
-    int forward(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const float* priors, float* uv, float* cov,
+    int forward(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const float* priors,
+                const float* prior_uv, const uint8_t* prior_mask, float* uv, float* cov,
                 float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s);
     int forward_staged(const float* in0_user, int L, float* logits_out, hipStream_t s);
     void set_use_graph(bool v) { use_graph_ = v; }

@@ -468,7 +468,8 @@ int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStre
     return SUO_OK;
 }
 
-int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const float* priors, float* uv, float* cov,
+int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const float* priors,
+                 const float* prior_uv, const uint8_t* prior_mask, float* uv, float* cov,
                  float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s) {
     if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_forward: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
     const bool own = (s == nullptr);
@@ -479,8 +480,8 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
         ws_mark_ = ws_used_;
-        const int in_c = priors ? IN_C : IMG_C;     // the slab is sized for IN_C; the prior-less layout uses a third of it
-        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, in_c, priors, in0, s));
+        const int in_c = (priors || prior_uv) ? IN_C : IMG_C;     // the slab is sized for IN_C; the prior-less layout uses a sixth of it
+        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, in_c, priors, prior_uv, prior_mask, in0, s));
         SUO_TRY(run_backbone(in0, in_c, logits, L, s));
         SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, s));
         SUO_LAUNCH(launch_classifier(d_mean_logit_, cls_w_, cls_b_, L, kp_logit, kp_prob, s));

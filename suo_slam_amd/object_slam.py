@@ -316,7 +316,7 @@ class ObjectSLAM:
                     full = np.zeros((m.shape[0], 2), dtype=np.float32)
                     full[m] = uvd[:, :2] / uvd[:, 2:3]
                     prior_det_uv[obj_id] = full
-                    prior_dets[obj_id] = make_prior_kp_input(full, m, self.pred_res, ndc=True)
+                    prior_dets[obj_id] = (full, m.astype(np.uint8))        # rendered on the device (pkpnet.PkpNet.forward)
         kp_det = self._run_kp_model(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt, prior_dets)
         if not self.no_network_cov:
             for det in kp_det:
@@ -364,14 +364,17 @@ class ObjectSLAM:
         if not self.debug_gt_kp:
             import torch
             from .pkpnet import keypoint_masks
-            priors = None
+            prior_uv = prior_mask = None
             if prior_dets:
-                priors_np = np.zeros([L, NUM_KP] + self.pred_res, dtype=np.float32)
+                # the reference stamps the heat-maps on the host (make_prior_kp_input) and uploads [L,41,256,256];
+                # here the projected keypoints go to the device and the stamps are rendered while the crop is staged
+                prior_uv = np.zeros((L, NUM_KP, 2), dtype=np.float32)
+                prior_mask = np.zeros((L, NUM_KP), dtype=np.uint8)
                 for k, obj_id in enumerate(obj_ids):
                     if obj_id in prior_dets:
-                        priors_np[k] = prior_dets[obj_id]
-                priors = [torch.from_numpy(priors_np)]
-            pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], priors)
+                        prior_uv[k], prior_mask[k] = prior_dets[obj_id]
+            pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None,
+                              prior_uv=prior_uv, prior_mask=prior_mask)
             if self.no_network_cov:
                 bt, vt = self.bbox_thresh, 1e30
             else:

@@ -87,7 +87,7 @@ class PkpNet:
     def workspace_bytes(self):
         return int(_lib.lib().suo_net_workspace_bytes(self._h))
 
-    def forward(self, images, boxes, prior_kp=None, want_prob=False):
+    def forward(self, images, boxes, prior_kp=None, want_prob=False, prior_uv=None, prior_mask=None):
         """images: uint8 [H,W,3] (cv2 layout) or float32 [1,3,H,W] device/host tensor; boxes: list with
         one Tensor[L,4] (xyxy); prior_kp: list with one Tensor[L,41,256,256] or None.
         Returns the reference's dict: uv, cov, prob_logits, kp_mask_logits, kp_mask (+ prob if asked)."""
@@ -108,6 +108,7 @@ class PkpNet:
         L = int(bx.shape[0])
         pr = None
         if prior_kp is not None:
+            assert prior_uv is None, "give the dense prior heat-maps OR the prior keypoints, not both"
             pr = torch.cat([torch.as_tensor(p, dtype=torch.float32) for p in prior_kp]).to(dev).contiguous()
             assert tuple(pr.shape) == (L, NUM_KP, 256, 256)
         uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
@@ -115,8 +116,16 @@ class PkpNet:
         kpm = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
         kpl = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
         logits = torch.empty((L, NUM_KP, HEAT, HEAT), dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().suo_net_forward(self._h, _ptr(img), fmt, H, W, _ptr(bx), L, _ptr(pr), _ptr(uv), _ptr(cov),
-                                              _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward")
+        if prior_uv is not None:
+            # the prior heat-maps are rendered on the device from the projected keypoints (suo_net_forward_prior_kp):
+            # prior_uv [L,41,2] NDC, prior_mask [L,41] -- what make_prior_kp_input takes per object (utils.py:398-411)
+            puv = torch.as_tensor(np.asarray(prior_uv, dtype=np.float32)).reshape(L, NUM_KP, 2).to(dev).contiguous()
+            pmk = torch.as_tensor(np.asarray(prior_mask, dtype=np.uint8)).reshape(L, NUM_KP).to(dev).contiguous()
+            _lib.check(_lib.lib().suo_net_forward_prior_kp(self._h, _ptr(img), fmt, H, W, _ptr(bx), None, L, _ptr(puv), _ptr(pmk), _ptr(uv),
+                                                           _ptr(cov), _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward_prior_kp")
+        else:
+            _lib.check(_lib.lib().suo_net_forward(self._h, _ptr(img), fmt, H, W, _ptr(bx), L, _ptr(pr), _ptr(uv), _ptr(cov),
+                                                  _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward")
         ret = {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
         if want_prob:
             ret["prob"] = torch.softmax(logits.reshape(L, NUM_KP, -1), -1).reshape(logits.shape)
@@ -143,6 +152,17 @@ class PkpNet:
                                                      None, _ptr(uv), _ptr(cov), _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()),
                    "suo_net_forward_frames")
         return {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
+
+
+def render_priors(prior_uv, prior_mask, device="cuda"):
+    """make_prior_kp_input (lib/utils/utils.py:398-411) for L objects at once, on the device: prior_uv [L,41,2] NDC,
+    prior_mask [L,41] -> float32 [L,41,256,256] (device tensor)."""
+    puv = torch.as_tensor(np.asarray(prior_uv, dtype=np.float32)).reshape(-1, NUM_KP, 2).to(device).contiguous()
+    L = int(puv.shape[0])
+    pmk = torch.as_tensor(np.asarray(prior_mask, dtype=np.uint8)).reshape(L, NUM_KP).to(device).contiguous()
+    out = torch.empty((L, NUM_KP, 256, 256), dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().suo_render_priors(_ptr(puv), _ptr(pmk), L, _ptr(out), _stream()), "suo_render_priors")
+    return out
 
 
 def keypoint_masks(uv, cov, kp_mask, model_kps_masks, bbox_thresh=0.9, kp_var_thresh=0.2):

@@ -277,3 +277,67 @@ def test_forward_matches_oracle_end_to_end(ops, state_dict):
     # priors given as zeros == priors omitted (pkpnet.py:95-97)
     out3 = net(img, [torch.from_numpy(boxes)], [torch.zeros(3, 41, 256, 256)])
     assert torch.equal(out3["prob_logits"], out["prob_logits"])
+
+
+def test_render_priors_matches_host_restatement_and_reference_windows(ops):
+    """make_prior_kp_input on the device (csrc/misc.hip) vs the host restatement (object_slam.make_prior_kp_input) and
+    vs the paste windows recorded from the REFERENCE's utils.make_prior_kp_input (tests/golden/host_golden.npz):
+    NDC->pixel, round-half-even, clipping, non-finite and masked keypoints."""
+    import os
+    from suo_slam_amd import object_slam as OS
+    from suo_slam_amd.pkpnet import render_priors
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "host_golden.npz"))
+    kp16, m16 = gold["prior_kp"], gold["prior_mask"]
+    rng = np.random.default_rng(4)
+    uv = np.zeros((3, 41, 2), np.float32)
+    mask = np.zeros((3, 41), bool)
+    uv[0, :16], mask[0, :16] = kp16, m16
+    uv[1] = rng.uniform(-1.2, 1.2, (41, 2))
+    mask[1] = rng.random(41) < 0.7
+    uv[2] = rng.uniform(-1, 1, (41, 2))
+    mask[2, ::3] = True
+    uv[2, 5] = [np.inf, 0.0]
+    out = render_priors(uv, mask).cpu().numpy()
+    assert out.shape == (3, 41, 256, 256)
+    for l in range(3):
+        host = OS.make_prior_kp_input(uv[l], mask[l], (256, 256), ndc=True)
+        assert np.abs(out[l] - host).max() <= 2.4e-7, l                      # <= 2 float32 ulp at 1.0 (exp in libm vs numpy)
+        assert np.array_equal(out[l] != 0, host != 0)
+    # the reference's windows: bounding rectangle and peak position of every stamped channel
+    def rects(x):
+        r = np.full((x.shape[0], 6), -1, np.int32)
+        for c in range(x.shape[0]):
+            ys, xs = np.nonzero(x[c])
+            if len(ys):
+                my, mx = np.unravel_index(np.argmax(x[c]), x[c].shape)
+                r[c] = [ys.min(), ys.max() + 1, xs.min(), xs.max() + 1, my, mx]
+        return r
+    assert np.array_equal(rects(out[0, :16]), gold["prior_ndc_rect"])
+    assert np.abs(out[0, :16] - gold["prior_ndc"].astype(np.float32)).max() < 1.3e-2
+
+
+def test_forward_with_prior_keypoints_equals_dense_priors(ops, state_dict):
+    """The SLAM pass: handing the projected keypoints to suo_net_forward_prior_kp gives bit-identical outputs to
+    handing the dense heat-maps (rendered by the same device code) to suo_net_forward, and matches host-rendered
+    priors to rounding."""
+    from suo_slam_amd import object_slam as OS
+    from suo_slam_amd.pkpnet import PkpNet, render_priors
+    rng = np.random.default_rng(9)
+    img = (rng.uniform(0, 1, (480, 640, 3)) * 255).astype(np.uint8)
+    boxes = np.array([[100, 80, 300, 290], [350.5, 100.25, 600, 400]], np.float32)
+    uv = rng.uniform(-0.9, 0.9, (2, 41, 2)).astype(np.float32)
+    mask = rng.random((2, 41)) < 0.4
+    net = PkpNet(state_dict=state_dict, max_crops=2)
+    a = net(img, [torch.from_numpy(boxes)], None, prior_uv=uv, prior_mask=mask)
+    dense = render_priors(uv, mask)
+    b = net(img, [torch.from_numpy(boxes)], [dense])
+    for k in ("prob_logits", "uv", "cov", "kp_mask"):
+        assert torch.equal(a[k], b[k]), k
+    host = np.stack([OS.make_prior_kp_input(uv[l], mask[l], (256, 256), ndc=True) for l in range(2)])
+    c = net(img, [torch.from_numpy(boxes)], [torch.from_numpy(host)])
+    lg = a["prob_logits"].cpu().numpy()
+    assert np.abs(lg - c["prob_logits"].cpu().numpy()).max() / np.abs(lg).max() < 1e-5
+    # priors do change the answer (the path is not silently ignoring them)
+    z = net(img, [torch.from_numpy(boxes)], None)
+    assert not torch.equal(z["prob_logits"], a["prob_logits"])
+    net.close()
