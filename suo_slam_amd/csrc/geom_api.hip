@@ -18,6 +18,7 @@ int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const doub
                      const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                      int* iters_out, hipStream_t s);
 int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
+int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
 int launch_ba_init(const void* P, hipStream_t s);
@@ -338,7 +339,12 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     Staged st;
     int rc = stage_problems(probs, n_prob, g_arena, st);
     if (rc != SUO_OK) return rc;
-    rc = launch_lm(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
+    // frame-sized graphs: 256-thread workgroups; a large graph in the batch (the global SLAM adjustment): 1024 threads
+    int max_edges = 0;
+    for (int i = 0; i < n_prob; ++i) max_edges = std::max(max_edges, probs[i].n_edge);
+    static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 1024;      // tuning aid
+    rc = max_edges >= big_from ? launch_lm_big(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream)
+                               : launch_lm(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
     if (rc != SUO_OK) return rc;
     return fetch_results(probs, n_prob, g_arena, st);
 }

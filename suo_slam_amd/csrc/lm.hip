@@ -295,34 +295,47 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                         rhs[row] -= acc;
                     }
                     __syncthreads();
-                    // workgroup Cholesky S = L L^T (lower, in place), then forward / backward substitution
-                    for (int j = 0; j < ns; ++j) {
-                        for (int i = j + tid; i < ns; i += LM_THREADS) {
-                            double s = S[i * ns + j];
-                            for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
-                            colbuf[i] = s;
+                    // Cholesky S = L L^T (lower, in place), then forward / backward substitution -- by ONE wave: the
+                    // system is at most 96 x 96 and its 5 dependent steps per column need no workgroup barrier this way
+                    // (5 * ns of them otherwise, with up to 16 waves each).  Same arithmetic per element as a
+                    // workgroup-wide version.  LDS operations of a wave complete in issue order; fences + wave barriers
+                    // pin the compiler.  (Measured: not the dominant cost of a global-BA trial -- the per-edge passes are.)
+                    if (tid < 64) {
+                        for (int j = 0; j < ns; ++j) {
+                            for (int i = j + tid; i < ns; i += 64) {
+                                double s = S[i * ns + j];
+                                for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
+                                colbuf[i] = s;
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const double piv = colbuf[j];
+                            if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
+                            const double d = sqrt(piv > 0 ? piv : 1.0);
+                            for (int i = j + tid; i < ns; i += 64) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
                         }
-                        __syncthreads();
-                        const double piv = colbuf[j];
-                        if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
-                        const double d = sqrt(piv > 0 ? piv : 1.0);
-                        for (int i = j + tid; i < ns; i += LM_THREADS) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
-                        __syncthreads();
+                        for (int j = 0; j < ns; ++j) {          // L y = rhs
+                            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const double yj = rhs[j];
+                            for (int i = j + 1 + tid; i < ns; i += 64) rhs[i] -= S[i * ns + j] * yj;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        for (int j = ns - 1; j >= 0; --j) {     // L^T x = y
+                            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const double xj = rhs[j];
+                            for (int i = tid; i < j; i += 64) rhs[i] -= S[j * ns + i] * xj;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                        }
                     }
-                    for (int j = 0; j < ns; ++j) {          // L y = rhs
-                        if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-                        __syncthreads();
-                        const double yj = rhs[j];
-                        for (int i = j + 1 + tid; i < ns; i += LM_THREADS) rhs[i] -= S[i * ns + j] * yj;
-                        __syncthreads();
-                    }
-                    for (int j = ns - 1; j >= 0; --j) {     // L^T x = y
-                        if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-                        __syncthreads();
-                        const double xj = rhs[j];
-                        for (int i = tid; i < j; i += LM_THREADS) rhs[i] -= S[j * ns + i] * xj;
-                        __syncthreads();
-                    }
+                    __syncthreads();
                     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
                         const int o = idx / 6;
                         P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
@@ -404,6 +417,21 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
     if (tid == 0) { P.stats[0] = rounds; P.stats[1] = lm_its; P.stats[2] = lm_trials; P.stats[3] = num_good; }
 }
 
+#ifdef SUO_LM_BIG
+// the 1024-thread build of this file (csrc/lm_big.hip): only the kernel and its launcher
+int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s) {
+    if (n_problems <= 0) return SUO_OK;
+    if (lds_bytes <= 0 || lds_bytes > LM_LDS_BYTES) lds_bytes = LM_LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SUO_HIP_CHECK(hipFuncSetAttribute((const void*)lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lm_kernel, dim3(n_problems), dim3(LM_THREADS), lds_bytes, s, (const LmProblem*)problems_dev, lds_bytes);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+#else
 // Dynamic LDS a problem of this size wants (everything resident), capped at LM_LDS_BYTES.  Small problems ask
 // for little, so their workgroup can share a CU with the CNN's workgroups instead of waiting for an empty one.
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur) {
@@ -433,5 +461,6 @@ int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream
 }
 
 size_t lm_problem_struct_size() { return sizeof(LmProblem); }
+#endif  // SUO_LM_BIG
 
 }  // namespace suo

@@ -9,7 +9,12 @@ namespace suo {
 
 #define DEV __device__ __forceinline__
 
-constexpr int LM_THREADS = 256;
+// threads of the workgroup that owns one problem: 256 (4 waves; frame-sized graphs share a CU with the CNN) or, for the
+// large SLAM graphs, 1024 (16 waves, csrc/lm_big.hip compiles the same source with SUO_LM_THREADS=1024)
+#ifndef SUO_LM_THREADS
+#define SUO_LM_THREADS 256
+#endif
+constexpr int LM_THREADS = SUO_LM_THREADS;
 constexpr int LM_MAX_SCHUR_OBJ = 16;                 // reduced system <= 96 x 96 doubles in LDS
 constexpr int LM_NS = 6 * LM_MAX_SCHUR_OBJ;
 
