@@ -123,16 +123,19 @@ def _chi2_inliers(T_OtoC, det, use_inlier_subset, manual_kp_std):
         return 0
     uv_proj = (uvw[:, :2] / uvw[:, 2:3])[pos]
     res = det["uv_pred"][sel][pos] - uv_proj
+    rx, ry = res[:, 0], res[:, 1]
     cov = det["cov_pred"]
     if cov is not None:
-        cov = np.array(cov[sel][pos], dtype=np.float64)
-        cov[:, [0, 1], [0, 1]] = np.maximum(cov[:, [0, 1], [0, 1]], 1e-4)      # ensure invertible (:669,:1054)
-        inf = np.linalg.inv(cov)
-        assert not np.any(np.isnan(inf)), "NaN in information matrix"
+        cov = np.asarray(cov[sel][pos], dtype=np.float64)
+        a = np.maximum(cov[:, 0, 0], 1e-4)                                     # ensure invertible (:669,:1054)
+        d = np.maximum(cov[:, 1, 1], 1e-4)
+        b, c = cov[:, 0, 1], cov[:, 1, 0]
+        det2 = a * d - b * c
+        # r^T inv([[a,b],[c,d]]) r in closed form (this runs O(objects^2 + 15 objects) times per SLAM view)
+        chi2 = (d * rx * rx - (b + c) * rx * ry + a * ry * ry) / det2
+        assert not np.any(np.isnan(chi2)), "NaN in information matrix"
     else:
-        inf = np.zeros((res.shape[0], 2, 2))
-        inf[:, [0, 1], [0, 1]] = 1.0 / manual_kp_std ** 2
-    chi2 = np.einsum("ni,nij,nj->n", res, inf, res)
+        chi2 = (rx * rx + ry * ry) / manual_kp_std ** 2
     return int(np.count_nonzero(chi2 <= CHI2_2DOF_95))
 
 
