@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
     // Wave index as an SGPR: the weight addresses and tile offsets derived from it become scalar, which frees 50-70
     // VGPRs (120 + 16 instead of 192).  Not for the 2x2-tile configuration: there the scalarised addresses let hipcc
     // hoist more loads and the allocation jumps from 136 + 64 to 248 + 64 registers, i.e. one wave per SIMD.
-    const int w = SUO_CONV_SCALAR_WAVE && TM * TN < 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    const int w = SUO_CONV_SCALAR_WAVE && (TM * TN < 4 || SUO_CONV_SCALAR_WAVE > 1) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int wm = w / WGN, wn = w % WGN;
     const int tiles_x = (a.OW + TW - 1) / TW, tiles_y = (a.OH + TH - 1) / TH;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement; used for speed only), so give each
