@@ -44,7 +44,18 @@ DEV void lds_relocate(T*& ptr, size_t count, unsigned char* lds, size_t& off, si
     off += bytes;
 }
 
+// optional phase timers (-DSUO_LM_PROFILE): cycles between consecutive LMPROF(i) marks are charged to section i
+#ifdef SUO_LM_PROFILE
+#define LMPROF(i) do { __syncthreads(); if (tid == 0) { const long long _t = clock64(); lmprof_acc[lmprof_last] += _t - lmprof_t; lmprof_t = _t; lmprof_last = (i); } } while (0)
+#else
+#define LMPROF(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restrict__ problems, int lds_bytes) {
+#ifdef SUO_LM_PROFILE
+    long long lmprof_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lmprof_t = clock64();
+    int lmprof_last = 10;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_lds[];
     const LmProblem& G = problems[blockIdx.x];      // the problem as laid out in HBM
     LmProblem P = G;                                // working copy whose pointers may be redirected to LDS
@@ -155,9 +166,12 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
         double lambda = -1, ni = 2;
         for (int it = 0; it < iterations; ++it) {
             // ---- errors, chi2, linearisation ---------------------------------------------------
+            LMPROF(0);
             double currentChi = active_errors_and_chi2(P, robust_on, true, red);
+            LMPROF(1);
             accumulate_pairs(P);
             __syncthreads();
+            LMPROF(2);
             // ---- gather the diagonal blocks (fixed summation order) ----------------------------
             for (int idx = tid; idx < P.n_cam * 27; idx += LM_THREADS) {
                 const int c = idx / 27, k = idx - c * 27;
@@ -188,6 +202,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                 lambda = 1e-5 * md;
                 ni = 2;
             }
+            LMPROF(3);
             // ---- trials ----------------------------------------------------------------------
             double rho = 0;
             int qmax = 0;
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                 for (int o = tid; o < P.n_obj; o += LM_THREADS) P.obj_bak[o] = P.obj[o];
                 if (tid == 0) sh_ok = 1;
                 __syncthreads();
+                LMPROF(4);
                 // cameras: (Hcc + lambda I)^-1 and y_c = Hcc^-1 b_c (the inverse is only needed for the Schur complement)
                 for (int c = tid; c < P.n_cam; c += LM_THREADS) {
                     if (P.cam_fixed[c]) continue;
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                         }
                         P.Y[idx] = s;
                     }
+                    LMPROF(5);
                     // S = blockdiag(Hoo + lambda I);  rhs = b_o
                     for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[idx] = 0;
                     __syncthreads();
@@ -295,6 +312,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                         rhs[row] -= acc;
                     }
                     __syncthreads();
+                    LMPROF(6);
                     // Cholesky S = L L^T (lower, in place), then forward / backward substitution -- by ONE wave: the
                     // system is at most 96 x 96 and its 5 dependent steps per column need no workgroup barrier this way
                     // (5 * ns of them otherwise, with up to 16 waves each).  Same arithmetic per element as a
@@ -341,6 +359,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                         P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
                     }
                     __syncthreads();
+                    LMPROF(7);
                     // x_c = y_c - sum_o Y(c,o) x_o
                     for (int idx = tid; idx < P.n_cam * 6; idx += LM_THREADS) {
                         const int c = idx / 6, r = idx - c * 6;
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     }
                     __syncthreads();
                 }
+                LMPROF(8);
                 const bool ok2 = sh_ok != 0;
                 // update(x)
                 if (ok2) {
@@ -364,7 +384,9 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     for (int o = tid; o < P.n_obj; o += LM_THREADS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
                 }
                 __syncthreads();
+                LMPROF(9);
                 double tempChi = active_errors_and_chi2(P, robust_on, false, red);
+                LMPROF(10);
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 // computeScale: sum x (lambda x + b)
                 double sc = 0;
@@ -415,6 +437,13 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
     for (int c = tid; c < P.n_cam; c += LM_THREADS) pose_to_T(P.cam[c], P.cam_T + 12 * c);
     for (int o = tid; o < P.n_obj; o += LM_THREADS) pose_to_T(P.obj[o], P.obj_T + 12 * o);
     if (tid == 0) { P.stats[0] = rounds; P.stats[1] = lm_its; P.stats[2] = lm_trials; P.stats[3] = num_good; }
+#ifdef SUO_LM_PROFILE
+    if (tid == 0 && P.n_edge >= 1000) {
+        printf("lm profile (edges %d, cams %d): its %d trials %d; Mcycles per section:", P.n_edge, P.n_cam, lm_its, lm_trials);
+        for (int i = 0; i < 11; ++i) printf(" [%d]%.2f", i, (double)lmprof_acc[i] * 1e-6);
+        printf("\n");
+    }
+#endif
 }
 
 #ifdef SUO_LM_BIG
