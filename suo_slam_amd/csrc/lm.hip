@@ -28,6 +28,7 @@ namespace suo {
 
 
 constexpr int LM_LDS_BYTES = 150 * 1024;     // dynamic LDS per workgroup (160 KiB per CU on gfx950)
+constexpr int LM_STAGE_EDGES = 384;          // LDS stage for the Jacobians of one batch of pairs (87 KiB), large graphs only
 
 // Move one array of the problem into LDS when it still fits (flat pointers address LDS transparently): the
 // working set of a single-view frame (poses, 6x6 blocks, ~100 edges and their Jacobians) then never leaves
@@ -87,6 +88,14 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
         off = ((size_t)ns * ns * sizeof(double) + 15) & ~(size_t)15;
         rhs = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
         colbuf = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
+    }
+    // Large graphs (the global SLAM adjustment): the [n_edge][29] Jacobians cannot live in LDS.  Instead of writing them
+    // to HBM and re-reading each pair's rows 90 times from L2 (47 % of a 7500-edge adjustment), the edges are linearised
+    // in batches of whole pairs straight into this LDS stage and the batch's pair blocks are summed from it.
+    double* jac_stage = nullptr;
+    if (P.n_edge > LM_STAGE_EDGES && off + (size_t)LM_STAGE_EDGES * 29 * sizeof(double) <= (size_t)lds_bytes) {
+        jac_stage = (double*)(lm_lds + off);
+        off += (size_t)LM_STAGE_EDGES * 29 * sizeof(double);
     }
     {
         const size_t C = P.n_cam, O = P.n_obj, E = P.n_edge, NP = P.n_pair, cap = (size_t)lds_bytes;
@@ -167,10 +176,33 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
         for (int it = 0; it < iterations; ++it) {
             // ---- errors, chi2, linearisation ---------------------------------------------------
             LMPROF(0);
-            double currentChi = active_errors_and_chi2(P, robust_on, true, red);
-            LMPROF(1);
-            accumulate_pairs(P);
-            __syncthreads();
+            double currentChi;
+            if (!jac_stage) {
+                currentChi = active_errors_and_chi2(P, robust_on, true, red);
+                LMPROF(1);
+                accumulate_pairs(P);
+                __syncthreads();
+            } else {
+                double part = 0;
+                for (int p0 = 0; p0 < P.n_pair;) {
+                    if (tid == 0) {                             // batch = as many whole pairs as the stage holds
+                        const int e0 = P.pair_start[p0];
+                        int p1 = p0 + 1;
+                        while (p1 < P.n_pair && P.pair_start[p1 + 1] - e0 <= LM_STAGE_EDGES) ++p1;
+                        sh_flag = p1;
+                    }
+                    __syncthreads();
+                    const int p1 = sh_flag, e0 = P.pair_start[p0], e1 = P.pair_start[p1];
+                    LmProblem Q = P;
+                    Q.jac = jac_stage - 29 * (size_t)e0;        // edge e of the batch -> stage row e - e0
+                    part += edge_pass_partial(Q, e0, e1, robust_on, true);
+                    __syncthreads();
+                    accumulate_pairs_range(Q, p0, p1);
+                    __syncthreads();
+                    p0 = p1;
+                }
+                currentChi = block_sum(part, red);
+            }
             LMPROF(2);
             // ---- gather the diagonal blocks (fixed summation order) ----------------------------
             for (int idx = tid; idx < P.n_cam * 27; idx += LM_THREADS) {

@@ -220,9 +220,10 @@ DEV double edge_chi2(const LmProblem& P, int e, const double* err) {
 
 // computeActiveErrors + activeRobustChi2; with_jac also stores the edge Jacobians (linearizeOplus) and the
 // Huber-weighted information / gradient factors used by constructQuadraticForm.  Threads over edges.
-DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, bool with_jac, double* red) {
+// this thread's share of the edges [e_begin, e_end): returns its partial (robustified) chi2
+DEV double edge_pass_partial(const LmProblem& P, int e_begin, int e_end, bool robust_on, bool with_jac) {
     double c = 0;
-    for (int e = threadIdx.x; e < P.n_edge; e += LM_THREADS) {
+    for (int e = e_begin + threadIdx.x; e < e_end; e += LM_THREADS) {
         if (!edge_active(P, e)) continue;
         double er[2], pw[3], pc[3];
         edge_error(P, e, er, pw, pc);
@@ -253,13 +254,16 @@ DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, bool with_
             J[28] = -(I[1] * er[0] + I[2] * er[1]) * w;
         }
     }
-    return block_sum(c, red);
+    return c;
+}
+DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, bool with_jac, double* red) {
+    return block_sum(edge_pass_partial(P, 0, P.n_edge, robust_on, with_jac), red);
 }
 
 // One thread per (pair, entry): entry k of [Hcc(21) | Hoo(21) | Hco(36) | bc(6) | bo(6)] summed over the pair's
-// active edges in edge order (deterministic, no cross-lane reduction).
-DEV void accumulate_pairs(const LmProblem& P) {
-    for (int idx = threadIdx.x; idx < P.n_pair * 90; idx += LM_THREADS) {
+// active edges in edge order (deterministic, no cross-lane reduction).  Pairs [p_begin, p_end).
+DEV void accumulate_pairs_range(const LmProblem& P, int p_begin, int p_end) {
+    for (int idx = p_begin * 90 + threadIdx.x; idx < p_end * 90; idx += LM_THREADS) {
         const int p = idx / 90, k = idx - p * 90;
         const bool cfree = !P.cam_fixed[P.pair_cam[p]], ofree = !P.obj_fixed[P.pair_obj[p]];
         int a_off, b_off, r, c, kind;      // kind 0: A^T O B block entry (r,c); 1: gradient entry r
@@ -279,6 +283,7 @@ DEV void accumulate_pairs(const LmProblem& P) {
         P.pair_part[idx] = s;
     }
 }
+DEV void accumulate_pairs(const LmProblem& P) { accumulate_pairs_range(P, 0, P.n_pair); }
 
 // solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if not PD
 __device__ bool spd_solve6(const double* A, const double* b, double* x) {
