@@ -19,6 +19,8 @@ int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const doub
                      int* iters_out, hipStream_t s);
 int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
+int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);
+size_t lm_grid_scratch_bytes();
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
 int launch_ba_init(const void* P, hipStream_t s);
@@ -339,12 +341,24 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     Staged st;
     int rc = stage_problems(probs, n_prob, g_arena, st);
     if (rc != SUO_OK) return rc;
-    // frame-sized graphs: 256-thread workgroups; a large graph in the batch (the global SLAM adjustment): 1024 threads
+    // frame-sized graphs: one 256-thread workgroup each (csrc/lm.hip).  A large graph (the global SLAM adjustment):
+    // ONE problem spread over up to 32 workgroups with grid barriers (csrc/lm_grid.hip); several large graphs in one
+    // call fall back to the 1024-thread single-workgroup build (csrc/lm_big.hip).
     int max_edges = 0;
     for (int i = 0; i < n_prob; ++i) max_edges = std::max(max_edges, probs[i].n_edge);
-    static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 1024;      // tuning aid
-    rc = max_edges >= big_from ? launch_lm_big(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream)
-                               : launch_lm(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
+    static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 1024;      // tuning aids
+    static const int grid_wgs = getenv("SUO_LM_GRID_WGS") ? atoi(getenv("SUO_LM_GRID_WGS")) : 32;          // 0: never use the grid kernel
+    if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {
+        static void* grid_scratch = nullptr;
+        if (!grid_scratch) SUO_HIP_CHECK(hipMalloc(&grid_scratch, lm_grid_scratch_bytes()));
+        SUO_HIP_CHECK(hipMemsetAsync(grid_scratch, 0, 64, g_arena.stream));
+        const int wgs = std::max(1, std::min(grid_wgs, (max_edges + 255) / 256));
+        rc = launch_lm_grid(g_arena.dev + st.o_structs, grid_scratch, wgs, g_arena.stream);
+    } else if (max_edges >= big_from) {
+        rc = launch_lm_big(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
+    } else {
+        rc = launch_lm(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
+    }
     if (rc != SUO_OK) return rc;
     return fetch_results(probs, n_prob, g_arena, st);
 }

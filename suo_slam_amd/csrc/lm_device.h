@@ -221,9 +221,11 @@ DEV double edge_chi2(const LmProblem& P, int e, const double* err) {
 // computeActiveErrors + activeRobustChi2; with_jac also stores the edge Jacobians (linearizeOplus) and the
 // Huber-weighted information / gradient factors used by constructQuadraticForm.  Threads over edges.
 // this thread's share of the edges [e_begin, e_end): returns its partial (robustified) chi2
-DEV double edge_pass_partial(const LmProblem& P, int e_begin, int e_end, bool robust_on, bool with_jac) {
+// (t0, stride): this thread's position in the loop -- one workgroup by default, a whole grid in csrc/lm_grid.hip
+DEV double edge_pass_partial(const LmProblem& P, int e_begin, int e_end, bool robust_on, bool with_jac, int t0 = threadIdx.x,
+                             int stride = LM_THREADS) {
     double c = 0;
-    for (int e = e_begin + threadIdx.x; e < e_end; e += LM_THREADS) {
+    for (int e = e_begin + t0; e < e_end; e += stride) {
         if (!edge_active(P, e)) continue;
         double er[2], pw[3], pc[3];
         edge_error(P, e, er, pw, pc);
@@ -262,8 +264,8 @@ DEV double active_errors_and_chi2(const LmProblem& P, bool robust_on, bool with_
 
 // One thread per (pair, entry): entry k of [Hcc(21) | Hoo(21) | Hco(36) | bc(6) | bo(6)] summed over the pair's
 // active edges in edge order (deterministic, no cross-lane reduction).  Pairs [p_begin, p_end).
-DEV void accumulate_pairs_range(const LmProblem& P, int p_begin, int p_end) {
-    for (int idx = p_begin * 90 + threadIdx.x; idx < p_end * 90; idx += LM_THREADS) {
+DEV void accumulate_pairs_range(const LmProblem& P, int p_begin, int p_end, int t0 = threadIdx.x, int stride = LM_THREADS) {
+    for (int idx = p_begin * 90 + t0; idx < p_end * 90; idx += stride) {
         const int p = idx / 90, k = idx - p * 90;
         const bool cfree = !P.cam_fixed[P.pair_cam[p]], ofree = !P.obj_fixed[P.pair_obj[p]];
         int a_off, b_off, r, c, kind;      // kind 0: A^T O B block entry (r,c); 1: gradient entry r

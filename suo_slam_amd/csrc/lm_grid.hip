@@ -1,0 +1,414 @@
+// The LM / bundle-adjustment algorithm of csrc/lm.hip for ONE large graph spread over many workgroups.
+//
+// The global SLAM adjustment (every 10 views: all cameras x objects x keypoints, /root/reference/lib/object_slam.py:
+// 444-447,703-903) has thousands of edges; one workgroup on one CU spends 150 ms on 60 cameras / 7500 edges, almost all
+// of it in per-edge / per-pair / per-camera loops that are embarrassingly parallel.  Here G workgroups (one per CU of a
+// single XCD, so they share an L2) execute the same rounds / iterations / trials in lock-step: every loop is grid-strided,
+// every workgroup barrier that orders data between phases is a grid barrier, every reduction is summed in workgroup
+// order (deterministic), and the (<= 96 x 96) reduced system is factorised by workgroup 0.  All state lives in the
+// problem's HBM arrays (no LDS relocation); decisions (gain ratio, lambda, termination) are taken redundantly by every
+// workgroup from identical reduced values, so control flow never diverges between workgroups.
+//
+// Same arithmetic per edge / block entry as csrc/lm.hip; only the partition of the chi2 sums differs (rounding-level).
+#include "lm_device.h"
+
+namespace suo {
+
+constexpr int LG_THREADS = 256;
+constexpr int LG_MAX_WGS = 32;                // CUs of one XCD
+
+struct LmGridScratch {
+    unsigned* bar;            // [2]: arrivals, generation (zeroed by the host before the launch)
+    double* red;              // [2][LG_MAX_WGS] alternating reduction buffers
+    double* S;                // [ns*ns + ns] reduced system assembled by the whole grid, solved by workgroup 0
+};
+
+struct GridCtx {
+    unsigned* bar; double* red; int G, wg; unsigned red_cnt;
+    bool same_xcd;            // every cooperating workgroup reported the same XCC id: they share one L2
+};
+
+// Grid barrier.  General form: agent-scope release / acquire fences, which on this multi-die part write back and invalidate
+// L2 (buffer_wbl2 sc1 / buffer_inv sc1) -- ~45 us per barrier, i.e. most of an LM trial.  When all cooperating workgroups
+// sit on ONE XCD (verified at kernel start from the XCC_ID hardware register, not assumed) they share a single L2, so it is
+// enough that each wave's stores have reached L2 (s_waitcnt vmcnt(0): the vector L1 is write-through) before arriving and
+// that the CU's L1 is dropped (buffer_inv sc0) after leaving; the barrier words are only touched by L2 atomics.
+DEV void grid_sync(GridCtx& g) {
+    if (g.same_xcd) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned gen = __hip_atomic_fetch_add(&g.bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(&g.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.G - 1) {
+                __hip_atomic_exchange(&g.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&g.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (__hip_atomic_fetch_add(&g.bar[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        asm volatile("buffer_inv sc1" ::: "memory");
+        return;
+    }
+    __threadfence();                                                         // release: every wave's writes -> L2 -> memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&g.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&g.bar[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.G - 1) {
+            __hip_atomic_store(&g.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&g.bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(&g.bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __threadfence();                                                         // acquire: drop stale cache lines (every wave)
+}
+
+// deterministic grid reductions: workgroup partial (fixed wave order) -> red[buf][wg] -> all sum / max in workgroup order
+DEV double grid_reduce(double v, bool is_max, GridCtx& g, double* red_lds) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = is_max ? fmax(v, u) : v + u; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red_lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double* buf = g.red + (g.red_cnt++ & 1) * LG_MAX_WGS;
+    if (threadIdx.x == 0) {
+        double s = red_lds[0];
+        for (int i = 1; i < LG_THREADS / 64; ++i) s = is_max ? fmax(s, red_lds[i]) : s + red_lds[i];
+        buf[g.wg] = s;
+    }
+    grid_sync(g);
+    double s = buf[0];
+    for (int i = 1; i < g.G; ++i) s = is_max ? fmax(s, buf[i]) : s + buf[i];
+    return s;
+}
+
+__global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __restrict__ Pp, LmGridScratch sc, int G) {
+    if (blockIdx.x & 7) return;                 // workgroup b runs on XCD b % 8 (observed; performance only): keep one XCD
+    const LmProblem& P = *Pp;
+    __shared__ double S[LM_NS * LM_NS];
+    __shared__ double rhs[LM_NS], colbuf[LM_NS];
+    __shared__ double red_lds[LG_THREADS / 64];
+    __shared__ int sh_flag, sh_ok;
+    GridCtx g;
+    g.bar = sc.bar; g.red = sc.red; g.G = G; g.wg = blockIdx.x >> 3; g.red_cnt = 0; g.same_xcd = false;
+    const int tid = threadIdx.x;
+    {   // which XCD is every cooperating workgroup on?  (HW_REG_XCC_ID = 20, bits [3:0]); one general barrier, then all agree
+        if (tid == 0) sc.red[g.wg] = (double)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15);
+        grid_sync(g);
+        bool same = true;
+        for (int i = 1; i < G; ++i) same = same && (sc.red[i] == sc.red[0]);
+        grid_sync(g);                           // everyone has read the ids before the buffer is reused by reductions
+        g.same_xcd = same;
+    }
+    const int gt = g.wg * LG_THREADS + tid, GS = G * LG_THREADS;      // position / stride of the grid-strided loops
+
+    if (tid == 0) {
+        int ns = 0, nfc = 0;
+        for (int o = 0; o < P.n_obj; ++o) { if (g.wg == 0) P.obj_slot[o] = P.obj_fixed[o] ? -1 : ns; if (!P.obj_fixed[o]) ++ns; }
+        for (int c = 0; c < P.n_cam; ++c) nfc += P.cam_fixed[c] ? 0 : 1;
+        sh_flag = ns | (nfc << 16);
+    }
+    __syncthreads();
+    const int n_free_obj = sh_flag & 0xffff, n_free_cam = sh_flag >> 16;
+    const bool schur = n_free_cam > 0 && n_free_obj > 0;
+    const int ns = 6 * n_free_obj;
+    if (schur && n_free_obj > LM_MAX_SCHUR_OBJ) {
+        if (gt == 0) { P.stats[0] = -1; P.stats[1] = P.stats[2] = P.stats[3] = 0; }
+        return;
+    }
+    for (int c = gt; c < P.n_cam; c += GS) pose_from_T(P.cam_T + 12 * c, P.cam[c]);
+    for (int o = gt; o < P.n_obj; o += GS) pose_from_T(P.obj_T + 12 * o, P.obj[o]);
+    for (int e = gt; e < P.n_edge; e += GS) P.level[e] = 0;
+    grid_sync(g);
+
+    // ---- initial classification (object_slam.py:848-866) --------------------------------------
+    int num_good;
+    if (P.init_with_outliers) {
+        num_good = P.n_edge;
+    } else {
+        double my_good = 0;
+        for (int e = gt; e < P.n_edge; e += GS) {
+            double er[2];
+            edge_error(P, e, er, nullptr, nullptr);
+            const double c2 = edge_chi2(P, e, er);
+            P.edge_chi2[e] = c2;
+            if (c2 > P.chi2_thr) { P.level[e] = 1; P.edge_inlier[e] = 0; }
+            else { P.level[e] = 0; P.edge_inlier[e] = 1; my_good += 1; }
+        }
+        num_good = (int)grid_reduce(my_good, false, g, red_lds);
+    }
+    bool robust_on = true;
+    int rounds = 0, lm_its = 0, lm_trials = 0;
+    const int drop = (P.n_rounds / 2) > 1 ? (P.n_rounds / 2) : 1;
+    const int diag21[6] = {0, 6, 11, 15, 18, 20};
+
+    for (int round = 0; round < P.n_rounds; ++round) {
+        if (P.n_edge < 4 || num_good < 4) break;
+        ++rounds;
+        double nact = 0;
+        for (int e = gt; e < P.n_edge; e += GS) nact += edge_active(P, e) ? 1.0 : 0.0;
+        nact = grid_reduce(nact, false, g, red_lds);
+        const int iterations = nact > 0 ? P.its[round] : 0;
+        double lambda = -1, ni = 2;
+        for (int it = 0; it < iterations; ++it) {
+            // ---- errors, chi2, Jacobians (HBM), pair blocks, diagonal blocks ---------------------
+            double currentChi = grid_reduce(edge_pass_partial(P, 0, P.n_edge, robust_on, true, gt, GS), false, g, red_lds);
+            accumulate_pairs_range(P, 0, P.n_pair, gt, GS);
+            grid_sync(g);
+            for (int idx = gt; idx < P.n_cam * 27; idx += GS) {
+                const int c = idx / 27, k = idx - c * 27;
+                if (P.cam_fixed[c]) continue;
+                double s = 0;
+                for (int j = P.cam_pair_ptr[c]; j < P.cam_pair_ptr[c + 1]; ++j)
+                    s += P.pair_part[90 * (size_t)P.cam_pair_idx[j] + (k < 21 ? k : 78 + (k - 21))];
+                if (k < 21) P.Hcc[36 * c + k] = s; else P.bc[6 * c + (k - 21)] = s;
+            }
+            for (int idx = gt; idx < P.n_obj * 27; idx += GS) {
+                const int o = idx / 27, k = idx - o * 27;
+                if (P.obj_fixed[o]) continue;
+                double s = 0;
+                for (int j = P.obj_pair_ptr[o]; j < P.obj_pair_ptr[o + 1]; ++j)
+                    s += P.pair_part[90 * (size_t)P.obj_pair_idx[j] + (k < 21 ? 21 + k : 84 + (k - 21))];
+                if (k < 21) P.Hoo[36 * o + k] = s; else P.bo[6 * o + (k - 21)] = s;
+            }
+            grid_sync(g);
+            if (it == 0) {      // computeLambdaInit: tau * max |diag|
+                double md = 0;
+                for (int idx = gt; idx < (P.n_cam + P.n_obj) * 6; idx += GS) {
+                    const int v = idx / 6, d = idx - v * 6;
+                    if (v < P.n_cam) { if (!P.cam_fixed[v]) md = fmax(md, fabs(P.Hcc[36 * v + diag21[d]])); }
+                    else { const int o = v - P.n_cam; if (!P.obj_fixed[o]) md = fmax(md, fabs(P.Hoo[36 * o + diag21[d]])); }
+                }
+                md = grid_reduce(md, true, g, red_lds);
+                lambda = 1e-5 * md;
+                ni = 2;
+            }
+            // ---- trials ----------------------------------------------------------------------
+            double rho = 0;
+            int qmax = 0;
+            bool lam_finite = true;
+            do {
+                double bad = 0;                                  // any failed factorisation in this workgroup's share
+                for (int c = gt; c < P.n_cam; c += GS) P.cam_bak[c] = P.cam[c];          // push()
+                for (int o = gt; o < P.n_obj; o += GS) P.obj_bak[o] = P.obj[o];
+                for (int c = gt; c < P.n_cam; c += GS) {
+                    if (P.cam_fixed[c]) continue;
+                    double A[36];
+                    unpack_sym21(P.Hcc + 36 * c, A);
+                    for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
+                    if (schur) {
+                        double Ai[36];
+                        if (!spd_inverse6(A, Ai)) { bad = 1; for (int i = 0; i < 36; ++i) Ai[i] = 0; }
+                        for (int i = 0; i < 36; ++i) P.Hcc_inv[36 * c + i] = Ai[i];
+                        for (int r = 0; r < 6; ++r) {
+                            double sacc = 0;
+                            for (int k = 0; k < 6; ++k) sacc += Ai[r * 6 + k] * P.bc[6 * c + k];
+                            P.yc[6 * c + r] = sacc;
+                        }
+                    } else {
+                        double x[6] = {0, 0, 0, 0, 0, 0};
+                        if (!spd_solve6(A, P.bc + 6 * c, x)) bad = 1;
+                        for (int r = 0; r < 6; ++r) P.yc[6 * c + r] = x[r];
+                    }
+                }
+                grid_sync(g);
+                if (!schur) {
+                    for (int o = gt; o < P.n_obj; o += GS) {
+                        if (P.obj_fixed[o]) continue;
+                        double A[36], x[6] = {0, 0, 0, 0, 0, 0};
+                        unpack_sym21(P.Hoo + 36 * o, A);
+                        for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
+                        if (!spd_solve6(A, P.bo + 6 * o, x)) bad = 1;
+                        for (int r = 0; r < 6; ++r) P.xo[6 * o + r] = x[r];
+                    }
+                    for (int idx = gt; idx < P.n_cam * 6; idx += GS) P.xc[idx] = P.cam_fixed[idx / 6] ? 0.0 : P.yc[idx];
+                } else {
+                    // Y[p] = Hcc^-1 Hco[p]
+                    for (int idx = gt; idx < P.n_pair * 36; idx += GS) {
+                        const int p = idx / 36, rc = idx - p * 36, r = rc / 6, cc = rc - r * 6;
+                        const int c = P.pair_cam[p];
+                        double s = 0;
+                        if (!P.cam_fixed[c] && !P.obj_fixed[P.pair_obj[p]]) {
+                            const double* Hco = P.pair_part + 90 * (size_t)p + 42;
+                            for (int k = 0; k < 6; ++k) s += P.Hcc_inv[36 * c + r * 6 + k] * Hco[k * 6 + cc];
+                        }
+                        P.Y[idx] = s;
+                    }
+                    grid_sync(g);
+                    // reduced system in HBM, one entry per thread of the grid:
+                    //   S = blockdiag(Hoo + lambda I) - sum_c Hco(c,o1)^T Y(c,o2);   rhs = b_o - sum_c Hco(c,o)^T y_c
+                    for (int idx = gt; idx < ns * ns; idx += GS) {
+                        const int row = idx / ns, col = idx - row * ns;
+                        const int s1 = row / 6, i = row - s1 * 6, s2 = col / 6, j = col - s2 * 6;
+                        int o1 = -1, o2 = -1;
+                        for (int o = 0; o < P.n_obj; ++o) { if (P.obj_slot[o] == s1) o1 = o; if (P.obj_slot[o] == s2) o2 = o; }
+                        double diag = 0;
+                        if (s1 == s2) {
+                            const int rr = i < j ? i : j, c2 = i < j ? j : i;
+                            diag = P.Hoo[36 * o1 + rr * 6 - rr * (rr - 1) / 2 + (c2 - rr)] + (i == j ? lambda : 0.0);
+                        }
+                        double acc = 0;
+                        for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
+                            const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
+                            if (P.cam_fixed[c]) continue;
+                            int p2 = -1;
+                            for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b)
+                                if (P.pair_obj[P.cam_pair_idx[b]] == o2) { p2 = P.cam_pair_idx[b]; break; }
+                            if (p2 < 0) continue;
+                            const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
+                            const double* Y2 = P.Y + 36 * (size_t)p2;
+                            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
+                        }
+                        sc.S[idx] = diag - acc;
+                    }
+                    for (int row = gt; row < ns; row += GS) {
+                        const int s1 = row / 6, i = row - s1 * 6;
+                        int o1 = -1;
+                        for (int o = 0; o < P.n_obj; ++o) if (P.obj_slot[o] == s1) o1 = o;
+                        double acc = 0;
+                        for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
+                            const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
+                            if (P.cam_fixed[c]) continue;
+                            const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
+                            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * P.yc[6 * c + k];
+                        }
+                        sc.S[ns * ns + row] = P.bo[6 * o1 + i] - acc;
+                    }
+                    grid_sync(g);
+                    if (g.wg == 0) {                             // Cholesky + substitutions by one wave of workgroup 0
+                        for (int idx = tid; idx < ns * ns; idx += LG_THREADS) S[idx] = sc.S[idx];
+                        for (int idx = tid; idx < ns; idx += LG_THREADS) rhs[idx] = sc.S[ns * ns + idx];
+                        if (tid == 0) sh_ok = 1;
+                        __syncthreads();
+                        if (tid < 64) {
+                            for (int j = 0; j < ns; ++j) {
+                                for (int i = j + tid; i < ns; i += 64) {
+                                    double s = S[i * ns + j];
+                                    for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
+                                    colbuf[i] = s;
+                                }
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                const double piv = colbuf[j];
+                                if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
+                                const double d = sqrt(piv > 0 ? piv : 1.0);
+                                for (int i = j + tid; i < ns; i += 64) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                            for (int j = 0; j < ns; ++j) {
+                                if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                const double yj = rhs[j];
+                                for (int i = j + 1 + tid; i < ns; i += 64) rhs[i] -= S[i * ns + j] * yj;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                            for (int j = ns - 1; j >= 0; --j) {
+                                if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                const double xj = rhs[j];
+                                for (int i = tid; i < j; i += 64) rhs[i] -= S[j * ns + i] * xj;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
+                        __syncthreads();
+                        if (sh_ok == 0) bad = 1;
+                        for (int idx = tid; idx < P.n_obj * 6; idx += LG_THREADS) {
+                            const int o = idx / 6;
+                            P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
+                        }
+                    }
+                    grid_sync(g);
+                    // x_c = y_c - sum_o Y(c,o) x_o
+                    for (int idx = gt; idx < P.n_cam * 6; idx += GS) {
+                        const int c = idx / 6, r = idx - c * 6;
+                        double s = 0;
+                        if (!P.cam_fixed[c]) {
+                            s = P.yc[idx];
+                            for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b) {
+                                const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
+                                if (P.obj_fixed[o]) continue;
+                                for (int k = 0; k < 6; ++k) s -= P.Y[36 * (size_t)p + r * 6 + k] * P.xo[6 * o + k];
+                            }
+                        }
+                        P.xc[idx] = s;
+                    }
+                }
+                const bool ok2 = grid_reduce(bad, true, g, red_lds) == 0;        // (also orders xo / xc before the update)
+                if (ok2) {
+                    for (int c = gt; c < P.n_cam; c += GS) if (!P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
+                    for (int o = gt; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
+                }
+                grid_sync(g);
+                double tempChi = grid_reduce(edge_pass_partial(P, 0, P.n_edge, robust_on, false, gt, GS), false, g, red_lds);
+                if (!ok2) tempChi = 1.7976931348623157e308;
+                double scl = 0;
+                if (ok2) {
+                    for (int idx = gt; idx < P.n_cam * 6; idx += GS)
+                        if (!P.cam_fixed[idx / 6]) scl += P.xc[idx] * (lambda * P.xc[idx] + P.bc[idx]);
+                    for (int idx = gt; idx < P.n_obj * 6; idx += GS)
+                        if (!P.obj_fixed[idx / 6]) scl += P.xo[idx] * (lambda * P.xo[idx] + P.bo[idx]);
+                }
+                scl = grid_reduce(scl, false, g, red_lds);
+                rho = (currentChi - tempChi) / (scl + 1e-3);
+                if (rho > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow(2 * rho - 1, 3.0);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                    for (int c = gt; c < P.n_cam; c += GS) P.cam[c] = P.cam_bak[c];     // pop()
+                    for (int o = gt; o < P.n_obj; o += GS) P.obj[o] = P.obj_bak[o];
+                    grid_sync(g);
+                    if (!isfinite(lambda)) { lam_finite = false; break; }
+                }
+                ++qmax;
+                ++lm_trials;
+            } while (rho < 0 && qmax < 10);
+            ++lm_its;
+            if (qmax == 10 || rho == 0 || !lam_finite) break;
+        }
+        // ---- re-classification (object_slam.py:877-896), chi2 at the accepted state -----------
+        double my_good = 0;
+        for (int e = gt; e < P.n_edge; e += GS) {
+            double er[2];
+            edge_error(P, e, er, nullptr, nullptr);
+            const double c2 = edge_chi2(P, e, er);
+            P.edge_chi2[e] = c2;
+            if (c2 > P.chi2_thr) { P.level[e] = 1; P.edge_inlier[e] = 0; }
+            else { P.level[e] = 0; P.edge_inlier[e] = 1; my_good += 1; }
+        }
+        num_good = (int)grid_reduce(my_good, false, g, red_lds);
+        if (round == drop) robust_on = false;
+    }
+    for (int c = gt; c < P.n_cam; c += GS) pose_to_T(P.cam[c], P.cam_T + 12 * c);
+    for (int o = gt; o < P.n_obj; o += GS) pose_to_T(P.obj[o], P.obj_T + 12 * o);
+    if (gt == 0) { P.stats[0] = rounds; P.stats[1] = lm_its; P.stats[2] = lm_trials; P.stats[3] = num_good; }
+}
+
+size_t lm_grid_scratch_bytes() { return 64 + 2 * LG_MAX_WGS * sizeof(double) + (LM_NS * LM_NS + LM_NS) * sizeof(double); }
+
+// `scratch_dev`: lm_grid_scratch_bytes() of device memory whose first 64 bytes are ZERO (the barrier words)
+int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s) {
+    if (n_wgs < 1) n_wgs = 1;
+    if (n_wgs > LG_MAX_WGS) n_wgs = LG_MAX_WGS;
+    LmGridScratch sc;
+    sc.bar = (unsigned*)scratch_dev;
+    sc.red = (double*)((char*)scratch_dev + 64);
+    sc.S = sc.red + 2 * LG_MAX_WGS;
+    hipLaunchKernelGGL(lm_grid_kernel, dim3(8 * n_wgs), dim3(LG_THREADS), 0, s, (const LmProblem*)problem_dev, sc, n_wgs);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+}  // namespace suo

@@ -1,0 +1,24 @@
+"""Time one global bundle adjustment (first camera fixed, everything else free) through suo_optimize:
+python tools/bench_global_ba.py [n_cam] [n_obj]   (SUO_LM_GRID_WGS=0/4/8/16/32 selects the kernel, one process each)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from suo_slam_amd import ba as BA  # noqa: E402
+from tests.test_gpu_geometry import _multi_view_scene  # noqa: E402
+
+n_cam = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+P, _ = _multi_view_scene(np.random.default_rng(1), n_cam, n_obj)
+args = [P[k] for k in ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")]
+ts = []
+for rep in range(4):
+    a = [x.copy() for x in args]
+    t0 = time.perf_counter()
+    out = BA.optimize(*a)
+    ts.append(time.perf_counter() - t0)
+print(f"SUO_LM_GRID_WGS={os.environ.get('SUO_LM_GRID_WGS', 'default')}: {n_cam} cams x {n_obj} objs, {len(P['edge_cam'])} edges: "
+      f"{1e3 * min(ts):.2f} ms (stats rounds/its/trials/good = {list(out[4])})")
