@@ -137,6 +137,22 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
 
     auto epilogue = [&]() {
         float* T = &Tp[w][0];
+        // every residual / bias value of the tile is requested BEFORE the first accumulator is transposed: one HBM round
+        // trip per tile instead of one per 32 x 32 accumulator (K = 128 layers: the epilogue used to outlast the main loop)
+        f32x4 rvall[TM][TN][4], bvall[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bvall[j] = *(const f32x4*)(a.bias + n0 + (wn * TN + j) * 32 + (lane & 7) * 4);
+        if (HAS_R) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
+                        rvall[i][j][k] = *(const f32x4*)(a.R + (size_t)row * a.ldr + n0 + (wn * TN + j) * 32 + (lane & 7) * 4);
+                    }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -145,13 +161,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
                 for (int r = 0; r < 16; ++r) { T[acc_row_s(r, lane) * PK + (lane & 31)] = acc[i][j][r]; acc[i][j][r] = 0.f; }
                 __builtin_amdgcn_wave_barrier();
                 const int col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-                const f32x4 bv = *(const f32x4*)(a.bias + col);
+                const f32x4 bv = bvall[j];
                 f32x4 v[4], rv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int row = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
-                    rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (HAS_R) rv[k] = *(const f32x4*)(a.R + (size_t)row * a.ldr + col);      // compile-time: keeps vmcnt exact
+                    rv[k] = HAS_R ? rvall[i][j][k] : f32x4{0.f, 0.f, 0.f, 0.f};
                     v[k] = *(const f32x4*)&T[((lane >> 3) + 8 * k) * PK + (lane & 7) * 4];
                 }
 #pragma unroll
