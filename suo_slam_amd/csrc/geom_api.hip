@@ -24,10 +24,11 @@ size_t lm_grid_scratch_bytes();
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
 int launch_ba_init(const void* P, hipStream_t s);
-int launch_ba_classify(const void* P, int keep_all, double* out, hipStream_t s);
-int launch_ba_linearize(const void* P, int robust_on, double* out, hipStream_t s);
-int launch_ba_schur(const void* P, double lambda, int ns, double* out, hipStream_t s);
-int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, hipStream_t s);
+size_t ba_scratch_doubles();
+int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch, hipStream_t s);
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, hipStream_t s);
+int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s);
+int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, double* scratch, hipStream_t s);
 int launch_ba_restore(const void* P, hipStream_t s);
 int launch_ba_finalize(const void* P, hipStream_t s);
 
@@ -370,7 +371,8 @@ struct suo_ba_ctx {
     Arena arena;            // the device-resident problem (private: lives across calls)
     Staged st;
     int n_cam = 0, n_obj = 0, ns = 0;
-    double* d_io = nullptr; double* h_io = nullptr; size_t io_doubles = 0;
+    double* d_io = nullptr; double* h_io = nullptr; size_t io_doubles = 0;   // [out | in | workgroup partials (device only)]
+    double* scratch() const { return d_io + io_doubles; }
     const void* dev_problem() const { return arena.dev + st.o_structs; }
 };
 
@@ -385,7 +387,7 @@ int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
     c->ns = 6 * nfo;
     if (nfo > 16) { suo_set_error("suo_ba_ctx_create: %d free objects exceed the reduced-system limit of 16", nfo); delete c; return SUO_ERR_ARG; }
     c->io_doubles = 2 * ((size_t)c->ns * c->ns + c->ns + 27 * (size_t)p->n_obj + 16);
-    if (hipMalloc((void**)&c->d_io, c->io_doubles * sizeof(double)) != hipSuccess ||
+    if (hipMalloc((void**)&c->d_io, (c->io_doubles + ba_scratch_doubles()) * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_io, c->io_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         suo_set_error("suo_ba_ctx_create: allocation failed"); delete c; return SUO_ERR_HIP;
     }
@@ -416,17 +418,17 @@ static int ba_fetch(suo_ba_ctx* c, double* out, size_t n) {
 }
 
 int suo_ba_classify(suo_ba_ctx* c, int keep_all, double* num_good_local) {
-    int rc = launch_ba_classify(c->dev_problem(), keep_all, c->d_io, c->arena.stream);
+    int rc = launch_ba_classify(c->dev_problem(), keep_all, c->d_io, c->scratch(), c->arena.stream);
     return rc != SUO_OK ? rc : ba_fetch(c, num_good_local, 1);
 }
 
 int suo_ba_linearize(suo_ba_ctx* c, int robust_on, double* out) {
-    int rc = launch_ba_linearize(c->dev_problem(), robust_on, c->d_io, c->arena.stream);
+    int rc = launch_ba_linearize(c->dev_problem(), robust_on, c->d_io, c->scratch(), c->arena.stream);
     return rc != SUO_OK ? rc : ba_fetch(c, out, 2 + 27 * (size_t)c->n_obj);
 }
 
 int suo_ba_schur(suo_ba_ctx* c, double lambda, double* out) {
-    int rc = launch_ba_schur(c->dev_problem(), lambda, c->ns, c->d_io, c->arena.stream);
+    int rc = launch_ba_schur(c->dev_problem(), lambda, c->ns, c->d_io, c->scratch(), c->arena.stream);
     return rc != SUO_OK ? rc : ba_fetch(c, out, (size_t)c->ns * c->ns + c->ns + 1);
 }
 
@@ -436,7 +438,7 @@ int suo_ba_solve_update(suo_ba_ctx* c, double lambda, int robust_on, const doubl
     double* d_in = c->d_io + c->io_doubles / 2;
     memcpy(h_in, in, n_in * sizeof(double));
     SUO_HIP_CHECK(hipMemcpyAsync(d_in, h_in, n_in * sizeof(double), hipMemcpyHostToDevice, c->arena.stream));
-    int rc = launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, d_in, c->d_io, c->arena.stream);
+    int rc = launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, d_in, c->d_io, c->scratch(), c->arena.stream);
     return rc != SUO_OK ? rc : ba_fetch(c, out, 4);
 }
 

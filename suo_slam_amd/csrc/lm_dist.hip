@@ -8,35 +8,52 @@
 //     local:   every rank solves the SAME reduced system (blockdiag(Hoo + lambda I) - S) x_o = b_o - r,
 //              back-substitutes its own cameras, updates poses, evaluates its part of chi2
 //     RCCL:    all-reduce(sum) of [chi2, step-scale] -> identical accept / reject and lambda on every rank
-// which is exactly the system the single-GPU kernel (csrc/lm.hip) forms in LDS; g2o's lambda schedule
+// which is exactly the system the single-GPU kernels (csrc/lm.hip, csrc/lm_grid.hip) form; g2o's lambda schedule
 // (optimization_algorithm_levenberg.cpp:58-150) runs on the host between phases (suo_slam_amd/ba_dist.py).
-// Each phase is one single-workgroup launch over the device-resident problem (same LmProblem SoA).
+//
+// A rank's share of a large graph is thousands of edges, so every data-parallel step of a phase is its own grid-strided
+// launch over BA_WGS workgroups (the kernel boundary is the barrier between steps); sums are taken per workgroup in a
+// fixed wave order and combined in workgroup order by a one-workgroup tail kernel (deterministic); only the reduced
+// (<= 96 x 96) system is factorised by a single workgroup.
 #include "lm_device.h"
 
 namespace suo {
 
 constexpr int DIAG21[6] = {0, 6, 11, 15, 18, 20};
+constexpr int BA_WGS = 64;                     // workgroups of the grid-strided steps
+// scratch (device, per context): [0, BA_WGS) workgroup partials | [BA_WGS] failure counter (as double bits of an int)
+constexpr int BA_SCRATCH_DOUBLES = BA_WGS + 8;
+
+#define GT (blockIdx.x * LM_THREADS + threadIdx.x)
+#define GS (gridDim.x * LM_THREADS)
 
 // ---- phase 0: poses from the 3x4 matrices, reset levels ---------------------------------------------------
 __global__ __launch_bounds__(LM_THREADS) void ba_init_kernel(const LmProblem* __restrict__ Pp) {
     const LmProblem& P = *Pp;
-    const int tid = threadIdx.x;
-    for (int c = tid; c < P.n_cam; c += LM_THREADS) pose_from_T(P.cam_T + 12 * c, P.cam[c]);
-    for (int o = tid; o < P.n_obj; o += LM_THREADS) pose_from_T(P.obj_T + 12 * o, P.obj[o]);
-    for (int e = tid; e < P.n_edge; e += LM_THREADS) P.level[e] = 0;
-    if (tid == 0) {
+    for (int c = GT; c < P.n_cam; c += GS) pose_from_T(P.cam_T + 12 * c, P.cam[c]);
+    for (int o = GT; o < P.n_obj; o += GS) pose_from_T(P.obj_T + 12 * o, P.obj[o]);
+    for (int e = GT; e < P.n_edge; e += GS) P.level[e] = 0;
+    if (GT == 0) {
         int ns = 0;
         for (int o = 0; o < P.n_obj; ++o) P.obj_slot[o] = P.obj_fixed[o] ? -1 : ns++;
     }
 }
 
-// ---- chi2 (re-)classification of the local edges (object_slam.py:855-866, 877-893); out[0] = local num_good ----
-__global__ __launch_bounds__(LM_THREADS) void ba_classify_kernel(const LmProblem* __restrict__ Pp, int keep_all, double* __restrict__ out) {
+// out[idx] = partial[0] + partial[1] + ... in workgroup order
+__global__ void ba_sum_kernel(const double* __restrict__ partial, int n, double* __restrict__ out, int idx) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += partial[i];
+        out[idx] = s;
+    }
+}
+
+// ---- chi2 (re-)classification of the local edges (object_slam.py:855-866, 877-893) ---------------------------
+__global__ __launch_bounds__(LM_THREADS) void ba_classify_kernel(const LmProblem* __restrict__ Pp, int keep_all, double* __restrict__ partial) {
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
-    const int tid = threadIdx.x;
     double good = 0;
-    for (int e = tid; e < P.n_edge; e += LM_THREADS) {
+    for (int e = GT; e < P.n_edge; e += GS) {
         double er[2];
         edge_error(P, e, er, nullptr, nullptr);
         const double c2 = edge_chi2(P, e, er);
@@ -46,18 +63,24 @@ __global__ __launch_bounds__(LM_THREADS) void ba_classify_kernel(const LmProblem
         else { P.level[e] = 0; P.edge_inlier[e] = 1; good += 1; }
     }
     good = block_sum(good, red);
-    if (tid == 0) out[0] = good;
+    if (threadIdx.x == 0) partial[blockIdx.x] = good;
 }
 
-// ---- linearise: out = [chi2_local | (Hoo 21 + bo 6) per object | max |diag Hcc| of local free cameras] -----
-__global__ __launch_bounds__(LM_THREADS) void ba_linearize_kernel(const LmProblem* __restrict__ Pp, int robust_on, double* __restrict__ out) {
+// ---- linearise: edge pass | pair blocks | diagonal blocks | tail --------------------------------------------
+__global__ __launch_bounds__(LM_THREADS) void ba_edge_pass_kernel(const LmProblem* __restrict__ Pp, int robust_on, int with_jac,
+                                                                   double* __restrict__ partial) {
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
-    const int tid = threadIdx.x;
-    const double chi = active_errors_and_chi2(P, robust_on != 0, true, red);
-    accumulate_pairs(P);
-    __syncthreads();
-    for (int idx = tid; idx < P.n_cam * 27; idx += LM_THREADS) {
+    const double c = block_sum(edge_pass_partial(P, 0, P.n_edge, robust_on != 0, with_jac != 0, GT, GS), red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = c;
+}
+__global__ __launch_bounds__(LM_THREADS) void ba_accumulate_kernel(const LmProblem* __restrict__ Pp) {
+    accumulate_pairs_range(*Pp, 0, Pp->n_pair, GT, GS);
+}
+// own cameras: Hcc / bc; objects: this rank's share of (Hoo 21 + bo 6) -> out[1 + 27 o + k]
+__global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ out) {
+    const LmProblem& P = *Pp;
+    for (int idx = GT; idx < P.n_cam * 27; idx += GS) {
         const int c = idx / 27, k = idx - c * 27;
         if (P.cam_fixed[c]) continue;
         double s = 0;
@@ -65,7 +88,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_linearize_kernel(const LmProble
             s += P.pair_part[90 * (size_t)P.cam_pair_idx[j] + (k < 21 ? k : 78 + (k - 21))];
         if (k < 21) P.Hcc[36 * c + k] = s; else P.bc[6 * c + (k - 21)] = s;
     }
-    for (int idx = tid; idx < P.n_obj * 27; idx += LM_THREADS) {
+    for (int idx = GT; idx < P.n_obj * 27; idx += GS) {
         const int o = idx / 27, k = idx - o * 27;
         double s = 0;
         if (!P.obj_fixed[o])
@@ -73,31 +96,37 @@ __global__ __launch_bounds__(LM_THREADS) void ba_linearize_kernel(const LmProble
                 s += P.pair_part[90 * (size_t)P.obj_pair_idx[j] + (k < 21 ? 21 + k : 84 + (k - 21))];
         out[1 + idx] = s;
     }
-    __syncthreads();
+}
+// out[0] = chi2_local, out[1 + 27 n_obj] = max |diag Hcc| over the local free cameras
+__global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ partial, int n,
+                                                                        double* __restrict__ out) {
+    const LmProblem& P = *Pp;
+    __shared__ double red[LM_THREADS / 64];
     double md = 0;
-    for (int idx = tid; idx < P.n_cam * 6; idx += LM_THREADS) {
+    for (int idx = threadIdx.x; idx < P.n_cam * 6; idx += LM_THREADS) {
         const int c = idx / 6;
         if (!P.cam_fixed[c]) md = fmax(md, fabs(P.Hcc[36 * c + DIAG21[idx - c * 6]]));
     }
     md = block_max(md, red);
-    if (tid == 0) { out[0] = chi; out[1 + 27 * P.n_obj] = md; }
+    if (threadIdx.x == 0) {
+        double chi = 0;
+        for (int i = 0; i < n; ++i) chi += partial[i];
+        out[0] = chi;
+        out[1 + 27 * P.n_obj] = md;
+    }
 }
 
-// ---- local Schur complement for this lambda: out = [S_g (ns x ns) | r_g (ns) | ok] ; also push() ------------
-__global__ __launch_bounds__(LM_THREADS) void ba_schur_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns, double* __restrict__ out) {
+// ---- local Schur complement for this lambda: push() + camera inverses | Y | S_g, r_g ---------------------------
+__global__ __launch_bounds__(LM_THREADS) void ba_schur_cams_kernel(const LmProblem* __restrict__ Pp, double lambda, int* __restrict__ bad) {
     const LmProblem& P = *Pp;
-    __shared__ int sh_ok;
-    const int tid = threadIdx.x;
-    for (int c = tid; c < P.n_cam; c += LM_THREADS) P.cam_bak[c] = P.cam[c];
-    for (int o = tid; o < P.n_obj; o += LM_THREADS) P.obj_bak[o] = P.obj[o];
-    if (tid == 0) sh_ok = 1;
-    __syncthreads();
-    for (int c = tid; c < P.n_cam; c += LM_THREADS) {
+    for (int c = GT; c < P.n_cam; c += GS) P.cam_bak[c] = P.cam[c];
+    for (int o = GT; o < P.n_obj; o += GS) P.obj_bak[o] = P.obj[o];
+    for (int c = GT; c < P.n_cam; c += GS) {
         if (P.cam_fixed[c]) continue;
         double A[36], Ai[36];
         unpack_sym21(P.Hcc + 36 * c, A);
         for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
-        if (!spd_inverse6(A, Ai)) { sh_ok = 0; for (int i = 0; i < 36; ++i) Ai[i] = 0; }
+        if (!spd_inverse6(A, Ai)) { atomicAdd(bad, 1); for (int i = 0; i < 36; ++i) Ai[i] = 0; }
         for (int i = 0; i < 36; ++i) P.Hcc_inv[36 * c + i] = Ai[i];
         for (int r = 0; r < 6; ++r) {
             double s = 0;
@@ -105,8 +134,10 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_kernel(const LmProblem* _
             P.yc[6 * c + r] = s;
         }
     }
-    __syncthreads();
-    for (int idx = tid; idx < P.n_pair * 36; idx += LM_THREADS) {
+}
+__global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem* __restrict__ Pp) {
+    const LmProblem& P = *Pp;
+    for (int idx = GT; idx < P.n_pair * 36; idx += GS) {
         const int p = idx / 36, rc = idx - p * 36, r = rc / 6, cc = rc - r * 6;
         const int c = P.pair_cam[p];
         double s = 0;
@@ -116,8 +147,12 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_kernel(const LmProblem* _
         }
         P.Y[idx] = s;
     }
-    __syncthreads();
-    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) {
+}
+// out = [S_g (ns x ns) | r_g (ns) | ok]
+__global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem* __restrict__ Pp, int ns, const int* __restrict__ bad,
+                                                                 double* __restrict__ out) {
+    const LmProblem& P = *Pp;
+    for (int idx = GT; idx < ns * ns; idx += GS) {
         const int row = idx / ns, col = idx - row * ns;
         const int s1 = row / 6, i = row - s1 * 6, s2 = col / 6, j = col - s2 * 6;
         int o1 = -1, o2 = -1;
@@ -136,7 +171,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_kernel(const LmProblem* _
         }
         out[idx] = acc;
     }
-    for (int row = tid; row < ns; row += LM_THREADS) {
+    for (int row = GT; row < ns; row += GS) {
         const int s1 = row / 6, i = row - s1 * 6;
         int o1 = -1;
         for (int o = 0; o < P.n_obj; ++o) if (P.obj_slot[o] == s1) o1 = o;
@@ -149,19 +184,16 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_kernel(const LmProblem* _
         }
         out[ns * ns + row] = acc;
     }
-    __syncthreads();
-    if (tid == 0) out[ns * ns + ns] = (double)sh_ok;
+    if (GT == 0) out[ns * ns + ns] = *bad == 0 ? 1.0 : 0.0;
 }
 
-// ---- solve the reduced system (identical on every rank), back-substitute own cameras, update, re-evaluate ----
+// ---- solve the reduced system (identical on every rank) | back-substitute + update | chi2 | tail -----------------
 // in  = [Hoo_total(21)+bo_total(6) per object | S_total (ns x ns) | r_total (ns)]
-// out = [chi2_local after the step | sum x_c (lambda x_c + b_c) over own cameras | same over objects | ok]
-__global__ __launch_bounds__(LM_THREADS) void ba_solve_update_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns, int robust_on,
-                                                                      const double* __restrict__ in, double* __restrict__ out) {
+__global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
+                                                               const double* __restrict__ in, int* __restrict__ bad) {
     const LmProblem& P = *Pp;
     __shared__ double S[LM_NS * LM_NS];
     __shared__ double rhs[LM_NS], colbuf[LM_NS];
-    __shared__ double red[LM_THREADS / 64];
     __shared__ int sh_ok;
     const int tid = threadIdx.x;
     const double* HB = in;
@@ -183,59 +215,79 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_update_kernel(const LmPro
         if (P.obj_slot[o] >= 0) rhs[6 * P.obj_slot[o] + r] = HB[27 * o + 21 + r] - rt[6 * P.obj_slot[o] + r];
     }
     __syncthreads();
-    for (int j = 0; j < ns; ++j) {                  // workgroup Cholesky, as in csrc/lm.hip
-        for (int i = j + tid; i < ns; i += LM_THREADS) {
-            double s = S[i * ns + j];
-            for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
-            colbuf[i] = s;
+    if (tid < 64) {                                   // Cholesky + substitutions by one wave, as in csrc/lm.hip
+        for (int j = 0; j < ns; ++j) {
+            for (int i = j + tid; i < ns; i += 64) {
+                double s = S[i * ns + j];
+                for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
+                colbuf[i] = s;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double piv = colbuf[j];
+            if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
+            const double d = sqrt(piv > 0 ? piv : 1.0);
+            for (int i = j + tid; i < ns; i += 64) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
-        const double piv = colbuf[j];
-        if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
-        const double d = sqrt(piv > 0 ? piv : 1.0);
-        for (int i = j + tid; i < ns; i += LM_THREADS) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
-        __syncthreads();
+        for (int j = 0; j < ns; ++j) {
+            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double yj = rhs[j];
+            for (int i = j + 1 + tid; i < ns; i += 64) rhs[i] -= S[i * ns + j] * yj;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int j = ns - 1; j >= 0; --j) {
+            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double xj = rhs[j];
+            for (int i = tid; i < j; i += 64) rhs[i] -= S[j * ns + i] * xj;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    for (int j = 0; j < ns; ++j) {
-        if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-        __syncthreads();
-        const double yj = rhs[j];
-        for (int i = j + 1 + tid; i < ns; i += LM_THREADS) rhs[i] -= S[i * ns + j] * yj;
-        __syncthreads();
-    }
-    for (int j = ns - 1; j >= 0; --j) {
-        if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-        __syncthreads();
-        const double xj = rhs[j];
-        for (int i = tid; i < j; i += LM_THREADS) rhs[i] -= S[j * ns + i] * xj;
-        __syncthreads();
-    }
+    __syncthreads();
     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
         const int o = idx / 6;
         P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
     }
-    __syncthreads();
-    for (int idx = tid; idx < P.n_cam * 6; idx += LM_THREADS) {
-        const int c = idx / 6, r = idx - c * 6;
-        double s = 0;
-        if (!P.cam_fixed[c]) {
-            s = P.yc[idx];
-            for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b) {
-                const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
-                if (P.obj_fixed[o]) continue;
-                for (int k = 0; k < 6; ++k) s -= P.Y[36 * (size_t)p + r * 6 + k] * P.xo[6 * o + k];
+    if (tid == 0 && sh_ok == 0) atomicAdd(bad, 1);
+}
+// x_c = y_c - sum_o Y(c,o) x_o for the own cameras, then T <- exp(x) T for cameras and objects (one thread per pose)
+__global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* __restrict__ Pp, const int* __restrict__ bad) {
+    const LmProblem& P = *Pp;
+    const bool ok = *bad == 0;
+    for (int c = GT; c < P.n_cam; c += GS) {
+        for (int r = 0; r < 6; ++r) {
+            double s = 0;
+            if (!P.cam_fixed[c]) {
+                s = P.yc[6 * c + r];
+                for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b) {
+                    const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
+                    if (P.obj_fixed[o]) continue;
+                    for (int k = 0; k < 6; ++k) s -= P.Y[36 * (size_t)p + r * 6 + k] * P.xo[6 * o + k];
+                }
             }
+            P.xc[6 * c + r] = s;
         }
-        P.xc[idx] = s;
+        if (ok && !P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
     }
-    __syncthreads();
-    const bool ok = sh_ok != 0;
-    if (ok) {
-        for (int c = tid; c < P.n_cam; c += LM_THREADS) if (!P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
-        for (int o = tid; o < P.n_obj; o += LM_THREADS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
-    }
-    __syncthreads();
-    const double chi = active_errors_and_chi2(P, robust_on != 0, false, red);
+    if (ok)
+        for (int o = GT; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
+}
+// out = [chi2_local after the step | sum x_c (lambda x_c + b_c) over own cameras | same over objects | ok]
+__global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProblem* __restrict__ Pp, double lambda, const double* __restrict__ partial,
+                                                                     int n, const double* __restrict__ in, const int* __restrict__ bad,
+                                                                     double* __restrict__ out) {
+    const LmProblem& P = *Pp;
+    __shared__ double red[LM_THREADS / 64];
+    const int tid = threadIdx.x;
+    const bool ok = *bad == 0;
+    const double* HB = in;
     double sc_c = 0, sc_o = 0;
     if (ok) {
         for (int idx = tid; idx < P.n_cam * 6; idx += LM_THREADS)
@@ -245,35 +297,62 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_update_kernel(const LmPro
     }
     sc_c = block_sum(sc_c, red);
     sc_o = block_sum(sc_o, red);
-    if (tid == 0) { out[0] = chi; out[1] = sc_c; out[2] = sc_o; out[3] = ok ? 1.0 : 0.0; }
+    if (tid == 0) {
+        double chi = 0;
+        for (int i = 0; i < n; ++i) chi += partial[i];
+        out[0] = chi; out[1] = sc_c; out[2] = sc_o; out[3] = ok ? 1.0 : 0.0;
+    }
 }
 
-// ---- pop(): restore the poses saved by ba_schur_kernel ---------------------------------------------------
+// ---- pop(): restore the poses saved by the Schur phase -------------------------------------------------------
 __global__ __launch_bounds__(LM_THREADS) void ba_restore_kernel(const LmProblem* __restrict__ Pp) {
     const LmProblem& P = *Pp;
-    for (int c = threadIdx.x; c < P.n_cam; c += LM_THREADS) P.cam[c] = P.cam_bak[c];
-    for (int o = threadIdx.x; o < P.n_obj; o += LM_THREADS) P.obj[o] = P.obj_bak[o];
+    for (int c = GT; c < P.n_cam; c += GS) P.cam[c] = P.cam_bak[c];
+    for (int o = GT; o < P.n_obj; o += GS) P.obj[o] = P.obj_bak[o];
 }
 
 __global__ __launch_bounds__(LM_THREADS) void ba_finalize_kernel(const LmProblem* __restrict__ Pp) {
     const LmProblem& P = *Pp;
-    for (int c = threadIdx.x; c < P.n_cam; c += LM_THREADS) pose_to_T(P.cam[c], P.cam_T + 12 * c);
-    for (int o = threadIdx.x; o < P.n_obj; o += LM_THREADS) pose_to_T(P.obj[o], P.obj_T + 12 * o);
+    for (int c = GT; c < P.n_cam; c += GS) pose_to_T(P.cam[c], P.cam_T + 12 * c);
+    for (int o = GT; o < P.n_obj; o += GS) pose_to_T(P.obj[o], P.obj_T + 12 * o);
 }
 
-#define BA_LAUNCH(k, ...)                                                                 \
-    hipLaunchKernelGGL(k, dim3(1), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ##__VA_ARGS__); \
-    SUO_HIP_CHECK(hipGetLastError());                                                     \
-    return SUO_OK;
+#define BA_GRID(k, ...) hipLaunchKernelGGL(k, dim3(BA_WGS), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ##__VA_ARGS__)
+#define BA_ONE(k, ...) hipLaunchKernelGGL(k, dim3(1), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ##__VA_ARGS__)
+#define BA_DONE SUO_HIP_CHECK(hipGetLastError()); return SUO_OK;
 
-int launch_ba_init(const void* P, hipStream_t s) { BA_LAUNCH(ba_init_kernel) }
-int launch_ba_classify(const void* P, int keep_all, double* out, hipStream_t s) { BA_LAUNCH(ba_classify_kernel, keep_all, out) }
-int launch_ba_linearize(const void* P, int robust_on, double* out, hipStream_t s) { BA_LAUNCH(ba_linearize_kernel, robust_on, out) }
-int launch_ba_schur(const void* P, double lambda, int ns, double* out, hipStream_t s) { BA_LAUNCH(ba_schur_kernel, lambda, ns, out) }
-int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, hipStream_t s) {
-    BA_LAUNCH(ba_solve_update_kernel, lambda, ns, robust_on, in, out)
+size_t ba_scratch_doubles() { return BA_SCRATCH_DOUBLES; }
+
+int launch_ba_init(const void* P, hipStream_t s) { BA_GRID(ba_init_kernel); BA_DONE }
+int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch, hipStream_t s) {
+    BA_GRID(ba_classify_kernel, keep_all, scratch);
+    hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)scratch, BA_WGS, out, 0);
+    BA_DONE
 }
-int launch_ba_restore(const void* P, hipStream_t s) { BA_LAUNCH(ba_restore_kernel) }
-int launch_ba_finalize(const void* P, hipStream_t s) { BA_LAUNCH(ba_finalize_kernel) }
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, hipStream_t s) {
+    BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch);
+    BA_GRID(ba_accumulate_kernel);
+    BA_GRID(ba_gather_kernel, out);
+    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out);
+    BA_DONE
+}
+int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s) {
+    int* bad = (int*)(scratch + BA_WGS);
+    SUO_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
+    BA_GRID(ba_schur_cams_kernel, lambda, bad);
+    BA_GRID(ba_schur_y_kernel);
+    BA_GRID(ba_schur_s_kernel, ns, (const int*)bad, out);
+    BA_DONE
+}
+int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, double* scratch, hipStream_t s) {
+    int* bad = (int*)(scratch + BA_WGS);          // carries over from the Schur phase of the same trial
+    BA_ONE(ba_solve_kernel, lambda, ns, in, bad);
+    BA_GRID(ba_update_kernel, (const int*)bad);
+    BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch);
+    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, in, (const int*)bad, out);
+    BA_DONE
+}
+int launch_ba_restore(const void* P, hipStream_t s) { BA_GRID(ba_restore_kernel); BA_DONE }
+int launch_ba_finalize(const void* P, hipStream_t s) { BA_GRID(ba_finalize_kernel); BA_DONE }
 
 }  // namespace suo

@@ -22,3 +22,13 @@ for rep in range(4):
     ts.append(time.perf_counter() - t0)
 print(f"SUO_LM_GRID_WGS={os.environ.get('SUO_LM_GRID_WGS', 'default')}: {n_cam} cams x {n_obj} objs, {len(P['edge_cam'])} edges: "
       f"{1e3 * min(ts):.2f} ms (stats rounds/its/trials/good = {list(out[4])})")
+
+# the multi-GPU phase kernels (csrc/lm_dist.hip) under the host schedule, one rank (no exchange)
+from suo_slam_amd import ba_dist  # noqa: E402
+ts = []
+for rep in range(4):
+    prob = BA.Problem(*[x.copy() for x in args])
+    t0 = time.perf_counter()
+    ba_dist.optimize_distributed(prob)
+    ts.append(time.perf_counter() - t0)
+print(f"phase-wise (1 rank): {1e3 * min(ts):.2f} ms (stats = {list(prob.stats)})")
