@@ -24,6 +24,18 @@
 #ifndef SUO_CONV_SCALAR_WAVE
 #define SUO_CONV_SCALAR_WAVE 1
 #endif
+#ifndef SUO_CONV_AF_PIPE
+#define SUO_CONV_AF_PIPE 0          // 1: A fragments one k-group ahead through a register ring (+8 VGPRs; measured slower:
+#endif                              //    with 3 workgroups per CU the other waves already hide the LDS latency)
+#ifndef SUO_CONV_WAVES_PER_EU
+#define SUO_CONV_WAVES_PER_EU 2     // two workgroups per CU: one's prologue / epilogue hides under the other's MFMAs
+#endif
+#ifndef SUO_CONV_BRING3
+#define SUO_CONV_BRING3 4           // weight-ring slots of the 3x3 kernels (must divide 9 * CK / 8)
+#endif
+#ifndef SUO_CONV_EXP
+#define SUO_CONV_EXP 0
+#endif
 #ifndef SUO_GEMM_SCALAR_WAVE
 #define SUO_GEMM_SCALAR_WAVE 1
 #endif
@@ -33,11 +45,41 @@ namespace suo {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DSUO_CONV_PROFILE (tools/micro/conv_prof.hip only): per-workgroup timestamps of the KxK kernel's phases
+#ifdef SUO_CONV_PROFILE
+__device__ long long g_conv_prof[16384 * 8];
+__device__ long long g_conv_prof_clk[16384 * 8];     // the same points on the shader clock (s_memtime)
+#define CPROF(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) { g_conv_prof[blockIdx.x * 8 + (i)] = wall_clock64(); \
+                                                                    g_conv_prof_clk[blockIdx.x * 8 + (i)] = clock64(); } } while (0)
+#else
+#define CPROF(i) do { } while (0)
+#endif
+
 size_t packed_weight_floats(int n_pad, int k_pad) { return (size_t)n_pad * (size_t)k_pad; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// Buffer descriptors (SRD) for the KxK kernel's three streams.  32-bit per-lane byte offsets in ONE VGPR each, the
+// loop-variant part in an SGPR (soffset), and the hardware range check gives zero padding (loads) / discarded
+// out-of-tile pixels (stores) without a branch -- so every load and store is unconditional and `s_waitcnt vmcnt(N)`
+// stays exact.  The descriptor inputs go through readfirstlane so hipcc can prove them wave-uniform (otherwise each
+// buffer op is wrapped in a waterfall loop).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BUF_OOB = (int)0x80000000;      // beyond any num_records used here
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, size_t bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane((unsigned)bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+
 // row of accumulator register r for this lane inside a 32x32 tile (col = lane & 31)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -239,7 +281,7 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
 // KxK convolution as implicit GEMM over an LDS-resident halo tile
 // =================================================================================================
 template <int KS, int ST, int CK, int TH, int TW, int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(SUO_CONV_WAVES_PER_EU))) void convk_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, NT = WGM * WGN * 64;
     static_assert(BM == TH * TW, "pixel tile mismatch");
@@ -267,7 +309,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
     const int n0 = blockIdx.y * BN;
     const int NB = a.N >> 5;
     const int nch = a.C / CK;
-    const int qtot = nch * KS * KS;
     const float* in_l = a.in + (size_t)l * a.H * a.W * a.C;
 
     f32x16 acc[TM][TN];
@@ -278,42 +319,55 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 areg[NLD];
-    f32x4 bcur[S][TN], bnxt[S][TN];
+    // k-groups: G per channel chunk (one group = 8 channels of one tap = 4 MFMA k-steps per accumulator tile).
+    // Weights travel through a STATIC ring of R group slots (group gg of the whole K loop lives in slot gg % R and is
+    // requested R-1 groups before its MFMAs; G % R == 0 keeps the slot of every unrolled group a compile-time constant
+    // across chunks -- no register copies for hipcc to coalesce away, no second copy of the loop body).
+    constexpr int G = KS * KS * S;
+    constexpr int R = KS == 3 ? SUO_CONV_BRING3 : 7;
+    static_assert(G % R == 0 && R >= 2, "weight ring must divide the groups of a chunk");
+    // activations: the halo tile of the next chunk is fetched in two halves (registers for half a tile only)
+    constexpr int NLH = (NLD + 1) / 2;
+    f32x4 areg[NLH];
+    f32x4 bring[R][TN];
 
-    auto gload = [&](int c) {
+    const __amdgpu_buffer_rsrc_t in_srd = make_srd(in_l, (size_t)a.H * a.W * a.C * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * KS * KS * sizeof(float));
+    const __amdgpu_buffer_rsrc_t out_srd = make_srd(a.out + (size_t)l * a.OH * a.OW * a.N, (size_t)a.OH * a.OW * a.N * sizeof(float));
+    // halo staging: byte offset of this thread's i-th 16-byte piece inside the crop (channel chunk 0), out of range
+    // for the zero padding and for the unused tail of the last round
+    int avoff[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * NT;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < NF4) {
-                const int pix = idx / C4, cc = idx - pix * C4;
-                const int py = pix / IW, px = pix - py * IW;
-                const int iy = iy0 + py, ix = ix0 + px;
-                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                    v = *(const f32x4*)(in_l + ((size_t)iy * a.W + ix) * a.C + c * CK + cc * 4);
-            }
-            areg[i] = v;
-        }
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * NT;
+        const int pix = idx / C4, cc = idx - pix * C4;
+        const int py = pix / IW, px = pix - py * IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool ok = idx < NF4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        avoff[i] = ok ? ((iy * a.W + ix) * a.C + cc * 4) * 4 : BUF_OOB;
+    }
+    auto gload = [&](int c, int h) {
+#pragma unroll
+        for (int i = 0; i < NLH; ++i)
+            if (h * NLH + i < NLD) areg[i] = buf_load(in_srd, avoff[h * NLH + i], c * CK * 4);
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int h) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * NT;
-            if (idx < NF4) {
+        for (int i = 0; i < NLH; ++i) {
+            const int idx = tid + (h * NLH + i) * NT;
+            if (h * NLH + i < NLD && idx < NF4) {
                 const int pix = idx / C4, cc = idx - pix * C4;
                 *(f32x4*)&As[buf][pix * PK + cc * 4] = areg[i];
             }
         }
     };
-    auto bload = [&](int q, f32x4(&b)[S][TN]) {
+    // weights: Wp[gg][nb][lane][4] with gg = chunk * G + group; the lane / N-tile part is one VGPR, gg an SGPR
+    const int wvoff = (((n0 >> 5) + wn * TN) * 64 + lane) * 16;
+    const int gtot = nch * G;
+    auto bload = [&](int gg, f32x4(&b)[TN]) {
+        const int gc = gg < gtot ? gg : gtot - 1;
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nb = (n0 >> 5) + wn * TN + j;
-                b[s][j] = *(const f32x4*)(a.Wp + ((size_t)((q * S + s) * NB + nb) * 64 + lane) * 4);
-            }
+        for (int j = 0; j < TN; ++j) b[j] = buf_load(w_srd, wvoff + j * 1024, gc * NB * 1024);
     };
 
     int abase[TM];
@@ -324,62 +378,66 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
         abase[i] = ((py * ST) * IW + px * ST) * PK + (lane >> 5) * 4;
     }
 
-    gload(0);
-    bload(0, bcur);
-    sstore(0);
+    CPROF(0);
+    gload(0, 0);
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) bload(r, bring[r]);
+    sstore(0, 0);
+    gload(0, 1);
+    sstore(0, 1);
     __syncthreads();
+    CPROF(1);
 
-    // One tap = S k-groups of 8 channels: ds_read_b128 A fragments + 4*S*TM*TN MFMAs against B registers `b`.
-    auto tap = [&](const float* as, const f32x4(&b)[S][TN], int toff) {
+    // A fragments of group g (tap t = g / S, channels s*8 .. s*8+7 of the chunk): one ds_read_b128 per M-tile
+    auto aread = [&](const float* as, int g, f32x4(&af)[TM]) {
+        const int t = g / S, s = g - t * S;
+        const int toff = ((t / KS) * IW + (t % KS)) * PK;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            f32x4 af[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + abase[i] + toff + s * 8);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][t], b[s][j][t], acc[i][j]);
-        }
-        // (Tried and measured, not kept: sched_group_barrier hints that request group s+1's fragments right after the
-        // first two MFMAs of group s.  hipcc then pipelines the LDS reads a full group ahead, but the 2x2 configuration
-        // grows to 256 + 68 registers = one wave per SIMD and lands on the same 113 TFLOP/s; the smaller tiles gain
-        // < 1 %.  DESIGN.md section 4.)
+        for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + abase[i] + toff + s * 8);
     };
-    // All KS*KS taps of one channel chunk, fully unrolled, with a STATIC two-buffer register ring for the weights
-    // (bcur / bnxt swap roles every tap; PAR = which buffer holds tap 0).  The next tap's weights are requested
-    // before this tap's MFMAs and first touched one tap later -- no register copies for hipcc to coalesce away.
-    auto chunk = [&](int c, const float* as, auto par) {
-        constexpr int PAR = decltype(par)::value;
+    auto group = [&](const f32x4(&af)[TM], const f32x4(&bs)[TN]) {
 #pragma unroll
-        for (int t = 0; t < KS * KS; ++t) {
-            const int q = c * KS * KS + t;
-            const int qn = q + 1 < qtot ? q + 1 : q;
-            const int toff = ((t / KS) * IW + (t % KS)) * PK;
-            if (((t + PAR) & 1) == 0) {
-                bload(qn, bnxt);
-                __builtin_amdgcn_sched_barrier(0);
-                tap(as, bcur, toff);
-            } else {
-                bload(qn, bcur);
-                __builtin_amdgcn_sched_barrier(0);
-                tap(as, bnxt, toff);
-            }
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i][t], bs[j][t], acc[i][j]);
     };
+    // (Tried and measured, not kept: sched_group_barrier hints instead of the explicit fragment ring -- hipcc then
+    // pipelines the LDS reads but the 2x2 configuration grows past 256 registers.  DESIGN.md section 4.)
 
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
+        const float* as = &As[buf][0];
+#if defined(SUO_CONV_PROFILE) && (SUO_CONV_EXP & 2)              // timing experiment: activations staged once (wrong results)
+        const bool more = false;
+#else
         const bool more = c + 1 < nch;
-        if (more) gload(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // KS*KS is odd, so the ring parity flips every chunk
-        if (((c * KS * KS) & 1) == 0) chunk(c, &As[buf][0], std::integral_constant<int, 0>());
-        else chunk(c, &As[buf][0], std::integral_constant<int, 1>());
-        if (more) sstore(buf ^ 1);
+#endif
+        // the G groups of this chunk, fully unrolled; every load is requested well ahead of its use and pinned there
+        f32x4 afr[2][TM];
+        aread(as, 0, afr[0]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g == 0 && more) gload(c + 1, 0);
+            if (g == G / 2 && more) { sstore(buf ^ 1, 0); gload(c + 1, 1); }
+#if !(defined(SUO_CONV_PROFILE) && (SUO_CONV_EXP & 1))      // timing experiment: weights never re-fetched (wrong results)
+            bload(c * G + g + R - 1, bring[(g + R - 1) % R]);
+#endif
+#if SUO_CONV_AF_PIPE
+            if (g + 1 < G) aread(as, g + 1, afr[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            group(afr[g & 1], bring[g % R]);
+#else
+            __builtin_amdgcn_sched_barrier(0);
+            aread(as, g, afr[0]);
+            group(afr[0], bring[g % R]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) sstore(buf ^ 1, 1);
         __syncthreads();
+        if (c < 4) CPROF(2 + c);
     }
 
 #pragma unroll
@@ -405,10 +463,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void convk_kernel(const ConvArgs a) 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
                 }
-                if (oy < a.OH && ox < a.OW) *(f32x4*)(a.out + (((size_t)l * a.OH + oy) * a.OW + ox) * a.N + col) = o;
+                buf_store(o, out_srd, (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N + col) * 4 : BUF_OOB);
             }
             __builtin_amdgcn_wave_barrier();
         }
+    CPROF(6);
+#ifdef SUO_CONV_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        unsigned hw_id, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(20, 0, 4)" : "=s"(xcc));
+        g_conv_prof[blockIdx.x * 8 + 7] = ((long long)xcc << 32) | hw_id;
+    }
+#endif
 }
 
 template <int KS, int ST, int CK, int TH, int TW, int TM, int TN, int WGM, int WGN>
