@@ -19,6 +19,7 @@
 //    NCHW transpose (operands swapped so the wave's 32 columns are 32 consecutive pixels).
 #include <type_traits>
 
+#include "buffer_ops.h"
 #include "suo_internal.h"
 
 #ifndef SUO_CONV_SCALAR_WAVE
@@ -60,26 +61,6 @@ size_t packed_weight_floats(int n_pad, int k_pad) { return (size_t)n_pad * (size
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-// Buffer descriptors (SRD) for the KxK kernel's three streams.  32-bit per-lane byte offsets in ONE VGPR each, the
-// loop-variant part in an SGPR (soffset), and the hardware range check gives zero padding (loads) / discarded
-// out-of-tile pixels (stores) without a branch -- so every load and store is unconditional and `s_waitcnt vmcnt(N)`
-// stays exact.  The descriptor inputs go through readfirstlane so hipcc can prove them wave-uniform (otherwise each
-// buffer op is wrapped in a waterfall loop).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BUF_OOB = (int)0x80000000;      // beyond any num_records used here
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, size_t bytes) {
-    const unsigned long long u = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane((unsigned)bytes), 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
-}
-
 // row of accumulator register r for this lane inside a 32x32 tile (col = lane & 31)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -12,7 +12,11 @@
 //     it does not depend on),
 //   * so the first chunks of tile i+1 are already in flight while tile i finishes, and tile i's stores drain
 //     under tile i+1's MFMAs.  The epilogue uses its own wave-private LDS patches (the chunk buffers already hold the
-//     next tile).
+//     next tile),
+//   * every stream goes through a buffer descriptor (csrc/buffer_ops.h): one fixed 32-bit VGPR offset per stream, tile
+//     and chunk in the descriptor base / scalar offset -- no 64-bit address registers, which together with the 16-row
+//     epilogue patch (46 KB of LDS) lets THREE workgroups share a CU.
+#include "buffer_ops.h"
 #include "suo_internal.h"
 
 namespace suo {
@@ -22,14 +26,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int acc_row_s(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+constexpr int GP_MAX_PRO_K = 512;       // channels of a fused BN-ReLU prologue (scale / shift kept in LDS)
+
+#ifndef SUO_GEMM_A_DEPTH
+#define SUO_GEMM_A_DEPTH 1          // steps the activations are fetched ahead (1: one register set, 2: two)
+#endif
+#ifndef SUO_GEMM_WAVES_PER_EU
+#define SUO_GEMM_WAVES_PER_EU 3
+#endif
+
 template <int TM, int TN, int WGM, int WGN, bool HAS_R>
-__global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const GemmArgs a, int ntiles) {
+__global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(SUO_GEMM_WAVES_PER_EU))) void gemm_persist_kernel(const GemmArgs a, int ntiles) {
     constexpr int BK = 32, PK = BK + 4;
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, NT = WGM * WGN * 64;
     constexpr int NLD = BM * 8 / NT;
     static_assert(BM * 8 % NT == 0, "staging must divide evenly");
     __shared__ __attribute__((aligned(16))) float As[2][BM * PK];
-    __shared__ __attribute__((aligned(16))) float Tp[WGM * WGN][32 * PK];
+    __shared__ __attribute__((aligned(16))) float Tp[WGM * WGN][16 * PK];      // 128-row tiles: 50 KB in all = 3 workgroups per CU
+    __shared__ __attribute__((aligned(16))) float Ps[2][GP_MAX_PRO_K];         // prologue scale | shift
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifndef SUO_GEMM_SCALAR_WAVE
@@ -60,6 +74,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
     const int nsteps = n_mine * nch;
     if (nsteps == 0) return;
 
+    if (has_pro)
+        for (int k = tid; k < a.K1; k += NT) { Ps[0][k] = a.pro_scale[k]; Ps[1][k] = a.pro_shift[k]; }
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -68,14 +85,25 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ar0[NLD], ar1[NLD], sc0, sh0, sc1, sh1;
-    f32x4 b0[4][TN], b1[4][TN];
+    f32x4 ar0[NLD];
+#if SUO_GEMM_A_DEPTH == 2
+    f32x4 ar1[NLD];
+#endif
+    f32x4 bring[4][TN];
+
+    // fixed per-lane byte offsets of the four streams
+    const int av1 = (r0 * a.lda1 + c4 * 4) * 4, av2 = (r0 * a.lda2 + c4 * 4) * 4;           // activations (operand 1 / 2)
+    const int wv = (wn * TN * 64 + lane) * 16;                                                // packed weights
+    const int ov = ((wm * TM * 32 + (lane >> 3)) * a.ldo + wn * TN * 32 + (lane & 7) * 4) * 4;  // output tile
+    const int rv = ((wm * TM * 32 + (lane >> 3)) * a.ldr + wn * TN * 32 + (lane & 7) * 4) * 4;  // residual tile
+    const int bv = (wn * TN * 32 + (lane & 7) * 4) * 4;                                       // bias
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * (a.K1 + a.K2) * sizeof(float));
+    const __amdgpu_buffer_rsrc_t bias_srd = make_srd(a.bias, (size_t)a.N * sizeof(float));
 
     // step -> (tile origin, chunk); fetch cursor and compute cursor advance independently (no divisions in the loop)
-    // EVERY load of the steady state is unconditional (rows clamped instead of predicated, the cursor parks on the
-    // last step instead of stopping): a load under a branch makes hipcc fall back to s_waitcnt vmcnt(0) at the next
-    // use of ANY loaded value -- which would wait for the prefetches just issued and expose a full memory round
-    // trip every step.
+    // EVERY load of the steady state is unconditional (the cursor parks on the last step instead of stopping): a load
+    // under a branch makes hipcc fall back to s_waitcnt vmcnt(0) at the next use of ANY loaded value -- which would wait
+    // for the prefetches just issued and expose a full memory round trip every step.
     int f_kc = 0, f_m0 = (t_first / ntn) * BM, f_tile = t_first, f_left = nsteps - 1;      // fetch cursor (activations)
     auto fetch_advance = [&]() {
         if (f_left > 0) {
@@ -83,42 +111,32 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
             if (++f_kc == nch) { f_kc = 0; f_tile += t_stride; f_m0 = (f_tile / ntn) * BM; }
         }
     };
-    const float* const ps_base = has_pro ? a.pro_scale : a.bias;               // any readable floats when there is no prologue
-    const float* const ph_base = has_pro ? a.pro_shift : a.bias;
-    auto gload = [&](f32x4(&ar)[NLD], f32x4& sc, f32x4& sh) {
-        const float* A;
-        int lda, kk;
-        if (f_kc < nch1) { A = a.A1; lda = a.lda1; kk = f_kc * BK; }
-        else { A = a.A2; lda = a.lda2; kk = (f_kc - nch1) * BK; }
+    auto gload = [&](f32x4(&ar)[NLD]) {
+        const bool first = f_kc < nch1;
+        const int lda = first ? a.lda1 : a.lda2;
+        const float* A = (first ? a.A1 + f_kc * BK : a.A2 + (f_kc - nch1) * BK) + (size_t)f_m0 * lda;    // M % BM == 0 (launcher)
+        const __amdgpu_buffer_rsrc_t srd = make_srd(A, ((size_t)(BM - 1) * lda + BK) * sizeof(float));
+        const int v = first ? av1 : av2;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int row = f_m0 + r0 + i * (NT / 8);                         // M % BM == 0 (checked by the launcher)
-            ar[i] = *(const f32x4*)(A + (size_t)row * lda + kk + c4 * 4);
-        }
-        const int pk = has_pro && f_kc < nch1 ? kk + c4 * 4 : 0;
-        sc = *(const f32x4*)(ps_base + pk);
-        sh = *(const f32x4*)(ph_base + pk);
+        for (int i = 0; i < NLD; ++i) ar[i] = buf_load(srd, v, i * (NT / 8) * lda * 4);
         fetch_advance();
     };
-    auto sstore = [&](const f32x4(&ar)[NLD], const f32x4& sc, const f32x4& sh, bool pro, int buf) {
+    auto sstore = [&](const f32x4(&ar)[NLD], int pro_k, int buf) {      // pro_k < 0: no prologue for this chunk
+        f32x4 sc, sh;
+        if (pro_k >= 0) { sc = *(const f32x4*)&Ps[0][pro_k + c4 * 4]; sh = *(const f32x4*)&Ps[1][pro_k + c4 * 4]; }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             f32x4 v = ar[i];
-            if (pro) {
+            if (pro_k >= 0) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = fmaxf(fmaf(v[t], sc[t], sh[t]), 0.f);
             }
             *(f32x4*)&As[buf][(r0 + i * (NT / 8)) * PK + c4 * 4] = v;
         }
     };
-    auto bload = [&](int kc, int n0, f32x4(&b)[4][TN]) {
+    auto bgroup = [&](int kc, int n0, int ss, f32x4(&b)[TN]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nb = (n0 >> 5) + wn * TN + j;
-                b[s][j] = *(const f32x4*)(a.Wp + ((size_t)((kc * 4 + s) * NB + nb) * 64 + lane) * 4);
-            }
+        for (int j = 0; j < TN; ++j) b[j] = buf_load(w_srd, wv + j * 1024, ((kc * 4 + ss) * NB + (n0 >> 5)) * 1024);
     };
 
     // compute cursor
@@ -129,57 +147,60 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
         if (nkc == nch) { nkc = 0; nn0 = (min(tile + t_stride, ntiles - 1) % ntn) * BN; }
     };
 
-    bload(0, n0, b0);
-    gload(ar0, sc0, sh0);
-    gload(ar1, sc1, sh1);
-    sstore(ar0, sc0, sh0, has_pro && 0 < nch1, 0);
+#pragma unroll
+    for (int ss = 0; ss < 3; ++ss) bgroup(0, n0, ss, bring[ss]);
+    gload(ar0);
+#if SUO_GEMM_A_DEPTH == 2
+    gload(ar1);
+#endif
+    __syncthreads();                                          // Ps visible
+    sstore(ar0, has_pro && 0 < nch1 ? 0 : -1, 0);
     __syncthreads();
 
     auto epilogue = [&]() {
         float* T = &Tp[w][0];
+        const __amdgpu_buffer_rsrc_t o_srd = make_srd(a.out + (size_t)m0 * a.ldo + n0, ((size_t)(BM - 1) * a.ldo + BN) * sizeof(float));
         // every residual / bias value of the tile is requested BEFORE the first accumulator is transposed: one HBM round
         // trip per tile instead of one per 32 x 32 accumulator (K = 128 layers: the epilogue used to outlast the main loop)
-        f32x4 rvall[TM][TN][4], bvall[TN];
+        // the residual values of a 32-row block are requested together, block 0 before anything else of the epilogue
+        f32x4 rvall[TN][4], bvall[TN];
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(HAS_R ? a.R + (size_t)m0 * a.ldr + n0 : a.bias, HAS_R ? ((size_t)(BM - 1) * a.ldr + BN) * sizeof(float) : 16);
+        auto rload = [&](int i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bvall[j] = *(const f32x4*)(a.bias + n0 + (wn * TN + j) * 32 + (lane & 7) * 4);
-        if (HAS_R) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int k = 0; k < 4; ++k) rvall[j][k] = buf_load(r_srd, rv, ((i * 32 + 8 * k) * a.ldr + j * 32) * 4);
+        };
+        if (HAS_R) rload(0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) bvall[j] = buf_load(bias_srd, bv, (n0 + j * 32) * 4);
+        // each 32 x 32 accumulator goes through the 16-row patch in two halves: registers 0-7 hold rows 0-15, 8-15 rows 16-31
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
-                        rvall[i][j][k] = *(const f32x4*)(a.R + (size_t)row * a.ldr + n0 + (wn * TN + j) * 32 + (lane & 7) * 4);
-                    }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            if (HAS_R && i > 0) rload(i);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { T[acc_row_s(r, lane) * PK + (lane & 31)] = acc[i][j][r]; acc[i][j][r] = 0.f; }
-                __builtin_amdgcn_wave_barrier();
-                const int col = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-                const f32x4 bv = bvall[j];
-                f32x4 v[4], rv[4];
+                for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    rv[k] = HAS_R ? rvall[i][j][k] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    v[k] = *(const f32x4*)&T[((lane >> 3) + 8 * k) * PK + (lane & 7) * 4];
-                }
+                    for (int r = 8 * h; r < 8 * h + 8; ++r) { T[(acc_row_s(r, lane) - 16 * h) * PK + (lane & 31)] = acc[i][j][r]; acc[i][j][r] = 0.f; }
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 v[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
-                    f32x4 o = v[k] + bv + rv[k];
-                    if (a.relu) {
+                    for (int k = 0; k < 2; ++k) v[k] = *(const f32x4*)&T[((lane >> 3) + 8 * k) * PK + (lane & 7) * 4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+                    for (int k = 0; k < 2; ++k) {
+                        f32x4 o = v[k] + bvall[j] + (HAS_R ? rvall[j][2 * h + k] : f32x4{0.f, 0.f, 0.f, 0.f});
+                        if (a.relu) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
+                        }
+                        buf_store(o, o_srd, ov, ((i * 32 + 8 * (2 * h + k)) * a.ldo + j * 32) * 4);     // unpredicated: stores count in vmcnt too
                     }
-                    *(f32x4*)(a.out + (size_t)row * a.ldo + col) = o;     // unpredicated: stores count in vmcnt too
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
+        }
     };
 
     // One step: weights for step s+1 and activations for step s+2 are requested, then the 16*TM*TN MFMAs of step s run
@@ -187,17 +208,18 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
     //   b / bn        weight sets of step s / s+1
     //   a_free        register set that step s+2 is fetched into (it held step s, stored at the end of step s-1)
     //   a_next        register set holding step s+1
-    auto step = [&](int s, const f32x4(&b)[4][TN], f32x4(&bn)[4][TN], f32x4(&a_free)[NLD], f32x4& sc_free, f32x4& sh_free,
-                    const f32x4(&a_next)[NLD], const f32x4& sc_next, const f32x4& sh_next) {
+    auto step = [&](int s, f32x4(&a_free)[NLD], const f32x4(&a_next)[NLD]) {
         const int buf = s & 1;
         int nkc, nn0;
         next_b(nkc, nn0);
-        bload(nkc, nn0, bn);                                   // (past the last step: a harmless re-read of chunk 0)
-        gload(a_free, sc_free, sh_free);
-        __builtin_amdgcn_sched_barrier(0);
         const float* as = &As[buf][((wm * TM * 32) + (lane & 31)) * PK + (lane >> 5) * 4];
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
+            // weights ride a static ring of 4 k-group slots (slot = group of the chunk), requested 3 groups ahead into
+            // the slot the previous group just released; past the last step: a harmless re-read of chunk 0
+            if (ss == 0) { bgroup(kc, n0, 3, bring[3]); gload(a_free); }
+            else bgroup(nkc, nn0, ss - 1, bring[ss - 1]);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 af[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + i * 32 * PK + ss * 8);
@@ -206,9 +228,10 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], b[ss][j][t], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bring[ss][j][t], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        sstore(a_next, sc_next, sh_next, has_pro && nkc < nch1, buf ^ 1);
+        sstore(a_next, has_pro && nkc < nch1 ? nkc * BK : -1, buf ^ 1);
         __syncthreads();
         if (kc + 1 == nch) {                                   // workgroup-uniform: the tile is complete
             epilogue();
@@ -218,8 +241,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, 2) void gemm_persist_kernel(const Ge
         }
     };
     for (int s = 0; s < nsteps; s += 2) {
-        step(s, b0, b1, ar0, sc0, sh0, ar1, sc1, sh1);
-        if (s + 1 < nsteps) step(s + 1, b1, b0, ar1, sc1, sh1, ar0, sc0, sh0);
+#if SUO_GEMM_A_DEPTH == 2
+        step(s, ar0, ar1);
+        if (s + 1 < nsteps) step(s + 1, ar1, ar0);
+#else
+        step(s, ar0, ar0);
+        if (s + 1 < nsteps) step(s + 1, ar0, ar0);
+#endif
     }
 }
 
@@ -230,6 +258,7 @@ static int launch_persist_cfg(const GemmArgs& a, int max_wgs, hipStream_t s) {
         suo_set_error("gemm_persist: M=%d N=%d n_valid=%d must be whole %dx%d tiles", a.M, a.N, a.n_valid, BM, BN);
         return SUO_ERR_ARG;
     }
+    if (a.pro_scale && a.K1 > GP_MAX_PRO_K) { suo_set_error("gemm_persist: prologue over K1=%d > %d channels", a.K1, GP_MAX_PRO_K); return SUO_ERR_ARG; }
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     const int g = ntiles < max_wgs ? ntiles : max_wgs;
     if (a.R) hipLaunchKernelGGL((gemm_persist_kernel<TM, TN, WGM, WGN, true>), dim3(g), dim3(WGM * WGN * 64), 0, s, a, ntiles);
@@ -238,10 +267,10 @@ static int launch_persist_cfg(const GemmArgs& a, int max_wgs, hipStream_t s) {
     return SUO_OK;
 }
 
-// cfg: 1 = 128x128 tiles, 2 = 128x64 tiles, 3 = 64x64 tiles.  The grid is the number of RESIDENT workgroups (2 per CU
-// for the 128-row tiles, 4 for the 64x64 one, on the 256-CU part), not the number of tiles.
+// cfg: 1 = 128x128 tiles, 2 = 128x64 tiles, 3 = 64x64 tiles.  The grid is the number of RESIDENT workgroups (3 per CU
+// for the 128-row tiles, 6 for the 64x64 one, on the 256-CU part), not the number of tiles.
 int launch_gemm_persist(const GemmArgs& a, int cfg, hipStream_t s) {
-    static const int max_wgs = getenv("SUO_GEMM_WGS") ? atoi(getenv("SUO_GEMM_WGS")) : 512;       // tuning aid
+    static const int max_wgs = getenv("SUO_GEMM_WGS") ? atoi(getenv("SUO_GEMM_WGS")) : 768;       // tuning aid
     if (cfg == 3) return launch_persist_cfg<1, 1, 2, 2>(a, 2 * max_wgs, s);
     if (cfg == 2) return launch_persist_cfg<2, 1, 2, 2>(a, max_wgs, s);
     return launch_persist_cfg<2, 2, 2, 2>(a, max_wgs, s);
