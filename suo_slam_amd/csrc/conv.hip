@@ -249,7 +249,9 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
     // tile choice: keep >= ~2 workgroups per CU where the problem allows it
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128 > 0 ? a.N / 128 : 1);
     const long tiles12864 = (long)((a.M + 127) / 128) * (a.N / 64);
-    const int cfg = ((a.N % 128) == 0 && tiles128 >= 512) ? 1 : (tiles12864 >= 384 ? 2 : 3);      // 128x128 | 128x64 | 64x64
+    static const int force_cfg = getenv("SUO_GEMM_CFG") ? atoi(getenv("SUO_GEMM_CFG")) : 0;           // tuning aid only
+    int cfg = ((a.N % 128) == 0 && tiles128 >= 512) ? 1 : (tiles12864 >= 384 ? 2 : 3);      // 128x128 | 128x64 | 64x64
+    if (force_cfg >= 2 || (force_cfg == 1 && (a.N % 128) == 0)) cfg = force_cfg;
     // whole tiles (every shape of this network): the persistent, branch-free kernel of csrc/gemm_persist.hip
     static const int persist = getenv("SUO_GEMM_PERSIST") ? atoi(getenv("SUO_GEMM_PERSIST")) : 1;     // 0: A/B against the one-tile kernel
     if (persist && a.n_valid == a.N && a.M % (cfg == 3 ? 64 : 128) == 0) return launch_gemm_persist(a, cfg, s);
@@ -482,11 +484,15 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
     if (force == 1) return launch_conv_cfg<3, 1, 32, 8, 8, 1, 1, 2, 2>(a, s);
     if (force == 2 && (a.N % 128) == 0) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 2, 2, 2>(a, s);
     if (force == 3) return launch_conv_cfg<3, 1, 32, 8, 16, 1, 1, 4, 2>(a, s);
+    if (force == 4) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 1, 2, 2>(a, s);
     // 128-pixel x 128-channel workgroup tiles when all output channels fit one tile: every activation tile is then
     // fetched once (PMC: HBM fetch 2.8x -> 1.4x of the input, the 1.4x being the 3x3 halo)
-    if (a.OH >= 8 && a.OW >= 16 && (a.N % 128) == 0 && ((px + 127) / 128) * (a.N / 128) >= 256)
-        return launch_conv_cfg<3, 1, 32, 8, 16, 2, 2, 2, 2>(a, s);
-    if (a.OH >= 8 && a.OW >= 16 && t128 >= 384) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 1, 2, 2>(a, s);
+    // -- but only with >= 8 such tiles per CU: three workgroups share a CU, and a handful of long tiles per CU quantises
+    // badly (tools/bench_conv_shapes.py, 128 crops: 32x32 maps 117 -> 138 TFLOP/s with 128 x 64 tiles, 16x16 130 -> 134)
+    const bool big = a.OH >= 8 && a.OW >= 16;
+    if (big && (a.N % 128) == 0 && ((px + 127) / 128) * (a.N / 128) >= 2048) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 2, 2, 2>(a, s);
+    if (big && (a.N % 128) == 0 && t128 >= 1024) return launch_conv_cfg<3, 1, 32, 8, 16, 1, 1, 4, 2>(a, s);
+    if (big && t128 >= 2048) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 1, 2, 2>(a, s);
     const long t64 = ((px + 63) / 64) * (a.N / 64);
     if (a.OH >= 8 && a.OW >= 8 && t64 >= 256) return launch_conv_cfg<3, 1, 32, 8, 8, 1, 1, 2, 2>(a, s);
     return launch_conv_cfg<3, 1, 32, 4, 8, 1, 1, 1, 2>(a, s);

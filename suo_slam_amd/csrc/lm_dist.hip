@@ -36,6 +36,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_init_kernel(const LmProblem* __
     if (GT == 0) {
         int ns = 0;
         for (int o = 0; o < P.n_obj; ++o) P.obj_slot[o] = P.obj_fixed[o] ? -1 : ns++;
+        for (int k = 0; k < 4; ++k) P.stats[k] = 0;      // the host schedule keeps the counters (ba_dist.py); download checks stats[0] >= 0
     }
 }
 
