@@ -31,6 +31,18 @@ constexpr int GP_MAX_PRO_K = 512;       // channels of a fused BN-ReLU prologue 
 #ifndef SUO_GEMM_A_DEPTH
 #define SUO_GEMM_A_DEPTH 1          // steps the activations are fetched ahead (1: one register set, 2: two)
 #endif
+#ifndef SUO_GEMM_STORE_AT
+#define SUO_GEMM_STORE_AT 1         // (A_DEPTH 2) k-group of the step before whose MFMAs the next activations go to LDS
+#endif
+#ifndef SUO_GEMM_STORE_MIX
+#define SUO_GEMM_STORE_MIX 0
+#endif
+#ifndef SUO_GEMM_EPI_PREFETCH
+#define SUO_GEMM_EPI_PREFETCH 0     // 1: request bias / first residual block during the tile's last K-step (measured: no gain
+#endif                              //    with 3 workgroups per CU, and the 128x128 residual variant starts to spill)
+#ifndef SUO_GEMM_EXP
+#define SUO_GEMM_EXP 0
+#endif
 #ifndef SUO_GEMM_WAVES_PER_EU
 #define SUO_GEMM_WAVES_PER_EU 3
 #endif
@@ -157,27 +169,32 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     sstore(ar0, has_pro && 0 < nch1 ? 0 : -1, 0);
     __syncthreads();
 
+    // Epilogue operands: the bias and the residual values of the tile's first 32-row block are requested before anything
+    // else of the epilogue (or, with SUO_GEMM_EPI_PREFETCH, during the tile's last K-step); the second block's residuals
+    // reuse the same registers and are requested as soon as the first block has been consumed.
+    f32x4 rvall[TN][4], bvall[TN];
+    auto rload = [&](int i) {
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(HAS_R ? a.R + (size_t)m0 * a.ldr + n0 : a.bias, HAS_R ? ((size_t)(BM - 1) * a.ldr + BN) * sizeof(float) : 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rvall[j][k] = buf_load(r_srd, rv, ((i * 32 + 8 * k) * a.ldr + j * 32) * 4);
+    };
+    auto epi_prefetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bvall[j] = buf_load(bias_srd, bv, (n0 + j * 32) * 4);
+        if (HAS_R && !(SUO_GEMM_EXP & 8)) rload(0);
+    };
     auto epilogue = [&]() {
         float* T = &Tp[w][0];
         const __amdgpu_buffer_rsrc_t o_srd = make_srd(a.out + (size_t)m0 * a.ldo + n0, ((size_t)(BM - 1) * a.ldo + BN) * sizeof(float));
-        // every residual / bias value of the tile is requested BEFORE the first accumulator is transposed: one HBM round
-        // trip per tile instead of one per 32 x 32 accumulator (K = 128 layers: the epilogue used to outlast the main loop)
-        // the residual values of a 32-row block are requested together, block 0 before anything else of the epilogue
-        f32x4 rvall[TN][4], bvall[TN];
-        const __amdgpu_buffer_rsrc_t r_srd = make_srd(HAS_R ? a.R + (size_t)m0 * a.ldr + n0 : a.bias, HAS_R ? ((size_t)(BM - 1) * a.ldr + BN) * sizeof(float) : 16);
-        auto rload = [&](int i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) rvall[j][k] = buf_load(r_srd, rv, ((i * 32 + 8 * k) * a.ldr + j * 32) * 4);
-        };
-        if (HAS_R) rload(0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bvall[j] = buf_load(bias_srd, bv, (n0 + j * 32) * 4);
+#if !SUO_GEMM_EPI_PREFETCH
+        epi_prefetch();
+#endif
         // each 32 x 32 accumulator goes through the 16-row patch in two halves: registers 0-7 hold rows 0-15, 8-15 rows 16-31
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (HAS_R && i > 0) rload(i);
+            if (HAS_R && i > 0 && !(SUO_GEMM_EXP & 8)) rload(i);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -195,6 +212,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 #pragma unroll
                             for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
                         }
+#if SUO_GEMM_EXP & 2
+                        if (o[0] == 12345.678f)
+#endif
                         buf_store(o, o_srd, ov, ((i * 32 + 8 * (2 * h + k)) * a.ldo + j * 32) * 4);     // unpredicated: stores count in vmcnt too
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -217,12 +237,30 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         for (int ss = 0; ss < 4; ++ss) {
             // weights ride a static ring of 4 k-group slots (slot = group of the chunk), requested 3 groups ahead into
             // the slot the previous group just released; past the last step: a harmless re-read of chunk 0
-            if (ss == 0) { bgroup(kc, n0, 3, bring[3]); gload(a_free); }
+#if !(SUO_GEMM_EXP & 4)      // SUO_GEMM_EXP: timing-only experiments (wrong results): 1 no activation loads, 2 no stores,
+            if (ss == 0) bgroup(kc, n0, 3, bring[3]);      //               4 no weight loads, 8 no residual loads
             else bgroup(nkc, nn0, ss - 1, bring[ss - 1]);
+#endif
+#if !(SUO_GEMM_EXP & 1)
+            if (ss == 0) gload(a_free);
+#endif
+#if SUO_GEMM_EPI_PREFETCH
+            if (ss == 1 && kc + 1 == nch) epi_prefetch();      // workgroup-uniform: last K-step of the tile
+#endif
+#if SUO_GEMM_A_DEPTH == 2
+            // two register sets: step s+1's activations were requested a whole step ago, so they can go to the other LDS
+            // buffer (free since the barrier that ended step s-1) in the MIDDLE of this step's MFMAs instead of between
+            // the last MFMA and the barrier
+            if (ss == SUO_GEMM_STORE_AT && !SUO_GEMM_STORE_MIX) sstore(a_next, has_pro && nkc < nch1 ? nkc * BK : -1, buf ^ 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             f32x4 af[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + i * 32 * PK + ss * 8);
+#if SUO_GEMM_A_DEPTH == 2 && SUO_GEMM_STORE_MIX
+            // same scheduling region as the group's MFMAs: hipcc may slot the prologue VALU and ds_write between them
+            if (ss == SUO_GEMM_STORE_AT) sstore(a_next, has_pro && nkc < nch1 ? nkc * BK : -1, buf ^ 1);
+#endif
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -231,9 +269,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bring[ss][j][t], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if SUO_GEMM_A_DEPTH != 2 && !(SUO_GEMM_EXP & 32)             // (32: no LDS staging, 16: no per-step barrier)
         sstore(a_next, has_pro && nkc < nch1 ? nkc * BK : -1, buf ^ 1);
+#endif
+#if !(SUO_GEMM_EXP & 16)
         __syncthreads();
-        if (kc + 1 == nch) {                                   // workgroup-uniform: the tile is complete
+#endif
+        if (kc + 1 == nch) {                                // workgroup-uniform: the tile is complete
             epilogue();
             kc = 0; tile += t_stride; m0 = (tile / ntn) * BM; n0 = (tile % ntn) * BN;
         } else {
