@@ -62,8 +62,9 @@ def test_conv1x1_fused_prologue_dual_residual_relu(ops):
 
 
 @pytest.mark.parametrize("M,K1,K2,N,pro,res,relu", [
-    (131072, 128, 0, 256, False, True, False),     # 128x128 tiles, 2048 tiles over 512 persistent workgroups (4 each)
-    (66048, 256, 0, 128, True, False, True),       # 128x128 tiles, 516 tiles over 512 workgroups: uneven lists, no XCD split
+    (131072, 128, 0, 256, False, True, False),     # 128x128 tiles, 2048 tiles over 768 persistent workgroups (2-3 each)
+    (66048, 256, 0, 128, True, False, True),       # 128x128 tiles, 516 tiles (not a multiple of 8): plain round-robin lists
+    (262144, 256, 0, 128, True, False, True),      # 2048 tiles over 768 workgroups, prologue constants from LDS
     (65536, 256, 64, 256, False, True, False),     # dual operand with a 2-chunk tail (re-injection shape)
     (65536, 64, 64, 128, False, False, False),     # 2 + 2 chunks per tile
     (32768, 256, 0, 128, True, False, True),       # 128x64 tiles, one tile per workgroup
@@ -73,8 +74,9 @@ def test_conv1x1_fused_prologue_dual_residual_relu(ops):
     (4160, 64, 0, 64, False, False, False),        # 65 tiles: odd count, fewer than the resident workgroups
 ])
 def test_conv1x1_persistent_tile_walk(ops, M, K1, K2, N, pro, res, relu):
-    """Whole-tile shapes take the persistent kernel (csrc/gemm_persist.hip): tile lists per workgroup, the two-step
-    prefetch across tile boundaries and the parked fetch cursor at the tail must not change a single output."""
+    """Whole-tile shapes take the persistent kernel (csrc/gemm_persist.hip): tile lists per workgroup, the activation
+    prefetch and the weight ring running across tile boundaries, and the parked fetch cursor at the tail must not change
+    a single output."""
     rng = np.random.default_rng(M % 1000 + K1 + N)
     a1 = rng.standard_normal((M, K1)).astype(np.float32)
     w1 = (rng.standard_normal((N, K1)) / np.sqrt(K1 + K2)).astype(np.float32)
@@ -124,6 +126,26 @@ def test_conv3x3(ops, L, H, C, N):
     out = ops.nchw(ops.conv_kxk(ops.nhwc(x), w, b, relu=True))
     ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)).numpy()
     assert _rel(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("L,H,W,C,N,why", [
+    (80, 60, 60, 128, 128, "128x128 tiles (>= 2048 of them), 3 workgroups per CU, ragged bottom / right tiles"),
+    (20, 60, 60, 128, 128, "128x64 tiles, 8-wave workgroups, ragged"),
+    (20, 120, 104, 64, 64, "N = 64: 128x64 tiles with 4 waves, ragged, non-square"),
+    (70, 64, 64, 128, 128, "128x128 tiles, tile count not a multiple of 8 (no XCD remap)"),
+])
+def test_conv3x3_large_launches(ops, L, H, W, C, N, why):
+    """The tile configurations only large launches select (csrc/conv.hip: launch_conv3x3), with the zero padding and the
+    out-of-tile pixels left to the buffer descriptors' range check."""
+    rng = np.random.default_rng(L + H + C)
+    x = rng.standard_normal((L, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((N, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    out = ops.nchw(ops.conv_kxk(ops.nhwc(x), w, b, relu=True))
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)).numpy()
+    assert _rel(out, ref) < 5e-6, why
+    bad = np.abs(out - ref).reshape(L, -1).max(1) > 1e-3 * (1 + np.abs(ref).max())
+    assert not bad.any(), (why, np.flatnonzero(bad)[:8])     # per crop: a stray out-of-tile store lands in a neighbouring row
 
 
 def test_conv7x7_stride2(ops):
