@@ -139,6 +139,103 @@ def _chi2_inliers(T_OtoC, det, use_inlier_subset, manual_kp_std):
     return int(np.count_nonzero(chi2 <= CHI2_2DOF_95))
 
 
+def _det_cache(d):
+    """Padded copies of a detection's immutable arrays (keypoints, predictions, covariances, intrinsics), built once
+    per detection: the scoring rules below run O(objects^2 + 15 objects) times per SLAM view and the graph assembly
+    once per keypoint, which as per-detection numpy calls dominated a view's host time."""
+    c = d.get("_cache")
+    if c is not None and c["src"][0] is d["uv_pred"] and c["src"][1] is d["cov_pred"] and c["src"][2] is d["model_kp"] and c["src"][3] is d["K"]:
+        return c
+    n = int(d["uv_pred"].shape[0])
+    nk = max(NUM_KP, n)
+    pts = np.zeros((nk, 3))
+    uv = np.zeros((nk, 2))
+    pts[:n] = d["model_kp"]
+    uv[:n] = d["uv_pred"]
+    cov = None
+    if d["cov_pred"] is not None:
+        cov = np.zeros((nk, 2, 2))
+        cov[:, 0, 0] = cov[:, 1, 1] = 1.0
+        cov[:n] = np.asarray(d["cov_pred"], dtype=np.float64)
+    c = {"src": (d["uv_pred"], d["cov_pred"], d["model_kp"], d["K"]), "n": n, "pts": pts, "uv": uv, "cov": cov,
+         "K": np.asarray(d["K"], dtype=np.float64)}
+    d["_cache"] = c
+    return c
+
+
+def _det_edges(d):
+    """Per-keypoint graph-edge data of a detection (object_slam.py:795-821): information matrices [n,3] as
+    (xx, xy, yy) and the pinhole parameters (fx, fy, cx, cy)."""
+    c = _det_cache(d)
+    if "info" not in c:
+        Kd = c["K"]
+        assert np.allclose(Kd[[0, 1, 2, 2, 2], [1, 0, 0, 1, 2]], [0, 0, 0, 0, 1]), f"K matrix has off-diagonals!\n\n{Kd}"
+        n = c["n"]
+        if d["cov_pred"] is not None and n > 0:
+            Om = np.linalg.inv(np.asarray(d["cov_pred"], dtype=np.float64).reshape(n, 2, 2))
+            info = np.stack([Om[:, 0, 0], Om[:, 0, 1], Om[:, 1, 1]], axis=1)
+        else:
+            info = np.tile(np.array([1.0, 0.0, 1.0]), (n, 1))
+        c["info"] = info
+        c["camk"] = np.array([Kd[0, 0], Kd[1, 1], Kd[0, 2], Kd[1, 2]])
+    return c
+
+
+def _chi2_inliers_many(Ts, dets, use_inlier_subset, manual_kp_std):
+    """``_chi2_inliers`` for B (pose, detection) pairs at once: the same arithmetic on arrays padded to NUM_KP
+    keypoints.  Returns B counts."""
+    B = len(dets)
+    if B == 0:
+        return np.zeros(0, dtype=np.int64)
+    cs = [_det_cache(d) for d in dets]
+    has_cov = cs[0]["cov"] is not None
+    if any(((c["cov"] is not None) != has_cov) or c["n"] > NUM_KP for c in cs):
+        return np.array([_chi2_inliers(T, d, use_inlier_subset, manual_kp_std) for T, d in zip(Ts, dets)], dtype=np.int64)
+    n = np.array([c["n"] for c in cs])
+    sel = np.arange(NUM_KP)[None, :] < n[:, None]
+    if use_inlier_subset:
+        inl = np.zeros((B, NUM_KP), dtype=bool)
+        for i, d in enumerate(dets):
+            inl[i, :n[i]] = d["inliers"]
+        sel &= inl
+    pts = np.stack([c["pts"] for c in cs])
+    uv = np.stack([c["uv"] for c in cs])
+    Ks = np.stack([c["K"] for c in cs])
+    Ts = np.asarray(Ts, dtype=np.float64)
+    p = pts @ Ts[:, :3, :3].transpose(0, 2, 1) + Ts[:, None, :3, 3]
+    uvw = p @ Ks.transpose(0, 2, 1)
+    pos = uvw[..., 2] > 0
+    z = np.where(pos, uvw[..., 2], 1.0)
+    rx = uv[..., 0] - uvw[..., 0] / z
+    ry = uv[..., 1] - uvw[..., 1] / z
+    if has_cov:
+        cov = np.stack([c["cov"] for c in cs])
+        a = np.maximum(cov[..., 0, 0], 1e-4)                                   # ensure invertible (:669,:1054)
+        dd = np.maximum(cov[..., 1, 1], 1e-4)
+        b, cc = cov[..., 0, 1], cov[..., 1, 0]
+        chi2 = (dd * rx * rx - (b + cc) * rx * ry + a * ry * ry) / (a * dd - b * cc)
+    else:
+        chi2 = (rx * rx + ry * ry) / manual_kp_std ** 2
+    ok = sel & pos
+    assert not np.any(np.isnan(chi2[ok])), "NaN in information matrix"
+    return np.count_nonzero(ok & (chi2 <= CHI2_2DOF_95), axis=1)
+
+
+class _EdgeRefs:
+    """(view, object, keypoint) of every graph edge, kept as per-detection segments [(view, object, first edge, n)]."""
+
+    def __init__(self, segs, n_edges):
+        self.segs, self.n_edges = segs, n_edges
+
+    def __len__(self):
+        return self.n_edges
+
+    def __iter__(self):
+        for v, o, _, n in self.segs:
+            for k in range(n):
+                yield (v, o, k)
+
+
 class ObjectSLAM:
     def __init__(self, chkpt_path, mesh_db, no_network_cov=False, no_prior_det=False, pred_res=(256, 256),
                  debug_gt_kp=False, sfm_mode=False, single_view_mode=False, viz_cov=False, do_viz_extra=False,
@@ -431,16 +528,16 @@ class ObjectSLAM:
         obj_ids = [o for o in curr if curr[o].get("pose") is not None and o in self.obj_poses]
         if not obj_ids:
             return None
+        hyps = [curr[i]["pose"] @ invert_SE3(to4x4(self.obj_poses[i])) for i in obj_ids]
+        scored = [j for j in obj_ids if np.count_nonzero(curr[j]["inliers"]) > 0]
+        T_obj = [to4x4(self.obj_poses[j]).astype(np.float32).astype(np.float64) for j in scored]   # float32 container (:1004)
+        # all |hypotheses| x |objects| scorings in one vectorised pass
+        counts = _chi2_inliers_many([Th @ To for Th in hyps for To in T_obj], [curr[j] for _ in hyps for j in scored],
+                                    True, self.manual_kp_std).reshape(len(hyps), len(scored)).sum(axis=1)
         best, best_n = None, -1
-        for i in obj_ids:
-            T_GtoC = curr[i]["pose"] @ invert_SE3(to4x4(self.obj_poses[i]))
-            n = 0
-            for j in obj_ids:
-                if np.count_nonzero(curr[j]["inliers"]) > 0:
-                    T_OtoC = T_GtoC @ to4x4(self.obj_poses[j]).astype(np.float32).astype(np.float64)   # float32 container (:1004)
-                    n += _chi2_inliers(T_OtoC, curr[j], True, self.manual_kp_std)
+        for T_GtoC, n in zip(hyps, counts):
             if n >= min_num_inliers and n > best_n:
-                best, best_n = T_GtoC, n
+                best, best_n = T_GtoC, int(n)
         return best
 
     def _maybe_reinit_objects(self, view_id, check_n_views=15):
@@ -455,17 +552,20 @@ class ObjectSLAM:
             return
         T_CtoG = invert_SE3(to4x4(self.cam_poses[view_id]))
         views = [self.view_ids[-(i + 1)] for i in range(check_n_views)]
-        for o in obj_ids:
-            T_pnp = T_CtoG @ curr[o]["pose"]
-            T_est = to4x4(self.obj_poses[o]).astype(np.float32).astype(np.float64)       # float32 containers (:619,:631)
-            n = {"estim": 0, "pnp": 0}
-            for v in views:
-                if o in self.detections[v]:
-                    T_GtoCi = to4x4(self.cam_poses[v]).astype(np.float32).astype(np.float64)
-                    n["pnp"] += _chi2_inliers(T_GtoCi @ T_pnp, self.detections[v][o], False, self.manual_kp_std)
-                    n["estim"] += _chi2_inliers(T_GtoCi @ T_est, self.detections[v][o], False, self.manual_kp_std)
-            if n["pnp"] >= 3 and n["pnp"] > 3 * n["estim"]:
-                self.obj_poses[o] = T_pnp
+        T_cam = {v: to4x4(self.cam_poses[v]).astype(np.float32).astype(np.float64) for v in views}   # float32 containers (:619,:631)
+        T_pnp = {o: T_CtoG @ curr[o]["pose"] for o in obj_ids}
+        T_est = {o: to4x4(self.obj_poses[o]).astype(np.float32).astype(np.float64) for o in obj_ids}
+        # every (object, recent view) pair under both poses in one vectorised pass; objects are independent of each other
+        pairs = [(k, v) for k, o in enumerate(obj_ids) for v in views if o in self.detections[v]]
+        dets = [self.detections[v][obj_ids[k]] for k, v in pairs]
+        Ts = [T_cam[v] @ T_pnp[obj_ids[k]] for k, v in pairs] + [T_cam[v] @ T_est[obj_ids[k]] for k, v in pairs]
+        counts = _chi2_inliers_many(Ts, dets + dets, False, self.manual_kp_std)
+        owner = np.array([k for k, _ in pairs], dtype=np.int64)
+        n_pnp = np.bincount(owner, weights=counts[:len(pairs)], minlength=len(obj_ids))
+        n_est = np.bincount(owner, weights=counts[len(pairs):], minlength=len(obj_ids))
+        for k, o in enumerate(obj_ids):
+            if n_pnp[k] >= 3 and n_pnp[k] > 3 * n_est[k]:
+                self.obj_poses[o] = T_pnp[o]
 
     def _backup_estimate_camera_pose(self, view_id, obj_ids_, bboxes):
         """object_slam.py:933-973: bbox-centroid PnP, else constant velocity, else copy the last pose."""
@@ -518,20 +618,23 @@ class ObjectSLAM:
                 cam_fixed.append(0 if curr_only else int(i == 0))          # gauge: enumeration index 0 only (:774, R11)
         if not cam_index or not obj_index:
             return None
-        e_cam, e_obj, e_k, e_p, e_uv, e_info, e_inl, e_ref = [], [], [], [], [], [], [], []
+        # one segment of edges per detection, in the reference's enumeration order (views, objects, keypoints); the
+        # per-keypoint data comes from the detection's cache instead of a Python loop over keypoints
+        segs, seg_cam, seg_obj, seg_n, e_k, e_p, e_uv, e_info, e_inl = [], [], [], [], [], [], [], [], []
+        E = 0
         for v, det in dets.items():
+            if v not in cam_index:
+                continue
             for o, d in det.items():
-                if v in cam_index and o in obj_index:
-                    Kd = d["K"]
-                    assert np.allclose(Kd[[0, 1, 2, 2, 2], [1, 0, 0, 1, 2]], [0, 0, 0, 0, 1]), f"K matrix has off-diagonals!\n\n{Kd}"
-                    camk = [Kd[0, 0], Kd[1, 1], Kd[0, 2], Kd[1, 2]]
-                    for k in range(d["uv_pred"].shape[0]):
-                        e_cam.append(cam_index[v]); e_obj.append(obj_index[o]); e_k.append(camk)
-                        e_p.append(d["model_kp"][k]); e_uv.append(d["uv_pred"][k])
-                        Om = np.linalg.inv(np.asarray(d["cov_pred"][k], np.float64)) if d["cov_pred"] is not None else np.eye(2)
-                        e_info.append([Om[0, 0], Om[0, 1], Om[1, 1]])
-                        e_inl.append(bool(d["inliers"][k])); e_ref.append((v, o, k))
-        E = len(e_cam)
+                if o in obj_index:
+                    c = _det_edges(d)
+                    n = c["n"]
+                    segs.append((v, o, E, n))
+                    seg_cam.append(cam_index[v]); seg_obj.append(obj_index[o]); seg_n.append(n)
+                    e_k.append(c["camk"]); e_p.append(c["pts"][:n]); e_uv.append(c["uv"][:n]); e_info.append(c["info"])
+                    e_inl.append(np.asarray(d["inliers"], dtype=np.uint8))
+                    E += n
+        seg_n = np.array(seg_n, dtype=np.int64)
         if self.sfm_mode or (self.slam_mode and not curr_only):
             its = (10, 10, 40, 40)
         else:
@@ -539,17 +642,19 @@ class ObjectSLAM:
         prob = _ba.Problem(np.stack([to4x4(self.cam_poses[v])[:3] for v in cam_index]), np.array(cam_fixed, np.uint8),
                            np.stack([to4x4(self.obj_poses[o])[:3] for o in obj_index]),
                            np.full(len(obj_index), 1 if curr_only else 0, np.uint8),
-                           np.array(e_cam, np.int32), np.array(e_obj, np.int32), np.array(e_k, np.float64).reshape(E, 4),
-                           np.array(e_p, np.float64).reshape(E, 3), np.array(e_uv, np.float64).reshape(E, 2),
-                           np.array(e_info, np.float64).reshape(E, 3), np.array(e_inl, np.uint8), its=its,
+                           np.repeat(np.array(seg_cam, np.int32), seg_n), np.repeat(np.array(seg_obj, np.int32), seg_n),
+                           np.repeat(np.array(e_k, np.float64).reshape(-1, 4), seg_n, axis=0),
+                           np.concatenate(e_p).reshape(E, 3), np.concatenate(e_uv).reshape(E, 2),
+                           np.concatenate(e_info).reshape(E, 3), np.concatenate(e_inl), its=its,
                            init_with_outliers=bool(self.opt_init_with_outliers and curr_only))
-        return prob, (cam_index, obj_index, e_ref, curr_only, view_curr)
+        return prob, (cam_index, obj_index, _EdgeRefs(segs, E), curr_only, view_curr)
 
     def apply_problem(self, prob, book):
         """Read-back + culling of optimize() (object_slam.py:898-930)."""
         cam_index, obj_index, e_ref, curr_only, view_curr = book
-        for (v, o, k), inl in zip(e_ref, prob.inlier):
-            self.detections[v][o]["inliers"][k] = bool(inl)
+        inl = np.asarray(prob.inlier).astype(bool)
+        for v, o, first, n in e_ref.segs:
+            self.detections[v][o]["inliers"][:] = inl[first:first + n]
         cam_T = prob.cam_T.reshape(-1, 3, 4)
         obj_T = prob.obj_T.reshape(-1, 3, 4)
         for v, i in cam_index.items():
@@ -561,9 +666,13 @@ class ObjectSLAM:
                     p = self.cam_poses[view_curr][:3, :3] @ self.obj_poses[o][:3, 3] + self.cam_poses[view_curr][:3, 3]
                     if p[2] < 0.5 * self.mesh_db[o]["diameter"]:
                         self.remove_obj(o)
+        n_inl = defaultdict(int)                                 # obj_num_inliers of every object in one pass over the detections
+        for det in self.detections.values():
+            for o, d in det.items():
+                n_inl[o] += int(np.count_nonzero(d["inliers"]))
         for o in list(self.obj_poses.keys()):
             need = 3 if self.obj_num_dets[o] < 3 else 6
-            if self.obj_num_inliers(o) < need:
+            if n_inl[o] < need:
                 self.remove_obj(o)
 
     def optimize(self, curr_only=False):

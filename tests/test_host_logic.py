@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror (suo_slam_amd/object_slam.py): prior rendering, chi2 scoring, graph
 flattening and read-back/culling rules -- everything that does not need the HIP extension to execute."""
 import numpy as np
+import pytest
 
 from suo_slam_amd import geometry as geo
 from suo_slam_amd import object_slam as OS
@@ -69,6 +70,43 @@ def test_chi2_scoring_counts_all_keypoints_at_the_true_pose():
         assert OS._chi2_inliers(T_bad, d, True, 0.005) < n // 2
         d2 = dict(d, cov_pred=None)                                   # manual sigma path (object_slam.py:1059-1061)
         assert OS._chi2_inliers(fr["T_OtoC"][k], d2, False, 0.005) == n
+
+
+@pytest.mark.parametrize("with_cov", [True, False])
+def test_vectorised_chi2_scoring_equals_the_per_detection_rule(with_cov):
+    """ObjectSLAM scores all (pose, detection) pairs of a view in one pass (_chi2_inliers_many); it must count exactly
+    what the per-detection rule counts: good and bad poses, points behind the camera, inlier subsets, empty detections."""
+    rng = np.random.default_rng(5)
+    slam, fr = _slam_with_state(rng, noise=0.004)
+    Ts, dets = [], []
+    for rep in range(6):
+        for k, o in enumerate(fr["obj_ids"]):
+            d = dict(slam.detections[0][o])
+            d.pop("_cache", None)
+            if not with_cov:
+                d["cov_pred"] = None
+            n = len(d["model_kp"])
+            d["inliers"] = rng.uniform(size=n) < 0.7
+            T = fr["T_OtoC"][k].copy()
+            if rep == 1:
+                T[:3, 3] += rng.normal(scale=3.0, size=3)            # a few keypoints drop out
+            elif rep == 2:
+                T[2, 3] = -T[2, 3]                                   # everything behind the camera
+            elif rep == 3:
+                T[2, 3] = 0.02                                       # some behind, some in front
+            elif rep == 4:
+                d["inliers"] = np.zeros(n, bool)
+            elif rep == 5:                                           # empty detection
+                d.update(model_kp=d["model_kp"][:0], uv_pred=d["uv_pred"][:0], inliers=np.zeros(0, bool),
+                         cov_pred=None if d["cov_pred"] is None else d["cov_pred"][:0])
+            Ts.append(T)
+            dets.append(d)
+    for subset in (True, False):
+        many = OS._chi2_inliers_many(Ts, dets, subset, 0.005)
+        one = [OS._chi2_inliers(T, d, subset, 0.005) for T, d in zip(Ts, dets)]
+        assert list(many) == one
+    assert max(one) > 0 and min(one) == 0
+    assert len(OS._chi2_inliers_many([], [], True, 0.005)) == 0
 
 
 def test_build_problem_flattens_the_reference_graph():
