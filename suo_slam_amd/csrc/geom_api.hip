@@ -91,6 +91,7 @@ struct LmProblemHost {
     const int* pair_cam; const int* pair_obj; const int* pair_start;
     const int* cam_pair_ptr; const int* cam_pair_idx;
     const int* obj_pair_ptr; const int* obj_pair_idx;
+    const int* cam_obj_pair;
     int its[8]; int n_rounds; int init_with_outliers; double chi2_thr; double huber_delta;
     void* cam; void* obj; void* cam_bak; void* obj_bak;
     double* err; double* jac; uint8_t* level; double* pair_part;
@@ -99,7 +100,7 @@ struct LmProblemHost {
 };
 
 struct Prep {
-    std::vector<int> order, edge_pair, pair_cam, pair_obj, pair_start, cam_ptr, cam_idx, obj_ptr, obj_idx;
+    std::vector<int> order, edge_pair, pair_cam, pair_obj, pair_start, cam_ptr, cam_idx, obj_ptr, obj_idx, cam_obj;
     size_t o[40];
 };
 struct Staged {
@@ -210,6 +211,8 @@ static int stage_problems(suo_ba_problem* probs, int n_prob, Arena& A, Staged& s
         P.obj_idx.resize(np);
         { std::vector<int> cc(P.cam_ptr.begin(), P.cam_ptr.end() - 1), oo(P.obj_ptr.begin(), P.obj_ptr.end() - 1);
           for (int p = 0; p < np; ++p) { P.cam_idx[cc[P.pair_cam[p]]++] = p; P.obj_idx[oo[P.pair_obj[p]]++] = p; } }
+        P.cam_obj.assign((size_t)q.n_cam * q.n_obj, -1);                    // dense (camera, object) -> pair lookup for the Schur sums
+        for (int p = 0; p < np; ++p) P.cam_obj[(size_t)P.pair_cam[p] * q.n_obj + P.pair_obj[p]] = p;
         const size_t E = q.n_edge, C = q.n_cam, O = q.n_obj, NP = np;
         size_t* o = P.o;
         o[0] = L.take(sizeof(double) * 12 * C); o[1] = L.take(sizeof(double) * 12 * O);           // cam_T, obj_T
@@ -221,6 +224,7 @@ static int stage_problems(suo_ba_problem* probs, int n_prob, Arena& A, Staged& s
         o[10] = L.take(sizeof(int) * NP); o[11] = L.take(sizeof(int) * NP); o[12] = L.take(sizeof(int) * (NP + 1));
         o[13] = L.take(sizeof(int) * (C + 1)); o[14] = L.take(sizeof(int) * NP);
         o[15] = L.take(sizeof(int) * (O + 1)); o[16] = L.take(sizeof(int) * NP);
+        o[37] = L.take(sizeof(int) * C * O);                                                     // cam_obj_pair
     }
     in_end = L.off;
     // outputs + scratch (device only, but laid out in the same arena; outputs first for one D2H)
@@ -276,6 +280,7 @@ static int stage_problems(suo_ba_problem* probs, int n_prob, Arena& A, Staged& s
         memcpy(h + o[14], P.cam_idx.data(), sizeof(int) * np);
         memcpy(h + o[15], P.obj_ptr.data(), sizeof(int) * (q.n_obj + 1));
         memcpy(h + o[16], P.obj_idx.data(), sizeof(int) * np);
+        memcpy(h + o[37], P.cam_obj.data(), sizeof(int) * P.cam_obj.size());
         LmProblemHost& S = hs[i];
         memset(&S, 0, sizeof(S));
         S.n_cam = q.n_cam; S.n_obj = q.n_obj; S.n_edge = E; S.n_pair = np;
@@ -287,6 +292,7 @@ static int stage_problems(suo_ba_problem* probs, int n_prob, Arena& A, Staged& s
         S.pair_cam = (const int*)(d + o[10]); S.pair_obj = (const int*)(d + o[11]); S.pair_start = (const int*)(d + o[12]);
         S.cam_pair_ptr = (const int*)(d + o[13]); S.cam_pair_idx = (const int*)(d + o[14]);
         S.obj_pair_ptr = (const int*)(d + o[15]); S.obj_pair_idx = (const int*)(d + o[16]);
+        S.cam_obj_pair = (const int*)(d + o[37]);
         for (int k = 0; k < 8; ++k) S.its[k] = k < q.n_rounds ? q.its[k] : 0;
         S.n_rounds = q.n_rounds; S.init_with_outliers = q.init_with_outliers; S.chi2_thr = q.chi2_thr; S.huber_delta = q.huber_delta;
         S.cam = d + o[19]; S.obj = d + o[20]; S.cam_bak = d + o[21]; S.obj_bak = d + o[22];

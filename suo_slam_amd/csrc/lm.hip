@@ -84,8 +84,9 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
     double* S = (double*)lm_lds;            // reduced (object) system / its Cholesky factor, ns x ns
     double* rhs = S;
     double* colbuf = S;
+    const int sp = ns | 1;                  // odd pitch of S in LDS (lm_device.h: wave_cholesky_solve)
     if (schur) {
-        off = ((size_t)ns * ns * sizeof(double) + 15) & ~(size_t)15;
+        off = (((size_t)ns * sp + 8) * sizeof(double) + 15) & ~(size_t)15;
         rhs = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
         colbuf = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
     }
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     }
                     LMPROF(5);
                     // S = blockdiag(Hoo + lambda I);  rhs = b_o
-                    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[idx] = 0;
+                    for (int idx = tid; idx < ns * sp; idx += LM_THREADS) S[idx] = 0;
                     __syncthreads();
                     for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
                         const int o = idx / 36, rc = idx - o * 36, r = rc / 6, cc = rc - r * 6;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                         if (so < 0) continue;
                         const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
                         const int packed = rr * 6 - rr * (rr - 1) / 2 + (c2 - rr);
-                        S[(6 * so + r) * ns + 6 * so + cc] = P.Hoo[36 * o + packed] + (r == cc ? lambda : 0.0);
+                        S[(6 * so + r) * sp + 6 * so + cc] = P.Hoo[36 * o + packed] + (r == cc ? lambda : 0.0);
                     }
                     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
                         const int o = idx / 6;
@@ -319,16 +320,13 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                         for (int o = 0; o < P.n_obj; ++o) { if (P.obj_slot[o] == s1) o1 = o; if (P.obj_slot[o] == s2) o2 = o; }
                         for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
                             const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
-                            if (P.cam_fixed[c]) continue;
-                            int p2 = -1;
-                            for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b)
-                                if (P.pair_obj[P.cam_pair_idx[b]] == o2) { p2 = P.cam_pair_idx[b]; break; }
-                            if (p2 < 0) continue;
+                            const int p2 = P.cam_obj_pair[(size_t)c * P.n_obj + o2];     // the same camera's pair with object o2
+                            if (P.cam_fixed[c] || p2 < 0) continue;
                             const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;   // Hco(c,o1) [6x6], row = cam dof
                             const double* Y2 = P.Y + 36 * (size_t)p2;
                             for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
                         }
-                        S[idx] -= acc;
+                        S[row * sp + col] -= acc;
                     }
                     for (int row = tid; row < ns; row += LM_THREADS) {
                         const int s1 = row / 6, i = row - s1 * 6;
@@ -349,42 +347,8 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     // system is at most 96 x 96 and its 5 dependent steps per column need no workgroup barrier this way
                     // (5 * ns of them otherwise, with up to 16 waves each).  Same arithmetic per element as a
                     // workgroup-wide version.  LDS operations of a wave complete in issue order; fences + wave barriers
-                    // pin the compiler.  (Measured: not the dominant cost of a global-BA trial -- the per-edge passes are.)
-                    if (tid < 64) {
-                        for (int j = 0; j < ns; ++j) {
-                            for (int i = j + tid; i < ns; i += 64) {
-                                double s = S[i * ns + j];
-                                for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
-                                colbuf[i] = s;
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            const double piv = colbuf[j];
-                            if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
-                            const double d = sqrt(piv > 0 ? piv : 1.0);
-                            for (int i = j + tid; i < ns; i += 64) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        for (int j = 0; j < ns; ++j) {          // L y = rhs
-                            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            const double yj = rhs[j];
-                            for (int i = j + 1 + tid; i < ns; i += 64) rhs[i] -= S[i * ns + j] * yj;
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        for (int j = ns - 1; j >= 0; --j) {     // L^T x = y
-                            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            const double xj = rhs[j];
-                            for (int i = tid; i < j; i += 64) rhs[i] -= S[j * ns + i] * xj;
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                    }
+                    // pin the compiler (lm_device.h: wave_cholesky_solve; odd LDS pitch sp against the 64-way bank conflict).
+                    if (tid < 64) wave_cholesky_solve(S, sp, rhs, colbuf, ns, tid, &sh_ok);
                     __syncthreads();
                     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
                         const int o = idx / 6;
@@ -498,7 +462,7 @@ int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipSt
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur) {
     size_t b = 0;
     const size_t ns = 6 * (size_t)n_free_obj_schur;
-    b += 8 * (ns * ns + 2 * ns) + 48;
+    b += 8 * (ns * (ns + 1) + 8 + 2 * ns) + 48;
     b += 4 * 56 * (size_t)(C + O) / 2 * 2 + 2 * (size_t)(C + O) + 4 * (size_t)O;
     b += 8 * 48 * (size_t)O + 8 * 54 * (size_t)C;
     b += 4 * (3 * (size_t)NP + 1) + 4 * ((size_t)C + 1 + NP) + 4 * ((size_t)O + 1 + NP);

@@ -161,11 +161,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
         double acc = 0;
         for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
             const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
-            if (P.cam_fixed[c]) continue;
-            int p2 = -1;
-            for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b)
-                if (P.pair_obj[P.cam_pair_idx[b]] == o2) { p2 = P.cam_pair_idx[b]; break; }
-            if (p2 < 0) continue;
+            const int p2 = P.cam_obj_pair[(size_t)c * P.n_obj + o2];
+            if (P.cam_fixed[c] || p2 < 0) continue;
             const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
             const double* Y2 = P.Y + 36 * (size_t)p2;
             for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
@@ -193,15 +190,16 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
 __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
                                                                const double* __restrict__ in, int* __restrict__ bad) {
     const LmProblem& P = *Pp;
-    __shared__ double S[LM_NS * LM_NS];
+    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch + slack for the masked dot-product rounds
     __shared__ double rhs[LM_NS], colbuf[LM_NS];
     __shared__ int sh_ok;
     const int tid = threadIdx.x;
+    const int sp = ns | 1;                          // odd LDS pitch (lm_device.h: wave_cholesky_solve)
     const double* HB = in;
     const double* St = in + 27 * P.n_obj;
     const double* rt = St + ns * ns;
     if (tid == 0) sh_ok = 1;
-    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[idx] = -St[idx];
+    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[(idx / ns) * sp + idx % ns] = -St[idx];
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
         const int o = idx / 36, rc = idx - o * 36, r = rc / 6, cc = rc - r * 6;
@@ -209,48 +207,14 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
         if (so < 0) continue;
         const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
         const int packed = rr * 6 - rr * (rr - 1) / 2 + (c2 - rr);
-        S[(6 * so + r) * ns + 6 * so + cc] += HB[27 * o + packed] + (r == cc ? lambda : 0.0);
+        S[(6 * so + r) * sp + 6 * so + cc] += HB[27 * o + packed] + (r == cc ? lambda : 0.0);
     }
     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
         const int o = idx / 6, r = idx - o * 6;
         if (P.obj_slot[o] >= 0) rhs[6 * P.obj_slot[o] + r] = HB[27 * o + 21 + r] - rt[6 * P.obj_slot[o] + r];
     }
     __syncthreads();
-    if (tid < 64) {                                   // Cholesky + substitutions by one wave, as in csrc/lm.hip
-        for (int j = 0; j < ns; ++j) {
-            for (int i = j + tid; i < ns; i += 64) {
-                double s = S[i * ns + j];
-                for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
-                colbuf[i] = s;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const double piv = colbuf[j];
-            if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
-            const double d = sqrt(piv > 0 ? piv : 1.0);
-            for (int i = j + tid; i < ns; i += 64) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        for (int j = 0; j < ns; ++j) {
-            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const double yj = rhs[j];
-            for (int i = j + 1 + tid; i < ns; i += 64) rhs[i] -= S[i * ns + j] * yj;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        for (int j = ns - 1; j >= 0; --j) {
-            if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const double xj = rhs[j];
-            for (int i = tid; i < j; i += 64) rhs[i] -= S[j * ns + i] * xj;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    if (tid < 64) wave_cholesky_solve(S, sp, rhs, colbuf, ns, tid, &sh_ok);      // one wave, as in csrc/lm.hip
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
         const int o = idx / 6;

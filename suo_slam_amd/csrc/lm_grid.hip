@@ -5,7 +5,7 @@
 // of it in per-edge / per-pair / per-camera loops that are embarrassingly parallel.  Here G workgroups (one per CU of a
 // single XCD, so they share an L2) execute the same rounds / iterations / trials in lock-step: every loop is grid-strided,
 // every workgroup barrier that orders data between phases is a grid barrier, every reduction is summed in workgroup
-// order (deterministic), and the (<= 96 x 96) reduced system is factorised by workgroup 0.  All state lives in the
+// order (deterministic), and the (<= 96 x 96) reduced system is factorised redundantly by every workgroup.  All state lives in the
 // problem's HBM arrays (no LDS relocation); decisions (gain ratio, lambda, termination) are taken redundantly by every
 // workgroup from identical reduced values, so control flow never diverges between workgroups.
 //
@@ -14,13 +14,25 @@
 
 namespace suo {
 
+// -DSUO_LG_PROFILE: thread 0 of workgroup 0 charges the wall clock between consecutive LGPROF(i) marks to section i
+// (read back with suo_debug_lg_prof; tools/bench_global_ba.py prints it when the symbol exists)
+#ifdef SUO_LG_PROFILE
+__device__ long long g_lg_prof[16];
+#define LGPROF(i) do { if (gt == 0) { const long long _t = wall_clock64(); g_lg_prof[(i)] += _t - lgprof_t; lgprof_t = _t; } } while (0)
+#else
+#define LGPROF(i) do { } while (0)
+#endif
+
 constexpr int LG_THREADS = 256;
 constexpr int LG_MAX_WGS = 32;                // CUs of one XCD
+constexpr int LG_RED_N = 3;                   // values one grid reduction can carry
+constexpr int LG_IDX_MAX = 4096;              // pairs whose index arrays are mirrored in LDS (2 x 16 KB)
+constexpr int LG_TAB_MAX = 8192;              // entries of the camera x object pair table mirrored in LDS (32 KB)
 
 struct LmGridScratch {
     unsigned* bar;            // [2]: arrivals, generation (zeroed by the host before the launch)
-    double* red;              // [2][LG_MAX_WGS] alternating reduction buffers
-    double* S;                // [ns*ns + ns] reduced system assembled by the whole grid, solved by workgroup 0
+    double* red;              // [2][LG_RED_N][LG_MAX_WGS] alternating reduction buffers
+    double* S;                // [ns*ns + ns] reduced system assembled by the whole grid, factorised by every workgroup
 };
 
 struct GridCtx {
@@ -73,7 +85,7 @@ DEV double grid_reduce(double v, bool is_max, GridCtx& g, double* red_lds) {
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red_lds[threadIdx.x >> 6] = v;
     __syncthreads();
-    double* buf = g.red + (g.red_cnt++ & 1) * LG_MAX_WGS;
+    double* buf = g.red + (g.red_cnt++ & 1) * LG_RED_N * LG_MAX_WGS;
     if (threadIdx.x == 0) {
         double s = red_lds[0];
         for (int i = 1; i < LG_THREADS / 64; ++i) s = is_max ? fmax(s, red_lds[i]) : s + red_lds[i];
@@ -84,13 +96,38 @@ DEV double grid_reduce(double v, bool is_max, GridCtx& g, double* red_lds) {
     for (int i = 1; i < g.G; ++i) s = is_max ? fmax(s, buf[i]) : s + buf[i];
     return s;
 }
+// three values behind ONE grid barrier: v[0], v[1] summed, v[2] maximised (same orders as grid_reduce)
+DEV void grid_reduce3(double (&v)[LG_RED_N], GridCtx& g, double* red_lds) {
+#pragma unroll
+    for (int k = 0; k < LG_RED_N; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v[k], o, 64); v[k] = k == 2 ? fmax(v[k], u) : v[k] + u; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < LG_RED_N; ++k) red_lds[k * (LG_THREADS / 64) + (threadIdx.x >> 6)] = v[k];
+    __syncthreads();
+    double* buf = g.red + (g.red_cnt++ & 1) * LG_RED_N * LG_MAX_WGS;
+    if (threadIdx.x < LG_RED_N) {
+        const int k = threadIdx.x;
+        double s = red_lds[k * (LG_THREADS / 64)];
+        for (int i = 1; i < LG_THREADS / 64; ++i) s = k == 2 ? fmax(s, red_lds[k * (LG_THREADS / 64) + i]) : s + red_lds[k * (LG_THREADS / 64) + i];
+        buf[k * LG_MAX_WGS + g.wg] = s;
+    }
+    grid_sync(g);
+#pragma unroll
+    for (int k = 0; k < LG_RED_N; ++k) {
+        double s = buf[k * LG_MAX_WGS];
+        for (int i = 1; i < g.G; ++i) s = k == 2 ? fmax(s, buf[k * LG_MAX_WGS + i]) : s + buf[k * LG_MAX_WGS + i];
+        v[k] = s;
+    }
+}
 
 __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __restrict__ Pp, LmGridScratch sc, int G) {
     if (blockIdx.x & 7) return;                 // workgroup b runs on XCD b % 8 (observed; performance only): keep one XCD
     const LmProblem& P = *Pp;
-    __shared__ double S[LM_NS * LM_NS];
+    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch + slack for the masked dot-product rounds
     __shared__ double rhs[LM_NS], colbuf[LM_NS];
-    __shared__ double red_lds[LG_THREADS / 64];
+    __shared__ double red_lds[LG_RED_N * (LG_THREADS / 64)];
     __shared__ int sh_flag, sh_ok;
     GridCtx g;
     g.bar = sc.bar; g.red = sc.red; g.G = G; g.wg = blockIdx.x >> 3; g.red_cnt = 0; g.same_xcd = false;
@@ -104,6 +141,9 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
         g.same_xcd = same;
     }
     const int gt = g.wg * LG_THREADS + tid, GS = G * LG_THREADS;      // position / stride of the grid-strided loops
+#ifdef SUO_LG_PROFILE
+    long long lgprof_t = wall_clock64();
+#endif
 
     if (tid == 0) {
         int ns = 0, nfc = 0;
@@ -119,6 +159,19 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
         if (gt == 0) { P.stats[0] = -1; P.stats[1] = P.stats[2] = P.stats[3] = 0; }
         return;
     }
+    // LDS copies of the small index arrays the Schur sums chase (global pointers stay in use when a graph is too large)
+    __shared__ int l_slot_obj[LM_NS / 6 + 1];
+    __shared__ int l_pair_cam[LG_IDX_MAX], l_obj_pair_idx[LG_IDX_MAX], l_cam_obj[LG_TAB_MAX];
+    const bool idx_in_lds = P.n_pair <= LG_IDX_MAX && (long)P.n_cam * P.n_obj <= LG_TAB_MAX;
+    if (idx_in_lds) {
+        for (int k = tid; k < P.n_pair; k += LG_THREADS) { l_pair_cam[k] = P.pair_cam[k]; l_obj_pair_idx[k] = P.obj_pair_idx[k]; }
+        for (int k = tid; k < P.n_cam * P.n_obj; k += LG_THREADS) l_cam_obj[k] = P.cam_obj_pair[k];
+    }
+    if (tid == 0) { int s = 0; for (int o = 0; o < P.n_obj; ++o) if (!P.obj_fixed[o] && s <= LM_NS / 6) l_slot_obj[s++] = o; }
+    __syncthreads();
+    const int* x_pair_cam = idx_in_lds ? l_pair_cam : P.pair_cam;
+    const int* x_obj_pair_idx = idx_in_lds ? l_obj_pair_idx : P.obj_pair_idx;
+    const int* x_cam_obj = idx_in_lds ? l_cam_obj : P.cam_obj_pair;
     for (int c = gt; c < P.n_cam; c += GS) pose_from_T(P.cam_T + 12 * c, P.cam[c]);
     for (int o = gt; o < P.n_obj; o += GS) pose_from_T(P.obj_T + 12 * o, P.obj[o]);
     for (int e = gt; e < P.n_edge; e += GS) P.level[e] = 0;
@@ -155,9 +208,12 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
         double lambda = -1, ni = 2;
         for (int it = 0; it < iterations; ++it) {
             // ---- errors, chi2, Jacobians (HBM), pair blocks, diagonal blocks ---------------------
+            LGPROF(9);
             double currentChi = grid_reduce(edge_pass_partial(P, 0, P.n_edge, robust_on, true, gt, GS), false, g, red_lds);
+            LGPROF(0);
             accumulate_pairs_range(P, 0, P.n_pair, gt, GS);
             grid_sync(g);
+            LGPROF(1);
             for (int idx = gt; idx < P.n_cam * 27; idx += GS) {
                 const int c = idx / 27, k = idx - c * 27;
                 if (P.cam_fixed[c]) continue;
@@ -175,6 +231,7 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
                 if (k < 21) P.Hoo[36 * o + k] = s; else P.bo[6 * o + (k - 21)] = s;
             }
             grid_sync(g);
+            LGPROF(2);
             if (it == 0) {      // computeLambdaInit: tau * max |diag|
                 double md = 0;
                 for (int idx = gt; idx < (P.n_cam + P.n_obj) * 6; idx += GS) {
@@ -215,6 +272,7 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
                     }
                 }
                 grid_sync(g);
+                LGPROF(3);
                 if (!schur) {
                     for (int o = gt; o < P.n_obj; o += GS) {
                         if (P.obj_fixed[o]) continue;
@@ -224,7 +282,10 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
                         if (!spd_solve6(A, P.bo + 6 * o, x)) bad = 1;
                         for (int r = 0; r < 6; ++r) P.xo[6 * o + r] = x[r];
                     }
-                    for (int idx = gt; idx < P.n_cam * 6; idx += GS) P.xc[idx] = P.cam_fixed[idx / 6] ? 0.0 : P.yc[idx];
+                    for (int c = gt; c < P.n_cam; c += GS) {                // x_c = y_c, applied by the same thread
+                        for (int r = 0; r < 6; ++r) P.xc[6 * c + r] = P.cam_fixed[c] ? 0.0 : P.yc[6 * c + r];
+                        if (!P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
+                    }
                 } else {
                     // Y[p] = Hcc^-1 Hco[p]
                     for (int idx = gt; idx < P.n_pair * 36; idx += GS) {
@@ -238,125 +299,131 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
                         P.Y[idx] = s;
                     }
                     grid_sync(g);
-                    // reduced system in HBM, one entry per thread of the grid:
+                    LGPROF(4);
+                    // reduced system in HBM:
                     //   S = blockdiag(Hoo + lambda I) - sum_c Hco(c,o1)^T Y(c,o2);   rhs = b_o - sum_c Hco(c,o)^T y_c
-                    for (int idx = gt; idx < ns * ns; idx += GS) {
-                        const int row = idx / ns, col = idx - row * ns;
+                    // Only the lower triangle is referenced by the factorisation.  Eight adjacent lanes share an entry (or a
+                    // row of rhs): each sums every eighth camera of o1 and the partial sums are combined by a fixed shuffle
+                    // tree.  The partner pair of (c, o2) comes from the dense cam_obj_pair table, and the index arrays this
+                    // loop chases (three dependent L2 round trips per camera otherwise) are read from their LDS copies.
+                    const int n_low = ns * (ns + 1) / 2;
+                    for (int q8 = gt; q8 < 8 * (n_low + ns); q8 += GS) {        // GS is a multiple of 8: an octet stays together
+                        const int t = q8 >> 3, part = q8 & 7;
+                        const bool is_rhs = t >= n_low;
+                        int row, col = 0;
+                        if (is_rhs) {
+                            row = t - n_low;
+                        } else {                                                  // t = row (row + 1) / 2 + col, col <= row
+                            row = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                            while ((row + 1) * (row + 2) / 2 <= t) ++row;
+                            while (row * (row + 1) / 2 > t) --row;
+                            col = t - row * (row + 1) / 2;
+                        }
                         const int s1 = row / 6, i = row - s1 * 6, s2 = col / 6, j = col - s2 * 6;
-                        int o1 = -1, o2 = -1;
-                        for (int o = 0; o < P.n_obj; ++o) { if (P.obj_slot[o] == s1) o1 = o; if (P.obj_slot[o] == s2) o2 = o; }
-                        double diag = 0;
-                        if (s1 == s2) {
-                            const int rr = i < j ? i : j, c2 = i < j ? j : i;
-                            diag = P.Hoo[36 * o1 + rr * 6 - rr * (rr - 1) / 2 + (c2 - rr)] + (i == j ? lambda : 0.0);
-                        }
+                        const int o1 = l_slot_obj[s1], o2 = l_slot_obj[s2];
                         double acc = 0;
-                        for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
-                            const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
-                            if (P.cam_fixed[c]) continue;
-                            int p2 = -1;
-                            for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b)
-                                if (P.pair_obj[P.cam_pair_idx[b]] == o2) { p2 = P.cam_pair_idx[b]; break; }
-                            if (p2 < 0) continue;
-                            const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
-                            const double* Y2 = P.Y + 36 * (size_t)p2;
-                            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
-                        }
-                        sc.S[idx] = diag - acc;
-                    }
-                    for (int row = gt; row < ns; row += GS) {
-                        const int s1 = row / 6, i = row - s1 * 6;
-                        int o1 = -1;
-                        for (int o = 0; o < P.n_obj; ++o) if (P.obj_slot[o] == s1) o1 = o;
-                        double acc = 0;
-                        for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
-                            const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
+                        for (int a = P.obj_pair_ptr[o1] + part; a < P.obj_pair_ptr[o1 + 1]; a += 8) {
+                            const int p1 = x_obj_pair_idx[a], c = x_pair_cam[p1];
                             if (P.cam_fixed[c]) continue;
                             const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
-                            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * P.yc[6 * c + k];
+                            if (is_rhs) {
+                                for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * P.yc[6 * c + k];
+                            } else {
+                                const int p2 = x_cam_obj[c * P.n_obj + o2];
+                                if (p2 < 0) continue;
+                                const double* Y2 = P.Y + 36 * (size_t)p2;
+                                for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
+                            }
                         }
-                        sc.S[ns * ns + row] = P.bo[6 * o1 + i] - acc;
+                        acc += __shfl_down(acc, 4, 8);
+                        acc += __shfl_down(acc, 2, 8);
+                        acc += __shfl_down(acc, 1, 8);
+                        if (part == 0) {
+                            if (is_rhs) {
+                                sc.S[t] = P.bo[6 * o1 + i] - acc;                 // packed: [lower triangle by rows | rhs]
+                            } else {
+                                double diag = 0;
+                                if (s1 == s2) {
+                                    const int rr = i < j ? i : j, c2 = i < j ? j : i;
+                                    diag = P.Hoo[36 * o1 + rr * 6 - rr * (rr - 1) / 2 + (c2 - rr)] + (i == j ? lambda : 0.0);
+                                }
+                                sc.S[t] = diag - acc;
+                            }
+                        }
                     }
                     grid_sync(g);
-                    if (g.wg == 0) {                             // Cholesky + substitutions by one wave of workgroup 0
-                        for (int idx = tid; idx < ns * ns; idx += LG_THREADS) S[idx] = sc.S[idx];
-                        for (int idx = tid; idx < ns; idx += LG_THREADS) rhs[idx] = sc.S[ns * ns + idx];
-                        if (tid == 0) sh_ok = 1;
-                        __syncthreads();
-                        if (tid < 64) {
-                            for (int j = 0; j < ns; ++j) {
-                                for (int i = j + tid; i < ns; i += 64) {
-                                    double s = S[i * ns + j];
-                                    for (int k = 0; k < j; ++k) s -= S[i * ns + k] * S[j * ns + k];
-                                    colbuf[i] = s;
-                                }
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                                const double piv = colbuf[j];
-                                if (!(piv > 0) || !isfinite(piv)) { if (tid == 0) sh_ok = 0; }
-                                const double d = sqrt(piv > 0 ? piv : 1.0);
-                                for (int i = j + tid; i < ns; i += 64) S[i * ns + j] = (i == j) ? d : colbuf[i] / d;
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                            }
-                            for (int j = 0; j < ns; ++j) {
-                                if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                                const double yj = rhs[j];
-                                for (int i = j + 1 + tid; i < ns; i += 64) rhs[i] -= S[i * ns + j] * yj;
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                            }
-                            for (int j = ns - 1; j >= 0; --j) {
-                                if (tid == 0) rhs[j] = rhs[j] / S[j * ns + j];
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                                const double xj = rhs[j];
-                                for (int i = tid; i < j; i += 64) rhs[i] -= S[j * ns + i] * xj;
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
+                    LGPROF(5);
+                    {   // Cholesky + substitutions by one wave of EVERY workgroup: identical inputs, identical instruction
+                        // stream, identical x_o everywhere -- which saves the grid barrier that would publish workgroup 0's
+                        const int sp = ns | 1;                           // odd LDS pitch (lm_device.h: wave_cholesky_solve)
+                        // the packed system: all of a thread's loads are issued before the first LDS store (one L2 round trip)
+                        constexpr int NCP = (LM_NS * (LM_NS + 1) / 2 + LM_NS + LG_THREADS - 1) / LG_THREADS;
+                        double v[NCP];
+#pragma unroll
+                        for (int u = 0; u < NCP; ++u) { const int t = tid + u * LG_THREADS; v[u] = t < n_low + ns ? sc.S[t] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < NCP; ++u) {
+                            const int t = tid + u * LG_THREADS;
+                            if (t < n_low) {
+                                int row = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                                while ((row + 1) * (row + 2) / 2 <= t) ++row;
+                                while (row * (row + 1) / 2 > t) --row;
+                                S[row * sp + t - row * (row + 1) / 2] = v[u];
+                            } else if (t < n_low + ns) {
+                                rhs[t - n_low] = v[u];
                             }
                         }
+                        if (tid == 0) sh_ok = 1;
                         __syncthreads();
+                        LGPROF(10);
+                        if (tid < 64) wave_cholesky_solve(S, sp, rhs, colbuf, ns, tid, &sh_ok);
+                        __syncthreads();
+                        LGPROF(11);
+                        // solution (every workgroup writes the same words)
                         if (sh_ok == 0) bad = 1;
                         for (int idx = tid; idx < P.n_obj * 6; idx += LG_THREADS) {
                             const int o = idx / 6;
                             P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
                         }
                     }
-                    grid_sync(g);
-                    // x_c = y_c - sum_o Y(c,o) x_o
-                    for (int idx = gt; idx < P.n_cam * 6; idx += GS) {
-                        const int c = idx / 6, r = idx - c * 6;
+                    __syncthreads();                                     // this workgroup's x_o is visible to its threads
+                    LGPROF(6);
+                    // x_c = y_c - sum_o Y(c,o) x_o and the camera update: eight adjacent lanes per camera, lane r < 6 computes
+                    // row r, lane 0 collects the six rows by shuffles and applies them -- no barrier between the two
+                    for (int q8 = gt; q8 < 8 * P.n_cam; q8 += GS) {          // GS is a multiple of 8: an octet stays together
+                        const int c = q8 >> 3, r = q8 & 7;
+                        const bool free_cam = !P.cam_fixed[c];
                         double s = 0;
-                        if (!P.cam_fixed[c]) {
-                            s = P.yc[idx];
+                        if (r < 6 && free_cam) {
+                            s = P.yc[6 * c + r];
                             for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b) {
                                 const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
                                 if (P.obj_fixed[o]) continue;
                                 for (int k = 0; k < 6; ++k) s -= P.Y[36 * (size_t)p + r * 6 + k] * P.xo[6 * o + k];
                             }
                         }
-                        P.xc[idx] = s;
+                        if (r < 6) P.xc[6 * c + r] = s;
+                        double x[6];
+                        for (int k = 0; k < 6; ++k) x[k] = __shfl(s, k, 8);
+                        if (r == 0 && free_cam) pose_oplus(P.cam[c], x);
                     }
                 }
-                const bool ok2 = grid_reduce(bad, true, g, red_lds) == 0;        // (also orders xo / xc before the update)
-                if (ok2) {
-                    for (int c = gt; c < P.n_cam; c += GS) if (!P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
-                    for (int o = gt; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
-                }
+                // The update is applied whether or not a factorisation failed anywhere: a failure is reduced together with
+                // chi2 and the step scale below and turns the trial into a rejection, whose pop() restores the poses.  One
+                // grid barrier (poses -> edge pass) and one three-value reduction per trial instead of four barriers.
+                for (int o = gt; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
                 grid_sync(g);
-                double tempChi = grid_reduce(edge_pass_partial(P, 0, P.n_edge, robust_on, false, gt, GS), false, g, red_lds);
-                if (!ok2) tempChi = 1.7976931348623157e308;
-                double scl = 0;
-                if (ok2) {
-                    for (int idx = gt; idx < P.n_cam * 6; idx += GS)
-                        if (!P.cam_fixed[idx / 6]) scl += P.xc[idx] * (lambda * P.xc[idx] + P.bc[idx]);
-                    for (int idx = gt; idx < P.n_obj * 6; idx += GS)
-                        if (!P.obj_fixed[idx / 6]) scl += P.xo[idx] * (lambda * P.xo[idx] + P.bo[idx]);
-                }
-                scl = grid_reduce(scl, false, g, red_lds);
+                LGPROF(7);
+                double red3[LG_RED_N] = {edge_pass_partial(P, 0, P.n_edge, robust_on, false, gt, GS), 0.0, bad};
+                for (int idx = gt; idx < P.n_cam * 6; idx += GS)
+                    if (!P.cam_fixed[idx / 6]) red3[1] += P.xc[idx] * (lambda * P.xc[idx] + P.bc[idx]);
+                for (int idx = gt; idx < P.n_obj * 6; idx += GS)
+                    if (!P.obj_fixed[idx / 6]) red3[1] += P.xo[idx] * (lambda * P.xo[idx] + P.bo[idx]);
+                grid_reduce3(red3, g, red_lds);
+                LGPROF(8);
+                const bool ok2 = red3[2] == 0;
+                const double tempChi = ok2 ? red3[0] : 1.7976931348623157e308;
+                const double scl = ok2 ? red3[1] : 0.0;
                 rho = (currentChi - tempChi) / (scl + 1e-3);
                 if (rho > 0 && isfinite(tempChi)) {
                     double alpha = 1. - pow(2 * rho - 1, 3.0);
@@ -396,7 +463,7 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
     if (gt == 0) { P.stats[0] = rounds; P.stats[1] = lm_its; P.stats[2] = lm_trials; P.stats[3] = num_good; }
 }
 
-size_t lm_grid_scratch_bytes() { return 64 + 2 * LG_MAX_WGS * sizeof(double) + (LM_NS * LM_NS + LM_NS) * sizeof(double); }
+size_t lm_grid_scratch_bytes() { return 64 + 2 * LG_RED_N * LG_MAX_WGS * sizeof(double) + (LM_NS * LM_NS + LM_NS) * sizeof(double); }
 
 // `scratch_dev`: lm_grid_scratch_bytes() of device memory whose first 64 bytes are ZERO (the barrier words)
 int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s) {
@@ -405,10 +472,21 @@ int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStr
     LmGridScratch sc;
     sc.bar = (unsigned*)scratch_dev;
     sc.red = (double*)((char*)scratch_dev + 64);
-    sc.S = sc.red + 2 * LG_MAX_WGS;
+    sc.S = sc.red + 2 * LG_RED_N * LG_MAX_WGS;
     hipLaunchKernelGGL(lm_grid_kernel, dim3(8 * n_wgs), dim3(LG_THREADS), 0, s, (const LmProblem*)problem_dev, sc, n_wgs);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
 
 }  // namespace suo
+
+#ifdef SUO_LG_PROFILE
+// profile builds only: microseconds per section since the last call (and reset)
+extern "C" int suo_debug_lg_prof(double* out16) {
+    long long h[16], z[16] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(suo::g_lg_prof), sizeof(h)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(suo::g_lg_prof), z, sizeof(z)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out16[i] = h[i] * 0.01;          // s_memrealtime ticks of 10 ns
+    return 0;
+}
+#endif

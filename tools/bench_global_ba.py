@@ -23,6 +23,20 @@ for rep in range(4):
 print(f"SUO_LM_GRID_WGS={os.environ.get('SUO_LM_GRID_WGS', 'default')}: {n_cam} cams x {n_obj} objs, {len(P['edge_cam'])} edges: "
       f"{1e3 * min(ts):.2f} ms (stats rounds/its/trials/good = {list(out[4])})")
 
+from suo_slam_amd import _lib  # noqa: E402
+if hasattr(_lib.lib(), "suo_debug_lg_prof"):          # -DSUO_LG_PROFILE build (tools/build_variant.sh lgprof -DSUO_LG_PROFILE)
+    import ctypes
+    buf = (ctypes.c_double * 16)()
+    _lib.lib().suo_debug_lg_prof(buf)                 # reset
+    BA.optimize(*[x.copy() for x in args])
+    _lib.lib().suo_debug_lg_prof(buf)
+    names = ["edge pass + chi2 reduce", "pair blocks", "diagonal gather", "push + camera inverses", "Y = Hcc^-1 Hco", "reduced system",
+             "x_o write-back", "x_c + update", "edge pass + reduce3", "trial / iteration bookkeeping, reclassification",
+             "reduced system -> LDS", "wave Cholesky + substitutions"]
+    tot = sum(buf[:12])
+    for i, nm in enumerate(names):
+        print(f"    {nm:48s} {buf[i] / 1e3:8.2f} ms  {100 * buf[i] / tot:5.1f} %")
+
 # the multi-GPU phase kernels (csrc/lm_dist.hip) under the host schedule, one rank (no exchange)
 from suo_slam_amd import ba_dist  # noqa: E402
 ts = []
