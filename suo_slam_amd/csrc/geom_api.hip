@@ -20,6 +20,7 @@ int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const doub
 int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);
+int launch_lm_cam(const void* problems_dev, int n_problems, hipStream_t s);
 size_t lm_grid_scratch_bytes();
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
@@ -355,7 +356,18 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     for (int i = 0; i < n_prob; ++i) max_edges = std::max(max_edges, probs[i].n_edge);
     static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 1024;      // tuning aids
     static const int grid_wgs = getenv("SUO_LM_GRID_WGS") ? atoi(getenv("SUO_LM_GRID_WGS")) : 32;          // 0: never use the grid kernel
-    if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {
+    // camera tracking (ObjectSLAM.optimize(curr_only=True)): one free camera, every object fixed -> one wave per problem
+    static const int cam_kernel = getenv("SUO_LM_CAM") ? atoi(getenv("SUO_LM_CAM")) : 1;                    // 0: general kernel (A/B)
+    bool cam_only = cam_kernel != 0;
+    for (int i = 0; i < n_prob && cam_only; ++i) {
+        int nfc = 0, nfo = 0;
+        for (int c = 0; c < probs[i].n_cam; ++c) nfc += probs[i].cam_fixed[c] ? 0 : 1;
+        for (int o = 0; o < probs[i].n_obj; ++o) nfo += probs[i].obj_fixed[o] ? 0 : 1;
+        cam_only = nfc == 1 && nfo == 0;
+    }
+    if (cam_only) {
+        rc = launch_lm_cam(g_arena.dev + st.o_structs, n_prob, g_arena.stream);
+    } else if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {
         static void* grid_scratch = nullptr;
         if (!grid_scratch) SUO_HIP_CHECK(hipMalloc(&grid_scratch, lm_grid_scratch_bytes()));
         SUO_HIP_CHECK(hipMemsetAsync(grid_scratch, 0, 64, g_arena.stream));

@@ -152,6 +152,36 @@ def test_curr_only_camera_tracking_matches_oracle(ba):
         _compare_ba(ba, P, its=(10, 10, 10, 10), init_with_outliers=iwo)
 
 
+@pytest.mark.parametrize("n_obj,noise,outliers", [(1, 0.002, 0.0), (8, 0.004, 0.15), (16, 0.01, 0.1)])
+def test_camera_tracking_one_wave_kernel(ba, n_obj, noise, outliers):
+    """One free camera and only fixed objects takes the one-wave kernel (csrc/lm_cam.hip): against the oracle, as a batch of
+    several views at once, and with further (fixed) cameras in the same problem."""
+    rng = np.random.default_rng(300 + n_obj)
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    probs, singles = [], []
+    for f in range(4):
+        fr = S.make_frame(rng, n_obj, noise=noise, outlier_frac=outliers, with_image=False)
+        P = S.frame_to_ba_problem(fr, fr["T_OtoC"])
+        P["cam_T"] = _perturb(np.eye(4), rng, 2e-4, 0.1)[None]
+        P["cam_fixed"] = np.array([0], np.uint8)
+        P["obj_fixed"] = np.ones(n_obj, np.uint8)
+        got, ref = _compare_ba(ba, P, its=(10, 10, 10, 10))
+        probs.append(ba.Problem(*[P[k] for k in keys], its=(10, 10, 10, 10)))
+        singles.append(got)
+    ba.optimize_batch(probs)                                        # one workgroup (= one wave) per problem
+    for p, s in zip(probs, singles):
+        assert np.array_equal(p.cam_T.reshape(-1, 3, 4), s[0]) and np.array_equal(p.inlier, s[2])
+    # a second, fixed camera with its own edges: they are inactive (camera and objects fixed) and must stay untouched
+    P2 = {k: np.array(P[k]) for k in keys}
+    P2["cam_T"] = np.concatenate([P["cam_T"], P["cam_T"]])
+    P2["cam_fixed"] = np.array([1, 0], np.uint8)
+    P2["edge_cam"] = np.concatenate([np.zeros_like(P["edge_cam"]), np.ones_like(P["edge_cam"])])
+    for k in ("edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier"):
+        P2[k] = np.concatenate([P[k], P[k]])
+    got2, ref2 = _compare_ba(ba, P2, its=(10, 10, 10, 10))
+    np.testing.assert_allclose(got2[0][0], P["cam_T"][0], rtol=0, atol=1e-12)      # (matrix -> quaternion -> matrix round trip)
+
+
 def _multi_view_scene(rng, n_cam, n_obj, noise_px=0.5):
     k = np.array([600.0, 600.0, 320.0, 240.0])
     cam_gt = np.zeros((n_cam, 3, 4))
