@@ -161,19 +161,20 @@ def test_conv7x7_stride2(ops):
     assert _rel(out, ref) < 5e-6
 
 
-def test_pool_and_upsample(ops):
+@pytest.mark.parametrize("L,C,H", [(2, 64, 16), (3, 48, 12), (5, 256, 64)])       # power-of-two extents (shift path) and not
+def test_pool_and_upsample(ops, L, C, H):
     from suo_slam_amd import _lib
     rng = np.random.default_rng(12)
-    x = rng.standard_normal((2, 64, 16, 16)).astype(np.float32)
+    x = rng.standard_normal((L, C, H, H)).astype(np.float32)
     xd = ops.nhwc(x)
-    out = torch.empty((2, 8, 8, 64), device="cuda")
-    _lib.check(_lib.lib().suo_maxpool2(ops.P(xd), ops.P(out), 2, 16, 16, 64, ops.S()))
+    out = torch.empty((L, H // 2, H // 2, C), device="cuda")
+    _lib.check(_lib.lib().suo_maxpool2(ops.P(xd), ops.P(out), L, H, H, C, ops.S()))
     torch.cuda.synchronize()
     assert np.array_equal(ops.nchw(out), F.max_pool2d(torch.from_numpy(x), 2, 2).numpy())
-    low = rng.standard_normal((2, 64, 8, 8)).astype(np.float32)
-    o2 = torch.empty((2, 16, 16, 64), device="cuda")
+    low = rng.standard_normal((L, C, H // 2, H // 2)).astype(np.float32)
+    o2 = torch.empty((L, H, H, C), device="cuda")
     lowd = ops.nhwc(low)
-    _lib.check(_lib.lib().suo_upsample2_add(ops.P(xd), ops.P(lowd), ops.P(o2), 2, 16, 16, 64, ops.S()))
+    _lib.check(_lib.lib().suo_upsample2_add(ops.P(xd), ops.P(lowd), ops.P(o2), L, H, H, C, ops.S()))
     torch.cuda.synchronize()
     ref = torch.from_numpy(x) + F.interpolate(torch.from_numpy(low), scale_factor=2)
     assert np.array_equal(ops.nchw(o2), ref.numpy())
