@@ -185,6 +185,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         for (int j = 0; j < TN; ++j) bvall[j] = buf_load(bias_srd, bv, (n0 + j * 32) * 4);
         if (HAS_R && !(SUO_GEMM_EXP & 8)) rload(0);
     };
+    // (Tried, not kept: storing / loading straight in the accumulator layout -- one dword op of a wave covers two full
+    // 128-byte row segments, no LDS patch, no wave barriers -- is 2-10 % SLOWER than this transposed 16-byte form: four
+    // times the VMEM instructions cost more than the LDS round trips they replace.)
     auto epilogue = [&]() {
         float* T = &Tp[w][0];
         const __amdgpu_buffer_rsrc_t o_srd = make_srd(a.out + (size_t)m0 * a.ldo + n0, ((size_t)(BM - 1) * a.ldo + BN) * sizeof(float));
