@@ -250,10 +250,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # (SUO_LOCAL_DEVICE / SUO_DIST_BACKEND: rehearsal of the multi-process flow on a box with fewer GPUs than ranks --
+    #  e.g. two ranks sharing GPU 0 over gloo; RCCL itself refuses duplicate devices.  Not used by the driver.)
+    local = int(os.environ.get("SUO_LOCAL_DEVICE", local))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SUO_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     L = args.objects
     # frames shard embarrassingly: rank r processes its own stream (weak scaling: K frames per GPU)
     pool = make_pool(np.random.default_rng(1000 + rank), args.pool, L)
@@ -278,7 +285,8 @@ def main():
     dt = time.perf_counter() - t0
     # max-over-ranks time + the only collective of the path: metric accumulators (RCCL all-reduce over xGMI)
     from suo_slam_amd import sharding
-    dt, (pose_err, n_pose, n_inl) = sharding.reduce_metrics(dt, [pipe.pose_err, pipe.n_pose, pipe.n_inl], device="cuda")
+    dt, (pose_err, n_pose, n_inl) = sharding.reduce_metrics(dt, [pipe.pose_err, pipe.n_pose, pipe.n_inl],
+                                                            device="cuda" if os.environ.get("SUO_DIST_BACKEND", "nccl") == "nccl" else "cpu")
     if rank == 0:
         fps = world * args.steps / dt
         line = {
