@@ -7,15 +7,15 @@
 // main loop, so the one-tile-per-workgroup kernel measures  t = flops / 141 TFLOP/s + bytes / 4.2 TB/s  -- a SUM, no
 // overlap (the 3x3 kernel has 9x longer chunks and does not suffer).  Here
 //   * a workgroup is persistent and walks a list of tiles; (tile, chunk) pairs form one flat sequence of STEPS,
-//   * activations are fetched TWO steps ahead (two static register sets; weights one step ahead, and issued BEFORE
-//     the activation loads because vmcnt retires in order: a fast L2 weight load must not queue behind an HBM load
-//     it does not depend on),
-//   * so the first chunks of tile i+1 are already in flight while tile i finishes, and tile i's stores drain
+//   * activations are fetched one step ahead (one register set; -DSUO_GEMM_A_DEPTH=2: two steps, two sets -- measured
+//     no faster), weights ride a static ring of four k-group slots requested three groups ahead (vmcnt retires in order,
+//     so a weight load issued after an activation load also waits for it: the ring bounds how long),
+//   * so the first chunk of tile i+1 is already in flight while tile i finishes, and tile i's stores drain
 //     under tile i+1's MFMAs.  The epilogue uses its own wave-private LDS patches (the chunk buffers already hold the
 //     next tile),
 //   * every stream goes through a buffer descriptor (csrc/buffer_ops.h): one fixed 32-bit VGPR offset per stream, tile
 //     and chunk in the descriptor base / scalar offset -- no 64-bit address registers, which together with the 16-row
-//     epilogue patch (46 KB of LDS) lets THREE workgroups share a CU.
+//     epilogue patch (50 KB of LDS in all) lets THREE workgroups share a CU.
 #include "buffer_ops.h"
 #include "suo_internal.h"
 
@@ -226,11 +226,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         }
     };
 
-    // One step: weights for step s+1 and activations for step s+2 are requested, then the 16*TM*TN MFMAs of step s run
-    // from LDS buffer s&1; afterwards step s+1's activations (requested during step s-1) go to the other buffer.
-    //   b / bn        weight sets of step s / s+1
-    //   a_free        register set that step s+2 is fetched into (it held step s, stored at the end of step s-1)
-    //   a_next        register set holding step s+1
+    // One step = the four k-groups of one 32-channel chunk: before each group's 4*TM*TN MFMAs (from LDS buffer s&1) the
+    // weights three groups ahead are requested, before the first also the next activations; afterwards the activations
+    // of step s+1 go to the other LDS buffer.
+    //   a_free        register set the new activations are fetched into
+    //   a_next        register set holding step s+1 (the same set with SUO_GEMM_A_DEPTH 1, the other one with 2)
     auto step = [&](int s, f32x4(&a_free)[NLD], const f32x4(&a_next)[NLD]) {
         const int buf = s & 1;
         int nkc, nn0;
