@@ -503,7 +503,10 @@ int launch_conv7x7s2(const ConvArgs& a, hipStream_t s) {
         suo_set_error("conv7x7s2: bad shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;
     }
-    if (a.C == 8) return launch_conv_cfg<7, 2, 8, 8, 8, 1, 1, 2, 2>(a, s);       // image-only stem: 3 channels in one 8-wide chunk
+    // image-only stem: 3 channels in one 8-wide chunk.  (8 x 16-pixel tiles with 4 or 8 waves: 823 / 810 us against 777 at
+    // 128 crops.  The kernel is MFMA-bound on the PADDED work -- 5 of its 8 channels are zeros; pairing taps, 2 x 4
+    // channels per k-group, would halve it and is the remaining 1 % of the network.)
+    if (a.C == 8) return launch_conv_cfg<7, 2, 8, 8, 8, 1, 1, 2, 2>(a, s);
     if (a.C & 15) { suo_set_error("conv7x7s2: C=%d must be 8 or a multiple of 16", a.C); return SUO_ERR_ARG; }
     return launch_conv_cfg<7, 2, 16, 8, 8, 1, 1, 2, 2>(a, s);
 }
