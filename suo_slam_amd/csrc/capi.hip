@@ -107,7 +107,8 @@ int suo_pack_gemm_weight(const float* w, int N, int K, int Np, int Kp, float* ou
 }
 
 int suo_pack_conv_weight(const float* w, int N, int C, int KS, int Np, int Cp, int CK, float* out) {
-    if (Np % 32 || Cp % CK || CK % 8 || N > Np || C > Cp) { suo_set_error("suo_pack_conv_weight: bad padding"); return SUO_ERR_ARG; }
+    // (CK = 4: paired taps of the image-only stem)
+    if (Np % 32 || Cp % CK || (CK % 8 && CK != 4) || N > Np || C > Cp) { suo_set_error("suo_pack_conv_weight: bad padding"); return SUO_ERR_ARG; }
     suo::pack_conv_weight(w, N, C, KS, Np, Cp, CK, nullptr, out);
     return SUO_OK;
 }

@@ -268,7 +268,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     constexpr int PAD = KS / 2;
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, NT = WGM * WGN * 64;
     static_assert(BM == TH * TW, "pixel tile mismatch");
-    constexpr int PK = CK + 4, S = CK / 8, C4 = CK / 4;
+    // CK == 4 (the image-only stem: 3 channels): a k-group pairs TWO taps, lanes 0-31 the even one, lanes 32-63 the odd one
+    // (4 channels each), so no MFMA k-step multiplies padding -- half the work of one tap per 8-channel group
+    constexpr bool PAIR = CK == 4;
+    constexpr int PK = CK + 4, S = PAIR ? 1 : CK / 8, C4 = CK / 4;
     constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, NPIX = IH * IW;
     constexpr int NF4 = NPIX * C4, NLD = (NF4 + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float As[2][NPIX * PK];
@@ -306,8 +309,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     // Weights travel through a STATIC ring of R group slots (group gg of the whole K loop lives in slot gg % R and is
     // requested R-1 groups before its MFMAs; G % R == 0 keeps the slot of every unrolled group a compile-time constant
     // across chunks -- no register copies for hipcc to coalesce away, no second copy of the loop body).
-    constexpr int G = KS * KS * S;
-    constexpr int R = KS == 3 ? SUO_CONV_BRING3 : 7;
+    constexpr int G = PAIR ? (KS * KS + 1) / 2 : KS * KS * S;
+    constexpr int R = KS == 3 ? SUO_CONV_BRING3 : (PAIR ? 5 : 7);
     static_assert(G % R == 0 && R >= 2, "weight ring must divide the groups of a chunk");
     // activations: the halo tile of the next chunk is fetched in two halves (registers for half a tile only)
     constexpr int NLH = (NLD + 1) / 2;
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     f32x4 bring[R][TN];
 
     const __amdgpu_buffer_rsrc_t in_srd = make_srd(in_l, (size_t)a.H * a.W * a.C * sizeof(float));
-    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * KS * KS * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)nch * G * a.N * 8 * sizeof(float));      // G k-groups of N x 8 weights per chunk
     const __amdgpu_buffer_rsrc_t out_srd = make_srd(a.out + (size_t)l * a.OH * a.OW * a.N, (size_t)a.OH * a.OW * a.N * sizeof(float));
     // halo staging: byte offset of this thread's i-th 16-byte piece inside the crop (channel chunk 0), out of range
     // for the zero padding and for the unused tail of the last round
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     for (int i = 0; i < TM; ++i) {
         const int p = (wm * TM + i) * 32 + (lane & 31);
         const int py = p / TW, px = p - py * TW;
-        abase[i] = ((py * ST) * IW + px * ST) * PK + (lane >> 5) * 4;
+        abase[i] = ((py * ST) * IW + px * ST) * PK + (PAIR ? 0 : (lane >> 5) * 4);
     }
 
     CPROF(0);
@@ -373,6 +376,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 
     // A fragments of group g (tap t = g / S, channels s*8 .. s*8+7 of the chunk): one ds_read_b128 per M-tile
     auto aread = [&](const float* as, int g, f32x4(&af)[TM]) {
+        if (PAIR) {
+            const int ta = 2 * g, tb = 2 * g + 1 < KS * KS ? 2 * g + 1 : ta;      // (the last odd tap does not exist: zero weights)
+            const int toff = (lane >> 5) ? ((tb / KS) * IW + (tb % KS)) * PK : ((ta / KS) * IW + (ta % KS)) * PK;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + abase[i] + toff);
+            return;
+        }
         const int t = g / S, s = g - t * S;
         const int toff = ((t / KS) * IW + (t % KS)) * PK;
 #pragma unroll
@@ -499,13 +509,14 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv7x7s2(const ConvArgs& a, hipStream_t s) {
-    if (a.OH * 2 != a.H || a.OW * 2 != a.W || (a.C & 7) || (a.N & 63)) {
+    if (a.OH * 2 != a.H || a.OW * 2 != a.W || ((a.C & 7) && a.C != 4) || (a.N & 63)) {
         suo_set_error("conv7x7s2: bad shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;
     }
-    // image-only stem: 3 channels in one 8-wide chunk.  (8 x 16-pixel tiles with 4 or 8 waves: 823 / 810 us against 777 at
-    // 128 crops.  The kernel is MFMA-bound on the PADDED work -- 5 of its 8 channels are zeros; pairing taps, 2 x 4
-    // channels per k-group, would halve it and is the remaining 1 % of the network.)
+    // image-only stem: 3 channels.  As one 8-channel chunk (what the network uses, suo_internal.h: IMG_C) the kernel is
+    // MFMA-bound on PADDED work (5 of 8 channels are zeros: 777 us at 128 crops; 8 x 16-pixel tiles with 4 / 8 waves are
+    // slower, 823 / 810 us); with 4-channel staging two taps share a k-group (CK = 4) and half of those MFMAs disappear.
+    if (a.C == 4) return launch_conv_cfg<7, 2, 4, 8, 8, 1, 1, 2, 2>(a, s);
     if (a.C == 8) return launch_conv_cfg<7, 2, 8, 8, 8, 1, 1, 2, 2>(a, s);
     if (a.C & 15) { suo_set_error("conv7x7s2: C=%d must be 8 or a multiple of 16", a.C); return SUO_ERR_ARG; }
     return launch_conv_cfg<7, 2, 16, 8, 8, 1, 1, 2, 2>(a, s);

@@ -84,7 +84,7 @@ void pack_gemm_weight(const float* W, int N, int K, int ldw, int Np, int Kp, flo
 
 // Conv weight W[n][c][ky][kx] -> GEMM weight with K' = [chunk][ky][kx][kk] (kk < CK), then packed.
 void pack_conv_weight(const float* W, int N, int C, int KS, int Np, int Cp, int CK, const float* out_scale, float* out) {
-    const int nch = Cp / CK, Kp = nch * KS * KS * CK;
+    const int nch = Cp / CK, Kraw = nch * KS * KS * CK, Kp = (Kraw + 15) / 16 * 16;      // CK = 4 (paired taps): 196 -> 208
     std::vector<float> g((size_t)Np * Kp, 0.f);
     for (int n = 0; n < N; ++n)
         for (int ch = 0; ch < nch; ++ch)
@@ -151,7 +151,7 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
     const int Np = round_up(N, 64), Cp = round_up(C, CK);
     std::vector<float> scale, shift;
     if (!bn_after.empty()) bn_affine(*this, bn_after, scale, shift);
-    std::vector<float> packed(2 * (size_t)Np * Cp * KS * KS), bias(Np, 0.f);
+    std::vector<float> packed(2 * (size_t)Np * ((Cp * KS * KS + 15) / 16 * 16)), bias(Np, 0.f);
     std::vector<float> sliced;
     const float* wdata = w.data;
     if (C != Cw) {

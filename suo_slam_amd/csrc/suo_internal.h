@@ -26,7 +26,14 @@ constexpr int NUM_KP = 41;
 constexpr int HEAT = 64;          // heat-map side
 constexpr int CROP = 256;         // network input side
 constexpr int IN_C = 48;          // 3 + 41 = 44 input channels, padded to 48 in the NHWC staging buffer
-constexpr int IMG_C = 8;          // staging without priors: 3 image channels padded to one 8-channel conv chunk
+#ifndef SUO_IMG_C
+#define SUO_IMG_C 8
+#endif
+constexpr int IMG_C = SUO_IMG_C;  // staging without priors: 3 image channels padded to one 8-channel conv chunk.  (4 channels with
+                                  // two taps per MFMA k-group -- conv.hip supports it, tests/test_gpu_cnn.py covers it -- halves the
+                                  // stem kernel, 790 -> 450 us at 128 crops, and the bench gains 1.1 % (same-box A/B, -DSUO_IMG_C=4
+                                  // via tools/build_variant.sh), but the sums are then no longer in the order of the 48-channel stem,
+                                  // i.e. the prior-less pass is no longer BIT-identical to feeding zero priors.  Not worth 1 %.)
 
 // ---- packed-weight geometry (B operand of v_mfma_f32_32x32x2_f32) -------------------------------
 // A GEMM weight W[N][K] (row = output channel) is stored as  Wp[K/8][N/32][64 lanes][4]  with

@@ -36,7 +36,7 @@ def pack_gemm(w, Np, Kp):
 
 def pack_conv(w, Np, Cp, CK):
     w = np.ascontiguousarray(w, np.float32)
-    out = np.empty(2 * Np * Cp * w.shape[2] * w.shape[3], np.float32)
+    out = np.empty(2 * Np * ((Cp * w.shape[2] * w.shape[3] + 15) // 16 * 16), np.float32)     # K padded to 16 (CK = 4 / 8 stems)
     _lib.check(_lib.lib().suo_pack_conv_weight(w.ctypes.data, w.shape[0], w.shape[1], w.shape[2], Np, Cp, CK, out.ctypes.data), "pack_conv")
     return out
 
@@ -73,7 +73,7 @@ def conv1x1(a1, w1, bias, pro=None, a2=None, w2=None, res=None, relu=False, nchw
 def conv_kxk(x_nhwc, w, bias, relu=False):
     L, H, W, C = x_nhwc.shape
     N, Cw, KS, _ = w.shape
-    CK = 32 if KS == 3 else 16
+    CK = 32 if KS == 3 else (C if C in (4, 8) else 16)           # image-only stems: one chunk of 4 (paired taps) or 8 channels
     Np = (N + 63) // 64 * 64
     assert C % CK == 0 and Cw <= C
     wp = dev(pack_conv(w, Np, C, CK))

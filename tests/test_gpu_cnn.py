@@ -161,6 +161,22 @@ def test_conv7x7_stride2(ops):
     assert _rel(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("cpad,L,H", [(4, 3, 64), (8, 3, 64), (4, 2, 76)])
+def test_conv7x7_image_only_stem(ops, cpad, L, H):
+    """The prior-less stem multiplies only the 3 image channels: staged as 4 channels with two taps per MFMA k-group
+    (what the network uses) or as one 8-channel chunk; ragged tiles included (76 -> 38 = 4.75 tiles)."""
+    rng = np.random.default_rng(21 + cpad)
+    x = rng.standard_normal((L, 3, H, H)).astype(np.float32)
+    xp = np.zeros((L, cpad, H, H), np.float32)
+    xp[:, :3] = x
+    xp[:, 3:] = rng.standard_normal((L, cpad - 3, H, H))          # the pad channels carry no weight: must not matter
+    w = (rng.standard_normal((64, 3, 7, 7)) / np.sqrt(49 * 3)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    out = ops.nchw(ops.conv_kxk(ops.nhwc(xp), w, b, relu=True))
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=3)).numpy()
+    assert _rel(out, ref) < 5e-6
+
+
 @pytest.mark.parametrize("L,C,H", [(2, 64, 16), (3, 48, 12), (5, 256, 64)])       # power-of-two extents (shift path) and not
 def test_pool_and_upsample(ops, L, C, H):
     from suo_slam_amd import _lib
