@@ -268,13 +268,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     constexpr int PAD = KS / 2;
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, NT = WGM * WGN * 64;
     static_assert(BM == TH * TW, "pixel tile mismatch");
-    // CK == 4 (the image-only stem: 3 channels): a k-group pairs TWO taps, lanes 0-31 the even one, lanes 32-63 the odd one
-    // (4 channels each), so no MFMA k-step multiplies padding -- half the work of one tap per 8-channel group
+    // CK == 4 (the image-only stem: 3 real channels + 1 pad in the staging buffer): the GEMM-K axis is the DENSE sequence
+    // kk = tap * 3 + channel (147 terms), two consecutive kk per MFMA k-step (lanes 0-31 the even one, lanes 32-63 the odd
+    // one).  No k-step multiplies padding (76 instead of 196 MFMAs per accumulator), and since v_mfma_f32_32x32x2_f32 adds
+    // its two products in k order, the nonzero products are summed in exactly the order of the 8- / 48-channel kernels
+    // (tap-major, channel-minor, zeros in between): bit-identical results.
     constexpr bool PAIR = CK == 4;
-    constexpr int PK = CK + 4, S = PAIR ? 1 : CK / 8, C4 = CK / 4;
+    constexpr int KDENSE = KS * KS * 3;
+    constexpr int PK = PAIR ? 5 : CK + 4, S = PAIR ? 1 : CK / 8, C4 = CK / 4;      // (pitch 5: stride-2 pixel reads spread over the banks)
     constexpr int IH = (TH - 1) * ST + KS, IW = (TW - 1) * ST + KS, NPIX = IH * IW;
     constexpr int NF4 = NPIX * C4, NLD = (NF4 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float As[2][NPIX * PK];
+    constexpr int ASZ = NPIX * PK > WGM * WGN * 32 * 36 / 2 ? NPIX * PK : WGM * WGN * 32 * 36 / 2;      // (also hosts the epilogue patches)
+    __shared__ __attribute__((aligned(16))) float As[2][ASZ];
 
     const int tid = threadIdx.x, lane = tid & 63;
     // Wave index as an SGPR: the weight addresses and tile offsets derived from it become scalar, which frees 50-70
@@ -309,9 +314,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     // Weights travel through a STATIC ring of R group slots (group gg of the whole K loop lives in slot gg % R and is
     // requested R-1 groups before its MFMAs; G % R == 0 keeps the slot of every unrolled group a compile-time constant
     // across chunks -- no register copies for hipcc to coalesce away, no second copy of the loop body).
-    constexpr int G = PAIR ? (KS * KS + 1) / 2 : KS * KS * S;
-    constexpr int R = KS == 3 ? SUO_CONV_BRING3 : (PAIR ? 5 : 7);
-    static_assert(G % R == 0 && R >= 2, "weight ring must divide the groups of a chunk");
+    constexpr int G = PAIR ? ((KDENSE + 1) / 2 + 3) / 4 : KS * KS * S;
+    constexpr int R = KS == 3 ? SUO_CONV_BRING3 : (PAIR ? 4 : 7);
+    static_assert((PAIR || G % R == 0) && R >= 2, "weight ring must divide the groups of a chunk (single-chunk PAIR mode excepted)");
     // activations: the halo tile of the next chunk is fetched in two halves (registers for half a tile only)
     constexpr int NLH = (NLD + 1) / 2;
     f32x4 areg[NLH];
@@ -343,7 +348,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
             const int idx = tid + (h * NLH + i) * NT;
             if (h * NLH + i < NLD && idx < NF4) {
                 const int pix = idx / C4, cc = idx - pix * C4;
-                *(f32x4*)&As[buf][pix * PK + cc * 4] = areg[i];
+                if (PAIR) {                                          // 3 real channels at pitch 5 (no 16-byte alignment)
+                    float* d = &As[buf][pix * PK];
+                    d[0] = areg[i][0]; d[1] = areg[i][1]; d[2] = areg[i][2];
+                } else {
+                    *(f32x4*)&As[buf][pix * PK + cc * 4] = areg[i];
+                }
             }
         }
     };
@@ -376,11 +386,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 
     // A fragments of group g (tap t = g / S, channels s*8 .. s*8+7 of the chunk): one ds_read_b128 per M-tile
     auto aread = [&](const float* as, int g, f32x4(&af)[TM]) {
-        if (PAIR) {
-            const int ta = 2 * g, tb = 2 * g + 1 < KS * KS ? 2 * g + 1 : ta;      // (the last odd tap does not exist: zero weights)
-            const int toff = (lane >> 5) ? ((tb / KS) * IW + (tb % KS)) * PK : ((ta / KS) * IW + (ta % KS)) * PK;
+        if (PAIR) {                                                  // k-step t of group g: kk = 8 g + 2 t + (lane >> 5)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(as + abase[i] + toff);
+            for (int t = 0; t < 4; ++t) {
+                const int ka = 8 * g + 2 * t < KDENSE ? 8 * g + 2 * t : KDENSE - 1;          // (past the end: zero weights)
+                const int kb = 8 * g + 2 * t + 1 < KDENSE ? 8 * g + 2 * t + 1 : KDENSE - 1;
+                const int offa = (((ka / 3) / KS) * IW + ((ka / 3) % KS)) * PK + ka % 3;
+                const int offb = (((kb / 3) / KS) * IW + ((kb / 3) % KS)) * PK + kb % 3;
+                const int off = (lane >> 5) ? offb : offa;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i][t] = as[abase[i] + off];
+            }
             return;
         }
         const int t = g / S, s = g - t * S;
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             // LDS transpose of the accumulator tile (wave-private patch of the free A buffers) -> 16-byte stores
-            static_assert(2 * NPIX * PK >= WGM * WGN * 32 * 36, "epilogue patch must fit the A buffers");
+            static_assert(2 * ASZ >= WGM * WGN * 32 * 36, "epilogue patch must fit the A buffers");
             float* T = &As[0][0] + w * (32 * 36);
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[acc_row(r, lane) * 36 + (lane & 31)] = acc[i][j][r];
@@ -513,9 +529,9 @@ int launch_conv7x7s2(const ConvArgs& a, hipStream_t s) {
         suo_set_error("conv7x7s2: bad shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;
     }
-    // image-only stem: 3 channels.  As one 8-channel chunk (what the network uses, suo_internal.h: IMG_C) the kernel is
-    // MFMA-bound on PADDED work (5 of 8 channels are zeros: 777 us at 128 crops; 8 x 16-pixel tiles with 4 / 8 waves are
-    // slower, 823 / 810 us); with 4-channel staging two taps share a k-group (CK = 4) and half of those MFMAs disappear.
+    // image-only stem: 3 channels.  As one 8-channel chunk the kernel is MFMA-bound on PADDED work (5 of 8 channels are
+    // zeros: 777 us at 128 crops; 8 x 16-pixel tiles with 4 / 8 waves are slower, 823 / 810 us); with 4-channel staging
+    // (what the network uses, suo_internal.h: IMG_C) the K axis is dense -- see PAIR in convk_kernel.
     if (a.C == 4) return launch_conv_cfg<7, 2, 4, 8, 8, 1, 1, 2, 2>(a, s);
     if (a.C == 8) return launch_conv_cfg<7, 2, 8, 8, 8, 1, 1, 2, 2>(a, s);
     if (a.C & 15) { suo_set_error("conv7x7s2: C=%d must be 8 or a multiple of 16", a.C); return SUO_ERR_ARG; }

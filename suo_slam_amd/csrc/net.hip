@@ -84,8 +84,22 @@ void pack_gemm_weight(const float* W, int N, int K, int ldw, int Np, int Kp, flo
 
 // Conv weight W[n][c][ky][kx] -> GEMM weight with K' = [chunk][ky][kx][kk] (kk < CK), then packed.
 void pack_conv_weight(const float* W, int N, int C, int KS, int Np, int Cp, int CK, const float* out_scale, float* out) {
-    const int nch = Cp / CK, Kraw = nch * KS * KS * CK, Kp = (Kraw + 15) / 16 * 16;      // CK = 4 (paired taps): 196 -> 208
+    const int nch = Cp / CK, Kraw = nch * KS * KS * CK, Kp = (Kraw + 15) / 16 * 16;
     std::vector<float> g((size_t)Np * Kp, 0.f);
+    if (CK == 4) {
+        // image-only stem (csrc/conv.hip, PAIR mode): dense K axis kk = tap * 3 + channel; MFMA k-step t of group kb multiplies
+        // kk = 8 kb + 2 t (lanes 0-31) and 8 kb + 2 t + 1 (lanes 32-63), which pack_gemm_weight reads from column kb*8 + half*4 + t
+        for (int n = 0; n < N; ++n)
+            for (int kk = 0; kk < KS * KS * 3; ++kk) {
+                const int tap = kk / 3, c = kk % 3;
+                if (c >= C) continue;
+                const int kb = kk / 8, r = kk % 8, t = r / 2, half = r % 2;
+                const float s = out_scale ? out_scale[n] : 1.f;
+                g[(size_t)n * Kp + kb * 8 + half * 4 + t] = W[(((size_t)n * C + c) * KS + tap / KS) * KS + tap % KS] * s;
+            }
+        pack_gemm_weight(g.data(), Np, Kp, Kp, Np, Kp, out);
+        return;
+    }
     for (int n = 0; n < N; ++n)
         for (int ch = 0; ch < nch; ++ch)
             for (int ky = 0; ky < KS; ++ky)

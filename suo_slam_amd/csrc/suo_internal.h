@@ -27,13 +27,13 @@ constexpr int HEAT = 64;          // heat-map side
 constexpr int CROP = 256;         // network input side
 constexpr int IN_C = 48;          // 3 + 41 = 44 input channels, padded to 48 in the NHWC staging buffer
 #ifndef SUO_IMG_C
-#define SUO_IMG_C 8
+#define SUO_IMG_C 4
 #endif
-constexpr int IMG_C = SUO_IMG_C;  // staging without priors: 3 image channels padded to one 8-channel conv chunk.  (4 channels with
-                                  // two taps per MFMA k-group -- conv.hip supports it, tests/test_gpu_cnn.py covers it -- halves the
-                                  // stem kernel, 790 -> 450 us at 128 crops, and the bench gains 1.1 % (same-box A/B, -DSUO_IMG_C=4
-                                  // via tools/build_variant.sh), but the sums are then no longer in the order of the 48-channel stem,
-                                  // i.e. the prior-less pass is no longer BIT-identical to feeding zero priors.  Not worth 1 %.)
+constexpr int IMG_C = SUO_IMG_C;  // staging without priors: 3 image channels + 1 pad.  The stem then runs a DENSE K axis (tap * 3 +
+                                  // channel, two consecutive terms per MFMA k-step: csrc/conv.hip, PAIR mode) -- 76 instead of 196
+                                  // MFMAs per accumulator, and the nonzero products are summed in the order of the 48-channel stem, so
+                                  // the prior-less pass stays bit-identical to feeding zero priors (tests/test_gpu_cnn.py checks it).
+                                  // -DSUO_IMG_C=8: the older form, one 8-channel chunk with 5 zero channels.
 
 // ---- packed-weight geometry (B operand of v_mfma_f32_32x32x2_f32) -------------------------------
 // A GEMM weight W[N][K] (row = output channel) is stored as  Wp[K/8][N/32][64 lanes][4]  with
