@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark of the suo_slam hot path on MI355X (contract: see the task statement).
 
-One "step" = one synthetic YCB-V-shaped frame (640x480 uint8, 8 object boxes) through the whole per-frame
-path of BASELINE.json configs[1] (single-view eval, no SLAM):
+One STEP = one network call over `--frames-per-step` (16) consecutive synthetic YCB-V-shaped frames (640x480 uint8,
+8 object boxes each = 128 crops) through the whole per-frame path of BASELINE.json configs[1] (single-view eval, no SLAM):
     RoI crop + prior concat -> stacked-hourglass keypoint CNN (fp32 MFMA) -> heat-map decode -> validity masks
-    -> batched P3P-RANSAC PnP (8 objects) -> uncertainty-weighted LM refinement, rounds [10,10,40,40].
-The network has random weights (no checkpoint ships), so -- exactly like the reference's --debug_gt_kp mode
+    -> D2H of uv / cov / masks (lib/object_slam.py:1100-1109) -> [the step's geometry waits for that read-back]
+    -> batched P3P-RANSAC PnP (all objects of the step in one launch) -> uncertainty-weighted LM, rounds [10,10,40,40].
+`value` is frames/s = steps * frames_per_step * n_gpus / elapsed; every network call processes exactly the frames that are
+counted (no tail call, no partially filled batch).  Frames of the single-view stream are independent (evaluate.py:345-346),
+which is what allows batching them; the reference's own call shape (one frame per call) is timed separately after the
+timed region and reported as config.latency_mode_fps.
+The network has random weights (no checkpoint ships), so -- like the reference's --debug_gt_kp mode
 (lib/object_slam.py:1129-1131) -- PnP / LM are driven by projected ground-truth keypoints + N(0, 0.01^2) noise
-with random SPD covariances, while the CNN runs on the frame's pixels; nothing is skipped or cached.
-Inputs (image, boxes) are resident in HBM before the timed region; PnP / LM take the small host arrays the
+with random SPD covariances, while the CNN runs on the frame's pixels and its outputs are read back; nothing is skipped or
+cached.  Inputs (images, boxes) are resident in HBM before the timed region; PnP / LM take the small host arrays the
 reference's FFI hands over (their H2D/D2H is inside the timed region).
+Outside the timed region: `roofline` (dominant kernel under HIP events), `global_ba` (BASELINE configs[4]'s exchange step:
+one 16-object global pose-graph adjustment with its cameras partitioned over the ranks, reduced system all-reduced over
+RCCL per LM trial), `cpu_baseline` (the oracle on the host cores, rank 0 at N=1 only).
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 """
@@ -36,16 +44,18 @@ N_OBJ = 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=32, help="network calls in the timed region (one step = --frames-per-step frames)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--objects", type=int, default=N_OBJ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pool", type=int, default=16, help="number of distinct synthetic frames cycled through")
-    ap.add_argument("--depth", type=int, default=2, help="frames in flight (independent network instances / streams)")
-    ap.add_argument("--frames-per-forward", type=int, default=16, help="consecutive frames batched into one network call (8 crops each)")
-    ap.add_argument("--geom-batch", type=int, default=16, help="frames whose PnP / LM problems share one launch")
+    ap.add_argument("--pool", type=int, default=0, help="number of distinct synthetic frames cycled through (0 = 2 steps' worth)")
+    ap.add_argument("--depth", type=int, default=2, help="network calls in flight (independent network instances / streams)")
+    ap.add_argument("--frames-per-step", "--frames-per-forward", dest="frames_per_step", type=int, default=16,
+                    help="frames of the stream batched into one network call = one step (--objects crops each)")
     ap.add_argument("--only", choices=["all", "cnn", "geometry"], default="all", help="diagnostic: run only one half of the step")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the one-frame-per-call measurement reported as config.latency_mode_fps")
+    ap.add_argument("--no-global-ba-leg", action="store_true", help="skip the (multi-GPU) global pose-graph adjustment reported as global_ba")
     return ap.parse_args()
 
 
@@ -69,88 +79,99 @@ def make_pool(rng, n, L):
 class FramePipeline:
     """The per-frame product path, called through the C ABI with pre-allocated device buffers.
 
-    `depth` frames are in flight at once: frame i runs on network instance i % depth (own workspace, own
-    hipGraph, own stream).  Frames of the single-view stream are independent (evaluate.py resets the SLAM state
-    for every frame, :345-346), and one frame alone cannot fill 256 CUs during the low-resolution hourglass
-    levels, so the next frame's kernels fill the gaps.  Every frame still executes the complete path."""
+    One STEP = one network call over F consecutive frames of the stream (L crops each) followed by the geometry of
+    exactly those frames:
+        forward (RoI crop, CNN, decode) + keypoint masks on the step's stream  ->  D2H of uv / cov / kp_mask / masks into
+        pinned host buffers (the three .cpu() of lib/object_slam.py:1100-1109)  ->  [host waits for that copy]  ->
+        ONE PnP launch (a wave per object) and ONE LM launch (a workgroup per frame) for the F frames.
+    `depth` steps are in flight: step i runs on slot i % depth (own network workspace, hipGraph, stream).  Before a slot is
+    reused the host awaits the read-back of the step that used it, launches the new network call, and then runs the awaited
+    step's geometry while the GPU executes `depth` network calls.  Frames of the single-view stream are independent
+    (evaluate.py:345-346 resets the SLAM state per frame).  Every network call processes exactly the frames that are
+    counted: there is no tail call."""
 
-    def __init__(self, L, pool, use_graph=True, only="all", depth=2, geom_batch=16, frames_per_forward=16):
+    def __init__(self, L, pool, F, use_graph=True, only="all", depth=2):
         import torch
         from suo_slam_amd import _lib, ba, lambdatwist, weights
         from suo_slam_amd.pkpnet import PkpNet
         self.only = only
         self.torch, self.lib, self._lib, self.ba, self.lt = torch, _lib.lib(), _lib, ba, lambdatwist
-        self.L = L
-        self.depth = depth
-        self.geom_batch = geom_batch
-        self.pending = []
+        self.L, self.F, self.depth = L, F, depth
         sd = weights.make_random_state_dict(0, 8.0)
         dev = "cuda"
         self.pool = pool
-        F = self.F = frames_per_forward
-        assert len(pool) % F == 0, "--pool must be a multiple of --frames-per-forward"
-        # the frame stream is resident in HBM as one stack; a forward call takes F consecutive frames (8F crops)
+        assert len(pool) % F == 0, "--pool must be a multiple of --frames-per-step"
+        self.n_groups = len(pool) // F
+        # the frame stream is resident in HBM as one stack; a network call takes F consecutive frames (L*F crops)
         self.imgs = torch.from_numpy(np.stack([fr["image"] for fr in pool])).to(dev)
         self.g_boxes, self.g_img, self.g_mm = [], [], []
-        for g in range(len(pool) // F):
+        for g in range(self.n_groups):
             ks = range(g * F, (g + 1) * F)
             self.g_boxes.append(torch.from_numpy(np.concatenate([pool[k]["boxes"] for k in ks])).to(dev))
             self.g_img.append(torch.from_numpy(np.repeat(np.array(list(ks), np.int32), L)).to(dev))
             self.g_mm.append(torch.from_numpy(np.concatenate([pool[k]["model_kps_masks"] for k in ks]).astype(np.uint8)).to(dev))
-        self.fwd_pending = 0
-        self.n_forward = 0
         LF = L * F
         self.slots = []
         for _ in range(depth):
             net = PkpNet(state_dict=sd, max_crops=LF)
             net.set_graph(use_graph)
             ts = torch.cuda.Stream()      # a real (non-NULL) stream: hipGraph replay is then fully asynchronous
-            self.slots.append({"net": net, "tstream": ts, "stream": C.c_void_p(ts.cuda_stream),
-                               "uv": torch.empty((LF, 41, 2), device=dev), "cov": torch.empty((LF, 41, 2, 2), device=dev),
-                               "kp": torch.empty((LF, 41), device=dev), "mask": torch.empty((LF, 41), dtype=torch.uint8, device=dev)})
-        self.pose_err = 0.0
-        self.n_pose = 0
-        self.n_inl = 0
+            S = {"net": net, "tstream": ts, "stream": C.c_void_p(ts.cuda_stream), "busy": None, "event": torch.cuda.Event(),
+                 "uv": torch.empty((LF, 41, 2), device=dev), "cov": torch.empty((LF, 41, 2, 2), device=dev),
+                 "kp": torch.empty((LF, 41), device=dev), "mask": torch.empty((LF, 41), dtype=torch.uint8, device=dev)}
+            for k in ("uv", "cov", "kp", "mask"):
+                S["h_" + k] = torch.empty(S[k].shape, dtype=S[k].dtype).pin_memory()
+            self.slots.append(S)
+        self.reset_metrics()
+
+    def reset_metrics(self):
+        self.pose_err, self.n_pose, self.n_inl, self.n_frames, self.n_crops, self.n_net_kp = 0.0, 0, 0, 0, 0, 0
 
     def step(self, i):
-        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        k = i % len(self.pool)
-        fr = self.pool[k]
-        L = self.L
-        # network + decode + masks for F consecutive frames in ONE forward (8F crops), asynchronous on a slot's stream
+        """Step i: await the outputs of the step that last used slot i % depth, launch this step's network call on the slot,
+        THEN run the awaited step's geometry -- so `depth` network calls stay in flight while the host does PnP / LM."""
+        S = self.slots[i % self.depth]
+        done = self.await_outputs(S)
+        g = i % self.n_groups
         if self.only != "geometry":
-            self.fwd_pending += 1
-            self.last_k = k
-            if self.fwd_pending == self.F:
-                self.forward_group(k // self.F)
+            P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            LF = self.L * self.F
+            self._lib.check(self.lib.suo_net_forward_frames(S["net"]._h, P(self.imgs), 0, 480, 640, P(self.g_boxes[g]), P(self.g_img[g]), LF, None,
+                                                            P(S["uv"]), P(S["cov"]), P(S["kp"]), None, None, S["stream"]), "suo_net_forward_frames")
+            self._lib.check(self.lib.suo_keypoint_masks(P(S["uv"]), P(S["cov"]), P(S["kp"]), P(self.g_mm[g]), LF, 0.9, 0.2, P(S["mask"]),
+                                                        S["stream"]), "suo_keypoint_masks")
+            with self.torch.cuda.stream(S["tstream"]):
+                for k in ("uv", "cov", "kp", "mask"):
+                    S["h_" + k].copy_(S[k], non_blocking=True)
+                S["event"].record(S["tstream"])
+            self.n_crops += LF
+        S["busy"] = (g, i)
+        self.geometry(done)
+
+    def await_outputs(self, S):
+        """Host waits until a step's uv / cov / kp_mask / masks have arrived in the pinned buffers (the reference's three
+        .cpu() calls, lib/object_slam.py:1100-1109) and consumes them; the slot's device buffers are free afterwards."""
+        if S["busy"] is None:
+            return None
+        done, S["busy"] = S["busy"], None
+        if self.only != "geometry":
+            S["event"].synchronize()
+            self.n_net_kp += int(np.count_nonzero(S["h_mask"].numpy()))      # random weights: few keypoints pass the masks
+            assert np.isfinite(S["h_uv"].numpy()).all() and np.isfinite(S["h_cov"].numpy()).all()
+        return done
+
+    def geometry(self, done):
+        """PnP + LM for the F frames of a step whose network outputs have been awaited."""
+        if done is None:
+            return
+        g, i = done
+        self.n_frames += self.F
         if self.only == "cnn":
             return
-        self.pending.append(i)
-        if len(self.pending) >= self.geom_batch:
-            self.flush()
-
-    def forward_group(self, g):
-        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        S = self.slots[self.n_forward % self.depth]
-        self.n_forward += 1
-        LF = self.L * self.F
-        self._lib.check(self.lib.suo_net_forward_frames(S["net"]._h, P(self.imgs), 0, 480, 640, P(self.g_boxes[g]), P(self.g_img[g]), LF, None,
-                                                        P(S["uv"]), P(S["cov"]), P(S["kp"]), None, None, S["stream"]), "suo_net_forward_frames")
-        self._lib.check(self.lib.suo_keypoint_masks(P(S["uv"]), P(S["cov"]), P(S["kp"]), P(self.g_mm[g]), LF, 0.9, 0.2, P(S["mask"]),
-                                                    S["stream"]), "suo_keypoint_masks")
-        self.fwd_pending = 0
-
-    def flush(self):
-        """Geometry for the pending frames: ONE PnP launch (a wave per object) and ONE LM launch (a workgroup per
-        frame) for the whole group -- frames are independent, so their problems batch like their crops do."""
-        if self.fwd_pending > 0:             # tail of the stream: a last (partially filled) network call
-            self.forward_group(self.last_k // self.F)
-        if not self.pending:
-            return
-        frames = [self.pool[i % len(self.pool)] for i in self.pending]
+        frames = self.pool[g * self.F:(g + 1) * self.F]
         xs = [x for fr in frames for x in fr["pnp_xs"]]
         ys = [y for fr in frames for y in fr["pnp_ys"]]
-        T, status = self.lt.pnp_batch(xs, ys, 1e-3, seed=self.pending[0])
+        T, status = self.lt.pnp_batch(xs, ys, 1e-3, seed=i)
         L = self.L
         probs = []
         for j, fr in enumerate(frames):
@@ -166,18 +187,29 @@ class FramePipeline:
             self.pose_err += float(d[ok].sum())
             self.n_pose += int(ok.sum())
             self.n_inl += int(prob.inlier.sum())
-        self.pending = []
+
+    def drain(self, next_step):
+        """Retire every step still in flight, oldest first."""
+        for k in range(self.depth):
+            self.geometry(self.await_outputs(self.slots[(next_step + k) % self.depth]))
+
+
+def pack_conv(w, Np, Cp, CK):
+    from suo_slam_amd import _lib
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty(2 * Np * ((Cp * w.shape[2] * w.shape[3] + 15) // 16 * 16), np.float32)
+    _lib.check(_lib.lib().suo_pack_conv_weight(w.ctypes.data, w.shape[0], w.shape[1], w.shape[2], Np, Cp, CK, out.ctypes.data), "pack_conv")
+    return out
 
 
 def conv_roofline(L, iters=30):
     """Live HIP-event timing of the dominant kernel: 3x3 conv 128->128 @ 64x64 (34.5 % of all MACs), L crops."""
     import torch
     from suo_slam_amd import _lib
-    from tests import hipops
     rng = np.random.default_rng(0)
     x = torch.rand((L, 64, 64, 128), device="cuda") - 0.5
     w = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
-    wp = hipops.dev(hipops.pack_conv(w, 128, 128, 32))
+    wp = torch.from_numpy(pack_conv(w, 128, 128, 32)).cuda()
     b = torch.zeros(128, device="cuda")
     out = torch.empty((L, 64, 64, 128), device="cuda")
     st = torch.cuda.current_stream()
@@ -243,6 +275,47 @@ def cpu_baseline(pool, L):
                       f"{n_geo} frames through the C PnP/LM oracle (1 thread, {t_geo * 1e3:.2f} ms/frame)"}
 
 
+def latency_leg(L, pool, use_graph, seconds=0.6):
+    """The reference's call shape (evaluate.py:338-395: one frame per network call), two calls in flight: not `value`,
+    reported as config.latency_mode_fps."""
+    import torch
+    pipe = FramePipeline(L, pool, 1, use_graph=use_graph, depth=2)
+    for i in range(8):
+        pipe.step(i)
+    pipe.drain(8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 16 or time.perf_counter() - t0 < seconds:
+        pipe.step(8 + n)
+        n += 1
+    pipe.drain(8 + n)
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0)
+
+
+def global_ba_leg(world, L, n_cam_per_rank=32, reps=3):
+    """BASELINE configs[4]'s exchange step: ONE global pose-graph adjustment (first camera fixed, all other cameras and all
+    L objects free, lib/object_slam.py:746-778) whose cameras are partitioned over the ranks; each LM trial all-reduces the
+    reduced object system over RCCL (suo_slam_amd/ba_dist.py).  Weak scaling: n_cam_per_rank cameras per GPU."""
+    from suo_slam_amd import ba, ba_dist
+    from suo_slam_amd import synthetic as S
+    n_cam = n_cam_per_rank * world
+    P = S.make_pose_graph(np.random.default_rng(5), n_cam, L)
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    ts = []
+    for _ in range(reps):
+        full = ba.Problem(*[P[k].copy() for k in keys])
+        t0 = time.perf_counter()
+        ba_dist.optimize_distributed(full)
+        ts.append(time.perf_counter() - t0)
+    err = float(max(np.linalg.norm(full.obj_T.reshape(-1, 3, 4)[o][:, 3] - P["obj_gt"][o][:, 3]) for o in range(L)))
+    return {"ranks": world, "cameras": n_cam, "objects": L, "edges": int(len(P["edge_cam"])), "ms": round(1e3 * min(ts), 2),
+            "lm_trials": int(full.stats[2]), "collectives_per_trial": ba_dist.COLLECTIVES_PER_TRIAL,
+            "reduce_bytes_per_trial": int(8 * ((6 * L) ** 2 + 6 * L + 4)),
+            "max_object_translation_err_mm": round(err, 3), "inlier_edges": int(full.inlier.sum())}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -261,10 +334,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    L = args.objects
-    # frames shard embarrassingly: rank r processes its own stream (weak scaling: K frames per GPU)
-    pool = make_pool(np.random.default_rng(1000 + rank), args.pool, L)
-    pipe = FramePipeline(L, pool, use_graph=not args.no_graph, only=args.only, depth=args.depth, geom_batch=args.geom_batch, frames_per_forward=args.frames_per_forward)
+    L, F = args.objects, args.frames_per_step
+    # frames shard embarrassingly: rank r processes its own stream (weak scaling: K steps = K*F frames per GPU)
+    n_pool = args.pool if args.pool > 0 else 2 * F
+    pool = make_pool(np.random.default_rng(1000 + rank), n_pool, L)
+    pipe = FramePipeline(L, pool, F, use_graph=not args.no_graph, only=args.only, depth=args.depth)
 
     def barrier():
         torch.cuda.synchronize()
@@ -274,42 +348,58 @@ def main():
 
     for i in range(args.warmup):
         pipe.step(i)
-    pipe.flush()
-    pipe.pose_err, pipe.n_pose, pipe.n_inl = 0.0, 0, 0
+    pipe.drain(args.warmup)
+    pipe.reset_metrics()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         pipe.step(args.warmup + i)
-    pipe.flush()                  # every timed frame's geometry completes inside the timed region
+    pipe.drain(args.warmup + args.steps)        # every timed step's read-back and geometry complete inside the timed region
     barrier()
     dt = time.perf_counter() - t0
-    # max-over-ranks time + the only collective of the path: metric accumulators (RCCL all-reduce over xGMI)
+    assert pipe.n_frames == args.steps * F and (args.only == "geometry" or pipe.n_crops == args.steps * F * L)
+    # max-over-ranks time + the only collective of the frame path: metric accumulators (RCCL all-reduce over xGMI)
     from suo_slam_amd import sharding
-    dt, (pose_err, n_pose, n_inl) = sharding.reduce_metrics(dt, [pipe.pose_err, pipe.n_pose, pipe.n_inl],
-                                                            device="cuda" if os.environ.get("SUO_DIST_BACKEND", "nccl") == "nccl" else "cpu")
+    dt, (pose_err, n_pose, n_inl, n_net_kp) = sharding.reduce_metrics(dt, [pipe.pose_err, pipe.n_pose, pipe.n_inl, pipe.n_net_kp],
+                                                                      device="cuda" if os.environ.get("SUO_DIST_BACKEND", "nccl") == "nccl" else "cpu")
+    gba = None
+    if not args.no_global_ba_leg and args.only == "all":
+        try:                                    # after the timed region; never part of `value`
+            gba = global_ba_leg(world, 16)
+        except Exception as e:                  # reported, not fatal: the frame-path line must survive
+            gba = {"error": repr(e)[:300]}
     if rank == 0:
-        fps = world * args.steps / dt
+        frames = world * args.steps * F
+        fps = frames / dt
+        exec_gflop = GFLOP_PER_CROP - GFLOP_SKIPPED_PER_CROP
         line = {
             "metric": "frames/sec (obj-crops/sec) YCB-V 640x480 8-obj; ADD(-S) vs ref",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> RoI crop, hourglass keypoint "
-                                   "CNN fp32, decode, masks, batched PnP, LM rounds [10,10,40,40]" % L,
-                       "objects_per_frame": L, "crops_per_s": round(fps * L, 2), "frames_per_gpu": args.steps, "frames_per_forward": args.frames_per_forward, "forwards_in_flight": args.depth, "geometry_frames_per_launch": args.geom_batch,
-                       "geometry_inputs": "projected GT keypoints + N(0,0.01^2) NDC noise, 5% outliers (debug_gt_kp mode)",
+                                   "CNN fp32, decode, masks, D2H of uv/cov/masks, batched PnP, LM rounds [10,10,40,40]" % L,
+                       "step": "one network call over frames_per_step consecutive frames + the PnP/LM of those frames (which waits for "
+                               "that call's read-back)",
+                       "frames_per_step": F, "objects_per_frame": L, "crops_per_step": L * F, "crops_per_s": round(fps * L, 2),
+                       "frames_timed": frames, "timed_region_s": round(dt, 4), "steps_in_flight": args.depth,
+                       "geometry_inputs": "projected GT keypoints + N(0,0.01^2) NDC noise, 5% outliers (debug_gt_kp mode: random weights "
+                                          "give meaningless keypoints); the network's uv/cov/masks are read back and awaited first",
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "cnn_tflops_algorithmic": round(fps * L * GFLOP_PER_CROP / 1e3, 2),           # reference-counted FLOPs per crop x crops/s
-            "cnn_tflops_executed": round(fps * L * (GFLOP_PER_CROP - GFLOP_SKIPPED_PER_CROP) / 1e3, 2),     # zero-prior MACs not issued
-            "cnn_executed_frac_of_fp32_mfma_peak": round(fps / world * L * (GFLOP_PER_CROP - GFLOP_SKIPPED_PER_CROP) / 1e3 / FP32_MFMA_PEAK_TF, 4),
-            "pose_check": {"mean_rel_translation_err": round(pose_err / max(n_pose, 1), 5), "poses": int(n_pose), "inlier_edges": int(n_inl)},
+            "cnn_tflops_executed": round(fps * L * exec_gflop / 1e3, 2),                  # zero-prior MACs not issued
+            "cnn_executed_frac_of_fp32_mfma_peak": round(fps / world * L * exec_gflop / 1e3 / FP32_MFMA_PEAK_TF, 4),
+            "pose_check": {"mean_rel_translation_err": round(pose_err / max(n_pose, 1), 5), "poses": int(n_pose), "inlier_edges": int(n_inl),
+                           "network_keypoints_read_back": int(n_net_kp)},
         }
-        if world == 1:
-            line["roofline"] = conv_roofline(L * args.frames_per_forward)      # the launch shape of the timed region
+        line["roofline"] = conv_roofline(L * F)      # the launch shape of the timed region
+        if gba is not None:
+            line["global_ba"] = gba
+        if world == 1 and args.only == "all":
+            if not args.no_latency_leg and F > 1:
+                line["config"]["latency_mode_fps"] = round(latency_leg(L, pool, not args.no_graph), 2)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(pool, L)
-        else:
-            line["roofline"] = conv_roofline(L * args.frames_per_forward)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -22,6 +22,7 @@ from . import _lib
 from . import ba as _ba
 
 DBL_MAX = float(np.finfo(np.float64).max)
+COLLECTIVES_PER_TRIAL = 2          # [S | r | ok] and [chi2 | scale | ok]; +2 per LM iteration for the linearisation totals
 _DIAG21 = (0, 6, 11, 15, 18, 20)
 
 

@@ -124,3 +124,60 @@ def frame_to_ba_problem(frame, init_poses, use_cov=True):
             "edge_cam": np.array(e_cam, np.int32), "edge_obj": np.array(e_obj, np.int32), "edge_camk": np.array(e_k),
             "edge_p": np.array(e_p), "edge_uv": np.array(e_uv), "edge_info": np.array(e_info),
             "edge_inlier": np.ones(len(e_cam), np.uint8)}
+
+
+def _perturb_pose(T34, rng, rot, trans):
+    """Left-multiply a 3x4 pose by a small random rotation (axis-angle ~ N(0, rot)) and add N(0, trans) mm."""
+    w = rng.normal(0, rot, 3)
+    th = np.linalg.norm(w)
+    Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + (np.sin(th) / th) * Wx + ((1 - np.cos(th)) / (th * th)) * (Wx @ Wx) if th > 1e-12 else np.eye(3)
+    out = np.array(T34, dtype=np.float64)
+    out[:, :3] = R @ out[:, :3]
+    out[:, 3] = R @ out[:, 3] + rng.normal(0, trans, 3)
+    return out
+
+
+def make_pose_graph(rng, n_cam, n_obj, kp_per_obj=10, noise_px=0.5, miss=0.15, outlier_frac=0.05, rot=5e-4, trans=0.3):
+    """Flat SoA of ObjectSLAM.optimize's GLOBAL graph (object_slam.py:746-839) for a synthetic sequence: n_cam views on a
+    smooth arc looking at n_obj objects with kp_per_obj keypoints each; camera 0 fixed (the gauge, :774), every other
+    camera and every object free and perturbed from the ground truth; each object is missed in `miss` of the views and
+    `outlier_frac` of the measurements are gross outliers.  Also returns the ground truth as "cam_gt" / "obj_gt"."""
+    k = np.array([600.0, 600.0, 320.0, 240.0])
+    cam_gt = np.zeros((n_cam, 3, 4))
+    for c in range(n_cam):
+        s = c / max(n_cam - 1, 1) - 0.5
+        ang = 0.5 * s
+        cam_gt[c, :, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        cam_gt[c, :, 3] = [-300 * s, rng.uniform(-20, 20), rng.uniform(-20, 20)]
+    obj_gt = np.zeros((n_obj, 3, 4))
+    pts = rng.uniform(-60, 60, (n_obj, kp_per_obj, 3))
+    for o in range(n_obj):
+        obj_gt[o, :, :3] = random_rotation(rng)
+        obj_gt[o, :, 3] = [rng.uniform(-250, 250), rng.uniform(-150, 150), rng.uniform(800, 1100)]
+    e_cam, e_obj, e_p, e_uv = [], [], [], []
+    for c in range(n_cam):
+        for o in range(n_obj):
+            if rng.random() < miss:
+                continue
+            pw = pts[o] @ obj_gt[o, :, :3].T + obj_gt[o, :, 3]
+            pc = pw @ cam_gt[c, :, :3].T + cam_gt[c, :, 3]
+            uv = np.c_[k[0] * pc[:, 0] / pc[:, 2] + k[2], k[1] * pc[:, 1] / pc[:, 2] + k[3]] + rng.normal(0, noise_px, (kp_per_obj, 2))
+            out = rng.random(kp_per_obj) < outlier_frac
+            uv[out] = rng.uniform(0, 480, (int(out.sum()), 2))
+            e_cam += [c] * kp_per_obj
+            e_obj += [o] * kp_per_obj
+            e_p.append(pts[o])
+            e_uv.append(uv)
+    E = len(e_cam)
+    cam_fixed = np.zeros(n_cam, np.uint8)
+    cam_fixed[0] = 1
+    cam_init = cam_gt.copy()
+    for c in range(1, n_cam):
+        cam_init[c] = _perturb_pose(cam_gt[c], rng, rot, trans)
+    obj_init = np.stack([_perturb_pose(T, rng, rot, trans) for T in obj_gt])
+    return {"cam_T": cam_init, "cam_fixed": cam_fixed, "obj_T": obj_init, "obj_fixed": np.zeros(n_obj, np.uint8),
+            "edge_cam": np.array(e_cam, np.int32), "edge_obj": np.array(e_obj, np.int32), "edge_camk": np.tile(k, (E, 1)),
+            "edge_p": np.concatenate(e_p), "edge_uv": np.concatenate(e_uv),
+            "edge_info": np.tile([1.0 / noise_px ** 2, 0, 1.0 / noise_px ** 2], (E, 1)), "edge_inlier": np.ones(E, np.uint8),
+            "cam_gt": cam_gt, "obj_gt": obj_gt}
