@@ -1,0 +1,164 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the SLAM host rules of the reference's ObjectSLAM
+(/root/reference/lib/object_slam.py), written as the reference writes them: one Python loop per object / per view /
+per detection, numpy ``linalg.inv`` per covariance stack, the reference's float32 containers where it has them.
+Nothing under suo_slam_amd/ imports this file; the product's versions (suo_slam_amd/object_slam.py:
+``_estimate_camera_pose``, ``_maybe_reinit_objects``, ``_backup_estimate_camera_pose``) are vectorised and are
+checked against these.
+
+    estimate_camera_pose(...)          lib/object_slam.py:975-1072   (row a22)
+    maybe_reinit_objects(...)          lib/object_slam.py:595-697    (row a23)
+    backup_estimate_camera_pose(...)   lib/object_slam.py:933-973    (row a24)
+
+Parity status: *unpinned* -- lib/object_slam.py cannot be imported here (cv2, g2o, lambdatwist, glumpy are absent,
+SURVEY.md 8c), so no outputs of the reference itself exist for these rows; this is a line-by-line reading.
+A "state" is the reference's own bookkeeping: ``detections[view][obj]`` dicts with keys pose / inliers / model_kp /
+uv_pred / cov_pred / K, ``cam_poses[view]`` ([3,4] or [4,4]), ``obj_poses[obj]``, ``view_ids`` (list), ``cam_K[view]``.
+"""
+import numpy as np
+
+CHI2_2DOF_95 = 5.991
+
+
+def invert_SE3(T):
+    """lib/utils/utils.py:431-435."""
+    Tinv = np.eye(4)
+    Tinv[:3, :3] = T[:3, :3].T
+    Tinv[:3, 3] = -T[:3, :3].T @ T[:3, 3]
+    return Tinv
+
+
+def transform_pts(T, pts):
+    """lib/utils/utils.py:454-460 for one transform and [n,3] points."""
+    return pts @ T[:3, :3].T + T[:3, 3]
+
+
+def _count_chi2_inliers(T_OtoC, model_kp, uv, cov, K, manual_kp_std):
+    """The block both rules share (:1032-1066 and :648-681): project, keep positive depths, chi2 under the predicted
+    covariance (diagonal clamped at 1e-4, then inverted) or the manual sigma, count chi2 <= 5.991."""
+    p_FinC = transform_pts(T_OtoC, model_kp)
+    uv_proj = p_FinC @ K.T
+    d_pos_mask = uv_proj[:, 2] > 0
+    uv_proj = (uv_proj[:, :2] / uv_proj[:, 2:3])[d_pos_mask]
+    if uv_proj.shape[0] == 0:
+        return 0
+    res = uv[d_pos_mask] - uv_proj
+    if cov is not None:
+        cov = np.array(cov[d_pos_mask])                    # fancy indexing copies in the reference too
+        cov[:, [0, 1], [0, 1]] = np.maximum(cov[:, [0, 1], [0, 1]], 1e-4)
+        inf = np.linalg.inv(cov)
+        assert not np.any(np.isnan(inf))
+    else:
+        inf = np.zeros((res.shape[0], 2, 2), dtype=np.float32)
+        inf[:, [0, 1], [0, 1]] = 1 / manual_kp_std ** 2
+    chi2 = (res[:, None, :] @ inf @ res[:, :, None]).reshape(-1)
+    return int(np.count_nonzero(chi2 <= CHI2_2DOF_95))
+
+
+def estimate_camera_pose(detections, obj_poses, view_id, manual_kp_std, min_num_inliers=4):
+    """lib/object_slam.py:975-1072.  Returns (T_GtoC_best or None, best_num_inliers, per-hypothesis counts)."""
+    curr_det = detections[view_id]
+    obj_ids = []
+    for obj_id in curr_det.keys():
+        if curr_det.get(obj_id, {}).get("pose") is not None and obj_id in obj_poses:
+            obj_ids.append(obj_id)
+    if len(obj_ids) == 0:
+        return None, -1, []
+    Ts_GtoO = np.stack([invert_SE3(obj_poses[o]) for o in obj_ids])
+    Ts_OtoG = np.zeros((len(obj_ids), 4, 4), dtype=np.float32)                  # float32 container (:1004)
+    for j in range(len(obj_ids)):
+        Ts_OtoG[j, :3, :] = obj_poses[obj_ids[j]][:3, :]
+        Ts_OtoG[j, 3, 3] = 1
+    Ts_OtoC_pnp = np.stack([curr_det[o]["pose"] for o in obj_ids])
+    Ts_hypoth_GtoC = Ts_OtoC_pnp @ Ts_GtoO
+    Ts_OtoC_hypoth = Ts_hypoth_GtoC[:, None, :, :] @ Ts_OtoG[None, :, :, :]
+    best, best_n, counts = None, -1, []
+    for i in range(Ts_OtoC_hypoth.shape[0]):
+        n_i = 0
+        for j in range(len(obj_ids)):
+            d = curr_det[obj_ids[j]]
+            inl = np.asarray(d["inliers"], dtype=bool)
+            if np.count_nonzero(inl) > 0:
+                cov = d["cov_pred"][inl] if d["cov_pred"] is not None else None
+                n_i += _count_chi2_inliers(Ts_OtoC_hypoth[i, j], d["model_kp"][inl], d["uv_pred"][inl], cov, d["K"], manual_kp_std)
+        counts.append(n_i)
+        if n_i >= min_num_inliers and n_i > best_n:
+            best, best_n = Ts_hypoth_GtoC[i], n_i
+    return best, best_n, counts
+
+
+def maybe_reinit_objects(detections, cam_poses, obj_poses, view_ids, view_id, manual_kp_std, check_n_views=15):
+    """lib/object_slam.py:595-697.  Returns {obj_id: {"pnp": n, "estim": n, "reinit": bool, "T_OtoG_pnp": [4,4]}} for
+    every object the reference checks (empty when it returns early); obj_poses is NOT modified."""
+    if len(cam_poses) < 2 or view_id not in cam_poses:
+        return {}
+    check_n_views = min(len(view_ids), check_n_views)
+    curr_det = detections[view_id]
+    obj_ids = [o for o in obj_poses.keys() if curr_det.get(o, {}).get("pose") is not None]
+    if len(obj_ids) == 0:
+        return {}
+    Ts_OtoG_estim = np.zeros((len(obj_ids), 4, 4), dtype=np.float32)
+    for j in range(len(obj_ids)):
+        Ts_OtoG_estim[j, :3, :] = obj_poses[obj_ids[j]][:3, :]
+        Ts_OtoG_estim[j, 3, 3] = 1
+    Ts_OtoC_pnp = np.stack([curr_det[o]["pose"] for o in obj_ids])
+    T_cam = np.eye(4)
+    T_cam[:3, :] = np.asarray(cam_poses[view_id])[:3, :]
+    Ts_OtoG_pnp = invert_SE3(T_cam)[None, :, :] @ Ts_OtoC_pnp
+    views_to_check = [view_ids[-(i + 1)] for i in range(check_n_views)]
+    Ts_GtoCi = np.zeros((check_n_views, 4, 4), dtype=np.float32)
+    for i in range(check_n_views):
+        Ts_GtoCi[i, :3, :] = np.asarray(cam_poses[views_to_check[i]])[:3, :]
+        Ts_GtoCi[i, 3, 3] = 1
+    Ts_OtoCi = {"pnp": Ts_GtoCi[:, None, :, :] @ Ts_OtoG_pnp[None, :, :, :],          # float32 @ float64 -> float64
+                "estim": Ts_GtoCi[:, None, :, :] @ Ts_OtoG_estim[None, :, :, :]}      # float32 @ float32 -> float32
+    out = {}
+    for j, obj_id in enumerate(obj_ids):
+        num_inliers = {"estim": 0, "pnp": 0}
+        for i in range(check_n_views):
+            v = views_to_check[i]
+            if obj_id in detections[v].keys():
+                d = detections[v][obj_id]
+                for key in num_inliers.keys():
+                    num_inliers[key] += _count_chi2_inliers(Ts_OtoCi[key][i, j], d["model_kp"], d["uv_pred"], d["cov_pred"], d["K"],
+                                                            manual_kp_std)
+        reinit = num_inliers["pnp"] >= 3 and num_inliers["pnp"] > 3 * num_inliers["estim"]
+        out[obj_id] = {"pnp": num_inliers["pnp"], "estim": num_inliers["estim"], "reinit": bool(reinit), "T_OtoG_pnp": Ts_OtoG_pnp[j]}
+    return out
+
+
+def backup_estimate_camera_pose(cam_poses, obj_poses, view_ids, K, obj_ids_, bboxes, pnp_fn):
+    """lib/object_slam.py:933-973.  ``pnp_fn(points_3d, points_2d, K)`` is the module-level ``pnp`` (:25-41): returns
+    (T[3,4], inliers) or None.  Returns (pose, which) with which in {"centroid_pnp", "const_velocity", "copy"}."""
+    assert len(view_ids) > 0
+    bbox_centroids, obj_centers = [], []
+    for i, obj_id in enumerate(obj_ids_):
+        if obj_id in obj_poses.keys():
+            bbox_centroids.append(0.5 * (bboxes[i, :2] + bboxes[i, 2:]))
+            obj_centers.append(np.asarray(obj_poses[obj_id])[:3, 3])
+    ret_pnp = None
+    if len(bbox_centroids) > 0:
+        ret_pnp = pnp_fn(np.stack(obj_centers), np.stack(bbox_centroids), K)
+    if ret_pnp is not None:
+        return ret_pnp[0], "centroid_pnp"
+    if len(view_ids) > 1:
+        T_GtoC1 = np.eye(4)
+        T_GtoC1[:3, :] = np.asarray(cam_poses[view_ids[-2]])[:3, :]
+        T_GtoC2 = np.eye(4)
+        T_GtoC2[:3, :] = np.asarray(cam_poses[view_ids[-1]])[:3, :]
+        T_C1toC2 = T_GtoC2 @ invert_SE3(T_GtoC1)
+        return T_C1toC2 @ T_GtoC2, "const_velocity"
+    return cam_poses[view_ids[-1]], "copy"
+
+
+def pnp(points_3d, points_2d, camera_matrix, seed=0):
+    """The module-level ``pnp`` of lib/object_slam.py:25-41 over the C oracle of lambdatwist.pnp."""
+    from . import geometry as G
+    num_pts = points_3d.shape[0]
+    if num_pts < 4:
+        return None
+    KinvT = np.linalg.inv(camera_matrix).T
+    points_2d_norm = points_2d @ KinvT[:2, :2] + KinvT[2:3, :2]
+    res = G.pnp(np.asarray(points_3d, np.float64), points_2d_norm, 1e-3, seed=seed)[0]
+    if np.allclose(res, np.eye(4)):
+        return None
+    return res[:3, :], np.ones(num_pts, dtype=bool)

@@ -526,6 +526,7 @@ class ObjectSLAM:
         """object_slam.py:975-1072: hypotheses T_GtoC = T_OtoC(pnp) @ T_GtoO per object, scored by chi2 inliers."""
         curr = self.detections[view_id]
         obj_ids = [o for o in curr if curr[o].get("pose") is not None and o in self.obj_poses]
+        self.last_cam_hypotheses = None
         if not obj_ids:
             return None
         hyps = [curr[i]["pose"] @ invert_SE3(to4x4(self.obj_poses[i])) for i in obj_ids]
@@ -538,34 +539,42 @@ class ObjectSLAM:
         for T_GtoC, n in zip(hyps, counts):
             if n >= min_num_inliers and n > best_n:
                 best, best_n = T_GtoC, int(n)
+        self.last_cam_hypotheses = {"obj_ids": obj_ids, "counts": [int(n) for n in counts], "best_num_inliers": best_n}
         return best
 
     def _maybe_reinit_objects(self, view_id, check_n_views=15):
         """object_slam.py:595-697: re-initialise an object from its current PnP pose when that explains
         >= 3 and more than 3x as many keypoints (over the last views) as the map pose."""
         if self.num_views_processed() < 2 or view_id not in self.cam_poses:
-            return
+            return {}
         check_n_views = min(len(self.view_ids), check_n_views)
         curr = self.detections[view_id]
         obj_ids = [o for o in self.obj_poses if curr.get(o, {}).get("pose") is not None]
         if not obj_ids:
-            return
+            return {}
         T_CtoG = invert_SE3(to4x4(self.cam_poses[view_id]))
         views = [self.view_ids[-(i + 1)] for i in range(check_n_views)]
-        T_cam = {v: to4x4(self.cam_poses[v]).astype(np.float32).astype(np.float64) for v in views}   # float32 containers (:619,:631)
+        T_cam32 = {v: to4x4(self.cam_poses[v]).astype(np.float32) for v in views}                     # float32 containers (:619,:631)
+        T_cam = {v: T.astype(np.float64) for v, T in T_cam32.items()}
         T_pnp = {o: T_CtoG @ curr[o]["pose"] for o in obj_ids}
-        T_est = {o: to4x4(self.obj_poses[o]).astype(np.float32).astype(np.float64) for o in obj_ids}
-        # every (object, recent view) pair under both poses in one vectorised pass; objects are independent of each other
+        T_est32 = {o: to4x4(self.obj_poses[o]).astype(np.float32) for o in obj_ids}
+        # every (object, recent view) pair under both poses in one vectorised pass; objects are independent of each other.
+        # The reference's products keep numpy's promotion: float32 camera @ float64 PnP pose -> float64, but
+        # float32 camera @ float32 map pose -> a float32 product (:634-637)
         pairs = [(k, v) for k, o in enumerate(obj_ids) for v in views if o in self.detections[v]]
         dets = [self.detections[v][obj_ids[k]] for k, v in pairs]
-        Ts = [T_cam[v] @ T_pnp[obj_ids[k]] for k, v in pairs] + [T_cam[v] @ T_est[obj_ids[k]] for k, v in pairs]
+        Ts = [T_cam[v] @ T_pnp[obj_ids[k]] for k, v in pairs] + [(T_cam32[v] @ T_est32[obj_ids[k]]).astype(np.float64) for k, v in pairs]
         counts = _chi2_inliers_many(Ts, dets + dets, False, self.manual_kp_std)
         owner = np.array([k for k, _ in pairs], dtype=np.int64)
-        n_pnp = np.bincount(owner, weights=counts[:len(pairs)], minlength=len(obj_ids))
-        n_est = np.bincount(owner, weights=counts[len(pairs):], minlength=len(obj_ids))
+        n_pnp = np.bincount(owner, weights=counts[:len(pairs)], minlength=len(obj_ids)).astype(np.int64)
+        n_est = np.bincount(owner, weights=counts[len(pairs):], minlength=len(obj_ids)).astype(np.int64)
+        report = {}
         for k, o in enumerate(obj_ids):
-            if n_pnp[k] >= 3 and n_pnp[k] > 3 * n_est[k]:
+            reinit = bool(n_pnp[k] >= 3 and n_pnp[k] > 3 * n_est[k])
+            report[o] = {"pnp": int(n_pnp[k]), "estim": int(n_est[k]), "reinit": reinit}
+            if reinit:
                 self.obj_poses[o] = T_pnp[o]
+        return report                                  # (the reference returns nothing; the counts are for tests / logging)
 
     def _backup_estimate_camera_pose(self, view_id, obj_ids_, bboxes):
         """object_slam.py:933-973: bbox-centroid PnP, else constant velocity, else copy the last pose."""
