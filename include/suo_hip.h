@@ -168,6 +168,20 @@ int suo_ba_schur(suo_ba_ctx* ctx, double lambda, double* out);
 int suo_ba_solve_update(suo_ba_ctx* ctx, double lambda, int robust_on, const double* in, double* out);
 int suo_ba_restore(suo_ba_ctx* ctx);
 int suo_ba_ctx_download(suo_ba_ctx* ctx, suo_ba_problem* local_problem);
+/* The same phases on caller-owned DEVICE buffers: stream-ordered on `stream` (the caller's, e.g. the one RCCL orders its
+ * collectives against), no host synchronisation, nothing staged through host memory -- the buffers are all-reduced in place.
+ *   lin_dev [1 + 27 n_obj + world] = [chi2_local | (Hoo 21 + bo 6) per object | max |diag Hcc| in slot `rank`, 0 elsewhere]  (SUM)
+ *   sch_dev [ns*ns + ns + 1]       = [S_g | r_g | ok]                                                                    (SUM)
+ *   red_dev [4]                    = [chi2_local | scale over own cameras | ok | scale over objects (identical on every rank)]
+ *                                    (SUM over the first three)
+ * suo_ba_solve_update_dev takes the REDUCED lin_dev / sch_dev and treats the trial as failed unless sch_dev's ok count == world.
+ * Before suo_ba_ctx_download the caller synchronises `stream`. */
+int suo_ba_classify_dev(suo_ba_ctx* ctx, int keep_all, double* num_good_dev, void* stream);
+int suo_ba_linearize_dev(suo_ba_ctx* ctx, int robust_on, int rank, int world, double* lin_dev, void* stream);
+int suo_ba_schur_dev(suo_ba_ctx* ctx, double lambda, double* sch_dev, void* stream);
+int suo_ba_solve_update_dev(suo_ba_ctx* ctx, double lambda, int robust_on, int world, const double* lin_dev, const double* sch_dev,
+                            double* red_dev, void* stream);
+int suo_ba_restore_dev(suo_ba_ctx* ctx, void* stream);
 
 /* ---- evaluation meter: ADD / ADD-S pose errors ------------------------------------
  * Replaces the distance part of EvalMeter.update (lib/utils/eval_meter.py:126-155,233-242):

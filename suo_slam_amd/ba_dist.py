@@ -1,7 +1,9 @@
 """Multi-GPU global bundle adjustment (BASELINE config 5): cameras (views) are partitioned across
 ranks, every rank keeps all object poses, and each Levenberg-Marquardt trial exchanges only the reduced
 (Schur-complement) object system -- (6 n_obj)^2 + 6 n_obj doubles -- with one all-reduce, plus one all-reduce of
-two scalars for the gain ratio.  With RCCL over xGMI on GPUs (backend "nccl"); "gloo" in the CPU tests.
+three scalars for the gain ratio.  With RCCL over xGMI on GPUs (backend "nccl") both reduce device buffers in place --
+the phase kernels write them, the collective sums them, the next phase kernel reads them, all ordered on one stream;
+"gloo" in the CPU tests.
 
 The per-rank work runs in the phase kernels of csrc/lm_dist.hip (``HipPhases``); this module is the host
 schedule: g2o's lambda / nu logic (thirdparty/g2opy/g2o/core/optimization_algorithm_levenberg.cpp:58-150) and
@@ -22,14 +24,20 @@ from . import _lib
 from . import ba as _ba
 
 DBL_MAX = float(np.finfo(np.float64).max)
-COLLECTIVES_PER_TRIAL = 2          # [S | r | ok] and [chi2 | scale | ok]; +2 per LM iteration for the linearisation totals
+COLLECTIVES_PER_TRIAL = 2          # [S | r | ok] and [chi2 | scale | ok]; +1 per LM iteration for the linearisation totals
 _DIAG21 = (0, 6, 11, 15, 18, 20)
 
 
 class HipPhases:
-    """One rank's share of the graph, resident on its GPU (suo_ba_ctx_* of include/suo_hip.h)."""
+    """One rank's share of the graph, resident on its GPU (suo_ba_ctx_* of include/suo_hip.h), with the exchange buffers
+    of the LM schedule as DEVICE tensors that the collectives reduce in place:
+        lin  [1 + 27 n_obj + world]  linearisation totals: chi2 | (Hoo 21 + bo 6) per object | one max-|diag Hcc| slot per rank
+        sch  [ns^2 + ns + 1]         local Schur complement S_g | r_g | ok
+        red  [4]                     after the step: chi2 | scale over own cameras | ok | scale over objects (not summed)
+        good [1]                     chi2-inlier count of the own edges
+    Every phase is a stream-ordered launch on torch's current stream; nothing is staged through host memory."""
 
-    def __init__(self, local: _ba.Problem):
+    def __init__(self, local: _ba.Problem, world: int = 1):
         self.lib = _lib.lib()
         _lib.require_gpu()
         self.local = local
@@ -40,32 +48,46 @@ class HipPhases:
         self._h = h
         self.n_obj = len(local.obj_T)
         self.ns = int(self.lib.suo_ba_ctx_ns(h))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.lin = torch.zeros(1 + 27 * self.n_obj + world, dtype=torch.float64, device=dev)
+        self.sch = torch.zeros(self.ns * self.ns + self.ns + 1, dtype=torch.float64, device=dev)
+        self.red = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.good = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._pin = torch.empty(self.lin.numel(), dtype=torch.float64).pin_memory()
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def classify(self, keep_all):
-        out = np.zeros(1)
-        _lib.check(self.lib.suo_ba_classify(self._h, int(keep_all), out.ctypes.data), "suo_ba_classify")
-        return float(out[0])
+        _lib.check(self.lib.suo_ba_classify_dev(self._h, int(keep_all), self._p(self.good), self._stream()), "suo_ba_classify_dev")
 
-    def linearize(self, robust_on):
-        out = np.zeros(2 + 27 * self.n_obj)
-        _lib.check(self.lib.suo_ba_linearize(self._h, int(robust_on), out.ctypes.data), "suo_ba_linearize")
-        return out
+    def linearize(self, robust_on, rank, world):
+        _lib.check(self.lib.suo_ba_linearize_dev(self._h, int(robust_on), rank, world, self._p(self.lin), self._stream()), "suo_ba_linearize_dev")
 
     def schur(self, lam):
-        out = np.zeros(self.ns * self.ns + self.ns + 1)
-        _lib.check(self.lib.suo_ba_schur(self._h, float(lam), out.ctypes.data), "suo_ba_schur")
-        return out
+        _lib.check(self.lib.suo_ba_schur_dev(self._h, float(lam), self._p(self.sch), self._stream()), "suo_ba_schur_dev")
 
-    def solve_update(self, lam, robust_on, totals):
-        totals = np.ascontiguousarray(totals, np.float64)
-        out = np.zeros(4)
-        _lib.check(self.lib.suo_ba_solve_update(self._h, float(lam), int(robust_on), totals.ctypes.data, out.ctypes.data), "suo_ba_solve_update")
-        return out
+    def solve_update(self, lam, robust_on, world):
+        _lib.check(self.lib.suo_ba_solve_update_dev(self._h, float(lam), int(robust_on), world, self._p(self.lin), self._p(self.sch),
+                                                    self._p(self.red), self._stream()), "suo_ba_solve_update_dev")
 
     def restore(self):
-        _lib.check(self.lib.suo_ba_restore(self._h), "suo_ba_restore")
+        _lib.check(self.lib.suo_ba_restore_dev(self._h, self._stream()), "suo_ba_restore_dev")
+
+    def read(self, t):
+        """The host's look at a few reduced scalars (what the LM schedule decides on): one small D2H into pinned memory."""
+        n = t.numel()
+        self._pin[:n].copy_(t, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self._pin[:n].numpy().copy()
 
     def download(self):
+        torch.cuda.current_stream().synchronize()
         _lib.check(self.lib.suo_ba_ctx_download(self._h, C.byref(self._s)), "suo_ba_ctx_download")
         return self.local
 
@@ -81,15 +103,31 @@ def _world():
     return 0, 1
 
 
-def _allreduce(arr, op="sum"):
-    """All-reduce a small float64 numpy array (RCCL needs device tensors; gloo works on host tensors)."""
+def _reduce_(t):
+    """In-place SUM all-reduce of an exchange buffer.  RCCL ("nccl") reduces the device tensor where it lies; with gloo (CPU
+    tests; rehearsals with several ranks on one GPU) a device tensor is staged through the host."""
+    rank, world = _world()
+    if world == 1:
+        return t
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def _allreduce(arr):
+    """SUM all-reduce of a small host array (result assembly after the last round only)."""
     rank, world = _world()
     a = np.ascontiguousarray(arr, np.float64)
     if world == 1:
         return a.copy()
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.from_numpy(a.copy()).to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+    t = torch.from_numpy(a.copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
 
 
@@ -107,19 +145,27 @@ def split_problem(full: _ba.Problem, rank: int, world: int):
 
 def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
     """Run the robust LM rounds of `full` across the ranks of the default process group.  Every rank passes the
-    same `full` problem and gets the complete result back (cam_T, obj_T, inlier, chi2, stats) in `full`."""
+    same `full` problem and gets the complete result back (cam_T, obj_T, inlier, chi2, stats) in `full`.
+
+    Per LM iteration: one collective (linearisation totals; the lambda-init maximum travels in per-rank slots of the same SUM).
+    Per LM trial: COLLECTIVES_PER_TRIAL = 2 collectives -- the pose-graph reduce [S | r | ok] and the 3-scalar step result --
+    both in place on device buffers, and ONE read of 4 doubles on which g2o's accept / reject decision is taken."""
     rank, world = _world()
     local, cams, sel = split_problem(full, rank, world)
-    ph = phases_factory(local)
-    ns, O = ph.ns, len(full.obj_T)
+    ph = phases_factory(local, world)
+    O = len(full.obj_T)
     n_edge_total = len(full.edge_cam)
     free_obj = [o for o in range(O) if not full.obj_fixed[o]]
     rounds = lm_its = lm_trials = 0
+
+    def classify(keep_all):
+        ph.classify(keep_all)
+        return int(round(float(ph.read(_reduce_(ph.good))[0])))
     if full.init_with_outliers:
-        ph.classify(True)
+        classify(True)
         num_good = n_edge_total
     else:
-        num_good = int(round(_allreduce([ph.classify(False)])[0]))
+        num_good = classify(False)
     robust_on = True
     drop = max(1, len(full.its) // 2)
     for rnd, its in enumerate(full.its):
@@ -128,25 +174,24 @@ def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
         rounds += 1
         lam, ni = -1.0, 2.0
         for it in range(int(its)):
-            lin = ph.linearize(robust_on)
-            tot = _allreduce(lin[:1 + 27 * O])
-            current_chi, HB = float(tot[0]), tot[1:]
+            ph.linearize(robust_on, rank, world)
+            lin = ph.read(_reduce_(ph.lin))
+            current_chi, HB = float(lin[0]), lin[1:1 + 27 * O]
             if it == 0:                                        # computeLambdaInit: tau * max |diag H| over all free vertices
-                maxd = float(_allreduce([lin[1 + 27 * O]], "max")[0])
+                maxd = float(lin[1 + 27 * O:].max())
                 for o in free_obj:
                     maxd = max(maxd, max(abs(HB[27 * o + d]) for d in _DIAG21))
                 lam, ni = 1e-5 * maxd, 2.0
             rho, qmax, lam_finite = 0.0, 0, True
             while True:
-                sch = _allreduce(ph.schur(lam))                # the pose-graph reduce: [S | r | ok-count]
-                ok2 = int(round(sch[-1])) == world
+                ph.schur(lam)
+                _reduce_(ph.sch)                               # the pose-graph reduce: [S | r | ok-count], in place
+                ph.solve_update(lam, robust_on, world)         # refuses the step unless every rank's Schur phase was ok
+                _reduce_(ph.red[:3])
+                red = ph.read(ph.red)                          # [chi2 | scale_cams | ok-count | scale_objs]
                 temp_chi, scale = DBL_MAX, 0.0
-                if ok2:
-                    out = ph.solve_update(lam, robust_on, np.concatenate([HB, sch[:ns * ns + ns]]))
-                    red = _allreduce([out[0], out[1], out[3]])
-                    ok2 = int(round(red[2])) == world
-                    if ok2:
-                        temp_chi, scale = float(red[0]), float(red[1]) + float(out[2])
+                if int(round(red[2])) == world:
+                    temp_chi, scale = float(red[0]), float(red[1]) + float(red[3])
                 rho = (current_chi - temp_chi) / (scale + 1e-3)
                 if rho > 0 and math.isfinite(temp_chi):
                     alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
@@ -167,7 +212,7 @@ def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
             lm_its += 1
             if qmax == 10 or rho == 0 or not lam_finite:
                 break
-        num_good = int(round(_allreduce([ph.classify(False)])[0]))
+        num_good = classify(False)
         if rnd == drop:
             robust_on = False
     loc = ph.download()

@@ -27,9 +27,10 @@ size_t lm_problem_struct_size();
 int launch_ba_init(const void* P, hipStream_t s);
 size_t ba_scratch_doubles();
 int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch, hipStream_t s);
-int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, hipStream_t s);
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s);
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s);
-int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, double* scratch, hipStream_t s);
+int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
+                           double* scratch, hipStream_t s);
 int launch_ba_restore(const void* P, hipStream_t s);
 int launch_ba_finalize(const void* P, hipStream_t s);
 
@@ -441,7 +442,7 @@ int suo_ba_classify(suo_ba_ctx* c, int keep_all, double* num_good_local) {
 }
 
 int suo_ba_linearize(suo_ba_ctx* c, int robust_on, double* out) {
-    int rc = launch_ba_linearize(c->dev_problem(), robust_on, c->d_io, c->scratch(), c->arena.stream);
+    int rc = launch_ba_linearize(c->dev_problem(), robust_on, c->d_io, c->scratch(), 0, 1, c->arena.stream);
     return rc != SUO_OK ? rc : ba_fetch(c, out, 2 + 27 * (size_t)c->n_obj);
 }
 
@@ -456,8 +457,13 @@ int suo_ba_solve_update(suo_ba_ctx* c, double lambda, int robust_on, const doubl
     double* d_in = c->d_io + c->io_doubles / 2;
     memcpy(h_in, in, n_in * sizeof(double));
     SUO_HIP_CHECK(hipMemcpyAsync(d_in, h_in, n_in * sizeof(double), hipMemcpyHostToDevice, c->arena.stream));
-    int rc = launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, d_in, c->d_io, c->scratch(), c->arena.stream);
-    return rc != SUO_OK ? rc : ba_fetch(c, out, 4);
+    int rc = launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, d_in, d_in + 27 * (size_t)c->n_obj, 0, c->d_io, c->scratch(),
+                                    c->arena.stream);
+    if (rc != SUO_OK) return rc;
+    double dev_order[4];                       // device layout [chi2 | scale_cams | ok | scale_objs] -> documented host layout
+    rc = ba_fetch(c, dev_order, 4);
+    out[0] = dev_order[0]; out[1] = dev_order[1]; out[2] = dev_order[3]; out[3] = dev_order[2];
+    return rc;
 }
 
 int suo_ba_restore(suo_ba_ctx* c) {
@@ -466,6 +472,24 @@ int suo_ba_restore(suo_ba_ctx* c) {
     SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
     return SUO_OK;
 }
+
+// ---- the same phases on caller-owned DEVICE buffers, stream-ordered, no host synchronisation: the buffers are what RCCL
+// all-reduces in place between the phases (suo_slam_amd/ba_dist.py) ------------------------------------------------
+int suo_ba_classify_dev(suo_ba_ctx* c, int keep_all, double* num_good_dev, void* stream) {
+    return launch_ba_classify(c->dev_problem(), keep_all, num_good_dev, c->scratch(), (hipStream_t)stream);
+}
+int suo_ba_linearize_dev(suo_ba_ctx* c, int robust_on, int rank, int world, double* lin_dev, void* stream) {
+    if (rank < 0 || rank >= world) { suo_set_error("suo_ba_linearize_dev: rank %d of %d", rank, world); return SUO_ERR_ARG; }
+    return launch_ba_linearize(c->dev_problem(), robust_on, lin_dev, c->scratch(), rank, world, (hipStream_t)stream);
+}
+int suo_ba_schur_dev(suo_ba_ctx* c, double lambda, double* sch_dev, void* stream) {
+    return launch_ba_schur(c->dev_problem(), lambda, c->ns, sch_dev, c->scratch(), (hipStream_t)stream);
+}
+int suo_ba_solve_update_dev(suo_ba_ctx* c, double lambda, int robust_on, int world, const double* lin_dev, const double* sch_dev, double* red_dev,
+                            void* stream) {
+    return launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), (hipStream_t)stream);
+}
+int suo_ba_restore_dev(suo_ba_ctx* c, void* stream) { return launch_ba_restore(c->dev_problem(), (hipStream_t)stream); }
 
 int suo_ba_ctx_download(suo_ba_ctx* c, suo_ba_problem* p) {
     int rc = launch_ba_finalize(c->dev_problem(), c->arena.stream);

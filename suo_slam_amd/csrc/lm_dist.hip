@@ -98,9 +98,10 @@ __global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* 
         out[1 + idx] = s;
     }
 }
-// out[0] = chi2_local, out[1 + 27 n_obj] = max |diag Hcc| over the local free cameras
+// out[0] = chi2_local, out[1 + 27 n_obj + rank] = max |diag Hcc| over the local free cameras (the other ranks' slots are
+// zeroed: a SUM all-reduce then carries every rank's maximum, so the max needs no collective of its own)
 __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ partial, int n,
-                                                                        double* __restrict__ out) {
+                                                                        double* __restrict__ out, int rank, int world) {
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
     double md = 0;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmP
         double chi = 0;
         for (int i = 0; i < n; ++i) chi += partial[i];
         out[0] = chi;
-        out[1 + 27 * P.n_obj] = md;
+        for (int r = 0; r < world; ++r) out[1 + 27 * P.n_obj + r] = r == rank ? md : 0.0;
     }
 }
 
@@ -186,19 +187,19 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
 }
 
 // ---- solve the reduced system (identical on every rank) | back-substitute + update | chi2 | tail -----------------
-// in  = [Hoo_total(21)+bo_total(6) per object | S_total (ns x ns) | r_total (ns)]
+// HB = [Hoo_total(21)+bo_total(6) per object], St = [S_total (ns x ns) | r_total (ns) | number of ranks whose Schur phase was ok]
 __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
-                                                               const double* __restrict__ in, int* __restrict__ bad) {
+                                                               const double* __restrict__ HB, const double* __restrict__ St, int expect_ok,
+                                                               int* __restrict__ bad) {
     const LmProblem& P = *Pp;
     __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch + slack for the masked dot-product rounds
     __shared__ double rhs[LM_NS], colbuf[LM_NS];
     __shared__ int sh_ok;
     const int tid = threadIdx.x;
     const int sp = ns | 1;                          // odd LDS pitch (lm_device.h: wave_cholesky_solve)
-    const double* HB = in;
-    const double* St = in + 27 * P.n_obj;
     const double* rt = St + ns * ns;
     if (tid == 0) sh_ok = 1;
+    if (tid == 0 && expect_ok > 0 && (int)(rt[ns] + 0.5) != expect_ok) atomicAdd(bad, 1);      // some rank's camera block was singular
     for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[(idx / ns) * sp + idx % ns] = -St[idx];
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
@@ -244,15 +245,15 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* 
     if (ok)
         for (int o = GT; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
 }
-// out = [chi2_local after the step | sum x_c (lambda x_c + b_c) over own cameras | same over objects | ok]
+// out = [chi2_local after the step | sum x_c (lambda x_c + b_c) over own cameras | ok | the same sum over the objects]
+// (the first three are summed over ranks; the object part is identical on every rank)
 __global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProblem* __restrict__ Pp, double lambda, const double* __restrict__ partial,
-                                                                     int n, const double* __restrict__ in, const int* __restrict__ bad,
+                                                                     int n, const double* __restrict__ HB, const int* __restrict__ bad,
                                                                      double* __restrict__ out) {
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
     const int tid = threadIdx.x;
     const bool ok = *bad == 0;
-    const double* HB = in;
     double sc_c = 0, sc_o = 0;
     if (ok) {
         for (int idx = tid; idx < P.n_cam * 6; idx += LM_THREADS)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProb
     if (tid == 0) {
         double chi = 0;
         for (int i = 0; i < n; ++i) chi += partial[i];
-        out[0] = chi; out[1] = sc_c; out[2] = sc_o; out[3] = ok ? 1.0 : 0.0;
+        out[0] = chi; out[1] = sc_c; out[2] = ok ? 1.0 : 0.0; out[3] = sc_o;
     }
 }
 
@@ -294,11 +295,11 @@ int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch
     hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)scratch, BA_WGS, out, 0);
     BA_DONE
 }
-int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, hipStream_t s) {
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s) {
     BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch);
     BA_GRID(ba_accumulate_kernel);
     BA_GRID(ba_gather_kernel, out);
-    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out);
+    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world);
     BA_DONE
 }
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s) {
@@ -309,12 +310,13 @@ int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* s
     BA_GRID(ba_schur_s_kernel, ns, (const int*)bad, out);
     BA_DONE
 }
-int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* in, double* out, double* scratch, hipStream_t s) {
+int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
+                           double* scratch, hipStream_t s) {
     int* bad = (int*)(scratch + BA_WGS);          // carries over from the Schur phase of the same trial
-    BA_ONE(ba_solve_kernel, lambda, ns, in, bad);
+    BA_ONE(ba_solve_kernel, lambda, ns, HB, St, expect_ok, bad);
     BA_GRID(ba_update_kernel, (const int*)bad);
     BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch);
-    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, in, (const int*)bad, out);
+    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out);
     BA_DONE
 }
 int launch_ba_restore(const void* P, hipStream_t s) { BA_GRID(ba_restore_kernel); BA_DONE }

@@ -4,6 +4,11 @@ independently with dense numpy: poses as 4x4, SE3 exp-map left update, Huber-wei
 import numpy as np
 
 
+def torch_from(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, np.float64))
+
+
 def _skew(w):
     return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
 
@@ -33,8 +38,46 @@ def _huber(e2, delta):
 
 
 class NumpyPhases:
-    def __init__(self, local):
+    """Buffer interface of ba_dist.HipPhases (lin / sch / red / good tensors, here on the CPU) over the array-returning
+    numpy phases below."""
+
+    def __init__(self, local, world=1):
+        import torch
         self.P = local
+        O = len(local.obj_T)
+        nfo = sum(1 for o in range(O) if not local.obj_fixed[o])
+        self.lin = torch.zeros(1 + 27 * O + world, dtype=torch.float64)
+        self.sch = torch.zeros(36 * nfo * nfo + 6 * nfo + 1, dtype=torch.float64)
+        self.red = torch.zeros(4, dtype=torch.float64)
+        self.good = torch.zeros(1, dtype=torch.float64)
+        self._init(local)
+
+    def read(self, t):
+        return t.numpy().copy()
+
+    def classify(self, keep_all):
+        self.good[0] = self._classify(keep_all)
+
+    def linearize(self, robust_on, rank, world):
+        out = self._linearize(robust_on)
+        n = len(out) - 1
+        self.lin.zero_()
+        self.lin[:n] = torch_from(out[:n])
+        self.lin[n + rank] = float(out[-1])
+
+    def schur(self, lam):
+        self.sch[:] = torch_from(self._schur(lam))
+
+    def solve_update(self, lam, robust_on, world):
+        sch, lin = self.sch.numpy(), self.lin.numpy()
+        O = self.n_obj
+        if int(round(sch[-1])) != world:
+            self.red[:] = torch_from(np.array([self._chi(robust_on), 0.0, 0.0, 0.0]))
+            return
+        out = self._solve_update(lam, robust_on, np.concatenate([lin[1:1 + 27 * O], sch[:-1]]))
+        self.red[:] = torch_from(np.array([out[0], out[1], out[3], out[2]]))
+
+    def _init(self, local):
         self.cam = [np.vstack([t.reshape(3, 4), [0, 0, 0, 1]]) for t in local.cam_T]
         self.obj = [np.vstack([t.reshape(3, 4), [0, 0, 0, 1]]) for t in local.obj_T]
         self.E = len(local.edge_cam)
@@ -63,7 +106,7 @@ class NumpyPhases:
         P = self.P
         return self.level[e] == 0 and not (P.cam_fixed[int(P.edge_cam[e])] and P.obj_fixed[int(P.edge_obj[e])])
 
-    def classify(self, keep_all):
+    def _classify(self, keep_all):
         good = 0
         for e in range(self.E):
             err, _, _ = self._err(e)
@@ -89,7 +132,7 @@ class NumpyPhases:
                 chi += _huber(c2, self.P.huber_delta)[0] if robust_on else c2
         return chi
 
-    def linearize(self, robust_on):
+    def _linearize(self, robust_on):
         P = self.P
         C, O = len(self.cam), self.n_obj
         self.Hcc = np.zeros((C, 6, 6)); self.bc = np.zeros((C, 6))
@@ -133,7 +176,7 @@ class NumpyPhases:
         out[-1] = max([np.abs(np.diag(self.Hcc[c])).max() for c in free], default=0.0)
         return out
 
-    def schur(self, lam):
+    def _schur(self, lam):
         P = self.P
         ns = self.ns
         self.bak = ([T.copy() for T in self.cam], [T.copy() for T in self.obj])
@@ -161,7 +204,7 @@ class NumpyPhases:
                     S[6 * s1:6 * s1 + 6, 6 * s2:6 * s2 + 6] += self.Hco[(c, o1)].T @ Ai @ self.Hco[(c, o2)]
         return np.concatenate([S.ravel(), r, [ok]])
 
-    def solve_update(self, lam, robust_on, totals):
+    def _solve_update(self, lam, robust_on, totals):
         P = self.P
         ns, O = self.ns, self.n_obj
         HB = totals[:27 * O]

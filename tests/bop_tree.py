@@ -189,10 +189,41 @@ def write_saved_detections(bop_root, desc, dataset, seed=0, trans_noise_mm=3.0, 
     return offsets
 
 
-def build_sequence(bop_root, seed=0, n_views=12, n_objs=5, img_hw=(480, 640)):
+def write_saved_detections_pix2pose(bop_root, desc, dataset, seed=0, trans_noise_mm=3.0, box_jitter_px=2.0, drop_every=5):
+    """Pix2Pose / RetinaNet-format (T-LESS) saved detections (lib/utils/utils.py:538-569): per "scene/view" ``rois[n,4]`` stored as
+    (y1, x1, y2, x2) -- the loader swaps them to xyxy (:557-561) --, ``labels_txt[n]`` ending in "_<obj id>", ``poses[n]`` = 4x4
+    [R|t] with t in metres.  Ground-truth poses perturbed by ``trans_noise_mm``, boxes jittered, every ``drop_every``-th missing."""
+    import pickle
+    assert desc["dset"] == "tless"
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(bop_root, "saved_detections"), exist_ok=True)
+    results, k = {}, 0
+    for s in dataset.scene_ids():
+        for v in dataset.view_ids(s):
+            rois, poses, labels = [], [], []
+            for o in dataset.obj_ids(s, v):
+                k += 1
+                if k % drop_every == 0:
+                    continue
+                T = np.array(dataset.get_obj_pose(s, v, o), np.float64)
+                x, y, w, h = dataset.data[s][v]["objects"][o]["bbox"]
+                x1, y1, x2, y2 = np.array([x, y, x + w, y + h], np.float64) + rng.uniform(-box_jitter_px, box_jitter_px, 4)
+                rois.append([y1, x1, y2, x2])
+                P = np.eye(4)
+                P[:3, :3] = T[:3, :3]
+                P[:3, 3] = (T[:3, 3] + rng.standard_normal(3) * trans_noise_mm) / 1000.0
+                poses.append(P)
+                labels.append(f"obj_{o:02d}")
+            if rois:
+                results[f"{s}/{v}"] = {"rois": np.array(rois, np.float64), "poses": poses, "labels_txt": labels}
+    with open(os.path.join(bop_root, "saved_detections", "tless_pix2pose_retinanet_siso_top1.pkl"), "wb") as f:
+        pickle.dump(results, f)
+
+
+def build_sequence(bop_root, seed=0, n_views=12, n_objs=5, img_hw=(480, 640), dset="ycbv"):
     """A YCB-V-shaped tree with ONE geometrically consistent scene for the SLAM mode: fixed object poses in the world,
     a camera moving on a smooth arc, every frame a keyframe.  Reuses the model / kp_info files of ``build``."""
-    desc = build(bop_root, dset="ycbv", seed=seed, n_scenes=1, n_views=1)
+    desc = build(bop_root, dset=dset, seed=seed, n_scenes=1, n_views=1)
     rng = np.random.default_rng(seed + 1000)
     data_root, split = desc["data_root"], desc["split"]
     import shutil
@@ -200,7 +231,7 @@ def build_sequence(bop_root, seed=0, n_views=12, n_objs=5, img_hw=(480, 640)):
     scene_id = 59
     sdir = os.path.join(data_root, split, f"{scene_id:06d}")
     os.makedirs(os.path.join(sdir, "rgb"))
-    obj_ids = rng.choice(np.arange(1, 22), n_objs, replace=False).tolist()
+    obj_ids = rng.choice(np.arange(1, len(kp_config.TABLES[dset]) + 1), n_objs, replace=False).tolist()
     T_OtoW = {}
     for k, o in enumerate(obj_ids):
         T = np.eye(4)
@@ -209,7 +240,7 @@ def build_sequence(bop_root, seed=0, n_views=12, n_objs=5, img_hw=(480, 640)):
         T_OtoW[o] = T
     Kmat = np.array(K_YCBV).reshape(3, 3)
     H, W = img_hw
-    cam, gt, gt_info, keyframes = {}, {}, {}, []
+    cam, gt, gt_info, keyframes, targets = {}, {}, {}, [], []
     for vi in range(n_views):
         view_id = 1 + 7 * vi
         ang = np.deg2rad(-20 + 40 * vi / max(1, n_views - 1))
@@ -228,6 +259,7 @@ def build_sequence(bop_root, seed=0, n_views=12, n_objs=5, img_hw=(480, 640)):
             gts.append({"cam_R_m2c": T[:3, :3].ravel().tolist(), "cam_t_m2c": T[:3, 3].tolist(), "obj_id": int(o)})
             infos.append({"bbox_obj": [int(x0), int(y0), int(x1 - x0), int(y1 - y0)], "bbox_visib": [int(x0), int(y0), int(x1 - x0), int(y1 - y0)],
                           "px_count_all": 1000, "px_count_valid": 1000, "px_count_visib": 900, "visib_fract": 0.9})
+            targets.append({"im_id": int(view_id), "inst_count": 1, "obj_id": int(o), "scene_id": int(scene_id)})
         gt[str(view_id)], gt_info[str(view_id)] = gts, infos
         img = (rng.uniform(0, 1, (H // 16 + 1, W // 16 + 1, 3)) * 255).astype(np.uint8)
         Image.fromarray(np.kron(img, np.ones((16, 16, 1), np.uint8))[:H, :W]).save(os.path.join(sdir, "rgb", f"{view_id:06d}.png"))
@@ -235,8 +267,12 @@ def build_sequence(bop_root, seed=0, n_views=12, n_objs=5, img_hw=(480, 640)):
     for name, obj in (("scene_camera.json", cam), ("scene_gt.json", gt), ("scene_gt_info.json", gt_info)):
         with open(os.path.join(sdir, name), "w") as f:
             json.dump(obj, f)
-    with open(os.path.join(data_root, "keyframe.txt"), "w") as f:
-        f.write("\n".join(keyframes) + "\n")
+    if dset == "ycbv":
+        with open(os.path.join(data_root, "keyframe.txt"), "w") as f:
+            f.write("\n".join(keyframes) + "\n")
+    else:
+        with open(os.path.join(data_root, "all_target_tless.json"), "w") as f:
+            json.dump(targets, f)
     desc["scenes"] = {scene_id: {1 + 7 * vi: obj_ids for vi in range(n_views)}}
     desc["T_OtoW"] = T_OtoW
     return desc

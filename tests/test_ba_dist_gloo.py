@@ -1,4 +1,4 @@
-"""Multi-rank global bundle adjustment on CPU: two gloo ranks partition the cameras, exchange the reduced
+"""Multi-rank global bundle adjustment on CPU: two and four gloo ranks partition the cameras, exchange the reduced
 object system per LM trial (suo_slam_amd/ba_dist.py) and must reproduce the single-process oracle
 (oracle/lm_oracle.c, full dense system).  Phases run in numpy here (tests/ba_numpy_phases.py); on the GPU the
 same schedule drives csrc/lm_dist.hip (tests/test_gpu_geometry.py)."""
@@ -100,18 +100,24 @@ def test_single_rank_schedule_matches_oracle():
     _check_against_oracle(full.cam_T, full.obj_T, full.inlier, full.stats)
 
 
-def test_two_rank_gloo_pose_graph_reduce_matches_oracle():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gloo_pose_graph_reduce_matches_oracle(world):
+    """2 and 4 ranks (7 cameras: shares of 2/2/2/1 at world 4; rank 0 owns the fixed gauge camera)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # both ranks hold the identical, complete result
-    for a, b in zip(res[0][1:], res[1][1:]):
-        assert np.array_equal(a, b)
+    # every rank holds the identical, complete result
+    for other in res[1:]:
+        for a, b in zip(res[0][1:], other[1:]):
+            assert np.array_equal(a, b)
     _check_against_oracle(*res[0][1:])

@@ -1,0 +1,96 @@
+"""BASELINE configs[3] on the GPU: the T-LESS configuration of the reference's evaluate.py (:66-76 -- kp_var_thresh 0.5,
+bbox_thresh 1.0, manual_kp_std 0.1, opt_init_with_outliers=True, split test_primesense, no ADD meter) with saved Pix2Pose /
+RetinaNet detections (boxes stored (y1,x1,y2,x2) and swapped, lib/utils/utils.py:557-561), on 8- and 10-keypoint classes
+(kp_configs/tless_kp_config.csv).  Every call the run makes into libsuo_hip.so is recorded and replayed through the oracle
+on the same inputs (tests/replay.py): network + masks vs the torch-CPU oracle, PnP and LM vs the C oracles."""
+import os
+
+import numpy as np
+import pytest
+
+from suo_slam_amd import bop, evaluator, kp_config
+from tests import bop_tree, replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _confident_weights():
+    """Random weights whose keypoint classifier says "visible" (bias +4): with the stock random classifier nothing passes
+    kp_mask > 0.3 and the geometry half of the path would never run on network output."""
+    from suo_slam_amd import weights
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    sd["classifier.2.bias"] = (np.asarray(sd["classifier.2.bias"]) + 4.0).astype(np.float32)
+    return sd
+
+
+def test_tless_saved_detections_single_view_replays_against_the_oracle(tmp_path):
+    desc = bop_tree.build(str(tmp_path), dset="tless", seed=31, n_scenes=2, n_views=2)
+    reader = bop.BopDataset(desc["data_root"], desc["split"], bop_dset="tless", ignore_symmetry=True)
+    bop_tree.write_saved_detections_pix2pose(str(tmp_path), desc, reader, seed=4)
+    sd = _confident_weights()
+    ev = evaluator.Evaluator("tless", desc["data_root"], None, nviews=1, detection_type="saved", out_dir=str(tmp_path / "out"), state_dict=sd)
+    slam = ev.object_slam
+    # the per-dataset settings of evaluate.py:66-76 reached the driver
+    assert (slam.kp_var_thresh, slam.bbox_thresh, slam.manual_kp_std, slam.opt_init_with_outliers) == (0.5, 1.0, 0.1, True)
+    assert ev.do_add is False and ev.dataset.split == "test_primesense"
+    with replay.record() as rec:
+        out = ev.run()
+    assert out["result"] is None and out["saved_result"] is None            # no ADD meter on T-LESS (evaluate.py:72)
+    assert out["method"] == "pkpnet-epoch=-1-nviews=1-det=saved_tless-test_primesense" and os.path.exists(out["csv_path"])
+    # --- boxes: the column swap happened, and the network saw exactly the saved boxes ------------------------------
+    det = ev.saved_detections
+    n_frames = 0
+    for c in rec.forward:
+        n_frames += 1
+        for b in c["boxes"]:
+            assert any(np.array_equal(b, np.asarray(sb, np.float32)) for sb in det["bboxes"])
+            assert b[2] - b[0] > 5 and b[3] - b[1] > 5 and b[2] <= 660 and b[3] <= 500
+    assert n_frames >= 4
+    # --- classes: 8 keypoints for box-like, 10 for cylinder-like objects, nothing else ever reaches PnP -------------
+    seen = set()
+    for m in rec.masks:
+        assert (m["bt"], m["vt"]) == (1.0, 0.5)
+        for row, mm in zip(m["out"], m["mm"]):
+            n_model = int(np.count_nonzero(mm))
+            assert n_model in (8, 10) and not np.any(row & ~mm.astype(bool))
+            seen.add(n_model)
+    assert seen == {8, 10}
+    # --- replay through the oracle ----------------------------------------------------------------------------------
+    assert replay.check_network(rec, sd) >= 4
+    n_pnp = replay.check_pnp(rec)
+    n_ba = replay.check_ba(rec)
+    assert n_pnp >= 6 and n_ba >= 3, (n_pnp, n_ba)
+    for b in rec.ba:                                                         # single-view graphs: rounds [10,10,40,40], flag inert
+        assert tuple(b["its"]) == (10, 10, 40, 40) and not b["init_with_outliers"] and b["cam_fixed"].tolist() == [1]
+    # --- CSV: one line per target with a pose, BOP format ------------------------------------------------------------
+    lines = [ln for ln in open(out["csv_path"]).read().strip().split("\n") if ln]
+    for ln in lines:
+        s, v, o, score, R, t, tm = ln.split(",")
+        assert ev.dataset.is_target(int(s), int(v), int(o)) and tm == "-1" and len(R.split()) == 9 and len(t.split()) == 3
+
+
+def test_tless_slam_mode_starts_current_view_rounds_with_outliers(tmp_path):
+    """nviews=-1 on a consistent T-LESS-shaped sequence with ground-truth keypoints: the current-view adjustments carry
+    opt_init_with_outliers (evaluate.py:75 -> object_slam.py:848-852: every edge starts at level 0), the global ones do not;
+    all of them replay against the oracle, and the objects come back."""
+    desc = bop_tree.build_sequence(str(tmp_path), seed=6, n_views=11, n_objs=5, dset="tless")
+    ev = evaluator.Evaluator("tless", desc["data_root"], None, nviews=-1, debug_gt_kp=True, out_dir=str(tmp_path / "out"))
+    with replay.record() as rec:
+        out = ev.run()
+    assert out["num_views"] == 11 and out["num_cam_poses_found"] == 11
+    curr = [b for b in rec.ba if b["obj_fixed"].all()]
+    glob = [b for b in rec.ba if not b["obj_fixed"].any()]
+    assert len(curr) == 11 and len(glob) >= 2 and len(curr) + len(glob) == len(rec.ba)
+    assert all(b["init_with_outliers"] and tuple(b["its"]) == (10, 10, 10, 10) for b in curr)
+    assert all((not b["init_with_outliers"]) and tuple(b["its"]) == (10, 10, 40, 40) for b in glob)
+    assert replay.check_pnp(rec) >= 40
+    assert replay.check_ba(rec) == len(rec.ba)
+    ds = ev.dataset
+    good = n = 0
+    for ln in open(out["csv_path"]).read().strip().split("\n"):
+        s, v, o, score, R, t, tm = ln.split(",")
+        gt = ds.get_obj_pose(int(s), int(v), int(o))
+        n += 1
+        good += int(np.linalg.norm(np.array(t.split(), float) - gt[:3, 3]) < 0.03 * gt[2, 3])
+    assert n >= 11 * 5 - 6 and good >= n - 4, (n, good)
+    assert {len(kp_config.kp_list_of("tless", o)) for o in next(iter(desc["scenes"].values()))[1]} <= {8, 10}
