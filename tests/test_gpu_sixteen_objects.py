@@ -1,0 +1,78 @@
+"""BASELINE configs[4]'s frame shape on the GPU: 16 objects per 640x480 frame through the whole per-frame path --
+forward_frames (RoI crop, hourglass CNN, decode) -> keypoint masks -> one batched PnP launch -> one LM launch -- against
+the oracle, once on network output (random but confident weights: parity of every stage on identical inputs) and once
+with the reference's debug keypoints (the poses must also be right)."""
+import numpy as np
+import pytest
+
+from suo_slam_amd import synthetic as S
+from tests import replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh_db(fr):
+    return {o: {"diameter": float(fr["diameter"][i]), "is_symmetric": False} for i, o in enumerate(fr["obj_ids"])}
+
+
+def test_sixteen_object_frame_network_to_poses_replays_against_the_oracle():
+    from suo_slam_amd import weights
+    from suo_slam_amd.object_slam import ObjectSLAM
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    sd["classifier.2.bias"] = (np.asarray(sd["classifier.2.bias"]) + 4.0).astype(np.float32)
+    rng = np.random.default_rng(16)
+    fr = S.make_frame(rng, 16, noise=0.0)
+    slam = ObjectSLAM(None, _mesh_db(fr), sfm_mode=True, single_view_mode=True, state_dict=sd, max_crops=16, kp_var_thresh=0.5, bbox_thresh=1.0)
+    with replay.record() as rec:
+        slam.process_view(0, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"],
+                          fr["model_kps_masks"], fr["model_kps_masks"])
+    assert len(rec.forward) == 1 and rec.forward[0]["boxes"].shape == (16, 4) and rec.forward[0]["out"]["uv"].shape == (16, 41, 2)
+    assert replay.check_network(rec, sd) == 1
+    assert len(rec.pnp) == 1 and len(rec.pnp[0]["xs"]) >= 12            # one launch for the frame's objects
+    assert replay.check_pnp(rec) >= 12
+    assert len(rec.ba) == 1 and replay.check_ba(rec) == 1
+    assert set(slam.collect_results()[0]["poses"].keys()) == set(fr["obj_ids"])
+
+
+def test_four_frames_of_sixteen_objects_in_one_network_call():
+    """64 crops in one suo_net_forward_frames call vs the same frames one by one (the low-resolution levels pick other tile /
+    split-K shapes at 64 crops than at 16, so the sums differ in order: 1e-5 of the logit range), and frame 0 vs the oracle."""
+    import torch
+    from oracle import cnn_oracle as O
+    from suo_slam_amd import weights
+    from suo_slam_amd.pkpnet import PkpNet
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    rng = np.random.default_rng(17)
+    frames = [S.make_frame(rng, 16, noise=0.0) for _ in range(4)]
+    net = PkpNet(state_dict=sd, max_crops=64)
+    out = net.forward_frames(np.stack([f["image"] for f in frames]), [f["boxes"] for f in frames])
+    for i, f in enumerate(frames):
+        one = net(f["image"], [torch.from_numpy(f["boxes"])], None)
+        scale = float(one["prob_logits"].abs().max())
+        assert float((out["prob_logits"][16 * i:16 * (i + 1)] - one["prob_logits"]).abs().max()) < 1e-5 * scale
+        for k in ("uv", "cov", "kp_mask"):
+            assert float((out[k][16 * i:16 * (i + 1)] - one[k]).abs().max()) < 1e-5, (i, k)
+    ref = O.pkpnet_forward(frames[0]["image"], frames[0]["boxes"], None, sd)
+    lr = ref["prob_logits"].numpy()
+    assert np.abs(out["prob_logits"][:16].cpu().numpy() - lr).max() < 2e-4 * np.abs(lr).max()
+    assert np.abs(out["uv"][:16].cpu().numpy() - ref["uv"].numpy()).max() < 2e-4
+
+
+def test_sixteen_object_frame_debug_keypoints_recovers_every_pose():
+    from suo_slam_amd.object_slam import ObjectSLAM
+    from suo_slam_amd import geometry as geo
+    rng = np.random.default_rng(18)
+    fr = S.make_frame(rng, 16, noise=0.0, with_image=False)
+    slam = ObjectSLAM(None, _mesh_db(fr), debug_gt_kp=True, sfm_mode=True, single_view_mode=True, seed=3)
+    uv_gt = np.stack([geo.project_ndc(fr["K_bbox"][o], fr["T_OtoC"][o], fr["model_kps"][o].astype(np.float64))[0] for o in range(16)])
+    with replay.record() as rec:
+        slam.process_view(0, None, fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
+                          fr["model_kps_masks"], uv_gt=uv_gt)
+    assert replay.check_pnp(rec) == 16 and replay.check_ba(rec) == 1
+    b = rec.ba[0]
+    assert len(b["obj_T"]) == 16 and not b["obj_fixed"].any()            # one LM launch, 16 free objects under one lambda
+    res = slam.collect_results()[0]["poses"]
+    for k, o in enumerate(fr["obj_ids"]):
+        T = res[o]["T_OtoC"]
+        assert T is not None
+        assert np.linalg.norm(T[:3, 3] - fr["T_OtoC"][k][:3, 3]) < 0.03 * fr["T_OtoC"][k][2, 3]
