@@ -182,6 +182,10 @@ int suo_ba_schur_dev(suo_ba_ctx* ctx, double lambda, double* sch_dev, void* stre
 int suo_ba_solve_update_dev(suo_ba_ctx* ctx, double lambda, int robust_on, int world, const double* lin_dev, const double* sch_dev,
                             double* red_dev, void* stream);
 int suo_ba_restore_dev(suo_ba_ctx* ctx, void* stream);
+/* Test entry (finite-difference checks of what the KERNELS linearise, not of the oracle): after suo_ba_linearize, per edge in
+ * the caller's order jac_out[e][29] = [J_cam 2x6 | J_obj 2x6 | w*info (xx,xy,yy) | -w*info*err (2)] (EdgeSE3ProjectFromObject::
+ * linearizeOplus, types_object_slam.cpp:70-123, columns = [omega, upsilon]) and err_out[e][2] (computeError, :45-60). */
+int suo_debug_ba_jacobians(suo_ba_ctx* ctx, int n_edge, double* jac_out, double* err_out);
 
 /* ---- evaluation meter: ADD / ADD-S pose errors ------------------------------------
  * Replaces the distance part of EvalMeter.update (lib/utils/eval_meter.py:126-155,233-242):

@@ -64,6 +64,7 @@ SIGNATURES = {
     "suo_ba_schur_dev": (C.c_int, [VP, C.c_double, VP, VP]),
     "suo_ba_solve_update_dev": (C.c_int, [VP, C.c_double, C.c_int, C.c_int, VP, VP, VP, VP]),
     "suo_ba_restore_dev": (C.c_int, [VP, VP]),
+    "suo_debug_ba_jacobians": (C.c_int, [VP, C.c_int, VP, VP]),
     "suo_mesh_db_create": (C.c_int, [C.c_int, VP, VP, C.POINTER(VP)]),
     "suo_mesh_db_destroy": (None, [VP]),
     "suo_pose_errors": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),

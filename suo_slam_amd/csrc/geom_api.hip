@@ -491,6 +491,25 @@ int suo_ba_solve_update_dev(suo_ba_ctx* c, double lambda, int robust_on, int wor
 }
 int suo_ba_restore_dev(suo_ba_ctx* c, void* stream) { return launch_ba_restore(c->dev_problem(), (hipStream_t)stream); }
 
+// Test entry: what the LM kernels linearise.  After suo_ba_linearize (edge_pass_partial of csrc/lm_device.h, shared by every LM
+// kernel) the context holds, per edge in the CALLER's edge order: jac[29] = [Jc 2x6 | Jo 2x6 | w*info (xx,xy,yy) | -w*info*err (2)]
+// and err[2].  Inactive edges (outliers, fixed-fixed) keep whatever was there before: call it on all-inlier graphs.
+int suo_debug_ba_jacobians(suo_ba_ctx* c, int n_edge, double* jac_out, double* err_out) {
+    if (!c || !jac_out || !err_out) { suo_set_error("suo_debug_ba_jacobians: null argument"); return SUO_ERR_ARG; }
+    const Prep& P = c->st.prep[0];
+    if ((int)P.order.size() != n_edge) { suo_set_error("suo_debug_ba_jacobians: context has %d edges", (int)P.order.size()); return SUO_ERR_ARG; }
+    std::vector<double> jac((size_t)29 * n_edge), err((size_t)2 * n_edge);
+    SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
+    SUO_HIP_CHECK(hipMemcpy(jac.data(), c->arena.dev + P.o[36], jac.size() * sizeof(double), hipMemcpyDeviceToHost));
+    SUO_HIP_CHECK(hipMemcpy(err.data(), c->arena.dev + P.o[23], err.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n_edge; ++k) {
+        const int e = P.order[k];
+        memcpy(jac_out + (size_t)29 * e, jac.data() + (size_t)29 * k, 29 * sizeof(double));
+        err_out[2 * e] = err[2 * k]; err_out[2 * e + 1] = err[2 * k + 1];
+    }
+    return SUO_OK;
+}
+
 int suo_ba_ctx_download(suo_ba_ctx* c, suo_ba_problem* p) {
     int rc = launch_ba_finalize(c->dev_problem(), c->arena.stream);
     if (rc != SUO_OK) return rc;

@@ -104,6 +104,30 @@ def test_pnp_edge_cases(lt):
     assert _pose_close(T1[0], To) and np.linalg.norm(T1[0][:3, 3] - t) < 1e-6
 
 
+def test_pnp_statistical_contract_of_the_reference_benchmark(lt):
+    """thirdparty/lambdatwist/test_pnp.cpp:68-147 on suo_pnp_batch: 4 noise levels x 1000 problems x 250 points with 50 %
+    outlier draws (the reference's generator, tests/pnp_simulator.py), default threshold 0.001, ONE launch per level
+    (1000 wavefronts); < 5 % of the poses may be off by more than 0.05 (angle + translation).  A sample of each level is
+    also compared with the oracle pose by pose."""
+    import time
+    from tests import pnp_simulator as PS
+    rng = np.random.default_rng(21)
+    for sigma in (0.0, 0.25, 0.5, 1.0):
+        data = [PS.point_cloud_with_noisy_measurements(rng, 250, sigma, 0.5) for _ in range(1000)]
+        t0 = time.perf_counter()
+        T, status, info = lt.pnp_batch([d[0] for d in data], [d[1] for d in data], 1e-3, seed=77, return_info=True)
+        dt = time.perf_counter() - t0
+        assert np.isfinite(T).all()
+        errs = np.array([PS.pose_error(T[i], data[i][2]) for i in range(1000)])
+        fails = int((errs > 0.05).sum())
+        print(f"sigma {sigma}: {fails} bad poses of 1000, median err {np.median(errs):.2e}, median iterations "
+              f"{int(np.median(info['iterations']))}, {1e3 * dt:.1f} ms for the launch ({dt * 1e3:.3f} us per problem)")
+        assert fails / 1000 < 0.05, (sigma, fails)
+        for i in range(0, 1000, 97):
+            To, best, its = G.pnp(data[i][0], data[i][1], 1e-3, seed=(77 + i * SEED_STRIDE) % 2 ** 64)
+            assert _pose_close(T[i], To) and info["best_inliers"][i] == best and info["iterations"][i] == its
+
+
 def _perturb(T, rng, rot, trans):
     t = np.ascontiguousarray(np.asarray(T)[:3, :].ravel().copy())
     G.lib().orc_pose_oplus(t, np.r_[rng.normal(0, rot, 3), rng.normal(0, trans, 3)])
