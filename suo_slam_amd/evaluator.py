@@ -6,7 +6,9 @@ constructor keywords that affect results, same per-dataset thresholds (evaluate.
 (single-view ``nviews=1``, SfM ``nviews>1``, SLAM ``nviews<0``), same detection selection (ground-truth boxes or saved
 PoseCNN / Pix2Pose detections), same bookkeeping of missed detections, same CSV line format
 (``scene,im,obj,score,R(9),t(3),-1``).  The T-LESS VSD step (an external bop_toolkit subprocess, evaluate.py:323-336,
-row N4) is not run; ``run`` returns the CSV path so it can be handed to that script.
+row N4) is handed off exactly as the reference does it: ``run`` returns the command line, environment and working directory
+(``bop_eval_command``) and starts it when ``run_bop_eval=True`` and the toolkit is mounted; the CSV it consumes is pinned
+against the toolkit's own ``inout.load_bop_results`` (tests/golden/make_bop_results_golden.py).
 
 Everything numeric happens in ``ObjectSLAM`` (HIP network, PnP, bundle adjustment) and ``EvalMeter`` (HIP ADD-S).
 """
@@ -44,10 +46,22 @@ def bop_csv_line(scene_id, view_id, obj_id, score, T_OtoC):
     return f"{scene_id},{view_id},{obj_id},{score},{R},{t},-1\n"
 
 
+def bop_eval_command(csv_path, outdir, targets_filename, repo_root="."):
+    """The T-LESS VSD hand-off of evaluate.py:323-336 (row N4): the exact subprocess the reference starts after writing the
+    CSV -- bop_toolkit's ``scripts/eval_siso.py`` with the python renderer, run from ``thirdparty/bop_toolkit/`` with
+    PYTHONPATH = that directory and BOP_PATH = <cwd>/data/bop_datasets/.  Returns (argv, env additions, cwd); the toolkit
+    itself (renderer, VSD) is third-party and stays a subprocess here as it is there."""
+    toolkit = os.path.join(repo_root, "thirdparty/bop_toolkit/")
+    argv = ["python", "scripts/eval_siso.py", "--renderer_type", "python", "--result_filename", os.path.realpath(csv_path),
+            "--results_path", "", "--eval_path", os.path.realpath(outdir), "--targets_filename", targets_filename]
+    env = {"PYTHONPATH": os.path.realpath(toolkit), "BOP_PATH": os.path.join(os.path.abspath(repo_root), "data/bop_datasets/")}
+    return argv, env, toolkit
+
+
 class Evaluator:
     def __init__(self, dataset, data_root, chkpt_path, nviews=1, no_network_cov=False, detection_type="saved", debug_gt_kp=False,
                  gt_cam_pose=False, no_prior_det=False, debug_saved_only=False, give_all_prior=False, out_dir=None, state_dict=None,
-                 do_add=None, seed=666, verbose=False):
+                 do_add=None, seed=666, verbose=False, repo_root=".", run_bop_eval=False):
         """``dataset``: "ycbv" | "tless"; ``data_root``: the dataset directory of the BOP tree.  ``out_dir`` defaults to
         the checkpoint's directory like the reference.  ``do_add`` overrides the per-dataset default (the reference
         evaluates ADD only on YCB-V)."""
@@ -61,6 +75,7 @@ class Evaluator:
         self.debug_saved_only = debug_saved_only
         self.nviews, self.detection_type, self.debug_gt_kp, self.gt_cam_pose = nviews, detection_type, debug_gt_kp, gt_cam_pose
         self.verbose = verbose
+        self.repo_root, self.run_bop_eval = repo_root, run_bop_eval    # where thirdparty/bop_toolkit lives; start eval_siso.py after a T-LESS run
         self._rng = np.random.RandomState(seed)                       # evaluate.py:386 seeds numpy with 666
         if not debug_saved_only:
             self.object_slam = ObjectSLAM(chkpt_path, self.mesh_db, no_network_cov=no_network_cov, no_prior_det=no_prior_det,
@@ -210,5 +225,12 @@ class Evaluator:
             if meter is not None:
                 out["result"] = meter.result()
                 meter.close()
+            if ds.bop_dset == "tless":                             # evaluate.py:323-336: VSD recall via bop_toolkit (N4)
+                argv, env, cwd = bop_eval_command(out["csv_path"], outdir, ds.targets_filename, self.repo_root)
+                out["bop_eval"] = {"argv": argv, "env": env, "cwd": cwd, "returncode": None}
+                if self.run_bop_eval:
+                    import subprocess
+                    assert os.path.exists(env["PYTHONPATH"]), "thirdparty/bop_toolkit is not mounted"
+                    out["bop_eval"]["returncode"] = subprocess.call(argv, env={**os.environ, **env}, cwd=cwd)
         out["seconds"] = time() - t_start
         return out

@@ -37,6 +37,11 @@ def test_tless_saved_detections_single_view_replays_against_the_oracle(tmp_path)
         out = ev.run()
     assert out["result"] is None and out["saved_result"] is None            # no ADD meter on T-LESS (evaluate.py:72)
     assert out["method"] == "pkpnet-epoch=-1-nviews=1-det=saved_tless-test_primesense" and os.path.exists(out["csv_path"])
+    # the VSD hand-off of evaluate.py:323-336 is prepared (not started: bop_toolkit is not mounted here)
+    be = out["bop_eval"]
+    assert be["argv"][:4] == ["python", "scripts/eval_siso.py", "--renderer_type", "python"] and be["returncode"] is None
+    assert be["argv"][be["argv"].index("--result_filename") + 1] == os.path.realpath(out["csv_path"])
+    assert be["argv"][be["argv"].index("--targets_filename") + 1].endswith("all_target_tless.json")
     # --- boxes: the column swap happened, and the network saw exactly the saved boxes ------------------------------
     det = ev.saved_detections
     n_frames = 0
