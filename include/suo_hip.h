@@ -104,6 +104,11 @@ int suo_conv1x1(const float* a1_dev, int lda1, int K1, const float* pro_scale_de
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);
+/* The tail of a Residual block in ONE launch (layers/Residual.py:27-35): out = W3 relu(conv3x3(in) + bias2) + bias3 + skip with
+ * in [L,H,W,128], out / skip [L,H,W,256] NHWC; the 128-channel tensor between the two convolutions stays in the CU.  Large
+ * launches only (>= 1024 tiles of 128 pixels, the shapes the network uses it for); bit-identical to suo_conv_kxk + suo_conv1x1. */
+int suo_conv3x3_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wp2_dev, const float* bias2_dev, const float* wp3_dev,
+                             const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 

@@ -263,7 +263,13 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
 // =================================================================================================
 // KxK convolution as implicit GEMM over an LDS-resident halo tile
 // =================================================================================================
-template <int KS, int ST, int CK, int TH, int TW, int TM, int TN, int WGM, int WGN>
+// FUSE (3x3, 128-pixel x 128-channel tiles only): the workgroup holds the COMPLETE conv2 tile of a Residual block in its
+// accumulators, so conv3 (1x1, 128 -> 256) + bias + skip runs right here (Residual.py:27-35): relu(acc + bias2) goes
+// accumulator -> LDS (32 channels at a time, double-buffered) -> MFMA A operand, the 128-channel `mid` tensor never
+// exists in HBM.  Output channels in two passes of 128 (a second 64-register accumulator set; 2 workgroups per CU).
+// Same summation order as the separate launches (K chunks of 32 in order, bias after the sum, then the skip): the fused
+// block is bit-identical to conv3x3 followed by gemm_persist.
+template <int KS, int ST, int CK, int TH, int TW, int TM, int TN, int WGM, int WGN, bool FUSE = false>
 __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(SUO_CONV_WAVES_PER_EU))) void convk_kernel(const ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, NT = WGM * WGN * 64;
@@ -449,6 +455,116 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         if (c < 4) CPROF(2 + c);
     }
 
+    if constexpr (FUSE) {
+        static_assert(KS == 3 && TM == 2 && TN == 2 && WGM == 2 && WGN == 2 && TW == 16 && !PAIR, "fused conv3: 128 x 128 tiles");
+        constexpr int MP = 36;                                   // pitch of a staged 32-channel slice of the mid tile
+        constexpr int MSZ = BM * MP;
+        static_assert(2 * MSZ <= 2 * ASZ && 2 * ASZ >= WGM * WGN * 32 * 36, "mid slices / epilogue patches must fit the A buffers");
+        float* M2 = &As[0][0];
+        const int NB2 = a.N2 >> 5;
+        const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * sizeof(float));
+        const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
+        const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
+        float b2v[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b2v[j] = a.bias[(wn * TN + j) * 32 + (lane & 31)];
+        // slice kc = mid channels [32 kc, 32 kc + 32) = accumulator column tile (wn, j) = (kc >> 1, kc & 1): its two owner
+        // waves write relu(acc + bias2) transposed (lane & 31 = channel: 32 consecutive floats per pixel row)
+        auto stage = [&](int kc, int buf) {
+            if (wn == (kc >> 1)) {
+                float* d = M2 + buf * MSZ;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = (kc & 1) ? acc[i][1][r] + b2v[1] : acc[i][0][r] + b2v[0];
+                        d[((wm * TM + i) * 32 + acc_row(r, lane)) * MP + (lane & 31)] = fmaxf(v, 0.f);
+                    }
+            }
+        };
+        // conv3 weights: Wp[kg][nb][lane][4] (kg = k-group of 8 mid channels, nb = 32-channel tile of the 256 outputs),
+        // through the same static 4-slot ring as the 3x3 weights: 32 groups (2 passes x 16), requested 3 groups ahead
+        const int w3voff = lane * 16;
+        auto b3load = [&](int q, f32x4(&b)[TN]) {               // q = pass * 16 + kg
+            const int qc = q < 32 ? q : 31;
+            const int kg = qc & 15, nb0 = (qc >> 4) * 4 + wn * TN;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = buf_load(w3_srd, w3voff, (kg * NB2 + nb0 + j) * 1024);
+        };
+        __syncthreads();                                         // every wave is done with the last activation chunk
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) b3load(r, bring[r]);
+        stage(0, 0);
+        __syncthreads();
+#pragma unroll 1
+        for (int p = 0; p < 2; ++p) {
+            f32x16 acc2[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int buf = kc & 1;
+                if (kc + 1 < 4) stage(kc + 1, buf ^ 1);
+                const float* ms = M2 + buf * MSZ + ((wm * TM) * 32 + (lane & 31)) * MP + (lane >> 5) * 4;
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int q = kc * 4 + sg;                   // static slot: 16 groups per pass, R divides 16
+                    b3load(p * 16 + q + R - 1, bring[(q + R - 1) % R]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 af[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(ms + i * 32 * MP + sg * 8);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc2[i][j] = mfma32(af[i][t], bring[q % R][j][t], acc2[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+            // epilogue of this pass: + bias3 + skip, 16-byte stores (wave-private patches over the now idle slices)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float* T = M2 + w * (32 * 36);
+                    const int col = p * 128 + (wn * TN + j) * 32 + (lane & 7) * 4;
+                    const f32x4 bv = *(const f32x4*)(a.bias3 + col);
+                    int off[4];
+                    f32x4 rv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int pp = (wm * TM + i) * 32 + (lane >> 3) + 8 * k;
+                        const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+                        off[k] = (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
+                        rv[k] = buf_load(r_srd, off[k], 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) T[acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 o = (*(const f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                        buf_store(o, o2_srd, off[k]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            if (p == 0) {
+                __syncthreads();                                 // patches done before slice 0 is staged again
+                stage(0, 0);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -487,13 +603,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 #endif
 }
 
-template <int KS, int ST, int CK, int TH, int TW, int TM, int TN, int WGM, int WGN>
+template <int KS, int ST, int CK, int TH, int TW, int TM, int TN, int WGM, int WGN, bool FUSE = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = TN * 32 * WGN;
     if (a.N % BN || a.C % CK) { suo_set_error("conv%dx%d: N=%d C=%d unsupported", KS, KS, a.N, a.C); return SUO_ERR_ARG; }
     const int tiles = ((a.OW + TW - 1) / TW) * ((a.OH + TH - 1) / TH) * a.L;
     dim3 grid(tiles, a.N / BN);
-    hipLaunchKernelGGL((convk_kernel<KS, ST, CK, TH, TW, TM, TN, WGM, WGN>), grid, dim3(WGM * WGN * 64), 0, s, a);
+    static const int dyn_lds = getenv("SUO_CONV_DYN_LDS") ? atoi(getenv("SUO_CONV_DYN_LDS")) : 0;      // occupancy experiments only
+    hipLaunchKernelGGL((convk_kernel<KS, ST, CK, TH, TW, TM, TN, WGM, WGN, FUSE>), grid, dim3(WGM * WGN * 64), dyn_lds, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -522,6 +639,21 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
     const long t64 = ((px + 63) / 64) * (a.N / 64);
     if (a.OH >= 8 && a.OW >= 8 && t64 >= 256) return launch_conv_cfg<3, 1, 32, 8, 8, 1, 1, 2, 2>(a, s);
     return launch_conv_cfg<3, 1, 32, 4, 8, 1, 1, 1, 2>(a, s);
+}
+
+// conv2 (3x3, 128 -> 128) + conv3 (1x1, 128 -> 256) + skip of a Residual block in one launch (FUSE above)
+bool conv3x3_fusable(const ConvArgs& a) {
+    const long px = (long)a.L * a.OH * a.OW;
+    static const int fuse = getenv("SUO_CONV_FUSE") ? atoi(getenv("SUO_CONV_FUSE")) : 1;              // 0: A/B against the separate launches
+    static const long min_tiles = getenv("SUO_CONV_FUSE_TILES") ? atol(getenv("SUO_CONV_FUSE_TILES")) : 1024;
+    return fuse && a.N == 128 && a.C == 128 && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && (px + 127) / 128 >= min_tiles;
+}
+int launch_conv3x3_fused(const ConvArgs& a, hipStream_t s) {
+    if (!conv3x3_fusable(a) || a.N2 != 256 || !a.W3p || !a.bias3 || !a.R || !a.out2) {
+        suo_set_error("conv3x3_fused: unsupported shape C=%d N=%d N2=%d", a.C, a.N, a.N2);
+        return SUO_ERR_ARG;
+    }
+    return launch_conv_cfg<3, 1, 32, 8, 16, 2, 2, 2, 2, true>(a, s);
 }
 
 int launch_conv7x7s2(const ConvArgs& a, hipStream_t s) {

@@ -336,6 +336,12 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
     c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
+    if (!r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256 && conv3x3_fusable(c2)) {
+        // conv2 -> conv3 + skip in one launch: the 128-channel tensor between them never leaves the CU (csrc/conv.hip: FUSE)
+        c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256;
+        SUO_LAUNCH(launch_conv3x3_fused(c2, s));
+        return SUO_OK;
+    }
     SUO_LAUNCH(launch_conv3x3(c2, s));
     GemmArgs g3 = {};
     g3.A1 = mid2; g3.lda1 = r.c2.N; g3.K1 = r.c3.K1;

@@ -60,8 +60,12 @@ struct ConvArgs {
     const float* Wp;                                     // packed with K' = [chunk][ky][kx][kk]
     const float* bias; float* out; int OH, OW, N;        // out [L,OH,OW,N]
     int relu;
+    // fused Residual tail (launch_conv3x3_fused only): out2 = W3 relu(conv + bias) + bias3 + R, [L,OH,OW,N2]; `out` is not written
+    const float* W3p; const float* bias3; const float* R; float* out2; int N2;
 };
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+bool conv3x3_fusable(const ConvArgs& a);
+int launch_conv3x3_fused(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_small(const ConvArgs& a, hipStream_t s);
 int launch_gemm_small(const GemmArgs& a, hipStream_t s);
 int launch_gemm_persist(const GemmArgs& a, int cfg, hipStream_t s);    // cfg 1: 128x128, 2: 128x64, 3: 64x64 tiles

@@ -85,3 +85,17 @@ def conv_kxk(x_nhwc, w, bias, relu=False):
     _lib.check(_lib.lib().suo_conv_kxk(KS, P(x_nhwc), L, H, W, C, P(wp), P(b), P(out), Np, int(relu), S()), "suo_conv_kxk")
     torch.cuda.synchronize()
     return out[..., :N]
+
+
+def conv3x3_conv1x1_skip(x_nhwc, w2, b2, w3, b3, skip_nhwc):
+    """Fused tail of a Residual block: x [L,H,W,128], w2 [128,128,3,3], w3 [256,128], skip [L,H,W,256] -> [L,H,W,256]."""
+    L, H, W, C = x_nhwc.shape
+    assert C == 128 and w2.shape == (128, 128, 3, 3) and w3.shape == (256, 128) and tuple(skip_nhwc.shape) == (L, H, W, 256)
+    wp2 = dev(pack_conv(w2, 128, 128, 32))
+    wp3 = dev(pack_gemm(np.ascontiguousarray(w3, np.float32), 256, 128))
+    out = torch.empty((L, H, W, 256), device="cuda")
+    b2d, b3d = dev(b2), dev(b3)                       # (named: a temporary would be freed -- and its block reused -- before the launch)
+    _lib.check(_lib.lib().suo_conv3x3_conv1x1_skip(P(x_nhwc), L, H, W, P(wp2), P(b2d), P(wp3), P(b3d), P(skip_nhwc), P(out), S()),
+               "suo_conv3x3_conv1x1_skip")
+    torch.cuda.synchronize()
+    return out

@@ -148,6 +148,29 @@ def test_conv3x3_large_launches(ops, L, H, W, C, N, why):
     assert not bad.any(), (why, np.flatnonzero(bad)[:8])     # per crop: a stray out-of-tile store lands in a neighbouring row
 
 
+@pytest.mark.parametrize("L,H,W", [(128, 64, 64), (80, 60, 60), (70, 64, 72), (128, 32, 32)])
+def test_fused_residual_tail_equals_the_separate_launches(ops, L, H, W):
+    """conv2 (3x3) -> conv3 (1x1) + skip in one launch (csrc/conv.hip: FUSE), the shape class the network uses it for
+    (>= 1024 tiles), ragged and non-square maps included: bit-identical to suo_conv_kxk followed by suo_conv1x1 with the
+    residual operand (same summation order), and within 5e-6 of the fp64 reference (Residual.py:27-35)."""
+    rng = np.random.default_rng(L + H)
+    x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
+    skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    b2 = rng.standard_normal(128).astype(np.float32) * 0.3
+    w3 = (rng.standard_normal((256, 128)) / np.sqrt(128)).astype(np.float32)
+    b3 = rng.standard_normal(256).astype(np.float32)
+    out = ops.conv3x3_conv1x1_skip(x, w2, b2, w3, b3, skip)
+    mid = ops.conv_kxk(x, w2, b2, relu=True).contiguous()
+    sep = ops.conv1x1(mid.reshape(-1, 128), w3, b3, res=skip.reshape(-1, 256)).reshape(L, H, W, 256)
+    assert torch.equal(out, sep)
+    for l in (0, L // 2, L - 1):                         # fp64 reference on a few crops (the whole launch is covered by `sep`)
+        xm = x[l:l + 1].permute(0, 3, 1, 2).double().cpu()
+        m = F.relu(F.conv2d(xm, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1))
+        ref = F.conv2d(m, torch.from_numpy(w3).double()[:, :, None, None], torch.from_numpy(b3).double()) + skip[l:l + 1].permute(0, 3, 1, 2).double().cpu()
+        assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
+
+
 def test_conv7x7_stride2(ops):
     rng = np.random.default_rng(11)
     L, H, C, N = 2, 64, 44, 64
