@@ -85,8 +85,8 @@ class FramePipeline:
         pinned host buffers (the three .cpu() of lib/object_slam.py:1100-1109)  ->  [host waits for that copy]  ->
         ONE PnP launch (a wave per object) and ONE LM launch (a workgroup per frame) for the F frames.
     `depth` steps are in flight: step i runs on slot i % depth (own network workspace, hipGraph, stream).  Before a slot is
-    reused the host awaits the read-back of the step that used it, launches the new network call, and then runs the awaited
-    step's geometry while the GPU executes `depth` network calls.  Frames of the single-view stream are independent
+    reused the host awaits the read-back of the step that used it, hands that step's geometry to the geometry thread (one
+    thread, steps in order) and launches the new network call.  Frames of the single-view stream are independent
     (evaluate.py:345-346 resets the SLAM state per frame).  Every network call processes exactly the frames that are
     counted: there is no tail call."""
 
@@ -122,6 +122,11 @@ class FramePipeline:
             for k in ("uv", "cov", "kp", "mask"):
                 S["h_" + k] = torch.empty(S[k].shape, dtype=S[k].dtype).pin_memory()
             self.slots.append(S)
+        # PnP / LM of a step run on ONE worker thread, in step order (the C ABI releases the GIL): the thread that launches network
+        # calls never waits for geometry, and a step's geometry still starts only after that step's read-back was awaited
+        from concurrent.futures import ThreadPoolExecutor
+        self.worker = ThreadPoolExecutor(max_workers=1, initializer=torch.cuda.set_device, initargs=(torch.cuda.current_device(),))   # HIP's current device is per thread
+        self.futures = []
         self.reset_metrics()
 
     def reset_metrics(self):
@@ -146,7 +151,8 @@ class FramePipeline:
                 S["event"].record(S["tstream"])
             self.n_crops += LF
         S["busy"] = (g, i)
-        self.geometry(done)
+        if done is not None:
+            self.futures.append(self.worker.submit(self.geometry, done))
 
     def await_outputs(self, S):
         """Host waits until a step's uv / cov / kp_mask / masks have arrived in the pinned buffers (the reference's three
@@ -191,7 +197,12 @@ class FramePipeline:
     def drain(self, next_step):
         """Retire every step still in flight, oldest first."""
         for k in range(self.depth):
-            self.geometry(self.await_outputs(self.slots[(next_step + k) % self.depth]))
+            done = self.await_outputs(self.slots[(next_step + k) % self.depth])
+            if done is not None:
+                self.futures.append(self.worker.submit(self.geometry, done))
+        for f in self.futures:
+            f.result()                      # (re-raises anything the geometry thread hit)
+        self.futures = []
 
 
 def pack_conv(w, Np, Cp, CK):

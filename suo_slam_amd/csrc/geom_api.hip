@@ -21,6 +21,7 @@ int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream
 int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);
 int launch_lm_cam(const void* problems_dev, int n_problems, hipStream_t s);
+int launch_lm_frame(const void* problems_dev, int n_problems, int max_obj, hipStream_t s);
 size_t lm_grid_scratch_bytes();
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
@@ -61,7 +62,8 @@ struct Arena {
             // priority level the stream also gets its own hardware queue instead of sharing one with the CNN's streams.
             int lo = 0, hi = 0;
             SUO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            SUO_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
+            static const int prio = getenv("SUO_GEOM_PRIO") ? atoi(getenv("SUO_GEOM_PRIO")) : 2;      // 2: highest, 1: default, 0: lowest (A/B only)
+            SUO_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio == 2 ? hi : (prio == 0 ? lo : 0)));
         }
         if (bytes <= cap) return SUO_OK;
         size_t ncap = std::max(bytes, cap * 2);
@@ -366,8 +368,20 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         for (int o = 0; o < probs[i].n_obj; ++o) nfo += probs[i].obj_fixed[o] ? 0 : 1;
         cam_only = nfc == 1 && nfo == 0;
     }
+    // single-view frames (evaluate.py --nviews 1): no free camera -> block-diagonal system, one wave per object (csrc/lm_frame.hip)
+    static const int frame_kernel = getenv("SUO_LM_FRAME") ? atoi(getenv("SUO_LM_FRAME")) : 8;             // max objects per frame it takes; 0: off (A/B)
+    bool frame_only = frame_kernel > 0 && !cam_only;
+    int frame_max_obj = 0;
+    for (int i = 0; i < n_prob && frame_only; ++i) {
+        int nfc = 0;
+        for (int c = 0; c < probs[i].n_cam; ++c) nfc += probs[i].cam_fixed[c] ? 0 : 1;
+        frame_only = nfc == 0 && probs[i].n_obj >= 1 && probs[i].n_obj <= frame_kernel && probs[i].n_obj <= 16;
+        frame_max_obj = std::max(frame_max_obj, probs[i].n_obj);
+    }
     if (cam_only) {
         rc = launch_lm_cam(g_arena.dev + st.o_structs, n_prob, g_arena.stream);
+    } else if (frame_only) {
+        rc = launch_lm_frame(g_arena.dev + st.o_structs, n_prob, frame_max_obj, g_arena.stream);
     } else if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {
         static void* grid_scratch = nullptr;
         if (!grid_scratch) SUO_HIP_CHECK(hipMalloc(&grid_scratch, lm_grid_scratch_bytes()));
