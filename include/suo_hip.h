@@ -162,7 +162,7 @@ int suo_optimize_batch(suo_ba_problem* problems, int n_problems);
  *   suo_ba_schur       -> [S_g (ns x ns) | r_g (ns) | ok]   S_g = sum_c Hco^T (Hcc + lambda I)^-1 Hco  (sum)
  *   suo_ba_solve_update(in = [Hoo+bo totals | S_total | r_total]) -> [chi2_local | scale_cams | scale_objs | ok]
  *   suo_ba_restore      = pop() after a rejected trial;  suo_ba_classify = chi2 re-classification of own edges.
- * ns = 6 * (#free objects) <= 96. */
+ * ns = 6 * (#free objects); beyond 96 rows (16 free objects) the reduced system is factorised in global memory. */
 typedef struct suo_ba_ctx suo_ba_ctx;
 int suo_ba_ctx_create(suo_ba_problem* local_problem, suo_ba_ctx** out);
 void suo_ba_ctx_destroy(suo_ba_ctx* ctx);

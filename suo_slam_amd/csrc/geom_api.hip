@@ -31,7 +31,7 @@ int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch
 int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s);
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s);
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
-                           double* scratch, hipStream_t s);
+                           double* scratch, double* big, hipStream_t s);
 int launch_ba_restore(const void* P, hipStream_t s);
 int launch_ba_finalize(const void* P, hipStream_t s);
 
@@ -345,9 +345,30 @@ static int fetch_results(suo_ba_problem* probs, int n_prob, Arena& A, Staged& st
     return SUO_OK;
 }
 
+static int optimize_phasewise(suo_ba_problem* q);
+
 int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     if (n_prob <= 0) return SUO_OK;
     if (!probs) { suo_set_error("suo_optimize_batch: null argument"); return SUO_ERR_ARG; }
+    // more than 16 free objects next to free cameras (T-LESS scenes): the reduced system outgrows the single-kernel paths;
+    // those graphs run the phase kernels under the host schedule, one by one, the rest of the batch as usual
+    {
+        std::vector<int> small;
+        bool any_big = false;
+        for (int i = 0; i < n_prob; ++i) {
+            int nfo = 0, nfc = 0;
+            for (int o = 0; o < probs[i].n_obj; ++o) nfo += probs[i].obj_fixed[o] ? 0 : 1;
+            for (int c = 0; c < probs[i].n_cam; ++c) nfc += probs[i].cam_fixed[c] ? 0 : 1;
+            if (nfo > 16 && nfc > 0) any_big = true; else small.push_back(i);
+        }
+        if (any_big) {
+            for (int i = 0, k = 0; i < n_prob; ++i) {
+                if (k < (int)small.size() && small[k] == i) { ++k; int rc = suo_optimize_batch(&probs[i], 1); if (rc != SUO_OK) return rc; }
+                else { int rc = optimize_phasewise(&probs[i]); if (rc != SUO_OK) return rc; }
+            }
+            return SUO_OK;
+        }
+    }
     std::lock_guard<std::mutex> lock(g_arena.mu);
     Staged st;
     int rc = stage_problems(probs, n_prob, g_arena, st);
@@ -405,6 +426,7 @@ struct suo_ba_ctx {
     Staged st;
     int n_cam = 0, n_obj = 0, ns = 0;
     double* d_io = nullptr; double* h_io = nullptr; size_t io_doubles = 0;   // [out | in | workgroup partials (device only)]
+    double* d_big = nullptr;     // reduced system + right-hand side in global memory when it has more than 96 rows (> 16 free objects)
     double* scratch() const { return d_io + io_doubles; }
     const void* dev_problem() const { return arena.dev + st.o_structs; }
 };
@@ -418,7 +440,9 @@ int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
     int nfo = 0;
     for (int o = 0; o < p->n_obj; ++o) nfo += p->obj_fixed[o] ? 0 : 1;
     c->ns = 6 * nfo;
-    if (nfo > 16) { suo_set_error("suo_ba_ctx_create: %d free objects exceed the reduced-system limit of 16", nfo); delete c; return SUO_ERR_ARG; }
+    if (nfo > 16 && hipMalloc((void**)&c->d_big, ((size_t)c->ns * c->ns + c->ns) * sizeof(double)) != hipSuccess) {
+        suo_set_error("suo_ba_ctx_create: allocation failed"); delete c; return SUO_ERR_HIP;
+    }
     c->io_doubles = 2 * ((size_t)c->ns * c->ns + c->ns + 27 * (size_t)p->n_obj + 16);
     if (hipMalloc((void**)&c->d_io, (c->io_doubles + ba_scratch_doubles()) * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_io, c->io_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -434,6 +458,7 @@ int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
 void suo_ba_ctx_destroy(suo_ba_ctx* c) {
     if (!c) return;
     if (c->d_io) (void)hipFree(c->d_io);
+    if (c->d_big) (void)hipFree(c->d_big);
     if (c->h_io) (void)hipHostFree(c->h_io);
     if (c->arena.dev) (void)hipFree(c->arena.dev);
     if (c->arena.host) (void)hipHostFree(c->arena.host);
@@ -472,7 +497,7 @@ int suo_ba_solve_update(suo_ba_ctx* c, double lambda, int robust_on, const doubl
     memcpy(h_in, in, n_in * sizeof(double));
     SUO_HIP_CHECK(hipMemcpyAsync(d_in, h_in, n_in * sizeof(double), hipMemcpyHostToDevice, c->arena.stream));
     int rc = launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, d_in, d_in + 27 * (size_t)c->n_obj, 0, c->d_io, c->scratch(),
-                                    c->arena.stream);
+                                    c->d_big, c->arena.stream);
     if (rc != SUO_OK) return rc;
     double dev_order[4];                       // device layout [chi2 | scale_cams | ok | scale_objs] -> documented host layout
     rc = ba_fetch(c, dev_order, 4);
@@ -485,6 +510,70 @@ int suo_ba_restore(suo_ba_ctx* c) {
     if (rc != SUO_OK) return rc;
     SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
     return SUO_OK;
+}
+
+// ---- graphs whose reduced system does not fit the single-kernel paths (more than 16 free objects next to free cameras) ----
+// The phase kernels above under g2o's LM schedule (optimization_algorithm_levenberg.cpp:58-150) and the robust rounds of
+// ObjectSLAM.optimize (lib/object_slam.py:842-896), driven from the host: the one-rank form of suo_slam_amd/ba_dist.py.
+static int optimize_phasewise(suo_ba_problem* q) {
+    suo_ba_ctx* c = nullptr;
+    int rc = suo_ba_ctx_create(q, &c);
+    if (rc != SUO_OK) return rc;
+    struct Guard { suo_ba_ctx* c; ~Guard() { suo_ba_ctx_destroy(c); } } guard{c};
+    const int O = q->n_obj, ns = c->ns;
+    std::vector<double> lin(2 + 27 * (size_t)O), sch((size_t)ns * ns + ns + 1), tot(27 * (size_t)O + (size_t)ns * ns + ns);
+    double good = 0, red[4];
+    int rounds = 0, lm_its = 0, lm_trials = 0, num_good = q->n_edge;
+    if (q->init_with_outliers) { rc = suo_ba_classify(c, 1, &good); if (rc) return rc; }
+    else { rc = suo_ba_classify(c, 0, &good); if (rc) return rc; num_good = (int)(good + 0.5); }
+    bool robust_on = true;
+    const int drop = std::max(1, q->n_rounds / 2);
+    static const int diag21[6] = {0, 6, 11, 15, 18, 20};
+    for (int rnd = 0; rnd < q->n_rounds; ++rnd) {
+        if (q->n_edge < 4 || num_good < 4) break;
+        ++rounds;
+        double lam = -1, ni = 2;
+        for (int it = 0; it < q->its[rnd]; ++it) {
+            rc = suo_ba_linearize(c, robust_on, lin.data()); if (rc) return rc;
+            double current_chi = lin[0];
+            const double* HB = lin.data() + 1;
+            if (it == 0) {                                          // computeLambdaInit: tau * max |diag H| over all free vertices
+                double maxd = lin[1 + 27 * (size_t)O];
+                for (int o = 0; o < O; ++o)
+                    if (!q->obj_fixed[o]) for (int d = 0; d < 6; ++d) maxd = std::max(maxd, fabs(HB[27 * o + diag21[d]]));
+                lam = 1e-5 * maxd; ni = 2;
+            }
+            double rho = 0; int qmax = 0; bool lam_finite = true;
+            do {
+                rc = suo_ba_schur(c, lam, sch.data()); if (rc) return rc;
+                double temp_chi = 1.7976931348623157e308, scale = 0;
+                if (sch[(size_t)ns * ns + ns] > 0.5) {
+                    memcpy(tot.data(), HB, 27 * (size_t)O * sizeof(double));
+                    memcpy(tot.data() + 27 * (size_t)O, sch.data(), ((size_t)ns * ns + ns) * sizeof(double));
+                    rc = suo_ba_solve_update(c, lam, robust_on, tot.data(), red); if (rc) return rc;
+                    if (red[3] > 0.5) { temp_chi = red[0]; scale = red[1] + red[2]; }
+                }
+                rho = (current_chi - temp_chi) / (scale + 1e-3);
+                if (rho > 0 && std::isfinite(temp_chi)) {
+                    const double alpha = std::min(1.0 - pow(2 * rho - 1, 3.0), 2.0 / 3.0);
+                    lam *= std::max(1.0 / 3.0, alpha); ni = 2; current_chi = temp_chi;
+                } else {
+                    lam *= ni; ni *= 2;
+                    rc = suo_ba_restore(c); if (rc) return rc;
+                    if (!std::isfinite(lam)) { lam_finite = false; break; }
+                }
+                ++qmax; ++lm_trials;
+            } while (rho < 0 && qmax < 10);
+            ++lm_its;
+            if (qmax == 10 || rho == 0 || !lam_finite) break;
+        }
+        rc = suo_ba_classify(c, 0, &good); if (rc) return rc;
+        num_good = (int)(good + 0.5);
+        if (rnd == drop) robust_on = false;
+    }
+    rc = suo_ba_ctx_download(c, q);
+    q->stats[0] = rounds; q->stats[1] = lm_its; q->stats[2] = lm_trials; q->stats[3] = num_good;
+    return rc;
 }
 
 // ---- the same phases on caller-owned DEVICE buffers, stream-ordered, no host synchronisation: the buffers are what RCCL
@@ -501,7 +590,8 @@ int suo_ba_schur_dev(suo_ba_ctx* c, double lambda, double* sch_dev, void* stream
 }
 int suo_ba_solve_update_dev(suo_ba_ctx* c, double lambda, int robust_on, int world, const double* lin_dev, const double* sch_dev, double* red_dev,
                             void* stream) {
-    return launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), (hipStream_t)stream);
+    return launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), c->d_big,
+                                  (hipStream_t)stream);
 }
 int suo_ba_restore_dev(suo_ba_ctx* c, void* stream) { return launch_ba_restore(c->dev_problem(), (hipStream_t)stream); }
 

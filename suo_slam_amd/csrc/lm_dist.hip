@@ -223,6 +223,73 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
     }
     if (tid == 0 && sh_ok == 0) atomicAdd(bad, 1);
 }
+// The same solve for reduced systems beyond LM_NS rows (more than 16 free objects: T-LESS scenes; the reference's graph
+// has no such limit, lib/object_slam.py:746-778): S and the right-hand side live in a global scratch buffer (L2-resident,
+// ns^2 doubles), factorised by the whole workgroup with a right-looking Cholesky -- one barrier triple per column.  Only the
+// summation order differs from the LDS path.
+__global__ __launch_bounds__(LM_THREADS) void ba_solve_big_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
+                                                                   const double* __restrict__ HB, const double* __restrict__ St, int expect_ok,
+                                                                   int* __restrict__ bad, double* __restrict__ S, double* __restrict__ rhs) {
+    const LmProblem& P = *Pp;
+    __shared__ int sh_ok;
+    __shared__ double sh_d;
+    const int tid = threadIdx.x;
+    const double* rt = St + ns * ns;
+    if (tid == 0) sh_ok = 1;
+    if (tid == 0 && expect_ok > 0 && (int)(rt[ns] + 0.5) != expect_ok) atomicAdd(bad, 1);
+    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[idx] = -St[idx];
+    __syncthreads();
+    for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
+        const int o = idx / 36, rc = idx - o * 36, r = rc / 6, cc = rc - r * 6;
+        const int so = P.obj_slot[o];
+        if (so < 0) continue;
+        const int rr = r < cc ? r : cc, c2 = r < cc ? cc : r;
+        const int packed = rr * 6 - rr * (rr - 1) / 2 + (c2 - rr);
+        S[(6 * so + r) * ns + 6 * so + cc] += HB[27 * o + packed] + (r == cc ? lambda : 0.0);
+    }
+    for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
+        const int o = idx / 6, r = idx - o * 6;
+        if (P.obj_slot[o] >= 0) rhs[6 * P.obj_slot[o] + r] = HB[27 * o + 21 + r] - rt[6 * P.obj_slot[o] + r];
+    }
+    __syncthreads();
+    for (int j = 0; j < ns; ++j) {                                  // S = L L^T, lower triangle in place
+        if (tid == 0) {
+            const double piv = S[j * ns + j];
+            if (!(piv > 0) || !isfinite(piv)) sh_ok = 0;
+            sh_d = sqrt(piv > 0 ? piv : 1.0);
+            S[j * ns + j] = sh_d;
+        }
+        __syncthreads();
+        const double d = sh_d;
+        for (int i = j + 1 + tid; i < ns; i += LM_THREADS) S[i * ns + j] /= d;
+        __syncthreads();
+        const int m = ns - j - 1;                                    // trailing update of the lower triangle, rows j+1 .. ns-1
+        for (int idx = tid; idx < m * m; idx += LM_THREADS) {
+            const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+            if (k <= i) S[i * ns + k] -= S[i * ns + j] * S[k * ns + j];
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < ns; ++j) {                                  // L y = rhs
+        if (tid == 0) rhs[j] /= S[j * ns + j];
+        __syncthreads();
+        const double yj = rhs[j];
+        for (int i = j + 1 + tid; i < ns; i += LM_THREADS) rhs[i] -= S[i * ns + j] * yj;
+        __syncthreads();
+    }
+    for (int j = ns - 1; j >= 0; --j) {                             // L^T x = y
+        if (tid == 0) rhs[j] /= S[j * ns + j];
+        __syncthreads();
+        const double xj = rhs[j];
+        for (int i = tid; i < j; i += LM_THREADS) rhs[i] -= S[j * ns + i] * xj;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
+        const int o = idx / 6;
+        P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
+    }
+    if (tid == 0 && sh_ok == 0) atomicAdd(bad, 1);
+}
 // x_c = y_c - sum_o Y(c,o) x_o for the own cameras, then T <- exp(x) T for cameras and objects (one thread per pose)
 __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* __restrict__ Pp, const int* __restrict__ bad) {
     const LmProblem& P = *Pp;
@@ -311,9 +378,11 @@ int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* s
     BA_DONE
 }
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
-                           double* scratch, hipStream_t s) {
+                           double* scratch, double* big, hipStream_t s) {
     int* bad = (int*)(scratch + BA_WGS);          // carries over from the Schur phase of the same trial
-    BA_ONE(ba_solve_kernel, lambda, ns, HB, St, expect_ok, bad);
+    if (ns <= LM_NS) BA_ONE(ba_solve_kernel, lambda, ns, HB, St, expect_ok, bad);
+    else if (!big) { suo_set_error("bundle adjustment: reduced system of %d rows needs the big-system scratch", ns); return SUO_ERR_ARG; }
+    else BA_ONE(ba_solve_big_kernel, lambda, ns, HB, St, expect_ok, bad, big, big + (size_t)ns * ns);
     BA_GRID(ba_update_kernel, (const int*)bad);
     BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch);
     BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out);

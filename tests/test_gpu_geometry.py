@@ -257,6 +257,31 @@ def test_global_bundle_adjustment_matches_oracle(ba, n_cam, n_obj):
     assert err < 5.0
 
 
+@pytest.mark.parametrize("n_cam,n_obj", [(30, 20), (4, 18), (12, 33)])
+def test_global_bundle_adjustment_beyond_sixteen_free_objects(ba, n_cam, n_obj):
+    """The reference's graph has no object limit (lib/object_slam.py:746-778; T-LESS scenes hold ~20 objects).  Beyond 16 free
+    objects next to free cameras the reduced system (6 n_obj rows) leaves LDS: suo_optimize runs the phase kernels with the
+    system factorised in global memory (csrc/lm_dist.hip: ba_solve_big_kernel) under the host LM schedule -- same results as
+    the dense oracle, and a batch may mix such graphs with ordinary frames."""
+    rng = np.random.default_rng(n_cam * 13 + n_obj)
+    P = S.make_pose_graph(rng, n_cam, n_obj, kp_per_obj=8)
+    obj_gt = P.pop("obj_gt")
+    P.pop("cam_gt")
+    got, ref = _compare_ba(ba, P)
+    err = max(np.linalg.norm(got[1][o][:, 3] - obj_gt[o][:, 3]) for o in range(n_obj))
+    assert err < 5.0
+    # mixed batch: [frame, big graph, frame] == the three alone
+    fr = S.make_frame(rng, 8, noise=0.004, outlier_frac=0.1, with_image=False)
+    F = S.frame_to_ba_problem(fr, np.stack([_perturb(T, rng, 2e-4, 0.1) for T in fr["T_OtoC"]]))
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    probs = [ba.Problem(*[F[k] for k in keys]), ba.Problem(*[P[k] for k in keys]), ba.Problem(*[F[k] for k in keys])]
+    ba.optimize_batch(probs)
+    alone = ba.optimize(*[F[k] for k in keys])
+    for p in (probs[0], probs[2]):
+        assert np.array_equal(p.obj_T.reshape(-1, 3, 4), alone[1]) and np.array_equal(p.inlier, alone[2])
+    assert np.array_equal(probs[1].obj_T.reshape(-1, 3, 4), got[1]) and np.array_equal(probs[1].inlier, got[2])
+
+
 def test_batch_of_frames_equals_individual_calls(ba):
     rng = np.random.default_rng(42)
     probs, singles = [], []
@@ -283,7 +308,7 @@ def test_too_few_edges_is_a_noop(ba):
     assert got[4][0] == 0
 
 
-@pytest.mark.parametrize("n_cam,n_obj", [(5, 2), (12, 6), (40, 8), (70, 12)])
+@pytest.mark.parametrize("n_cam,n_obj", [(5, 2), (12, 6), (40, 8), (70, 12), (10, 20)])
 def test_phase_wise_global_ba_matches_oracle_and_single_kernel(ba, n_cam, n_obj):
     """The multi-GPU path's phase kernels (csrc/lm_dist.hip) under the host LM schedule (suo_slam_amd/ba_dist.py),
     here with one rank: must agree with the dense oracle and with the single-kernel path (csrc/lm.hip).  The
