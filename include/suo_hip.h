@@ -41,6 +41,11 @@ int suo_net_create(int n, const char* const* names, const float* const* data, co
                    const int* ndims, int max_crops, suo_net** out);
 void suo_net_destroy(suo_net* net);
 int suo_net_set_graph(suo_net* net, int enable);          /* hipGraph replay of the backbone (default on) */
+/* Capture the backbone graph for L crops ahead of time (with_priors: the 48-channel staging layout of the SLAM prior pass, else
+ * the image-only layout).  Graphs are otherwise captured on the first call that sees a crop count -- inside whatever that call is
+ * timing; a harness feeding frames with 3..max_crops detections calls this once per count at start-up.  `stream` as in the forwards
+ * the graphs will be replayed on (capture is stream-agnostic; NULL = internal). */
+int suo_net_prepare(suo_net* net, int L, int with_priors, void* stream);
 size_t suo_net_workspace_bytes(const suo_net* net);
 
 /* One frame: image either SUO_IMG_U8_HWC = uint8 [H,W,3] as cv2.imread gives it (scaled by 1/255 on

@@ -29,6 +29,7 @@ SIGNATURES = {
     "suo_net_create": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(VP), C.POINTER(VP), c_i32p, C.c_int, C.POINTER(VP)]),
     "suo_net_destroy": (None, [VP]),
     "suo_net_set_graph": (C.c_int, [VP, C.c_int]),
+    "suo_net_prepare": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "suo_net_workspace_bytes": (C.c_size_t, [VP]),
     "suo_net_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_net_forward_frames": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),

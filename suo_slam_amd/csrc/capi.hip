@@ -53,6 +53,11 @@ int suo_net_set_graph(suo_net* net, int enable) {
     return SUO_OK;
 }
 
+int suo_net_prepare(suo_net* net, int L, int with_priors, void* stream) {
+    if (!net) return SUO_ERR_ARG;
+    return net->impl->prepare(L, with_priors, (hipStream_t)stream);
+}
+
 size_t suo_net_workspace_bytes(const suo_net* net) { return net ? net->impl->workspace_bytes() : 0; }
 
 int suo_net_forward(suo_net* net, const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors,

@@ -29,8 +29,10 @@
 #define SUO_CONV_AF_PIPE 0          // 1: A fragments one k-group ahead through a register ring (+8 VGPRs; measured slower:
 #endif                              //    with 3 workgroups per CU the other waves already hide the LDS latency)
 #ifndef SUO_CONV_WAVES_PER_EU
-#define SUO_CONV_WAVES_PER_EU 2     // two workgroups per CU: one's prologue / epilogue hides under the other's MFMAs
-#endif
+#define SUO_CONV_WAVES_PER_EU 2     // amdgpu_waves_per_eu(2) is a FLOOR: it caps the allocation at 256 registers per lane.  What is
+#endif                              // resident is decided by what the build then uses: the plain 3x3 kernels take 144 registers and
+                                    // 51.8 KB of LDS = THREE workgroups per CU (measured 140.9 TFLOP/s; forced to two: 139.2, to one:
+                                    // 130.2 -- SUO_CONV_DYN_LDS experiment, round 2); the fused conv2 -> conv3 kernel takes 210 = two.
 #ifndef SUO_CONV_BRING3
 #define SUO_CONV_BRING3 4           // weight-ring slots of the 3x3 kernels (must divide 9 * CK / 8)
 #endif

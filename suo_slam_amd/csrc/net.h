@@ -40,6 +40,7 @@ public:
                 const float* prior_uv, const uint8_t* prior_mask, float* uv, float* cov,
                 float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s);
     int forward_staged(const float* in0_user, int L, float* logits_out, hipStream_t s);
+    int prepare(int L, int with_priors, hipStream_t s);
     void set_use_graph(bool v) { use_graph_ = v; }
     int max_crops() const { return max_crops_; }
     size_t workspace_bytes() const { return ws_floats_ * sizeof(float); }
@@ -57,6 +58,7 @@ private:
     int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx);
     int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s);
     int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s);
+    int ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec);
 
     std::map<std::string, HostTensor> tensors_;
     std::vector<float*> owned_;

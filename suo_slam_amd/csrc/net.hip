@@ -445,24 +445,52 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
     return SUO_OK;
 }
 
+int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec) {
+    const int key = L * 2 + (in_c == IMG_C ? 1 : 0);          // one captured graph per (crop count, staging layout)
+    auto it = graphs_.find(key);
+    if (it == graphs_.end()) {
+        GraphEntry ge;
+        SUO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        int r = backbone(in0, in_c, logits, L, s);
+        hipError_t e = hipStreamEndCapture(s, &ge.graph);
+        if (r != SUO_OK) return r;
+        SUO_HIP_CHECK(e);
+        SUO_HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+        it = graphs_.emplace(key, ge).first;
+    }
+    *exec = it->second.exec;
+    return SUO_OK;
+}
+
 int Net::run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s) {
     if (use_graph_) {
-        const int key = L * 2 + (in_c == IMG_C ? 1 : 0);          // one captured graph per (crop count, staging layout)
-        auto it = graphs_.find(key);
-        if (it == graphs_.end()) {
-            GraphEntry ge;
-            SUO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            int r = backbone(in0, in_c, logits, L, s);
-            hipError_t e = hipStreamEndCapture(s, &ge.graph);
-            if (r != SUO_OK) return r;
-            SUO_HIP_CHECK(e);
-            SUO_HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
-            it = graphs_.emplace(key, ge).first;
-        }
-        SUO_HIP_CHECK(hipGraphLaunch(it->second.exec, s));
+        hipGraphExec_t exec = nullptr;
+        SUO_TRY(ensure_graph(in0, in_c, logits, L, s, &exec));
+        SUO_HIP_CHECK(hipGraphLaunch(exec, s));
         return SUO_OK;
     }
     return backbone(in0, in_c, logits, L, s);
+}
+
+// Capture the backbone graph for L crops ahead of time (nothing runs): a stream of frames with a varying number of
+// detections then never pays a capture inside a timed / latency-critical call.
+int Net::prepare(int L, int with_priors, hipStream_t s) {
+    if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_prepare: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
+    if (!use_graph_) return SUO_OK;
+    const bool own = (s == nullptr);
+    if (own) s = own_stream_;
+    try {
+        ws_used_ = 0;                                             // the same persistent slabs as forward()
+        float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
+        float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+        ws_mark_ = ws_used_;
+        hipGraphExec_t exec = nullptr;
+        SUO_TRY(ensure_graph(in0, with_priors ? IN_C : IMG_C, logits, L, s, &exec));
+    } catch (const std::exception& e) {
+        suo_set_error("suo_net_prepare: %s", e.what());
+        return SUO_ERR_ARG;
+    }
+    return SUO_OK;
 }
 
 // Backbone only, from an already staged NHWC [L,256,256,48] input (test / profiling entry).

@@ -272,6 +272,8 @@ class ObjectSLAM:
                 state_dict = ck["model"]
                 self.model_epoch = ck.get("epoch", -1)
             self.model = PkpNet(calc_cov=True, state_dict=state_dict, max_crops=max_crops)
+            # frames carry a varying number of detections: capture the graph of every crop count now, not inside a timed view
+            self.model.prepare(with_priors=(False,) if (single_view_mode or no_prior_det) else (False, True))
         self.avg_std_meter = AverageMeter()
         self.track_time_meter = AverageMeter()
         self.opt_time_meter = AverageMeter()

@@ -84,6 +84,13 @@ class PkpNet:
     def set_graph(self, enable: bool):
         _lib.check(_lib.lib().suo_net_set_graph(self._h, int(enable)), "suo_net_set_graph")
 
+    def prepare(self, crop_counts=None, with_priors=(False, True)):
+        """Capture the backbone graphs for these crop counts (default: 1..max_crops) before the first frame arrives, so that no
+        frame with a not-yet-seen number of detections pays a graph capture (suo_net_prepare)."""
+        for L in (range(1, self.max_crops + 1) if crop_counts is None else crop_counts):
+            for wp in with_priors:
+                _lib.check(_lib.lib().suo_net_prepare(self._h, int(L), int(bool(wp)), _stream()), "suo_net_prepare")
+
     def workspace_bytes(self):
         return int(_lib.lib().suo_net_workspace_bytes(self._h))
 
