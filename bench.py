@@ -213,30 +213,56 @@ def pack_conv(w, Np, Cp, CK):
     return out
 
 
+def pack_gemm(w, Np, Kp):
+    from suo_slam_amd import _lib
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty(2 * Np * Kp, np.float32)
+    _lib.check(_lib.lib().suo_pack_gemm_weight(w.ctypes.data, w.shape[0], w.shape[1], Np, Kp, out.ctypes.data), "pack_gemm")
+    return out
+
+
 def conv_roofline(L, iters=30):
-    """Live HIP-event timing of the dominant kernel: 3x3 conv 128->128 @ 64x64 (34.5 % of all MACs), L crops."""
+    """Live HIP-event timing of the dominant kernel at the launch shape of the timed region: the fused tail of a Residual block
+    at 64x64 -- conv2 (3x3, 128 -> 128) + ReLU, conv3 (1x1, 128 -> 256) + skip in ONE launch, convk_kernel<3,1,32,8,16,2,2,2,2,true>
+    (8 launches per network call, ~38 % of its kernel time; the plain 3x3 kernel of the same tile shape is reported beside it)."""
     import torch
     from suo_slam_amd import _lib
     rng = np.random.default_rng(0)
     x = torch.rand((L, 64, 64, 128), device="cuda") - 0.5
-    w = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
-    wp = torch.from_numpy(pack_conv(w, 128, 128, 32)).cuda()
-    b = torch.zeros(128, device="cuda")
-    out = torch.empty((L, 64, 64, 128), device="cuda")
+    skip = torch.rand((L, 64, 64, 256), device="cuda") - 0.5
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
+    w3 = (rng.standard_normal((256, 128)) / 11.0).astype(np.float32)
+    wp2 = torch.from_numpy(pack_conv(w2, 128, 128, 32)).cuda()
+    wp3 = torch.from_numpy(pack_gemm(w3, 256, 128)).cuda()
+    b2 = torch.zeros(128, device="cuda")
+    b3 = torch.zeros(256, device="cuda")
+    mid = torch.empty((L, 64, 64, 128), device="cuda")
+    out = torch.empty((L, 64, 64, 256), device="cuda")
     st = torch.cuda.current_stream()
     s = C.c_void_p(st.cuda_stream)
     lib = _lib.lib()
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    for _ in range(5):
-        lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp), P(b), P(out), 128, 1, s)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp), P(b), P(out), 128, 1, s)
-    e1.record(st)
-    e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    flop = 2.0 * L * 64 * 64 * 128 * 128 * 9
+
+    def fused():
+        _lib.check(lib.suo_conv3x3_conv1x1_skip(P(x), L, 64, 64, P(wp2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "suo_conv3x3_conv1x1_skip")
+
+    def plain():
+        _lib.check(lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp2), P(b2), P(mid), 128, 1, s), "suo_conv_kxk")
+
+    def timed(f):
+        for _ in range(10):                                      # (the first launches of a kernel in a process run 5-25 % slow)
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            f()
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters
+    us, us_plain = timed(fused), timed(plain)
+    px = float(L) * 64 * 64
+    flop_plain = 2.0 * px * 128 * 128 * 9
+    flop = flop_plain + 2.0 * px * 128 * 256
     ach = flop / (us * 1e-6) / 1e12
     # HBM traffic per launch: rocprofv3 --pmc passes of this same kernel / launch shape (FETCH_SIZE doubled as the
     # microarch guide prescribes for gfx950, WRITE_SIZE as reported), collected by tools/profile_round.sh, stored under profiles/
@@ -244,11 +270,15 @@ def conv_roofline(L, iters=30):
     pmc = os.path.join(ROOT, "profiles", "pmc_dominant_conv.json")
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
-        if rec.get("crops_per_launch") == L:
+        if rec.get("crops_per_launch") == L and rec.get("kernel", "").endswith("true>"):
             traffic = rec.get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "convk_kernel<3,1,32,8,16,2,2,2,2> 3x3 128->128 @64x64, %d crops/launch" % L,
+    return {"bound": "mfma", "kernel": "convk_kernel<3,1,32,8,16,2,2,2,2,true> fused Residual tail: 3x3 128->128 + ReLU, 1x1 128->256 + skip @64x64, "
+                                       "%d crops/launch" % L,
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4),
-            "traffic": traffic, "avg_launch_us": round(us, 2), "flop_per_launch": flop}
+            "traffic": traffic, "avg_launch_us": round(us, 2), "flop_per_launch": flop,
+            "algorithmic_bytes_per_launch": 4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 9 + 128 * 256),
+            "plain_3x3_kernel": {"kernel": "convk_kernel<3,1,32,8,16,2,2,2,2,false>", "avg_launch_us": round(us_plain, 2),
+                                 "achieved": round(flop_plain / (us_plain * 1e-6) / 1e12, 2), "frac": round(flop_plain / (us_plain * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
 
 
 def cpu_baseline(pool, L):

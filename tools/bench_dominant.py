@@ -1,4 +1,5 @@
-"""Run only the dominant kernel (3x3 conv 128->128 @64x64, L=8) N times: target for rocprofv3 --pmc passes."""
+"""Run only the dominant kernel (the fused Residual tail, 3x3 128->128 + 1x1 128->256 + skip @64x64) and, beside it, the plain 3x3
+kernel of the same tile shape, N times each: target for rocprofv3 --kernel-trace / --pmc passes."""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profiles on the GPU box (one gpurun call): bench line, bench kernel stats, dominant-kernel stats, PMC passes.
 #   bash tools/profile_round.sh <round-tag>      -> gpurun_out/round_<tag>/...
-TAG=${1:-r01b}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 # 1. the bench line itself (with the CPU baseline)
 python3 $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 # 2. kernel trace of the same command (shorter run)
-rocprofv3 --kernel-trace -d $OUT/bench_trace -o trace -- python3 $R/bench.py --no-cpu-baseline --steps 128 --warmup 32 > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/bench_trace -o trace -- python3 $R/bench.py --no-cpu-baseline --no-latency-leg --steps 20 --warmup 5 > $OUT/bench_trace.log 2>&1
 python3 $R/tools/rocpd_stats.py $(find $OUT/bench_trace -name "*.db" | head -1) grid > $OUT/bench_kernel_stats.txt
 # 3. dominant kernel alone at the bench launch shape (128 crops)
 rocprofv3 --kernel-trace -d $OUT/dom_trace -o trace -- python3 $R/tools/bench_dominant.py 30 128 > $OUT/dom.log 2>&1
