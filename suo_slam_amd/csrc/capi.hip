@@ -138,6 +138,18 @@ int suo_conv_kxk(int KS, const float* in, int L, int H, int W, int C, const floa
     return SUO_ERR_ARG;
 }
 
+int suo_pack_wino_weight(const float* w, int N, int C, int Np, int Cp, float* out) {
+    if (Np % 32 || Cp % 16 || N > Np || C > Cp) { suo_set_error("suo_pack_wino_weight: bad padding"); return SUO_ERR_ARG; }
+    suo::pack_wino_weight(w, N, C, Np, Cp, nullptr, out);
+    return SUO_OK;
+}
+
+int suo_conv3x3_wino(const float* in, int L, int H, int W, int C, const float* wp, const float* bias, float* out, int N, int relu, void* stream) {
+    suo::ConvArgs c = {};
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = C; c.Wp = wp; c.bias = bias; c.out = out; c.OH = H; c.OW = W; c.N = N; c.relu = relu;
+    return suo::launch_conv3x3_wino(c, (hipStream_t)stream);
+}
+
 int suo_conv3x3_conv1x1_skip(const float* in, int L, int H, int W, const float* wp2, const float* bias2, const float* wp3, const float* bias3,
                              const float* skip, float* out, void* stream) {
     suo::ConvArgs c = {};

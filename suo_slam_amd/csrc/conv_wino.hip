@@ -1,0 +1,274 @@
+// 3x3 convolution by Winograd F(2x2, 3x3) on fp32 MFMA (gfx950): 16 element-wise products per 2x2 output tile and channel
+// pair instead of 36 -- 2.25x fewer MFMA MACs than the direct form of csrc/conv.hip, for the 128 -> 128 channel convolutions
+// of the Residual blocks (/root/reference/lib/models/layers/Residual.py:12-14,27-29: 60 % of a network call).
+//
+//   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A          (Lavin & Gray; correlation form, as torch.nn.Conv2d)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// Mapping (one workgroup = 8 x 16 output pixels = 32 Winograd tiles x 128 output channels, 4 waves):
+//   * U = G g G^T is computed on the host in fp64, rounded once, packed per (channel chunk, component, k-group, 32-channel
+//     tile) in MFMA B-operand order; it streams from L2 through a static register ring like the direct kernel's weights;
+//   * per 16-channel chunk the 10 x 18 halo tile is staged in LDS (double-buffered, register prefetch), then ALL threads
+//     transform it: thread (tile, channel quad, half) reads 3 x 4 halo pixels and writes 8 of the 16 components of
+//     V = B^T d B (additions only) into LDS in A-operand order;
+//   * MFMA phase: the 32 tiles are the 32 rows of v_mfma_f32_32x32x2_f32, wave w owns output channels [32 w, 32 w + 32):
+//     per component 8 MFMAs (K = 16) into a scratch accumulator, which is then added with its A^T (.) A sign (0, +1, -1)
+//     to the four output-position accumulators -- the output transform costs VALU additions, never MFMAs;
+//   * two barriers per chunk (V ready / V free); two workgroups per CU (70 KB of LDS each) run the phases against each other.
+// Numerics: fp32 throughout; the transforms add at most 4 terms on either side, so the result differs from the direct
+// kernel by summation order and by the rounding of U (observed <= 2e-6 of the output range).
+#include "buffer_ops.h"
+#include "suo_internal.h"
+
+namespace suo {
+
+typedef float w_f32x4 __attribute__((ext_vector_type(4)));
+typedef float w_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ w_f32x16 w_mfma32(float a, float b, w_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int w_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+constexpr int W_CK = 16, W_PKH = 20, W_PKV = 20, W_TH = 8, W_TW = 16, W_IH = 10, W_IW = 18, W_NPIX = W_IH * W_IW;
+constexpr int W_RING = 8;
+
+// host: U[n][c][comp] = (G g G^T)[xi][nu], comp = 4 xi + nu, in fp64; packed as
+//   Up[chunk][comp][s][nb][lane][t] = U[nb*32 + (lane&31)][chunk*16 + s*8 + (lane>>5)*4 + t][comp]        (N, C multiples of 32 / 16)
+void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float* out_scale, float* out) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int nch = Cp / W_CK, NB = Np / 32;
+    for (size_t i = 0; i < (size_t)Np * Cp * 16; ++i) out[i] = 0.f;
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            const float* g = W + ((size_t)n * C + c) * 9;
+            const double sc = out_scale ? (double)out_scale[n] : 1.0;
+            double Gg[4][3], U[4][4];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 3; ++j) Gg[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) U[i][j] = (Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2]) * sc;
+            const int chunk = c / W_CK, cc = c % W_CK, s = cc / 8, half = (cc % 8) / 4, t = cc % 4;
+            const int nb = n / 32, lane = half * 32 + (n % 32);
+            for (int comp = 0; comp < 16; ++comp)
+                out[((((size_t)(chunk * 16 + comp) * 2 + s) * NB + nb) * 64 + lane) * 4 + t] = (float)U[comp >> 2][comp & 3];
+        }
+    (void)nch;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_kernel(const ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float Hin[2][W_NPIX * W_PKH];
+    __shared__ __attribute__((aligned(16))) float V[16 * 32 * W_PKV];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (a.OW + W_TW - 1) / W_TW, tiles_y = (a.OH + W_TH - 1) / W_TH;
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
+    const int l = bid / (tiles_x * tiles_y);
+    bid -= l * tiles_x * tiles_y;
+    const int ty0 = bid / tiles_x, tx0 = bid - ty0 * tiles_x;
+    const int oy0 = ty0 * W_TH, ox0 = tx0 * W_TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int nch = a.C / W_CK, NB = a.N >> 5;
+    const float* in_l = a.in + (size_t)l * a.H * a.W * a.C;
+    const __amdgpu_buffer_rsrc_t in_srd = make_srd(in_l, (size_t)a.H * a.W * a.C * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * 16 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t out_srd = make_srd(a.out + (size_t)l * a.OH * a.OW * a.N, (size_t)a.OH * a.OW * a.N * sizeof(float));
+
+    // ---- halo staging: 180 pixels x 4 float4 per chunk = 720 pieces over 256 threads ------------------------------------
+    constexpr int NF4 = W_NPIX * 4, NLD = (NF4 + 255) / 256;
+    int avoff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int pix = idx >> 2, cc = idx & 3;
+        const int py = pix / W_IW, px = pix - py * W_IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool ok = idx < NF4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        avoff[i] = ok ? ((iy * a.W + ix) * a.C + cc * 4) * 4 : BUF_OOB;
+    }
+    w_f32x4 areg[NLD];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) areg[i] = buf_load(in_srd, avoff[i], c * W_CK * 4);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < NF4) *(w_f32x4*)&Hin[buf][(idx >> 2) * W_PKH + (idx & 3) * 4] = areg[i];
+        }
+    };
+    // ---- weights: Up[gg][nb][lane][4], gg = (chunk * 16 + comp) * 2 + s; wave w owns n-tile w ---------------------------
+    const int wvoff = (w * 64 + lane) * 16;
+    const int gtot = nch * 32;
+    w_f32x4 bring[W_RING];
+    auto bload = [&](int gg, w_f32x4& b) {
+#ifdef SUO_WINO_EXP_W0
+        const int gc = gg & 1;                                    // timing experiment: weights from two cache-resident groups (wrong results)
+#else
+        const int gc = gg < gtot ? gg : gtot - 1;
+#endif
+        b = buf_load(w_srd, wvoff, gc * NB * 1024);
+    };
+    // ---- transform: thread = (tile t, channel quad q, half h); h is wave-uniform (waves 0,1 / 2,3) -----------------------
+    const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;
+    const int t_ty = tt >> 3, t_tx = tt & 7;
+    const int hbase = ((2 * t_ty + th) * W_IW + 2 * t_tx) * W_PKH + tq * 4;       // input rows th, th+1, th+2 of the 4x4 patch
+    const int vbase = tt * W_PKV + tq * 4;
+    auto transform = [&](int buf) {
+        const float* hs = &Hin[buf][hbase];
+        w_f32x4 L0[4], L1[4], L2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            L0[c] = *(const w_f32x4*)(hs + c * W_PKH);
+            L1[c] = *(const w_f32x4*)(hs + (W_IW + c) * W_PKH);
+            L2[c] = *(const w_f32x4*)(hs + (2 * W_IW + c) * W_PKH);
+        }
+        // rows of B^T d:  half 0 (input rows 0,1,2): xi0 = r0 - r2, xi1 = r1 + r2;  half 1 (rows 1,2,3): xi3 = r1 - r3, xi2 = r2 - r1
+        w_f32x4 eA[4], eB[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            eA[c] = L0[c] - L2[c];
+            eB[c] = th ? (L1[c] - L0[c]) : (L1[c] + L2[c]);
+        }
+        const int xiA = th ? 3 : 0, xiB = th ? 2 : 1;
+        float* va = &V[(xiA * 4) * 32 * W_PKV + vbase];
+        float* vb = &V[(xiB * 4) * 32 * W_PKV + vbase];
+        // columns: nu0 = c0 - c2, nu1 = c1 + c2, nu2 = c2 - c1, nu3 = c1 - c3
+        *(w_f32x4*)(va + 0 * 32 * W_PKV) = eA[0] - eA[2];
+        *(w_f32x4*)(va + 1 * 32 * W_PKV) = eA[1] + eA[2];
+        *(w_f32x4*)(va + 2 * 32 * W_PKV) = eA[2] - eA[1];
+        *(w_f32x4*)(va + 3 * 32 * W_PKV) = eA[1] - eA[3];
+        *(w_f32x4*)(vb + 0 * 32 * W_PKV) = eB[0] - eB[2];
+        *(w_f32x4*)(vb + 1 * 32 * W_PKV) = eB[1] + eB[2];
+        *(w_f32x4*)(vb + 2 * 32 * W_PKV) = eB[2] - eB[1];
+        *(w_f32x4*)(vb + 3 * 32 * W_PKV) = eB[1] - eB[3];
+    };
+
+    w_f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    w_f32x16 out[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[p][r] = 0.f;
+
+    gload(0);
+#pragma unroll
+    for (int r = 0; r < W_RING - 2; ++r) bload(((r >> 2) * 2 + (r & 1)) * 2 + ((r >> 1) & 1), bring[r]);      // consumption order, see below
+    sstore(0);
+    __syncthreads();
+
+    const float* vs = &V[(lane & 31) * W_PKV + (lane >> 5) * 4];
+#ifdef SUO_WINO_PROF
+    long long pt[5] = {0, 0, 0, 0, 0}, p0 = clock64();
+#define WPROF(i) do { const long long _t = clock64(); pt[i] += _t - p0; p0 = _t; } while (0)
+#else
+#define WPROF(i) do { } while (0)
+#endif
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nch;
+        if (more) gload(c + 1);
+        transform(buf);
+        WPROF(0);
+        __syncthreads();
+        WPROF(1);
+        if (more) sstore(buf ^ 1);
+        WPROF(2);
+        // Components in pairs: two independent scratch accumulators keep the MFMA pipe fed back to back (one chain alone
+        // waits for its own result every time); the first MFMA of a component takes the persistent all-zero accumulator as C.
+        // Weight groups are consumed in the order k = 4 pair + 2 s + which <-> (comp = 2 pair + which, s); the ring slot of a
+        // group is its consumption index mod W_RING, its address comes from (comp, s).
+        constexpr int At[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+        auto fold = [&](int comp, const w_f32x16& tmp) {          // out(i,j) += A^T[i][xi] A^T[j][nu] M(xi,nu)
+            const int xi = comp >> 2, nu = comp & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cf = At[i][xi] * At[j][nu];
+                    if (cf == 1) out[i * 2 + j] += tmp;
+                    else if (cf == -1) out[i * 2 + j] -= tmp;
+                }
+        };
+        auto seq_gg = [&](int k) -> int {                         // consumption index (may run into the next chunk) -> packed group
+            const int cc = c + (k >> 5), kk = k & 31;
+            const int comp = (kk >> 2) * 2 + (kk & 1), sg = (kk >> 1) & 1;
+            return cc * 32 + comp * 2 + sg;
+        };
+#pragma unroll
+        for (int pair = 0; pair < 8; ++pair) {
+            w_f32x16 ta, tb;
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                const int k = pair * 4 + sg * 2;
+                bload(seq_gg(k + W_RING - 2), bring[(k + W_RING - 2) % W_RING]);      // the two slots the previous step consumed
+                bload(seq_gg(k + W_RING - 1), bring[(k + W_RING - 1) % W_RING]);
+                const w_f32x4 afa = *(const w_f32x4*)(vs + (2 * pair) * 32 * W_PKV + sg * 8);
+                const w_f32x4 afb = *(const w_f32x4*)(vs + (2 * pair + 1) * 32 * W_PKV + sg * 8);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ta = w_mfma32(afa[t], bring[k % W_RING][t], (sg == 0 && t == 0) ? zero16 : ta);
+                    tb = w_mfma32(afb[t], bring[(k + 1) % W_RING][t], (sg == 0 && t == 0) ? zero16 : tb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fold(2 * pair, ta);
+            fold(2 * pair + 1, tb);
+        }
+        WPROF(3);
+        __syncthreads();
+        WPROF(4);
+    }
+#ifdef SUO_WINO_PROF
+    if (blockIdx.x == 1000 && (tid & 63) == 0) printf("wave %d cycles: transform %lld  barrier1 %lld  sstore %lld  mfma+fold %lld  barrier2 %lld\n", w, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
+
+    // ---- epilogue: per output position (i,j) transpose the 32 tiles x 32 channels through a wave-private patch -> 16-byte stores
+    float* T = &V[0] + w * (32 * 36);
+    const int col = w * 32 + (lane & 7) * 4;
+    const w_f32x4 bv = *(const w_f32x4*)(a.bias + col);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int pi = p >> 1, pj = p & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[w_acc_row(r, lane) * 36 + (lane & 31)] = out[p][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = (lane >> 3) + 8 * k;
+            const int oy = oy0 + 2 * (t >> 3) + pi, ox = ox0 + 2 * (t & 7) + pj;
+            w_f32x4 o = *(const w_f32x4*)&T[t * 36 + (lane & 7) * 4] + bv;
+            if (a.relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
+            }
+            buf_store(o, out_srd, (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N + col) * 4 : BUF_OOB);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Measured at 128 -> 128 channels (tools/bench_wino.py): 1.46-1.75x the direct kernel from 256 tiles of 8 x 16 pixels up
+// (64x64 maps of 8 crops, 16x16 maps of 128 crops), 0.5x at 64 tiles -- there the direct kernel's smaller tiles fill more CUs.
+bool conv3x3_wino_pays(const ConvArgs& a) {
+    static const int on = getenv("SUO_CONV_WINO") ? atoi(getenv("SUO_CONV_WINO")) : 1;                  // 0: A/B against the direct kernels
+    static const long min_tiles = getenv("SUO_CONV_WINO_TILES") ? atol(getenv("SUO_CONV_WINO_TILES")) : 256;
+    const long tiles = (long)((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
+    return on && a.N == 128 && a.C == 128 && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && tiles >= min_tiles;
+}
+
+int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
+    if (a.OH != a.H || a.OW != a.W || a.N != 128 || (a.C % W_CK) || a.C <= 0) {
+        suo_set_error("conv3x3_wino: unsupported shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
+        return SUO_ERR_ARG;
+    }
+    const int tiles = ((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
+    hipLaunchKernelGGL(wino3x3_kernel, dim3(tiles), dim3(256), 0, s, a);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+}  // namespace suo

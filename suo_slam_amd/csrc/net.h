@@ -17,7 +17,7 @@ struct HostTensor {
 };
 
 struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; };
-struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; };
+struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; float* Wq = nullptr; };   // Wq: Winograd-packed (3x3, 128 -> 128 only)
 struct ResidualW {
     float* pro_scale = nullptr; float* pro_shift = nullptr;
     GemmW c1; ConvW c2; GemmW c3;

@@ -179,6 +179,11 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
     c.Wp = upload(packed);
     c.bias = upload(bias);
     c.N = Np; c.C = Cp; c.KS = KS;
+    if (KS == 3 && N == 128 && C == 128 && c_used <= 0) {       // the Residual blocks' 128 -> 128 convolutions: also in Winograd form
+        std::vector<float> wq((size_t)16 * 128 * 128);
+        pack_wino_weight(w.data, 128, 128, 128, 128, scale.empty() ? nullptr : scale.data(), wq.data());
+        c.Wq = upload(wq);
+    }
 }
 
 void Net::make_residual(const std::string& p, ResidualW& r) {
@@ -336,13 +341,19 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
     c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
-    if (!r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256 && conv3x3_fusable(c2)) {
+    const bool wino = r.c2.Wq && conv3x3_wino_pays(c2);       // 2.25x fewer MFMA MACs (csrc/conv_wino.hip)
+    if (!wino && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256 && conv3x3_fusable(c2)) {
         // conv2 -> conv3 + skip in one launch: the 128-channel tensor between them never leaves the CU (csrc/conv.hip: FUSE)
         c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256;
         SUO_LAUNCH(launch_conv3x3_fused(c2, s));
         return SUO_OK;
     }
-    SUO_LAUNCH(launch_conv3x3(c2, s));
+    if (wino) {
+        c2.Wp = r.c2.Wq;
+        SUO_LAUNCH(launch_conv3x3_wino(c2, s));
+    } else {
+        SUO_LAUNCH(launch_conv3x3(c2, s));
+    }
     GemmArgs g3 = {};
     g3.A1 = mid2; g3.lda1 = r.c2.N; g3.K1 = r.c3.K1;
     if (r.has_skip_conv) { g3.A2 = x; g3.lda2 = r.cin; g3.K2 = r.c3.K2; }

@@ -99,3 +99,18 @@ def conv3x3_conv1x1_skip(x_nhwc, w2, b2, w3, b3, skip_nhwc):
                "suo_conv3x3_conv1x1_skip")
     torch.cuda.synchronize()
     return out
+
+
+def conv3x3_wino(x_nhwc, w, bias, relu=False):
+    """3x3 convolution in Winograd F(2x2,3x3) form: x [L,H,W,C], w [128,C,3,3] -> [L,H,W,128]."""
+    L, H, W, C = x_nhwc.shape
+    N = w.shape[0]
+    assert N == 128 and C % 16 == 0
+    w = np.ascontiguousarray(w, np.float32)
+    packed = np.empty(16 * N * C, np.float32)
+    _lib.check(_lib.lib().suo_pack_wino_weight(w.ctypes.data, N, C, N, C, packed.ctypes.data), "pack_wino")
+    wp, b = dev(packed), dev(bias)
+    out = torch.empty((L, H, W, N), device="cuda")
+    _lib.check(_lib.lib().suo_conv3x3_wino(P(x_nhwc), L, H, W, C, P(wp), P(b), P(out), N, int(relu), S()), "suo_conv3x3_wino")
+    torch.cuda.synchronize()
+    return out
