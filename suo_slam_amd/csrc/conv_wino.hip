@@ -54,6 +54,7 @@ void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float*
     (void)nch;
 }
 
+template <bool FUSE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float Hin[2][W_NPIX * W_PKH];
     __shared__ __attribute__((aligned(16))) float V[16 * 32 * W_PKV];
@@ -226,6 +227,114 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     if (blockIdx.x == 1000 && (tid & 63) == 0) printf("wave %d cycles: transform %lld  barrier1 %lld  sstore %lld  mfma+fold %lld  barrier2 %lld\n", w, pt[0], pt[1], pt[2], pt[3], pt[4]);
 #endif
 
+    if constexpr (FUSE) {
+        // ---- tail of the Residual block in the same launch (layers/Residual.py:27-35): conv3 (1x1, 128 -> 256) + bias + skip on
+        // relu(conv2 + bias2), as in csrc/conv.hip (FUSE): the conv2 tile is complete in `out` (wave w: channels [32 w, 32 w + 32)
+        // of the 128 pixels, as 4 output positions x 32 Winograd tiles); slice kc of 32 channels is staged by wave kc through LDS
+        // (pixel-major, double-buffered) as the A operand, output channels in two passes of 128 with the waves as a 2 x 2 grid.
+        constexpr int MP = 36, MSZ = 128 * MP;
+        static_assert(2 * MSZ <= 16 * 32 * W_PKV, "mid slices must fit the V buffer");
+        float* M2 = &V[0];
+        const int wm = w >> 1, wn = w & 1;
+        const int NB2 = a.N2 >> 5;
+        const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * sizeof(float));
+        const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
+        const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
+        const float b2v = a.bias[w * 32 + (lane & 31)];
+        auto stage = [&](int kc, int buf) {
+            if (w == kc) {
+                float* d = M2 + buf * MSZ;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int t = w_acc_row(r, lane);                       // Winograd tile -> pixel of the 8 x 16 tile
+                        const int pix = (2 * (t >> 3) + (p >> 1)) * W_TW + 2 * (t & 7) + (p & 1);
+                        d[pix * MP + (lane & 31)] = fmaxf(out[p][r] + b2v, 0.f);
+                    }
+            }
+        };
+        const int w3voff = lane * 16;
+        auto b3load = [&](int q, w_f32x4(&b)[2]) {                // q = pass * 16 + k-group of 8 mid channels
+            const int qc = q < 32 ? q : 31;
+            const int kg = qc & 15, nb0 = (qc >> 4) * 4 + wn * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = buf_load(w3_srd, w3voff, (kg * NB2 + nb0 + j) * 1024);
+        };
+        constexpr int R3 = 4;
+        w_f32x4 b3[R3][2];
+#pragma unroll
+        for (int r = 0; r < R3 - 1; ++r) b3load(r, b3[r]);
+        stage(0, 0);
+        __syncthreads();
+#pragma unroll 1
+        for (int p = 0; p < 2; ++p) {
+            w_f32x16 acc2[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int buf = kc & 1;
+                if (kc + 1 < 4) stage(kc + 1, buf ^ 1);
+                const float* ms = M2 + buf * MSZ + ((wm * 2) * 32 + (lane & 31)) * MP + (lane >> 5) * 4;
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const int q = kc * 4 + sg;
+                    b3load(p * 16 + q + R3 - 1, b3[(q + R3 - 1) % R3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    w_f32x4 af[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = *(const w_f32x4*)(ms + i * 32 * MP + sg * 8);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc2[i][j] = w_mfma32(af[i][t], b3[q % R3][j][t], acc2[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* T = M2 + w * (32 * 36);
+                    const int col = p * 128 + (wn * 2 + j) * 32 + (lane & 7) * 4;
+                    const w_f32x4 bv = *(const w_f32x4*)(a.bias3 + col);
+                    int off[4];
+                    w_f32x4 rv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int pp = (wm * 2 + i) * 32 + (lane >> 3) + 8 * k;
+                        const int oy = oy0 + pp / W_TW, ox = ox0 + pp % W_TW;
+                        off[k] = (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
+                        rv[k] = buf_load(r_srd, off[k], 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) T[w_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const w_f32x4 o = (*(const w_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                        buf_store(o, o2_srd, off[k]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            if (p == 0) {
+                __syncthreads();
+                stage(0, 0);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: per output position (i,j) transpose the 32 tiles x 32 channels through a wave-private patch -> 16-byte stores
     float* T = &V[0] + w * (32 * 36);
     const int col = w * 32 + (lane & 7) * 4;
@@ -266,9 +375,23 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
-    hipLaunchKernelGGL(wino3x3_kernel, dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(wino3x3_kernel<false>, dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
 
+}  // namespace suo
+
+namespace suo {
+// conv2 (3x3, 128 -> 128, Winograd) + ReLU -> conv3 (1x1, 128 -> 256) + bias + skip in one launch
+int launch_conv3x3_wino_fused(const ConvArgs& a, hipStream_t s) {
+    if (a.OH != a.H || a.OW != a.W || a.N != 128 || a.C != 128 || a.N2 != 256 || !a.W3p || !a.bias3 || !a.R || !a.out2) {
+        suo_set_error("conv3x3_wino_fused: unsupported shape C=%d N=%d N2=%d", a.C, a.N, a.N2);
+        return SUO_ERR_ARG;
+    }
+    const int tiles = ((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
+    hipLaunchKernelGGL(wino3x3_kernel<true>, dim3(tiles), dim3(256), 0, s, a);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
 }  // namespace suo

@@ -68,6 +68,7 @@ bool conv3x3_fusable(const ConvArgs& a);
 // Winograd F(2x2,3x3) form (csrc/conv_wino.hip): weights packed by pack_wino_weight (16 floats per (n, c))
 void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float* out_scale, float* out);
 int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_wino_fused(const ConvArgs& a, hipStream_t s);
 bool conv3x3_wino_pays(const ConvArgs& a);             // enough 8 x 16-pixel tiles to fill the chip (measured: >= 256)
 int launch_conv3x3_fused(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_small(const ConvArgs& a, hipStream_t s);

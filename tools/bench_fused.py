@@ -54,6 +54,21 @@ def t(f, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+packed = np.empty(16 * 128 * 128, np.float32)
+lib.suo_pack_wino_weight(np.ascontiguousarray(w2).ctypes.data, 128, 128, 128, 128, packed.ctypes.data)
+wq2 = ops.dev(packed)
+
+
+def wino():
+    lib.suo_conv3x3_wino(P(x), L, H, W, 128, P(wq2), P(b2), P(mid), 128, 1, s)
+
+
+def wino_fused():
+    _lib.check(lib.suo_conv3x3_wino_conv1x1_skip(P(x), L, H, W, P(wq2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "wino fused")
+
+
+tw, twf = t(wino), t(wino_fused)
+print(f"L={L} {H}x{W}: winograd 3x3 {tw:.1f} us, + separate 1x1 = {tw:.1f} + gemm;  winograd fused tail {twf:.1f} us ({(2.0 * L * H * W * 128 * (128 * 9 + 256)) / twf / 1e6:.1f} TF algorithmic)")
 tc, tg, tf = t(conv), t(gemm), t(fused)
 f2, f3 = 2.0 * M * 128 * 128 * 9, 2.0 * M * 128 * 256
 print(f"L={L} {H}x{W}: conv3x3 {tc:.1f} us ({f2 / tc / 1e6:.1f} TF)  conv1x1+skip {tg:.1f} us ({f3 / tg / 1e6:.1f} TF)  sum {tc + tg:.1f} us | "
