@@ -38,6 +38,19 @@ GFLOP_PER_CROP = 31.495          # conv FLOPs, hook-counted on the reference mod
 # channels are structural zeros and their MACs are never issued (csrc/net.hip: stem_img_): 2*128*128*64*49*41 per crop.
 GFLOP_SKIPPED_PER_CROP = 2 * 128 * 128 * 64 * 49 * 41 / 1e9
 FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def winograd_saved_gflop_per_crop(crops_per_call):
+    """MACs the Winograd F(2x2,3x3) form does not execute (csrc/conv_wino.hip): the 128 -> 128 3x3 convolution of a Residual block runs
+    in that form when its launch has >= 256 tiles of 8 x 16 pixels (conv3x3_wino_pays), at 16 instead of 36 products per 2x2 tile.
+    Such convolutions per crop (hg.py:7-58, 2 stacks): 9 at 64x64 (r5, up1 and the post-hourglass blocks), 12 at 32x32, 12 at 16x16,
+    12 at 8x8."""
+    saved = 0.0
+    for hw, count in ((64, 9), (32, 12), (16, 12), (8, 12)):
+        tiles = crops_per_call * (hw // 8) * max(hw // 16, 1)
+        if hw >= 16 and tiles >= 256:
+            saved += count * 2.0 * hw * hw * 128 * 128 * 9 * (1 - 1 / 2.25) / 1e9
+    return saved
 N_OBJ = 8
 
 
@@ -222,9 +235,12 @@ def pack_gemm(w, Np, Kp):
 
 
 def conv_roofline(L, iters=30):
-    """Live HIP-event timing of the dominant kernel at the launch shape of the timed region: the fused tail of a Residual block
-    at 64x64 -- conv2 (3x3, 128 -> 128) + ReLU, conv3 (1x1, 128 -> 256) + skip in ONE launch, convk_kernel<3,1,32,8,16,2,2,2,2,true>
-    (8 launches per network call, ~38 % of its kernel time; the plain 3x3 kernel of the same tile shape is reported beside it)."""
+    """Live HIP-event timing of the dominant kernel at the launch shape of the timed region: the tail of a 256 -> 256 Residual block
+    at 64x64 in ONE launch -- conv2 (3x3, 128 -> 128, Winograd F(2x2,3x3)) + ReLU, conv3 (1x1, 128 -> 256) + skip:
+    wino3x3_kernel<true> (8 launches per network call, ~35 % of its kernel time).  `achieved` counts the ALGORITHMIC FLOPs of the
+    two convolutions (2 MACs x 9 taps for the 3x3, as SURVEY.md 8d counts the network's 31.495 GFLOP per crop); the Winograd form
+    EXECUTES 2.25x fewer MACs for the 3x3 part, so `frac` can exceed 1 -- the executed MFMA rate is reported beside it, and the
+    direct-form kernels (fused and plain 3x3) of the same tile shape are timed in the same process."""
     import torch
     from suo_slam_amd import _lib
     rng = np.random.default_rng(0)
@@ -232,6 +248,10 @@ def conv_roofline(L, iters=30):
     skip = torch.rand((L, 64, 64, 256), device="cuda") - 0.5
     w2 = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
     w3 = (rng.standard_normal((256, 128)) / 11.0).astype(np.float32)
+    lib = _lib.lib()
+    wq = np.empty(16 * 128 * 128, np.float32)
+    _lib.check(lib.suo_pack_wino_weight(np.ascontiguousarray(w2).ctypes.data, 128, 128, 128, 128, wq.ctypes.data), "pack_wino")
+    wq2 = torch.from_numpy(wq).cuda()
     wp2 = torch.from_numpy(pack_conv(w2, 128, 128, 32)).cuda()
     wp3 = torch.from_numpy(pack_gemm(w3, 256, 128)).cuda()
     b2 = torch.zeros(128, device="cuda")
@@ -240,13 +260,18 @@ def conv_roofline(L, iters=30):
     out = torch.empty((L, 64, 64, 256), device="cuda")
     st = torch.cuda.current_stream()
     s = C.c_void_p(st.cuda_stream)
-    lib = _lib.lib()
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
-    def fused():
+    def wino_fused():
+        _lib.check(lib.suo_conv3x3_wino_conv1x1_skip(P(x), L, 64, 64, P(wq2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "suo_conv3x3_wino_conv1x1_skip")
+
+    def wino_plain():
+        _lib.check(lib.suo_conv3x3_wino(P(x), L, 64, 64, 128, P(wq2), P(b2), P(mid), 128, 1, s), "suo_conv3x3_wino")
+
+    def direct_fused():
         _lib.check(lib.suo_conv3x3_conv1x1_skip(P(x), L, 64, 64, P(wp2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "suo_conv3x3_conv1x1_skip")
 
-    def plain():
+    def direct_plain():
         _lib.check(lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp2), P(b2), P(mid), 128, 1, s), "suo_conv_kxk")
 
     def timed(f):
@@ -259,26 +284,33 @@ def conv_roofline(L, iters=30):
         e1.record(st)
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e3 / iters
-    us, us_plain = timed(fused), timed(plain)
+    us, us_wp, us_df, us_dp = timed(wino_fused), timed(wino_plain), timed(direct_fused), timed(direct_plain)
     px = float(L) * 64 * 64
-    flop_plain = 2.0 * px * 128 * 128 * 9
-    flop = flop_plain + 2.0 * px * 128 * 256
+    flop3, flop1 = 2.0 * px * 128 * 128 * 9, 2.0 * px * 128 * 256
+    flop = flop3 + flop1
+    flop_exec = flop3 / 2.25 + flop1                               # 16 products per 2x2 tile and channel pair instead of 36
     ach = flop / (us * 1e-6) / 1e12
+    tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2)  # noqa: E731
     # HBM traffic per launch: rocprofv3 --pmc passes of this same kernel / launch shape (FETCH_SIZE doubled as the
     # microarch guide prescribes for gfx950, WRITE_SIZE as reported), collected by tools/profile_round.sh, stored under profiles/
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_dominant_conv.json")
     if os.path.exists(pmc):
         rec = json.load(open(pmc))
-        if rec.get("crops_per_launch") == L and rec.get("kernel", "").endswith("true>"):
+        if rec.get("crops_per_launch") == L and rec.get("kernel", "").startswith("wino3x3_kernel<true>"):
             traffic = rec.get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "convk_kernel<3,1,32,8,16,2,2,2,2,true> fused Residual tail: 3x3 128->128 + ReLU, 1x1 128->256 + skip @64x64, "
+    return {"bound": "mfma", "kernel": "wino3x3_kernel<true> fused Residual tail: 3x3 128->128 (Winograd F(2x2,3x3)) + ReLU, 1x1 128->256 + skip @64x64, "
                                        "%d crops/launch" % L,
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4),
             "traffic": traffic, "avg_launch_us": round(us, 2), "flop_per_launch": flop,
-            "algorithmic_bytes_per_launch": 4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 9 + 128 * 256),
-            "plain_3x3_kernel": {"kernel": "convk_kernel<3,1,32,8,16,2,2,2,2,false>", "avg_launch_us": round(us_plain, 2),
-                                 "achieved": round(flop_plain / (us_plain * 1e-6) / 1e12, 2), "frac": round(flop_plain / (us_plain * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
+            "algorithmic_bytes_per_launch": 4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 16 + 128 * 256),
+            "executed_flop_per_launch": flop_exec, "executed_tflops": tf(flop_exec, us), "executed_frac_of_mfma_peak": round(tf(flop_exec, us) / FP32_MFMA_PEAK_TF, 4),
+            "same_process": {"wino3x3_kernel<false> (3x3 alone)": {"avg_launch_us": round(us_wp, 2), "algorithmic_tflops": tf(flop3, us_wp),
+                                                                     "executed_frac_of_mfma_peak": round(tf(flop3 / 2.25, us_wp) / FP32_MFMA_PEAK_TF, 4)},
+                             "convk_kernel<3,1,32,8,16,2,2,2,2,true> (direct, fused tail)": {"avg_launch_us": round(us_df, 2), "tflops": tf(flop, us_df),
+                                                                                            "frac": round(tf(flop, us_df) / FP32_MFMA_PEAK_TF, 4)},
+                             "convk_kernel<3,1,32,8,16,2,2,2,2,false> (direct 3x3 alone)": {"avg_launch_us": round(us_dp, 2), "tflops": tf(flop3, us_dp),
+                                                                                           "frac": round(tf(flop3, us_dp) / FP32_MFMA_PEAK_TF, 4)}}}
 
 
 def cpu_baseline(pool, L):
@@ -412,7 +444,7 @@ def main():
     if rank == 0:
         frames = world * args.steps * F
         fps = frames / dt
-        exec_gflop = GFLOP_PER_CROP - GFLOP_SKIPPED_PER_CROP
+        exec_gflop = GFLOP_PER_CROP - GFLOP_SKIPPED_PER_CROP - winograd_saved_gflop_per_crop(L * F)
         line = {
             "metric": "frames/sec (obj-crops/sec) YCB-V 640x480 8-obj; ADD(-S) vs ref",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -428,8 +460,9 @@ def main():
                                           "give meaningless keypoints); the network's uv/cov/masks are read back and awaited first",
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "cnn_tflops_algorithmic": round(fps * L * GFLOP_PER_CROP / 1e3, 2),           # reference-counted FLOPs per crop x crops/s
-            "cnn_tflops_executed": round(fps * L * exec_gflop / 1e3, 2),                  # zero-prior MACs not issued
+            "cnn_tflops_executed": round(fps * L * exec_gflop / 1e3, 2),                  # zero-prior MACs not issued, Winograd 3x3 at 16/36
             "cnn_executed_frac_of_fp32_mfma_peak": round(fps / world * L * exec_gflop / 1e3 / FP32_MFMA_PEAK_TF, 4),
+            "cnn_algorithmic_frac_of_fp32_mfma_peak": round(fps / world * L * GFLOP_PER_CROP / 1e3 / FP32_MFMA_PEAK_TF, 4),
             "pose_check": {"mean_rel_translation_err": round(pose_err / max(n_pose, 1), 5), "poses": int(n_pose), "inlier_edges": int(n_inl),
                            "network_keypoints_read_back": int(n_net_kp)},
         }

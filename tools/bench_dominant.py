@@ -1,5 +1,5 @@
-"""Run only the dominant kernel (the fused Residual tail, 3x3 128->128 + 1x1 128->256 + skip @64x64) and, beside it, the plain 3x3
-kernel of the same tile shape, N times each: target for rocprofv3 --kernel-trace / --pmc passes."""
+"""Run only the dominant kernel (the fused Residual tail in Winograd form, 3x3 128->128 + 1x1 128->256 + skip @64x64) and, beside it,
+the Winograd 3x3 alone and the two direct-form kernels of the same tile shape, N times each: target for rocprofv3 --kernel-trace / --pmc."""
 import os
 import sys
 

@@ -14,12 +14,12 @@ tail -1 $SRC/bench_line.json > profiles/${P}_bench_line.json
   cat $SRC/bench_kernel_stats.txt
 } > profiles/${P}_bench_kernel_stats_final.txt
 {
-  echo "# rocprofv3 --kernel-trace -- python3 tools/bench_dominant.py 30 128   (the dominant kernel (fused tail) and the plain 3x3 kernel alone at the bench launch shape: 128 crops; tools/profile_round.sh $TAG)"
+  echo "# rocprofv3 --kernel-trace -- python3 tools/bench_dominant.py 30 128   (the dominant kernel (Winograd fused tail), the Winograd 3x3 alone and the two direct-form kernels at the bench launch shape: 128 crops; tools/profile_round.sh $TAG)"
   cat $SRC/dominant_kernel_stats.txt
 } > profiles/${P}_dominant_kernel_stats.txt
 {
   echo "# rocprofv3 --pmc <counter group> --kernel-trace -- python3 tools/bench_dominant.py 20 128   (tools/profile_round.sh $TAG; one pass per counter group)"
-  echo "# dominant kernel: fused Residual tail convk_kernel<3,1,32,8,16,2,2,2,2,true> (3x3 128->128 + ReLU, 1x1 128->256 + skip) @64x64, 128 crops per launch"
+  echo "# dominant kernel: fused Residual tail wino3x3_kernel<true> (3x3 128->128 in Winograd F(2x2,3x3) form + ReLU, 1x1 128->256 + skip) @64x64, 128 crops per launch"
   echo "# FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as reported"
   cat $SRC/pmc.txt
 } > profiles/${P}_pmc_dominant_conv.txt
