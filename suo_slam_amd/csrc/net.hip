@@ -378,7 +378,10 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     const int C = 256;
     const size_t n_hi = (size_t)L * H * W * C, n_lo = n_hi / 4;
     static const bool serial = getenv("SUO_SERIAL") != nullptr;     // profiling aid: one stream, kernels back to back
-    hipStream_t side = serial ? s : side_[depth_idx % kNumSide];
+    static const int n_side = getenv("SUO_NET_SIDE_STREAMS") ? std::max(1, std::min(kNumSide, atoi(getenv("SUO_NET_SIDE_STREAMS")))) : 2;
+    // (two side streams: with four, the streams of two networks in flight + the geometry stream oversubscribe the 4 hardware queues and
+    //  a frame's PnP / LM launches queue behind -- or ahead of -- network kernels: one frame per call 338 -> 361 frames/s, throughput mode unchanged)
+    hipStream_t side = serial ? s : side_[depth_idx % n_side];
     hipEvent_t ev_fork = ev_[(ev_next_++) % kNumEvents], ev_join = ev_[(ev_next_++) % kNumEvents];
     float* up_a = alloc(n_hi);
     float* up_b = alloc(n_hi);
