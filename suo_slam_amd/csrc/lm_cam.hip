@@ -15,11 +15,7 @@
 
 namespace suo {
 
-DEV double wave_sum_all(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+DEV double wave_sum_all(double v) { return wsum(v); }        // DPP + readlane form (csrc/lm_device.h)
 
 __global__ __launch_bounds__(64) void lm_cam_kernel(const LmProblem* __restrict__ problems) {
     const LmProblem& P = problems[blockIdx.x];

@@ -114,10 +114,27 @@ DEV double huber_rho(double e2, double delta, double& rho1) {
     return 2 * sq * delta - dsqr;
 }
 
+// Wave-wide sum, the same value in every lane.  Inside a row of 16 lanes the partners are reached by DPP register moves (quad
+// permutes for lane ^ 1 and lane ^ 2, then the half-row and row mirrors), the four row sums are read with v_readlane and added in
+// row order: no LDS crossbar round trips.  (__shfl_xor on a double is two ds_bpermute_b32 per step, ~120 cycles of dependent latency
+// each: six steps x 27 sums were 43 % of an LM iteration of the frame kernel, csrc/lm_frame.hip.)
+template <int CTRL>
+DEV double dpp_get(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 DEV double wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_get<0xB1>(v);            // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_get<0x4E>(v);            // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_get<0x141>(v);           // row_half_mirror: the other quad of the half row
+    v += dpp_get<0x140>(v);           // row_mirror: the other half row -> every lane of a row holds the row sum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return ((r0 + r1) + r2) + r3;
 }
 
 // deterministic workgroup sum / max (fixed order); `red` = LM_THREADS/64 doubles of LDS

@@ -57,18 +57,11 @@ DEV double lf_chi2(const LfEdge& E, const double* er) {
     return er[0] * (E.info[0] * er[0] + E.info[1] * er[1]) + er[1] * (E.info[1] * er[0] + E.info[2] * er[1]);
 }
 
-// all-reduce of N doubles per lane: step-major, so the N cross-lane exchanges of a step are in flight together (a value-major
-// loop of wsum() chains 6 dependent ds_bpermute round trips per value: 27 values took 20k cycles, 43 % of an LM iteration)
+// all-reduce of N doubles per lane (DPP + readlane sums of csrc/lm_device.h: no LDS crossbar round trips)
 template <int N>
 DEV void wsum_many(double* v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double t[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) t[k] = __shfl_xor(v[k], o, 64);
-#pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += t[k];
-    }
+    for (int k = 0; k < N; ++k) v[k] = wsum(v[k]);
 }
 
 template <int MAXW>
