@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--only", choices=["all", "cnn", "geometry"], default="all", help="diagnostic: run only one half of the step")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the one-frame-per-call measurement reported as config.latency_mode_fps")
     ap.add_argument("--no-global-ba-leg", action="store_true", help="skip the (multi-GPU) global pose-graph adjustment reported as global_ba")
+    ap.add_argument("--legs-timeout", type=int, default=420, help="seconds the legs after the timed region may take before the line is printed without them")
     return ap.parse_args()
 
 
@@ -347,7 +348,27 @@ def cpu_baseline(pool, L):
                        B["edge_uv"], B["edge_info"], B["edge_inlier"])
             n_geo += 1
     t_geo = (time.perf_counter() - t0) / n_geo
-    return {"value": round(1.0 / (t_cnn + t_geo), 4), "unit": "frames/s", "cores": n, "kind": "port",
+    # pose parity of the HIP geometry against this oracle on identical inputs (same sampler seeds): a sample of the pool
+    from suo_slam_amd import ba, lambdatwist
+    dT = dR = 0.0
+    n_cmp = min(8, len(pool))
+    for k in range(n_cmp):
+        fr = pool[k]
+        T, status = lambdatwist.pnp_batch(fr["pnp_xs"], fr["pnp_ys"], 1e-3, seed=k)
+        init = []
+        for o in range(L):
+            To, _, _ = G.pnp(fr["pnp_xs"][o], fr["pnp_ys"][o], 1e-3, seed=(k + o * lambdatwist.SEED_STRIDE) % 2 ** 64)
+            dT = max(dT, float(np.abs(T[o] - To).max()))
+            init.append(To[:3])
+        B = fr["ba"]
+        a = (B["cam_T"], B["cam_fixed"], np.array(init), B["obj_fixed"], B["edge_cam"], B["edge_obj"], B["edge_camk"], B["edge_p"], B["edge_uv"],
+             B["edge_info"], B["edge_inlier"])
+        got, ref = ba.optimize(*a), G.optimize(*a)
+        assert np.array_equal(got[2], ref[2]), "HIP and oracle disagree on the inlier flags"
+        dR = max(dR, float(np.abs(got[1][:, :, :3] - ref[1][:, :, :3]).max()))
+        dT = max(dT, float((np.abs(got[1][:, :, 3] - ref[1][:, :, 3]) / np.abs(ref[1][:, :, 3]).max()).max()))
+    parity = {"frames": n_cmp, "objects": n_cmp * L, "max_abs_dR_entry": float(f"{dR:.3e}"), "max_rel_dt": float(f"{dT:.3e}"), "inlier_flags": "identical"}
+    return {"pose_parity_vs_oracle": parity, "value": round(1.0 / (t_cnn + t_geo), 4), "unit": "frames/s", "cores": n, "kind": "port",
             "sample": f"{n_cnn} frames x {L} crops through the torch-CPU CNN oracle ({n} threads, {t_cnn * 1e3:.0f} ms/frame) + "
                       f"{n_geo} frames through the C PnP/LM oracle (1 thread, {t_geo * 1e3:.2f} ms/frame)"}
 
@@ -395,6 +416,8 @@ def global_ba_leg(world, L, n_cam_per_rank=32, reps=3):
 
 def main():
     args = parse()
+    import faulthandler
+    faulthandler.dump_traceback_later(1500, exit=True)        # a hung run leaves with every thread's stack instead of holding the box
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -439,12 +462,11 @@ def main():
     from suo_slam_amd import sharding
     dt, (pose_err, n_pose, n_inl, n_net_kp) = sharding.reduce_metrics(dt, [pipe.pose_err, pipe.n_pose, pipe.n_inl, pipe.n_net_kp],
                                                                       device="cuda" if os.environ.get("SUO_DIST_BACKEND", "nccl") == "nccl" else "cpu")
-    gba = None
-    if not args.no_global_ba_leg and args.only == "all":
-        try:                                    # after the timed region; never part of `value`
-            gba = global_ba_leg(world, 16)
-        except Exception as e:                  # reported, not fatal: the frame-path line must survive
-            gba = {"error": repr(e)[:300]}
+    # ---- the line: built from the timed region first, then extended by the legs that run AFTER it (roofline, global BA,
+    # latency mode, cpu baseline).  A watchdog prints what exists and leaves if those legs do not finish in time: they are
+    # reported beside `value`, they must never cost it.
+    import threading
+    line = None
     if rank == 0:
         frames = world * args.steps * F
         fps = frames / dt
@@ -470,15 +492,39 @@ def main():
             "pose_check": {"mean_rel_translation_err": round(pose_err / max(n_pose, 1), 5), "poses": int(n_pose), "inlier_edges": int(n_inl),
                            "network_keypoints_read_back": int(n_net_kp)},
         }
-        line["roofline"] = conv_roofline(L * F)      # the launch shape of the timed region
-        if gba is not None:
+    printed = threading.Lock()
+
+    def emit(extra=None):
+        if not printed.acquire(blocking=False):
+            return
+        if line is not None:
+            if extra:
+                line.update(extra)
+            print(json.dumps(line), flush=True)
+
+    def give_up():
+        emit({"legs_timed_out": "a leg after the timed region (roofline / global_ba / latency / cpu_baseline) did not finish in %d s" % args.legs_timeout})
+        os._exit(0 if line is not None else 3)
+    dog = threading.Timer(args.legs_timeout, give_up)
+    dog.daemon = True
+    dog.start()
+    if not args.no_global_ba_leg and args.only == "all":
+        try:                                    # BASELINE configs[4]'s exchange step, on every rank; never part of `value`
+            gba = global_ba_leg(world, 16)
+        except Exception as e:                  # reported, not fatal: the frame-path line must survive
+            gba = {"error": repr(e)[:300]}
+        if line is not None:
             line["global_ba"] = gba
+    if rank == 0:
+        line["roofline"] = conv_roofline(L * F)      # the launch shape of the timed region
         if world == 1 and args.only == "all":
             if not args.no_latency_leg and F > 1:
                 line["config"]["latency_mode_fps"] = round(latency_leg(L, pool, not args.no_graph), 2)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(pool, L)
-        print(json.dumps(line), flush=True)
+    dog.cancel()
+    emit()
+    faulthandler.cancel_dump_traceback_later()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
