@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test may hold a (GPU) box indefinitely: pytest-timeout is in the image; a stuck test fails after 10 minutes."""
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def cnn_golden():
     import numpy as np
