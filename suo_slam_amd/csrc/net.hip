@@ -275,8 +275,34 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
         make_gemm(b + ".lin_." + std::to_string(i) + ".0", b + ".lin_." + std::to_string(i) + ".1", "", lin_[i]);
         make_gemm(b + ".tmpOut." + std::to_string(i), "", "", head_[i]);
     }
-    // inter-stack re-injection: x + ll_(ll) + tmpOut_(tmpOut)  ==  one dual-operand GEMM + residual
-    make_gemm(b + ".ll_.0", "", b + ".tmpOut_.0", reinject_);
+    // inter-stack re-injection (hg.py:112-117): x + ll_(ll) + tmpOut_(tmpOut(ll)).  tmpOut and tmpOut_ are both plain 1x1
+    // convolutions with nothing between them, so the sum is ONE 256 -> 256 GEMM on ll with
+    //     W' = W_ll + W_tmpOut_ W_tmpOut ,   b' = b_ll + b_tmpOut_ + W_tmpOut_ b_tmpOut      (folded here in fp64, rounded once)
+    // + the residual x: the 41-channel stack-0 heat-maps -- which nothing else reads (only the last stack is returned,
+    // pkpnet.py:103-105) -- are never materialised and the 64 extra K columns of the dual-operand form are not multiplied.
+    {
+        const HostTensor& wl = T(b + ".ll_.0.weight");   const HostTensor& bl = T(b + ".ll_.0.bias");
+        const HostTensor& wt_ = T(b + ".tmpOut_.0.weight"); const HostTensor& bt_ = T(b + ".tmpOut_.0.bias");
+        const HostTensor& wh = T(b + ".tmpOut.0.weight");  const HostTensor& bh = T(b + ".tmpOut.0.bias");
+        const int N = (int)wl.shape[0], K = (int)wl.shape[1], J = (int)wh.shape[0];      // 256, 256, 41
+        if ((int)wt_.shape[0] != N || (int)wt_.shape[1] != J || (int)wh.shape[1] != K) throw std::runtime_error("re-injection convolutions have unexpected shapes");
+        std::vector<float> full((size_t)N * K), bias(N);
+        for (int n = 0; n < N; ++n) {
+            double bb = (double)bl.data[n] + (double)bt_.data[n];
+            for (int j = 0; j < J; ++j) bb += (double)wt_.data[(size_t)n * J + j] * (double)bh.data[j];
+            bias[n] = (float)bb;
+            for (int k = 0; k < K; ++k) {
+                double v = wl.data[(size_t)n * K + k];
+                for (int j = 0; j < J; ++j) v += (double)wt_.data[(size_t)n * J + j] * (double)wh.data[(size_t)j * K + k];
+                full[(size_t)n * K + k] = (float)v;
+            }
+        }
+        std::vector<float> packed(2 * (size_t)N * K);
+        pack_gemm_weight(full.data(), N, K, K, N, K, packed.data());
+        reinject_.Wp = upload(packed);
+        reinject_.bias = upload(bias);
+        reinject_.N = N; reinject_.n_valid = N; reinject_.K1 = K; reinject_.K2 = 0;
+    }
     {
         const HostTensor& w = T("classifier.2.weight");
         const HostTensor& bb = T("classifier.2.bias");
@@ -448,13 +474,10 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         GemmArgs gh = {};
         gh.A1 = ll; gh.lda1 = 256; gh.K1 = 256; gh.Wp = head_[i].Wp; gh.bias = head_[i].bias; gh.M = M; gh.N = 64;
         if (i == 0) {
-            // stack-0 head feeds tmpOut_: keep it NHWC, 41 channels padded to 64 (pad columns are exact zeros)
-            float* t0 = alloc((size_t)M * 64);
-            gh.out = t0; gh.ldo = 64; gh.n_valid = 64;
-            SUO_LAUNCH(launch_gemm1x1(gh, s));
+            // x <- x + ll_(ll) + tmpOut_(tmpOut(ll)) as one folded GEMM + residual (see the constructor)
             float* xn = alloc((size_t)M * 256);
             GemmArgs gr = {};
-            gr.A1 = ll; gr.lda1 = 256; gr.K1 = 256; gr.A2 = t0; gr.lda2 = 64; gr.K2 = reinject_.K2;
+            gr.A1 = ll; gr.lda1 = 256; gr.K1 = 256;
             gr.Wp = reinject_.Wp; gr.bias = reinject_.bias; gr.R = x; gr.ldr = 256; gr.out = xn; gr.ldo = 256;
             gr.M = M; gr.N = 256; gr.n_valid = 256;
             SUO_LAUNCH(launch_gemm1x1(gr, s));
