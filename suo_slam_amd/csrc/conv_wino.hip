@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = buf_load(w3_srd, w3voff, (kg * NB2 + nb0 + j) * 1024);
         };
-        constexpr int R3 = 4;
+        constexpr int R3 = 2;      // (a 4-slot ring spills 20 registers in this tail: out + acc2 are 128 of the 256)
         w_f32x4 b3[R3][2];
 #pragma unroll
         for (int r = 0; r < R3 - 1; ++r) b3load(r, b3[r]);

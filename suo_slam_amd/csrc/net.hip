@@ -376,10 +376,10 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     }
     if (wino) {
         c2.Wp = r.c2.Wq;
-        static const long fuse_tiles = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : 2048;      // (0: never)
+        static const long fuse_tiles = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : 256;       // (0: never)
         const long tiles = (long)((W + 15) / 16) * ((H + 7) / 8) * L;
         if (fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256) {
-            // conv2 -> conv3 + skip in one launch (1003 vs 701 + 346 us at 64x64 / 128 crops; no gain at 1024 tiles)
+            // conv2 -> conv3 + skip in one launch (933 vs 713 + 346 us at 64x64 / 128 crops, 257 vs 195 + 91 at 32x32)
             c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256;
             SUO_LAUNCH(launch_conv3x3_wino_fused(c2, s));
             return SUO_OK;
