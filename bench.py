@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark of the suo_slam hot path on MI355X (contract: see the task statement).
 
-One STEP = one network call over `--frames-per-step` (16) consecutive synthetic YCB-V-shaped frames (640x480 uint8,
-8 object boxes each = 128 crops) through the whole per-frame path of BASELINE.json configs[1] (single-view eval, no SLAM):
+One STEP = one network call over `--frames-per-step` (32) consecutive synthetic YCB-V-shaped frames (640x480 uint8,
+8 object boxes each = 256 crops) through the whole per-frame path of BASELINE.json configs[1] (single-view eval, no SLAM):
     RoI crop + prior concat -> stacked-hourglass keypoint CNN (fp32 MFMA) -> heat-map decode -> validity masks
     -> D2H of uv / cov / masks (lib/object_slam.py:1100-1109) -> [the step's geometry waits for that read-back]
     -> batched P3P-RANSAC PnP (all objects of the step in one launch) -> uncertainty-weighted LM, rounds [10,10,40,40].
@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pool", type=int, default=0, help="number of distinct synthetic frames cycled through (0 = 2 steps' worth)")
     ap.add_argument("--depth", type=int, default=2, help="network calls in flight (independent network instances / streams)")
-    ap.add_argument("--frames-per-step", "--frames-per-forward", dest="frames_per_step", type=int, default=16,
+    ap.add_argument("--frames-per-step", "--frames-per-forward", dest="frames_per_step", type=int, default=32,
                     help="frames of the stream batched into one network call = one step (--objects crops each)")
     ap.add_argument("--only", choices=["all", "cnn", "geometry"], default="all", help="diagnostic: run only one half of the step")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the one-frame-per-call measurement reported as config.latency_mode_fps")

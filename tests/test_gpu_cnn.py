@@ -443,25 +443,27 @@ def test_forward_with_prior_keypoints_equals_dense_priors(ops, state_dict):
     net.close()
 
 
-def test_bench_launch_shape_16_frames_128_crops(ops, state_dict):
-    """The launch shape of bench.py (BASELINE configs[1] batched 16 frames per call = 128 crops; 1.6 GB staged input,
-    21 GB workspace) through size-independent properties: frames 4..15 repeat frames 0..3, so their crops must come out
-    BIT-identical to their originals (every crop is computed by the same code path wherever it sits in the launch --
-    this catches index overflow and tile-walk errors at full size), and the first frame agrees with a call of its own."""
+@pytest.mark.parametrize("reps", [4, 8])
+def test_bench_launch_shape_frames_batched_per_call(ops, state_dict, reps):
+    """The launch shapes of bench.py (BASELINE configs[1] batched 32 frames per call = 256 crops: 3.2 GB staged input, 43 GB
+    workspace; 16 frames = 128 crops for the shorter runs) through size-independent properties: the frames repeat frames 0..3,
+    so their crops must come out BIT-identical to their originals (every crop is computed by the same code path wherever it sits
+    in the launch -- this catches index overflow and tile-walk errors at full size), and the first frame agrees with a call of
+    its own."""
     from suo_slam_amd.pkpnet import PkpNet
     rng = np.random.default_rng(77)
     base = (rng.uniform(0, 1, (4, 480, 640, 3)) * 255).astype(np.uint8)
-    imgs = np.concatenate([base] * 4)
+    imgs = np.concatenate([base] * reps)
     bx4 = [np.column_stack([x1 := rng.uniform(0, 400, 8), y1 := rng.uniform(0, 240, 8), x1 + rng.uniform(60, 240, 8), y1 + rng.uniform(60, 240, 8)]).astype(np.float32)
            for _ in range(4)]
-    boxes = bx4 * 4
-    net = PkpNet(state_dict=state_dict, max_crops=128)
+    boxes = bx4 * reps
+    net = PkpNet(state_dict=state_dict, max_crops=32 * reps)
     out = net.forward_frames(imgs, boxes)
-    assert out["prob_logits"].shape == (128, 41, 64, 64)
+    assert out["prob_logits"].shape == (32 * reps, 41, 64, 64)
     assert torch.isfinite(out["prob_logits"]).all()
     for key in ("prob_logits", "uv", "cov", "kp_mask"):
-        v = out[key].reshape(4, 32, *out[key].shape[1:])
-        for rep in range(1, 4):
+        v = out[key].reshape(reps, 32, *out[key].shape[1:])
+        for rep in range(1, reps):
             assert torch.equal(v[rep], v[0]), (key, rep)
     one = net(base[0], [torch.from_numpy(bx4[0])], None)
     lg = one["prob_logits"]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel serial timings of the bench's network calls (no side streams, no graph, one forward in flight):
 #   tools/profile_bench_serial.sh [frames_per_forward]
-F=${1:-16}
+F=${1:-32}
 cd /tmp && export TMPDIR=/tmp
 export SUO_SERIAL=1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/bench_serial_F$F
