@@ -41,17 +41,16 @@ FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip t
 
 
 def winograd_saved_gflop_per_crop(crops_per_call):
-    """MACs the Winograd F(2x2,3x3) form does not execute (csrc/conv_wino.hip): the 128 -> 128 3x3 convolution of a Residual block runs
-    in that form when its launch has >= 256 tiles of 8 x 16 pixels (conv3x3_wino_pays), at 16 instead of 36 products per 2x2 tile.
-    Such convolutions per crop (hg.py:7-58, 2 stacks): 9 at 64x64 (r5, up1 and the post-hourglass blocks), 12 at 32x32, 12 at 16x16,
-    12 at 8x8."""
+    """MACs the Winograd F(2x2,3x3) form does not execute (csrc/conv_wino.hip): the 3x3 convolution of a Residual block (128 -> 128,
+    or 64 -> 64 in r1 / r4) runs in that form when its launch has >= 256 tiles of 8 x 16 pixels (conv3x3_wino_pays), at 16 instead
+    of 36 products per 2x2 tile.  Such convolutions per crop (hg.py:7-58, 2 stacks): 128 channels -- 9 at 64x64 (r5, up1 and the
+    post-hourglass blocks), 12 at 32x32, 12 at 16x16; 64 channels -- r1 at 128x128, r4 at 64x64."""
     saved = 0.0
-    for hw, count in ((64, 9), (32, 12), (16, 12), (8, 12)):
-        tiles = crops_per_call * (hw // 8) * max(hw // 16, 1)
-        if hw >= 16 and tiles >= 256:
-            saved += count * 2.0 * hw * hw * 128 * 128 * 9 * (1 - 1 / 2.25) / 1e9
+    for hw, count, ch in ((64, 9, 128), (32, 12, 128), (16, 12, 128), (128, 1, 64), (64, 1, 64)):
+        tiles = crops_per_call * (hw // 8) * (hw // 16)
+        if tiles >= 256:
+            saved += count * 2.0 * hw * hw * ch * ch * 9 * (1 - 1 / 2.25) / 1e9
     return saved
-N_OBJ = 8
 
 
 def parse():

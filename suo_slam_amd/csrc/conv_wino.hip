@@ -54,7 +54,9 @@ void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float*
     (void)nch;
 }
 
-template <bool FUSE>
+// NT = output channels / 32: 4 (128 channels: wave w owns n-tile w and all 16 components) or 2 (64 channels: wave (wc, wn) owns
+// n-tile wn and the 8 components [8 wc, 8 wc + 8); the two partial sums are exchanged through LDS before the epilogue).
+template <bool FUSE, int NT = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float Hin[2][W_NPIX * W_PKH];
     __shared__ __attribute__((aligned(16))) float V[16 * 32 * W_PKV];
@@ -99,7 +101,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         }
     };
     // ---- weights: Up[gg][nb][lane][4], gg = (chunk * 16 + comp) * 2 + s; wave w owns n-tile w ---------------------------
-    const int wvoff = (w * 64 + lane) * 16;
+    static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
+    const int wn = NT == 4 ? w : (w & 1), wc = NT == 4 ? 0 : (w >> 1);      // n-tile, component half
+    constexpr int NPAIR = NT == 4 ? 8 : 4, KSEQ = NPAIR * 4;                 // component pairs / weight groups per chunk and wave
+    const int wvoff = (wn * 64 + lane) * 16;
     const int gtot = nch * 32;
     w_f32x4 bring[W_RING];
     auto bload = [&](int gg, w_f32x4& b) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 
     gload(0);
 #pragma unroll
-    for (int r = 0; r < W_RING - 2; ++r) bload(((r >> 2) * 2 + (r & 1)) * 2 + ((r >> 1) & 1), bring[r]);      // consumption order, see below
+    for (int r = 0; r < W_RING - 2; ++r) bload((wc * 8 + (r >> 2) * 2 + (r & 1)) * 2 + ((r >> 1) & 1), bring[r]);      // consumption order, see below
     sstore(0);
     __syncthreads();
 
@@ -194,20 +199,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 }
         };
         auto seq_gg = [&](int k) -> int {                         // consumption index (may run into the next chunk) -> packed group
-            const int cc = c + (k >> 5), kk = k & 31;
-            const int comp = (kk >> 2) * 2 + (kk & 1), sg = (kk >> 1) & 1;
+            const int cc = c + k / KSEQ, kk = k % KSEQ;
+            const int comp = wc * 8 + (kk >> 2) * 2 + (kk & 1), sg = (kk >> 1) & 1;
             return cc * 32 + comp * 2 + sg;
         };
 #pragma unroll
-        for (int pair = 0; pair < 8; ++pair) {
+        for (int pair = 0; pair < NPAIR; ++pair) {
             w_f32x16 ta, tb;
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
                 const int k = pair * 4 + sg * 2;
                 bload(seq_gg(k + W_RING - 2), bring[(k + W_RING - 2) % W_RING]);      // the two slots the previous step consumed
                 bload(seq_gg(k + W_RING - 1), bring[(k + W_RING - 1) % W_RING]);
-                const w_f32x4 afa = *(const w_f32x4*)(vs + (2 * pair) * 32 * W_PKV + sg * 8);
-                const w_f32x4 afb = *(const w_f32x4*)(vs + (2 * pair + 1) * 32 * W_PKV + sg * 8);
+                const w_f32x4 afa = *(const w_f32x4*)(vs + (wc * 8 + 2 * pair) * 32 * W_PKV + sg * 8);
+                const w_f32x4 afb = *(const w_f32x4*)(vs + (wc * 8 + 2 * pair + 1) * 32 * W_PKV + sg * 8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -216,8 +221,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            fold(2 * pair, ta);
-            fold(2 * pair + 1, tb);
+            if (NT == 4) { fold(2 * pair, ta); fold(2 * pair + 1, tb); }
+            else if (wc == 0) { fold(2 * pair, ta); fold(2 * pair + 1, tb); }          // (wave-uniform: the signs differ per half)
+            else { fold(8 + 2 * pair, ta); fold(8 + 2 * pair + 1, tb); }
         }
         WPROF(3);
         __syncthreads();
@@ -335,6 +341,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         return;
     }
 
+    if constexpr (NT == 2) {
+        // the two component halves of an n-tile meet: wave (wc, wn) keeps output positions {2 wc, 2 wc + 1} and hands the other two
+        // to its partner through LDS ([position][register][lane]: conflict-free), then both run the epilogue on their positions
+        float* X = &V[0];
+        __syncthreads();                                          // V is free
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[((w * 2 + q) * 16 + r) * 64 + lane] = wc == 0 ? out[2 + q][r] : out[q][r];
+        __syncthreads();
+        const int pw = (1 - wc) * 2 + wn;
+        w_f32x16 mine[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[q][r] = (wc == 0 ? out[q][r] : out[2 + q][r]) + X[((pw * 2 + q) * 16 + r) * 64 + lane];
+        __syncthreads();                                          // the exchange area becomes the transposition patches
+        float* T = &V[0] + w * (32 * 36);
+        const int col = wn * 32 + (lane & 7) * 4;
+        const w_f32x4 bv = *(const w_f32x4*)(a.bias + col);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = 2 * wc + q, pi = p >> 1, pj = p & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[w_acc_row(r, lane) * 36 + (lane & 31)] = mine[q][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = (lane >> 3) + 8 * k;
+                const int oy = oy0 + 2 * (t >> 3) + pi, ox = ox0 + 2 * (t & 7) + pj;
+                w_f32x4 o = *(const w_f32x4*)&T[t * 36 + (lane & 7) * 4] + bv;
+                if (a.relu) {
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) o[z] = fmaxf(o[z], 0.f);
+                }
+                buf_store(o, out_srd, (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N + col) * 4 : BUF_OOB);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+
     // ---- epilogue: per output position (i,j) transpose the 32 tiles x 32 channels through a wave-private patch -> 16-byte stores
     float* T = &V[0] + w * (32 * 36);
     const int col = w * 32 + (lane & 7) * 4;
@@ -366,16 +414,17 @@ bool conv3x3_wino_pays(const ConvArgs& a) {
     static const int on = getenv("SUO_CONV_WINO") ? atoi(getenv("SUO_CONV_WINO")) : 1;                  // 0: A/B against the direct kernels
     static const long min_tiles = getenv("SUO_CONV_WINO_TILES") ? atol(getenv("SUO_CONV_WINO_TILES")) : 256;
     const long tiles = (long)((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
-    return on && a.N == 128 && a.C == 128 && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && tiles >= min_tiles;
+    return on && ((a.N == 128 && a.C == 128) || (a.N == 64 && a.C == 64)) && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && tiles >= min_tiles;
 }
 
 int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
-    if (a.OH != a.H || a.OW != a.W || a.N != 128 || (a.C % W_CK) || a.C <= 0) {
+    if (a.OH != a.H || a.OW != a.W || (a.N != 128 && a.N != 64) || (a.C % W_CK) || a.C <= 0) {
         suo_set_error("conv3x3_wino: unsupported shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
-    hipLaunchKernelGGL(wino3x3_kernel<false>, dim3(tiles), dim3(256), 0, s, a);
+    if (a.N == 64) hipLaunchKernelGGL((wino3x3_kernel<false, 2>), dim3(tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wino3x3_kernel<false, 4>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -390,7 +439,7 @@ int launch_conv3x3_wino_fused(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
-    hipLaunchKernelGGL(wino3x3_kernel<true>, dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wino3x3_kernel<true, 4>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

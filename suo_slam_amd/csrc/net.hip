@@ -179,9 +179,9 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
     c.Wp = upload(packed);
     c.bias = upload(bias);
     c.N = Np; c.C = Cp; c.KS = KS;
-    if (KS == 3 && N == 128 && C == 128 && c_used <= 0) {       // the Residual blocks' 128 -> 128 convolutions: also in Winograd form
-        std::vector<float> wq((size_t)16 * 128 * 128);
-        pack_wino_weight(w.data, 128, 128, 128, 128, scale.empty() ? nullptr : scale.data(), wq.data());
+    if (KS == 3 && N == C && (N == 128 || N == 64) && c_used <= 0) {       // the Residual blocks' 128 -> 128 / 64 -> 64 convolutions: also in Winograd form
+        std::vector<float> wq((size_t)16 * N * C);
+        pack_wino_weight(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), wq.data());
         c.Wq = upload(wq);
     }
 }

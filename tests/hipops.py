@@ -105,7 +105,7 @@ def conv3x3_wino(x_nhwc, w, bias, relu=False):
     """3x3 convolution in Winograd F(2x2,3x3) form: x [L,H,W,C], w [128,C,3,3] -> [L,H,W,128]."""
     L, H, W, C = x_nhwc.shape
     N = w.shape[0]
-    assert N == 128 and C % 16 == 0
+    assert N in (64, 128) and C % 16 == 0
     w = np.ascontiguousarray(w, np.float32)
     packed = np.empty(16 * N * C, np.float32)
     _lib.check(_lib.lib().suo_pack_wino_weight(w.ctypes.data, N, C, N, C, packed.ctypes.data), "pack_wino")

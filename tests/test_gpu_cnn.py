@@ -171,15 +171,16 @@ def test_fused_residual_tail_equals_the_separate_launches(ops, L, H, W):
         assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
 
 
-@pytest.mark.parametrize("L,H,W,C", [(2, 64, 64, 128), (3, 40, 40, 128), (128, 16, 16, 128), (5, 24, 56, 128), (1, 8, 16, 128), (2, 32, 32, 64)])
-def test_conv3x3_winograd(ops, L, H, W, C):
+@pytest.mark.parametrize("L,H,W,C,N", [(2, 64, 64, 128, 128), (3, 40, 40, 128, 128), (128, 16, 16, 128, 128), (5, 24, 56, 128, 128), (1, 8, 16, 128, 128),
+                                        (2, 32, 32, 64, 128), (2, 128, 128, 64, 64), (3, 40, 72, 64, 64), (1, 8, 16, 64, 64), (40, 64, 64, 64, 64)])
+def test_conv3x3_winograd(ops, L, H, W, C, N):
     """3x3 convolution in Winograd F(2x2,3x3) form (csrc/conv_wino.hip): within 5e-6 of the fp64 reference (the direct kernel's
     bound; observed ~3x closer than the direct kernel, which sums 9x more terms per output), ragged and non-square maps, maps
-    of a single tile, per-crop check against stray stores."""
+    of a single tile, the 64 -> 64 form (components split over wave pairs), per-crop check against stray stores."""
     rng = np.random.default_rng(L * H + W)
     x = rng.standard_normal((L, C, H, W)).astype(np.float32)
-    w = (rng.standard_normal((128, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
-    b = rng.standard_normal(128).astype(np.float32)
+    w = (rng.standard_normal((N, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
     out = ops.nchw(ops.conv3x3_wino(ops.nhwc(x), w, b, relu=True))
     ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)).numpy()
     assert _rel(out, ref) < 5e-6
