@@ -53,6 +53,9 @@ def winograd_saved_gflop_per_crop(crops_per_call):
     return saved
 
 
+N_OBJ = 8
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
