@@ -1,0 +1,38 @@
+"""bench.py's command line and bookkeeping, without a GPU: the driver starts it with `--gpus N --steps K --warmup W` and with no
+flags at all; a NameError at import or parse time would cost the round its measurement."""
+import importlib
+import sys
+
+
+def _bench(argv):
+    old = sys.argv
+    sys.argv = ["bench.py"] + argv
+    try:
+        bench = importlib.import_module("bench")
+        return bench, bench.parse()
+    finally:
+        sys.argv = old
+
+
+def test_default_flags():
+    bench, args = _bench([])
+    assert args.gpus == 1 and args.objects == 8 and args.frames_per_step == 32
+    assert args.steps >= 1 and args.warmup >= 0
+
+
+def test_driver_flags():
+    _, args = _bench(["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    assert (args.gpus, args.steps, args.warmup) == (8, 20, 5)
+
+
+def test_winograd_accounting_follows_the_dispatch_threshold():
+    bench, _ = _bench([])
+    # 256 crops: every 128-channel 3x3 at >= 16x16 and both 64-channel ones run in Winograd form (csrc/conv_wino.hip: >= 256 tiles)
+    full = bench.winograd_saved_gflop_per_crop(256)
+    per = lambda hw, ch: 2.0 * hw * hw * ch * ch * 9 * (1 - 16 / 36) / 1e9
+    assert abs(full - (9 * per(64, 128) + 12 * per(32, 128) + 12 * per(16, 128) + per(128, 64) + per(64, 64))) < 1e-9
+    # 8 crops (one frame per call): 64x64 has 8*8*4 = 256 tiles and 128x128 has 1024; 32x32 (64 tiles) and 16x16 do not qualify
+    one = bench.winograd_saved_gflop_per_crop(8)
+    assert abs(one - (9 * per(64, 128) + per(128, 64) + per(64, 64))) < 1e-9
+    assert bench.winograd_saved_gflop_per_crop(1) < one
+    assert bench.GFLOP_PER_CROP - bench.GFLOP_SKIPPED_PER_CROP - full > 0
