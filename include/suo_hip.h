@@ -122,6 +122,9 @@ int suo_conv3x3_conv1x1_skip(const float* in_dev, int L, int H, int W, const flo
 /* The same with the 3x3 convolution in Winograd form (wq2 from suo_pack_wino_weight): what the network launches for its 256 -> 256 blocks */
 int suo_conv3x3_wino_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wq2_dev, const float* bias2_dev, const float* wp3_dev,
                                   const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);
+/* ... and with the Hourglass's "up1 + up2(low3)" (hg.py:56-58) folded in: out += nearest-neighbour 2x up-sampling of up_dev [L,H/2,W/2,256] */
+int suo_conv3x3_wino_conv1x1_skip_up(const float* in_dev, int L, int H, int W, const float* wq2_dev, const float* bias2_dev, const float* wp3_dev,
+                                     const float* bias3_dev, const float* skip_dev, const float* up_dev, float* out_dev, void* stream);
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "suo_pack_wino_weight": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_conv3x3_wino": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP]),
     "suo_conv3x3_wino_conv1x1_skip": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_conv3x3_wino_conv1x1_skip_up": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_conv3x3_conv1x1_skip": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_maxpool2": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_upsample2_add": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),

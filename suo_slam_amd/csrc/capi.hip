@@ -150,12 +150,18 @@ int suo_conv3x3_wino(const float* in, int L, int H, int W, int C, const float* w
     return suo::launch_conv3x3_wino(c, (hipStream_t)stream);
 }
 
-int suo_conv3x3_wino_conv1x1_skip(const float* in, int L, int H, int W, const float* wq2, const float* bias2, const float* wp3, const float* bias3,
-                                  const float* skip, float* out, void* stream) {
+int suo_conv3x3_wino_conv1x1_skip_up(const float* in, int L, int H, int W, const float* wq2, const float* bias2, const float* wp3, const float* bias3,
+                                     const float* skip, const float* up, float* out, void* stream) {
     suo::ConvArgs c = {};
     c.in = in; c.L = L; c.H = H; c.W = W; c.C = 128; c.Wp = wq2; c.bias = bias2; c.out = nullptr; c.OH = H; c.OW = W; c.N = 128; c.relu = 1;
-    c.W3p = wp3; c.bias3 = bias3; c.R = skip; c.out2 = out; c.N2 = 256;
+    c.W3p = wp3; c.bias3 = bias3; c.R = skip; c.out2 = out; c.N2 = 256; c.up = up;
+    if (up && ((H | W) & 1)) { suo_set_error("suo_conv3x3_wino_conv1x1_skip_up: odd map size"); return SUO_ERR_ARG; }
     return suo::launch_conv3x3_wino_fused(c, (hipStream_t)stream);
+}
+
+int suo_conv3x3_wino_conv1x1_skip(const float* in, int L, int H, int W, const float* wq2, const float* bias2, const float* wp3, const float* bias3,
+                                  const float* skip, float* out, void* stream) {
+    return suo_conv3x3_wino_conv1x1_skip_up(in, L, H, W, wq2, bias2, wp3, bias3, skip, nullptr, out, stream);
 }
 
 int suo_conv3x3_conv1x1_skip(const float* in, int L, int H, int W, const float* wp2, const float* bias2, const float* wp3, const float* bias3,

@@ -56,7 +56,7 @@ void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float*
 
 // NT = output channels / 32: 4 (128 channels: wave w owns n-tile w and all 16 components) or 2 (64 channels: wave (wc, wn) owns
 // n-tile wn and the 8 components [8 wc, 8 wc + 8); the two partial sums are exchanged through LDS before the epilogue).
-template <bool FUSE, int NT = 4>
+template <bool FUSE, int NT = 4, bool UP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float Hin[2][W_NPIX * W_PKH];
     __shared__ __attribute__((aligned(16))) float V[16 * 32 * W_PKV];
@@ -247,6 +247,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
         const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
         const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
+        constexpr bool has_up = UP;                               // (its own instantiation: the addend costs 16 registers in this tail)
+        const __amdgpu_buffer_rsrc_t up_srd = make_srd(has_up ? a.up + (size_t)l * (crop2 / 4) : a.R, has_up ? crop2 / 4 * sizeof(float) : 0);
         const float b2v = a.bias[w * 32 + (lane & 31)];
         auto stage = [&](int kc, int buf) {
             if (w == kc) {
@@ -314,20 +316,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                     const int col = p * 128 + (wn * 2 + j) * 32 + (lane & 7) * 4;
                     const w_f32x4 bv = *(const w_f32x4*)(a.bias3 + col);
                     int off[4];
-                    w_f32x4 rv[4];
+                    w_f32x4 rv[4], uv[UP ? 4 : 1];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int pp = (wm * 2 + i) * 32 + (lane >> 3) + 8 * k;
                         const int oy = oy0 + pp / W_TW, ox = ox0 + pp % W_TW;
-                        off[k] = (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
+                        const bool in = oy < a.OH && ox < a.OW;
+                        off[k] = in ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
                         rv[k] = buf_load(r_srd, off[k], 0);
+                        // the Hourglass's "up1 + up2(low3)" (hg.py:56-58) folded into this block's output: + low[oy / 2][ox / 2]
+                        // (added LAST, as the separate up-sample kernel would: the fused block stays bit-identical to the two launches;
+                        //  without an addend the descriptor has zero records and the load returns zeros)
+                        if constexpr (UP) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) T[w_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const w_f32x4 o = (*(const w_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                        w_f32x4 o = (*(const w_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                        if constexpr (UP) o += uv[k];
                         buf_store(o, o2_srd, off[k]);
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -439,7 +447,8 @@ int launch_conv3x3_wino_fused(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
-    hipLaunchKernelGGL((wino3x3_kernel<true, 4>), dim3(tiles), dim3(256), 0, s, a);
+    if (a.up) hipLaunchKernelGGL((wino3x3_kernel<true, 4, true>), dim3(tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wino3x3_kernel<true, 4, false>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

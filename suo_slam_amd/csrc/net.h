@@ -54,7 +54,8 @@ private:
     void make_residual(const std::string& p, ResidualW& r);
     void make_hourglass(const std::string& p, int n, HourglassW& h);
     float* alloc(size_t floats);
-    int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s);
+    int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr);
+    bool residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const;
     int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx);
     int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s);
     int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s);

@@ -356,7 +356,17 @@ float* Net::alloc(size_t floats) {
 #define SUO_HIP_LIVE(x) do { if (!dry_run_) SUO_HIP_CHECK(x); } while (0)
 
 // Residual.forward: three fused launches
-int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s) {
+// true when residual() ends in the fused Winograd tail (the only epilogue that can add an up-sampled tensor)
+bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const {
+    static const long fuse_tiles = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : 256;
+    ConvArgs c2 = {};
+    c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.OH = H; c2.OW = W; c2.N = r.c2.N;
+    const long tiles = (long)((W + 15) / 16) * ((H + 7) / 8) * L;
+    return r.c2.Wq && conv3x3_wino_pays(c2) && fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 &&
+           r.c3.K1 == 128 && r.cin == 256;
+}
+
+int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up) {
     const int M = L * H * W;
     float* mid1 = alloc((size_t)M * r.c1.N);
     float* mid2 = alloc((size_t)M * r.c2.N);
@@ -380,7 +390,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
         const long tiles = (long)((W + 15) / 16) * ((H + 7) / 8) * L;
         if (fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256) {
             // conv2 -> conv3 + skip in one launch (933 vs 713 + 346 us at 64x64 / 128 crops, 257 vs 195 + 91 at 32x32)
-            c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256;
+            c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256; c2.up = up;
             SUO_LAUNCH(launch_conv3x3_wino_fused(c2, s));
             return SUO_OK;
         }
@@ -388,6 +398,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     } else {
         SUO_LAUNCH(launch_conv3x3(c2, s));
     }
+    if (up) { suo_set_error("residual: an up-sampled addend needs the fused Winograd tail"); return SUO_ERR_ARG; }
     GemmArgs g3 = {};
     g3.A1 = mid2; g3.lda1 = r.c2.N; g3.K1 = r.c3.K1;
     if (r.has_skip_conv) { g3.A2 = x; g3.lda2 = r.cin; g3.K2 = r.c3.K2; }
@@ -413,8 +424,13 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     float* up_b = alloc(n_hi);
     SUO_HIP_LIVE(hipEventRecord(ev_fork, s));
     SUO_HIP_LIVE(hipStreamWaitEvent(side, ev_fork, 0));
+    // "up1 + up2(low3)" (hg.py:56-58): when the last up1 block ends in the fused Winograd tail, that tail adds the up-sampled low
+    // branch itself and writes `out` -- no up-sample kernel, no extra pass over the high-resolution tensor.  The block then has to
+    // wait for the low branch; its predecessor still runs beside it on the side stream.
+    static const int fuse_up = getenv("SUO_FUSE_UPSAMPLE") ? atoi(getenv("SUO_FUSE_UPSAMPLE")) : 1;              // 0: A/B
+    const bool up_in_tail = fuse_up && residual_tail_is_fused(h.up1[1], L, H, W);
     SUO_TRY(residual(h.up1[0], x, up_a, L, H, W, side));
-    SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
+    if (!up_in_tail) SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
     SUO_HIP_LIVE(hipEventRecord(ev_join, side));
 
     float* pooled = alloc(n_lo);
@@ -436,7 +452,8 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     SUO_TRY(residual(h.low3[0], low2, l3a, L, H / 2, W / 2, s));
     SUO_TRY(residual(h.low3[1], l3a, l3b, L, H / 2, W / 2, s));
     SUO_HIP_LIVE(hipStreamWaitEvent(s, ev_join, 0));
-    SUO_LAUNCH(launch_upsample2_add(up_b, l3b, out, L, H, W, C, s));
+    if (up_in_tail) SUO_TRY(residual(h.up1[1], up_a, out, L, H, W, s, l3b));
+    else SUO_LAUNCH(launch_upsample2_add(up_b, l3b, out, L, H, W, C, s));
     return SUO_OK;
 }
 

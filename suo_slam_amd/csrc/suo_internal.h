@@ -62,6 +62,7 @@ struct ConvArgs {
     int relu;
     // fused Residual tail (launch_conv3x3_fused only): out2 = W3 relu(conv + bias) + bias3 + R, [L,OH,OW,N2]; `out` is not written
     const float* W3p; const float* bias3; const float* R; float* out2; int N2;
+    const float* up;                                     // optional [L,OH/2,OW/2,N2]: out2 += nearest-neighbour 2x up-sampling of it (hg.py:56-58)
 };
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 bool conv3x3_fusable(const ConvArgs& a);

@@ -131,3 +131,19 @@ def conv3x3_wino_conv1x1_skip(x_nhwc, w2, b2, w3, b3, skip_nhwc):
                "suo_conv3x3_wino_conv1x1_skip")
     torch.cuda.synchronize()
     return out
+
+
+def conv3x3_wino_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc):
+    """The fused Winograd Residual tail with the Hourglass's up-sampled low branch added in its epilogue."""
+    L, H, W, C = x_nhwc.shape
+    w2 = np.ascontiguousarray(w2, np.float32)
+    packed = np.empty(16 * 128 * 128, np.float32)
+    _lib.check(_lib.lib().suo_pack_wino_weight(w2.ctypes.data, 128, 128, 128, 128, packed.ctypes.data), "pack_wino")
+    wq2 = dev(packed)
+    wp3 = dev(pack_gemm(np.ascontiguousarray(w3, np.float32), 256, 128))
+    out = torch.empty((L, H, W, 256), device="cuda")
+    b2d, b3d = dev(b2), dev(b3)
+    _lib.check(_lib.lib().suo_conv3x3_wino_conv1x1_skip_up(P(x_nhwc), L, H, W, P(wq2), P(b2d), P(wp3), P(b3d), P(skip_nhwc), P(up_nhwc), P(out), S()),
+               "suo_conv3x3_wino_conv1x1_skip_up")
+    torch.cuda.synchronize()
+    return out

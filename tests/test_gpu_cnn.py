@@ -210,6 +210,29 @@ def test_fused_winograd_residual_tail_equals_the_separate_launches(ops, L, H, W)
         assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("L,H,W", [(64, 64, 64), (9, 40, 56), (128, 16, 16)])
+def test_fused_tail_with_upsampled_addend_equals_tail_then_upsample_add(ops, L, H, W):
+    """Hourglass "up1 + up2(low3)" (hg.py:56-58) folded into the last up1 block's fused tail: bit-identical to the fused tail
+    followed by suo_upsample2_add (the addend goes in last, as that kernel adds it)."""
+    rng = np.random.default_rng(L + W)
+    x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
+    skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
+    low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda()
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    b2 = rng.standard_normal(128).astype(np.float32) * 0.3
+    w3 = (rng.standard_normal((256, 128)) / np.sqrt(128)).astype(np.float32)
+    b3 = rng.standard_normal(256).astype(np.float32)
+    got = ops.conv3x3_wino_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low)
+    tail = ops.conv3x3_wino_conv1x1_skip(x, w2, b2, w3, b3, skip)
+    want = torch.empty_like(tail)
+    from suo_slam_amd import _lib
+    _lib.check(_lib.lib().suo_upsample2_add(ops.P(tail), ops.P(low), ops.P(want), L, H, W, 256, ops.S()), "suo_upsample2_add")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = tail + low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    assert torch.equal(want, ref)
+
+
 def test_conv7x7_stride2(ops):
     rng = np.random.default_rng(11)
     L, H, C, N = 2, 64, 44, 64
