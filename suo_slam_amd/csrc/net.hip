@@ -409,16 +409,19 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
 }
 
 // Hourglass.forward (hg.py:37-58).  The up1 branch is independent of the low branch until the
-// final add: it runs on a side stream (fork/join with events) so the small, latency-bound low
-// levels overlap with the large up1 kernels.
+// final add: it can run on a side stream (fork/join with events) so the small, latency-bound low
+// levels overlap with the large up1 kernels -- see n_side below for when that pays.
 int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx) {
     const int C = 256;
     const size_t n_hi = (size_t)L * H * W * C, n_lo = n_hi / 4;
-    static const bool serial = getenv("SUO_SERIAL") != nullptr;     // profiling aid: one stream, kernels back to back
-    static const int n_side = getenv("SUO_NET_SIDE_STREAMS") ? std::max(1, std::min(kNumSide, atoi(getenv("SUO_NET_SIDE_STREAMS")))) : 2;
-    // (two side streams: with four, the streams of two networks in flight + the geometry stream oversubscribe the 4 hardware queues and
-    //  a frame's PnP / LM launches queue behind -- or ahead of -- network kernels: one frame per call 338 -> 361 frames/s, throughput mode unchanged)
-    hipStream_t side = serial ? s : side_[depth_idx % n_side];
+    // Side streams for the up1 branch are OFF by default (SUO_NET_SIDE_STREAMS=1|2 turns them on).  Measured on MI355X with the
+    // harness's two network calls in flight: one frame (8 crops) per call 351 frames/s with two side streams, 415 with one, 426
+    // with none; 32 frames per call 738 / 745 / 749.  The second call in flight already fills the gaps the fork was meant to fill,
+    // and every extra stream competes for the 4 hardware queues with the other network and the geometry stream.  With a single
+    // call in flight the fork is worth about 1 % (385 vs 381 frames/s at 8 crops).
+    static const int n_side = getenv("SUO_NET_SIDE_STREAMS") ? std::max(0, std::min(kNumSide, atoi(getenv("SUO_NET_SIDE_STREAMS")))) : 0;
+    static const bool serial = getenv("SUO_SERIAL") != nullptr || n_side == 0;     // one stream, kernels back to back
+    hipStream_t side = serial ? s : side_[depth_idx % (n_side > 0 ? n_side : 1)];
     hipEvent_t ev_fork = ev_[(ev_next_++) % kNumEvents], ev_join = ev_[(ev_next_++) % kNumEvents];
     float* up_a = alloc(n_hi);
     float* up_b = alloc(n_hi);
