@@ -7,9 +7,12 @@ TAG=$1; P=${2:-r02}
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/round_$TAG
 tail -1 $SRC/bench_line.json > profiles/${P}_bench_line.json
+for extra in driver_flags objects16; do
+  if [ -s $SRC/bench_line_$extra.json ]; then tail -1 $SRC/bench_line_$extra.json > profiles/${P}_bench_line_$extra.json; fi
+done
 {
   echo "# rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-latency-leg --steps 20 --warmup 5   (MI355X; tools/profile_round.sh $TAG)"
-  echo "# one step = 32 frames (256 crops) per network call + their PnP / LM, 2 steps in flight; kernels of different calls / hourglass branches overlap,"
+  echo "# one step = 32 frames (256 crops) per network call + their PnP / LM, 2 steps in flight; kernels of the two calls overlap,"
   echo "# so per-kernel durations here are concurrent-execution times (summarised per kernel x grid with tools/rocpd_stats.py)"
   cat $SRC/bench_kernel_stats.txt
 } > profiles/${P}_bench_kernel_stats_final.txt
@@ -27,7 +30,7 @@ cp $SRC/pmc_dominant_conv.json profiles/pmc_dominant_conv.json
 if [ -f gpurun_out/bench_serial_F32/stats.txt ]; then
   {
     echo "# SUO_SERIAL=1 rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-graph --only cnn --depth 1 --frames-per-step 32 --steps 6 --warmup 2   (tools/profile_bench_serial.sh)"
-    echo "# one network call at a time, hourglass branches on one stream, no graph: per-kernel NON-overlapped durations at 256 crops per call (8 calls;"
+    echo "# one network call at a time, one stream, no graph: per-kernel NON-overlapped durations at 256 crops per call (8 calls;"
     echo "# the dominant-kernel row also contains the launches of bench.py's roofline loop)."
     cat gpurun_out/bench_serial_F32/stats.txt
   } > profiles/${P}_cnn_serial_kernel_stats.txt
