@@ -106,6 +106,13 @@ int suo_conv1x1(const float* a1_dev, int lda1, int K1, const float* pro_scale_de
                 const float* a2_dev, int lda2, int K2, const float* wp_dev, const float* bias_dev,
                 const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int n_valid, int relu,
                 int nchw_hw, void* stream);
+/* ... followed by nn.MaxPool2d(2, 2) in the same launch (the stem's `pool(r1(x))`, pkpnet/hg.py; Hourglass `low1(max_pool(x))`, hg.py:41):
+ * the M pixels are images of H x W (W a multiple of 64, H even, N a multiple of 128); pool_out_dev is [M/4, ldo]; out_dev may be NULL
+ * when only the pooled tensor is wanted.  Bit-identical to suo_conv1x1 followed by suo_maxpool2. */
+int suo_conv1x1_pool(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev,
+                     const float* a2_dev, int lda2, int K2, const float* wp_dev, const float* bias_dev,
+                     const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, int H, int W,
+                     float* pool_out_dev, void* stream);
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);

@@ -46,6 +46,8 @@ SIGNATURES = {
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_conv_kxk": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP]),
     "suo_pack_wino_weight": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_conv1x1_pool": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "suo_conv3x3_wino": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP]),
     "suo_conv3x3_wino_conv1x1_skip": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_conv3x3_wino_conv1x1_skip_up": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),

@@ -128,6 +128,18 @@ int suo_conv1x1(const float* a1, int lda1, int K1, const float* pro_scale, const
     return suo::launch_gemm1x1(g, (hipStream_t)stream);
 }
 
+int suo_conv1x1_pool(const float* a1, int lda1, int K1, const float* pro_scale, const float* pro_shift, const float* a2, int lda2,
+                     int K2, const float* wp, const float* bias, const float* r, int ldr, float* out, int ldo, int M, int N, int relu,
+                     int H, int W, float* pool_out, void* stream) {
+    if (!pool_out) { suo_set_error("suo_conv1x1_pool: pool_out is NULL"); return SUO_ERR_ARG; }
+    suo::GemmArgs g = {};
+    g.A1 = a1; g.lda1 = lda1; g.K1 = K1; g.pro_scale = pro_scale; g.pro_shift = pro_shift;
+    g.A2 = a2; g.lda2 = lda2; g.K2 = a2 ? K2 : 0; g.Wp = wp; g.bias = bias; g.R = r; g.ldr = ldr;
+    g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = N; g.relu = relu;
+    g.pool_out = pool_out; g.pool_H = H; g.pool_W = W;
+    return suo::launch_gemm1x1(g, (hipStream_t)stream);
+}
+
 int suo_conv_kxk(int KS, const float* in, int L, int H, int W, int C, const float* wp, const float* bias, float* out, int N,
                  int relu, void* stream) {
     suo::ConvArgs c = {};

@@ -245,6 +245,11 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
         suo_set_error("gemm1x1: bad shape M=%d K1=%d K2=%d N=%d", a.M, a.K1, a.K2, a.N);
         return SUO_ERR_ARG;
     }
+    if (a.pool_out) {                                    // fused 2x2 max-pool: the persistent 128x128 kernel only (csrc/gemm_persist.hip: POOL)
+        if (!gemm1x1_can_pool(a)) { suo_set_error("gemm1x1: shape M=%d N=%d H=%d W=%d cannot take the fused max-pool", a.M, a.N, a.pool_H, a.pool_W); return SUO_ERR_ARG; }
+        return launch_gemm_persist(a, 1, s);
+    }
+    if (!a.out) { suo_set_error("gemm1x1: no output"); return SUO_ERR_ARG; }
     if (a.nchw_hw > 0) return launch_gemm_cfg<1, 1, 2, 2, true>(a, s);
     // small feature maps are latency problems: 16x16 tiles + split-K (csrc/conv_small.hip)
     if (a.M <= 4096 && ((a.K1 | a.K2) & 15) == 0 && (a.K1 + a.K2) <= 640) return launch_gemm_small(a, s);

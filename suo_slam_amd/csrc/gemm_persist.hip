@@ -47,8 +47,13 @@ constexpr int GP_MAX_PRO_K = 512;       // channels of a fused BN-ReLU prologue 
 #define SUO_GEMM_WAVES_PER_EU 3
 #endif
 
-template <int TM, int TN, int WGM, int WGN, bool HAS_R>
+// POOL: the workgroup's 128 rows are not 128 consecutive pixels but a 2 x 64 patch of the image (rows y, y+1; wave row wm owns 32
+// columns, its two 32-row MFMA blocks are the two image rows), so the four pixels of a 2x2 pooling window are register i / i+1 of the
+// same lane after the transposition through the LDS patch plus one DPP rotate: the epilogue writes the pooled tensor beside (or
+// instead of) the full-resolution one, pooling AFTER bias / residual / ReLU exactly as the separate kernel would.
+template <int TM, int TN, int WGM, int WGN, bool HAS_R, bool POOL = false>
 __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(SUO_GEMM_WAVES_PER_EU))) void gemm_persist_kernel(const GemmArgs a, int ntiles) {
+    static_assert(!POOL || (TM == 2 && WGM == 2), "POOL: 128-row tiles = 2 image rows x 64 columns");
     constexpr int BK = 32, PK = BK + 4;
     constexpr int BM = TM * 32 * WGM, BN = TN * 32 * WGN, NT = WGM * WGN * 64;
     constexpr int NLD = BM * 8 / NT;
@@ -68,6 +73,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     const int NB = a.N >> 5;
     const int c4 = tid & 7, r0 = tid >> 3;
     const bool has_pro = a.pro_scale != nullptr;
+    // POOL: pixel index of a tile's first row, and of the i-th group of 32 staged rows / the wave's second block relative to it
+    const int pW = POOL ? a.pool_W : 0, pxb = POOL ? a.pool_W >> 6 : 1;
+    auto tile_m0 = [&](int tm) { return POOL ? (tm / pxb) * 2 * pW + (tm % pxb) * 64 : tm * BM; };
+    const int span = POOL ? pW + 64 : BM;                      // pixels a tile's descriptor has to cover
 
     // tile list of this workgroup.  XCD-aware: workgroup b runs on XCD b % 8; each XCD owns a contiguous range of tiles
     // and its workgroups sweep it side by side, so the sibling N-tiles of a pixel tile are in flight together in one L2.
@@ -106,8 +115,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     // fixed per-lane byte offsets of the four streams
     const int av1 = (r0 * a.lda1 + c4 * 4) * 4, av2 = (r0 * a.lda2 + c4 * 4) * 4;           // activations (operand 1 / 2)
     const int wv = (wn * TN * 64 + lane) * 16;                                                // packed weights
-    const int ov = ((wm * TM * 32 + (lane >> 3)) * a.ldo + wn * TN * 32 + (lane & 7) * 4) * 4;  // output tile
-    const int rv = ((wm * TM * 32 + (lane >> 3)) * a.ldr + wn * TN * 32 + (lane & 7) * 4) * 4;  // residual tile
+    const int wrow = POOL ? wm * 32 : wm * TM * 32;                                           // the wave's first pixel within the tile
+    const int blk = POOL ? pW : 32;                                                           // pixels from its block i to block i + 1
+    const int ov = ((wrow + (lane >> 3)) * a.ldo + wn * TN * 32 + (lane & 7) * 4) * 4;        // output tile
+    const int rv = ((wrow + (lane >> 3)) * a.ldr + wn * TN * 32 + (lane & 7) * 4) * 4;        // residual tile
     const int bv = (wn * TN * 32 + (lane & 7) * 4) * 4;                                       // bias
     const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * (a.K1 + a.K2) * sizeof(float));
     const __amdgpu_buffer_rsrc_t bias_srd = make_srd(a.bias, (size_t)a.N * sizeof(float));
@@ -116,21 +127,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     // EVERY load of the steady state is unconditional (the cursor parks on the last step instead of stopping): a load
     // under a branch makes hipcc fall back to s_waitcnt vmcnt(0) at the next use of ANY loaded value -- which would wait
     // for the prefetches just issued and expose a full memory round trip every step.
-    int f_kc = 0, f_m0 = (t_first / ntn) * BM, f_tile = t_first, f_left = nsteps - 1;      // fetch cursor (activations)
+    int f_kc = 0, f_m0 = tile_m0(t_first / ntn), f_tile = t_first, f_left = nsteps - 1;      // fetch cursor (activations)
     auto fetch_advance = [&]() {
         if (f_left > 0) {
             --f_left;
-            if (++f_kc == nch) { f_kc = 0; f_tile += t_stride; f_m0 = (f_tile / ntn) * BM; }
+            if (++f_kc == nch) { f_kc = 0; f_tile += t_stride; f_m0 = tile_m0(f_tile / ntn); }
         }
     };
     auto gload = [&](f32x4(&ar)[NLD]) {
         const bool first = f_kc < nch1;
         const int lda = first ? a.lda1 : a.lda2;
         const float* A = (first ? a.A1 + f_kc * BK : a.A2 + (f_kc - nch1) * BK) + (size_t)f_m0 * lda;    // M % BM == 0 (launcher)
-        const __amdgpu_buffer_rsrc_t srd = make_srd(A, ((size_t)(BM - 1) * lda + BK) * sizeof(float));
+        const __amdgpu_buffer_rsrc_t srd = make_srd(A, ((size_t)(span - 1) * lda + BK) * sizeof(float));
         const int v = first ? av1 : av2;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) ar[i] = buf_load(srd, v, i * (NT / 8) * lda * 4);
+        for (int i = 0; i < NLD; ++i) ar[i] = buf_load(srd, v, (POOL ? (i & 1) * pW + (i >> 1) * 32 : i * (NT / 8)) * lda * 4);      // LDS rows 32 i ..: wave row i / 2, block i % 2
         fetch_advance();
     };
     auto sstore = [&](const f32x4(&ar)[NLD], int pro_k, int buf) {      // pro_k < 0: no prologue for this chunk
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     };
 
     // compute cursor
-    int kc = 0, tile = t_first, m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    int kc = 0, tile = t_first, m0 = tile_m0(tile / ntn), n0 = (tile % ntn) * BN;
     // weights of the step after the current one: same tile unless the current chunk is the last
     auto next_b = [&](int& nkc, int& nn0) {
         nkc = kc + 1; nn0 = n0;
@@ -174,11 +185,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     // reuse the same registers and are requested as soon as the first block has been consumed.
     f32x4 rvall[TN][4], bvall[TN];
     auto rload = [&](int i) {
-        const __amdgpu_buffer_rsrc_t r_srd = make_srd(HAS_R ? a.R + (size_t)m0 * a.ldr + n0 : a.bias, HAS_R ? ((size_t)(BM - 1) * a.ldr + BN) * sizeof(float) : 16);
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(HAS_R ? a.R + (size_t)m0 * a.ldr + n0 : a.bias, HAS_R ? ((size_t)(span - 1) * a.ldr + BN) * sizeof(float) : 16);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rvall[j][k] = buf_load(r_srd, rv, ((i * 32 + 8 * k) * a.ldr + j * 32) * 4);
+            for (int k = 0; k < 4; ++k) rvall[j][k] = buf_load(r_srd, rv, ((i * blk + 8 * k) * a.ldr + j * 32) * 4);
     };
     auto epi_prefetch = [&]() {
 #pragma unroll
@@ -190,7 +201,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     // times the VMEM instructions cost more than the LDS round trips they replace.)
     auto epilogue = [&]() {
         float* T = &Tp[w][0];
-        const __amdgpu_buffer_rsrc_t o_srd = make_srd(a.out + (size_t)m0 * a.ldo + n0, ((size_t)(BM - 1) * a.ldo + BN) * sizeof(float));
+        const bool full = !POOL || a.out != nullptr;          // POOL may be asked for the pooled tensor only
+        const __amdgpu_buffer_rsrc_t o_srd = make_srd(full ? a.out + (size_t)m0 * a.ldo + n0 : a.bias, full ? ((size_t)(span - 1) * a.ldo + BN) * sizeof(float) : 0);
+        // pooled tile: 16 pixels of image row y / 2 per wave row; pixel index m0 / 4 + ... because m0 = (2 W) * (row pair) + 64 * (column block)
+        const int pm0 = POOL ? (m0 / (2 * pW)) * (pW >> 1) + ((m0 % (2 * pW)) >> 1) : 0;
+        const __amdgpu_buffer_rsrc_t p_srd = make_srd(POOL ? a.pool_out + (size_t)pm0 * a.ldo + n0 : a.bias, POOL ? ((size_t)31 * a.ldo + BN) * sizeof(float) : 0);
+        // lane (row q = lane >> 3 of a 16-row patch, k-th half) holds pixel q + 8 k; after max with the lane 8 further (DPP row_ror:8
+        // = lane ^ 8 within a row of 16) both lanes of a pair hold the window's maximum: even q stores half 0, odd q half 1
+        const int pq = lane >> 3;
+        const int pv = ((wm * 16 + (pq >> 1) + 4 * (pq & 1)) * a.ldo + wn * TN * 32 + (lane & 7) * 4) * 4;
+        f32x4 keep[POOL ? TN : 1][4];                          // block 0's finished values (image row y) until block 1 (row y + 1) arrives
 #if !SUO_GEMM_EPI_PREFETCH
         epi_prefetch();
 #endif
@@ -208,6 +228,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
                     f32x4 v[2];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) v[k] = *(const f32x4*)&T[((lane >> 3) + 8 * k) * PK + (lane & 7) * 4];
+                    f32x4 pm[2];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         f32x4 o = v[k] + bvall[j] + (HAS_R ? rvall[j][2 * h + k] : f32x4{0.f, 0.f, 0.f, 0.f});
@@ -218,7 +239,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 #if SUO_GEMM_EXP & 2
                         if (o[0] == 12345.678f)
 #endif
-                        buf_store(o, o_srd, ov, ((i * 32 + 8 * (2 * h + k)) * a.ldo + j * 32) * 4);     // unpredicated: stores count in vmcnt too
+                        if (full) buf_store(o, o_srd, ov, ((i * blk + 8 * (2 * h + k)) * a.ldo + j * 32) * 4);     // unpredicated: stores count in vmcnt too
+                        if constexpr (POOL) {
+                            if (i == 0) keep[j][2 * h + k] = o;
+                            else {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    const float m = fmaxf(o[t], keep[j][2 * h + k][t]);
+                                    pm[k][t] = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x128, 0xf, 0xf, false)));
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (POOL) {
+                        if (i == 1) {                           // 8 pooled pixels x 32 channels per pass: 8 h + {0..3} from half 0 (even q), + 4 from half 1 (odd q)
+                            const f32x4 o = (pq & 1) ? pm[1] : pm[0];
+                            buf_store(o, p_srd, pv, (8 * h * a.ldo + j * 32) * 4);
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 #endif
         if (kc + 1 == nch) {                                // workgroup-uniform: the tile is complete
             epilogue();
-            kc = 0; tile += t_stride; m0 = (tile / ntn) * BM; n0 = (tile % ntn) * BN;
+            kc = 0; tile += t_stride; m0 = tile_m0(tile / ntn); n0 = (tile % ntn) * BN;
         } else {
             ++kc;
         }
@@ -306,6 +343,15 @@ static int launch_persist_cfg(const GemmArgs& a, int max_wgs, hipStream_t s) {
     if (a.pro_scale && a.K1 > GP_MAX_PRO_K) { suo_set_error("gemm_persist: prologue over K1=%d > %d channels", a.K1, GP_MAX_PRO_K); return SUO_ERR_ARG; }
     const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     const int g = ntiles < max_wgs ? ntiles : max_wgs;
+    if constexpr (TM == 2 && TN == 2 && WGM == 2 && WGN == 2) {
+        if (a.pool_out) {
+            if (a.R) hipLaunchKernelGGL((gemm_persist_kernel<TM, TN, WGM, WGN, true, true>), dim3(g), dim3(WGM * WGN * 64), 0, s, a, ntiles);
+            else hipLaunchKernelGGL((gemm_persist_kernel<TM, TN, WGM, WGN, false, true>), dim3(g), dim3(WGM * WGN * 64), 0, s, a, ntiles);
+            SUO_HIP_CHECK(hipGetLastError());
+            return SUO_OK;
+        }
+    }
+    if (a.pool_out) { suo_set_error("gemm_persist: the fused max-pool needs the 128x128 configuration"); return SUO_ERR_ARG; }
     if (a.R) hipLaunchKernelGGL((gemm_persist_kernel<TM, TN, WGM, WGN, true>), dim3(g), dim3(WGM * WGN * 64), 0, s, a, ntiles);
     else hipLaunchKernelGGL((gemm_persist_kernel<TM, TN, WGM, WGN, false>), dim3(g), dim3(WGM * WGN * 64), 0, s, a, ntiles);
     SUO_HIP_CHECK(hipGetLastError());
@@ -314,6 +360,11 @@ static int launch_persist_cfg(const GemmArgs& a, int max_wgs, hipStream_t s) {
 
 // cfg: 1 = 128x128 tiles, 2 = 128x64 tiles, 3 = 64x64 tiles.  The grid is the number of RESIDENT workgroups (3 per CU
 // for the 128-row tiles, 6 for the 64x64 one, on the 256-CU part), not the number of tiles.
+bool gemm1x1_can_pool(const GemmArgs& a) {
+    return a.pool_W > 0 && a.pool_H > 0 && (a.pool_W & 63) == 0 && (a.pool_H & 1) == 0 && a.M % (a.pool_H * a.pool_W) == 0 && (a.N & 127) == 0 &&
+           a.n_valid == a.N && a.nchw_hw == 0 && !(a.K1 & 31) && !(a.K2 & 31) && (!a.pro_scale || a.K1 <= GP_MAX_PRO_K);
+}
+
 int launch_gemm_persist(const GemmArgs& a, int cfg, hipStream_t s) {
     static const int max_wgs = getenv("SUO_GEMM_WGS") ? atoi(getenv("SUO_GEMM_WGS")) : 768;       // tuning aid
     if (cfg == 3) return launch_persist_cfg<1, 1, 2, 2>(a, 2 * max_wgs, s);

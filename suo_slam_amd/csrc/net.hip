@@ -366,7 +366,23 @@ bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const 
            r.c3.K1 == 128 && r.cin == 256;
 }
 
-int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up) {
+// A 1x1 convolution whose result is also wanted max-pooled (nn.MaxPool2d(2, 2)): pooled in the GEMM's epilogue when the launch
+// would use the persistent 128x128 kernel anyway (csrc/gemm_persist.hip: POOL), else GEMM + max-pool kernel.  g.out may be nullptr
+// when only the pooled tensor is wanted.
+int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s) {
+    static const int fuse_pool = getenv("SUO_FUSE_POOL") ? atoi(getenv("SUO_FUSE_POOL")) : 1;                    // 0: A/B
+    if (!pool_out) { SUO_LAUNCH(launch_gemm1x1(g, s)); return SUO_OK; }
+    GemmArgs gp = g;
+    gp.pool_out = pool_out; gp.pool_H = H; gp.pool_W = W;
+    const long tiles128 = (long)(g.M / 128) * (g.N / 128);
+    if (fuse_pool && g.M > 4096 && tiles128 >= 512 && gemm1x1_can_pool(gp)) { SUO_LAUNCH(launch_gemm1x1(gp, s)); return SUO_OK; }
+    if (!g.out) g.out = alloc((size_t)g.M * g.ldo);
+    SUO_LAUNCH(launch_gemm1x1(g, s));
+    SUO_LAUNCH(launch_maxpool2(g.out, pool_out, L, H, W, g.N, s));
+    return SUO_OK;
+}
+
+int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, float* pool_out) {
     const int M = L * H * W;
     float* mid1 = alloc((size_t)M * r.c1.N);
     float* mid2 = alloc((size_t)M * r.c2.N);
@@ -380,8 +396,10 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     const bool wino = r.c2.Wq && conv3x3_wino_pays(c2);       // 2.25x fewer MFMA MACs (csrc/conv_wino.hip)
     if (!wino && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256 && conv3x3_fusable(c2)) {
         // conv2 -> conv3 + skip in one launch: the 128-channel tensor between them never leaves the CU (csrc/conv.hip: FUSE)
+        if (!out) out = alloc((size_t)M * 256);
         c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256;
         SUO_LAUNCH(launch_conv3x3_fused(c2, s));
+        if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
         return SUO_OK;
     }
     if (wino) {
@@ -390,8 +408,10 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
         const long tiles = (long)((W + 15) / 16) * ((H + 7) / 8) * L;
         if (fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256) {
             // conv2 -> conv3 + skip in one launch (933 vs 713 + 346 us at 64x64 / 128 crops, 257 vs 195 + 91 at 32x32)
+            if (!out) out = alloc((size_t)M * 256);
             c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256; c2.up = up;
             SUO_LAUNCH(launch_conv3x3_wino_fused(c2, s));
+            if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
             return SUO_OK;
         }
         SUO_LAUNCH(launch_conv3x3_wino(c2, s));
@@ -404,14 +424,13 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     if (r.has_skip_conv) { g3.A2 = x; g3.lda2 = r.cin; g3.K2 = r.c3.K2; }
     else { g3.R = x; g3.ldr = r.cin; }
     g3.Wp = r.c3.Wp; g3.bias = r.c3.bias; g3.out = out; g3.ldo = r.cout; g3.M = M; g3.N = r.c3.N; g3.n_valid = r.c3.n_valid;
-    SUO_LAUNCH(launch_gemm1x1(g3, s));
-    return SUO_OK;
+    return gemm_maybe_pooled(g3, L, H, W, pool_out, s);
 }
 
 // Hourglass.forward (hg.py:37-58).  The up1 branch is independent of the low branch until the
 // final add: it can run on a side stream (fork/join with events) so the small, latency-bound low
 // levels overlap with the large up1 kernels -- see n_side below for when that pays.
-int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx) {
+int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx, const float* x_pooled) {
     const int C = 256;
     const size_t n_hi = (size_t)L * H * W * C, n_lo = n_hi / 4;
     // Side streams for the up1 branch are OFF by default (SUO_NET_SIDE_STREAMS=1|2 turns them on).  Measured on MI355X with the
@@ -436,10 +455,14 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     if (!up_in_tail) SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
     SUO_HIP_LIVE(hipEventRecord(ev_join, side));
 
-    float* pooled = alloc(n_lo);
+    const float* pooled = x_pooled;                           // (the caller's producer kernel may have pooled x already)
+    if (!pooled) {
+        float* p = alloc(n_lo);
+        SUO_LAUNCH(launch_maxpool2(x, p, L, H, W, C, s));
+        pooled = p;
+    }
     float* lo_a = alloc(n_lo);
     float* lo_b = alloc(n_lo);
-    SUO_LAUNCH(launch_maxpool2(x, pooled, L, H, W, C, s));
     SUO_TRY(residual(h.low1[0], pooled, lo_a, L, H / 2, W / 2, s));
     SUO_TRY(residual(h.low1[1], lo_a, lo_b, L, H / 2, W / 2, s));
     float* low2 = alloc(n_lo);
@@ -470,18 +493,18 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
     c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = in_c; c.Wp = sw.Wp; c.bias = sw.bias;
     c.out = stem; c.OH = 128; c.OW = 128; c.N = 64; c.relu = 1;
     SUO_LAUNCH(launch_conv7x7s2(c, s));
-    float* r1o = alloc((size_t)L * 128 * 128 * 128);
-    SUO_TRY(residual(r1_, stem, r1o, L, 128, 128, s));
+    // pool(r1(x)): the full-resolution r1 output has no other reader, so only its pooled form is written (csrc/gemm_persist.hip: POOL)
     float* p1 = alloc((size_t)L * 64 * 64 * 128);
-    SUO_LAUNCH(launch_maxpool2(r1o, p1, L, 128, 128, 128, s));
+    SUO_TRY(residual(r1_, stem, nullptr, L, 128, 128, s, nullptr, p1));
     float* r4o = alloc((size_t)L * 64 * 64 * 128);
     SUO_TRY(residual(r4_, p1, r4o, L, 64, 64, s));
     float* x = alloc((size_t)L * 64 * 64 * 256);
-    SUO_TRY(residual(r5_, r4o, x, L, 64, 64, s));
+    float* xp = alloc((size_t)L * 32 * 32 * 256);             // max_pool2d(x): the first thing each Hourglass computes from x (hg.py:41)
+    SUO_TRY(residual(r5_, r4o, x, L, 64, 64, s, nullptr, xp));
     const int M = L * 64 * 64;
     for (int i = 0; i < 2; ++i) {
         float* hg = alloc((size_t)M * 256);
-        SUO_TRY(hourglass(hg_[i], x, hg, L, 64, 64, s, 0));
+        SUO_TRY(hourglass(hg_[i], x, hg, L, 64, 64, s, 0, xp));
         float* ra = alloc((size_t)M * 256);
         float* rb = alloc((size_t)M * 256);
         SUO_TRY(residual(post_[i][0], hg, ra, L, 64, 64, s));
@@ -500,7 +523,8 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
             gr.A1 = ll; gr.lda1 = 256; gr.K1 = 256;
             gr.Wp = reinject_.Wp; gr.bias = reinject_.bias; gr.R = x; gr.ldr = 256; gr.out = xn; gr.ldo = 256;
             gr.M = M; gr.N = 256; gr.n_valid = 256;
-            SUO_LAUNCH(launch_gemm1x1(gr, s));
+            xp = alloc((size_t)L * 32 * 32 * 256);
+            SUO_TRY(gemm_maybe_pooled(gr, L, 64, 64, xp, s));
             x = xn;
         } else {
             gh.out = logits; gh.n_valid = NUM_KP; gh.nchw_hw = HEAT * HEAT;

@@ -51,8 +51,12 @@ struct GemmArgs {
     const float* R; int ldr;                             // optional residual [M, n_valid]
     float* out; int ldo;                                 // [M, ldo]   (NHWC)   or NCHW when nchw_hw>0
     int M; int N; int n_valid; int relu; int nchw_hw;    // nchw_hw = H*W of one crop for NCHW output
+    // optional fused 2x2 max-pool of the result (nn.MaxPool2d(2, 2) after a block, hg.py:41 / pkpnet.py stem): the M pixels are
+    // images of pool_H x pool_W, pool_out is [M / 4, ldo]; `out` may then be nullptr (only the pooled tensor is wanted)
+    float* pool_out; int pool_H; int pool_W;
 };
 int launch_gemm1x1(const GemmArgs& a, hipStream_t s);
+bool gemm1x1_can_pool(const GemmArgs& a);                // shapes the fused pool takes (128 x 128 tiles of 2 image rows x 64 columns)
 
 // KxK convolution (3x3 s1 p1 or 7x7 s2 p3), NHWC, input already activated, zero padding.
 struct ConvArgs {

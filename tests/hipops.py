@@ -70,6 +70,29 @@ def conv1x1(a1, w1, bias, pro=None, a2=None, w2=None, res=None, relu=False, nchw
     return out
 
 
+def conv1x1_pool(a1, w1, bias, H, W, pro=None, a2=None, w2=None, res=None, relu=False, want_full=True):
+    """conv1x1 with the 2x2 max-pool fused into its epilogue: returns (full [M,N] or None, pooled [M/4,N])."""
+    M, K1 = a1.shape
+    N = w1.shape[0]
+    assert N % 128 == 0
+    K2 = a2.shape[1] if a2 is not None else 0
+    full = np.zeros((N, K1 + K2), np.float32)
+    full[:, :K1] = w1
+    if a2 is not None:
+        full[:, K1:] = w2
+    wp = dev(pack_gemm(full, N, K1 + K2))
+    b = dev(np.ascontiguousarray(bias, np.float32))
+    out = torch.empty((M, N), device="cuda") if want_full else None
+    pooled = torch.empty((M // 4, N), device="cuda")
+    ps = dev(pro[0]) if pro is not None else None
+    pt = dev(pro[1]) if pro is not None else None
+    _lib.check(_lib.lib().suo_conv1x1_pool(P(a1), a1.stride(0), K1, P(ps), P(pt), P(a2), a2.stride(0) if a2 is not None else 0, K2,
+                                           P(wp), P(b), P(res), res.stride(0) if res is not None else 0, P(out), N, M, N,
+                                           int(relu), H, W, P(pooled), S()), "suo_conv1x1_pool")
+    torch.cuda.synchronize()
+    return out, pooled
+
+
 def conv_kxk(x_nhwc, w, bias, relu=False):
     L, H, W, C = x_nhwc.shape
     N, Cw, KS, _ = w.shape

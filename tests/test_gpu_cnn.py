@@ -233,6 +233,45 @@ def test_fused_tail_with_upsampled_addend_equals_tail_then_upsample_add(ops, L, 
     assert torch.equal(want, ref)
 
 
+@pytest.mark.parametrize("L,H,W,K1,K2,N,res,relu,want_full", [
+    (3, 128, 128, 64, 64, 128, False, False, False),     # r1: conv3 + conv4, only the pooled tensor is kept
+    (5, 64, 64, 128, 128, 256, False, False, True),      # r5 -> the first Hourglass: x and max_pool(x)
+    (2, 64, 64, 256, 64, 256, True, False, True),        # re-injection (x + ll_ + tmpOut_) -> the second Hourglass
+    (12, 6, 64, 256, 0, 128, False, True, True),         # ragged height, prologue + ReLU (M > 4096: below that suo_conv1x1 is the split-K kernel)
+    (16, 2, 192, 96, 0, 128, True, True, False),         # three column blocks, K not a power of two
+])
+def test_conv1x1_with_fused_maxpool_equals_conv1x1_then_maxpool(ops, L, H, W, K1, K2, N, res, relu, want_full):
+    """nn.MaxPool2d(2, 2) (hg.py:41, the stem's pool) folded into the epilogue of the 1x1 convolution that produces its input:
+    both tensors bit-identical to suo_conv1x1 followed by suo_maxpool2."""
+    from suo_slam_amd import _lib
+    rng = np.random.default_rng(H * W + K1)
+    M = L * H * W
+    a1 = torch.from_numpy(rng.standard_normal((M, K1)).astype(np.float32)).cuda()
+    a2 = torch.from_numpy(rng.standard_normal((M, K2)).astype(np.float32)).cuda() if K2 else None
+    r = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda() if res else None
+    w1 = (rng.standard_normal((N, K1)) / np.sqrt(K1)).astype(np.float32)
+    w2 = (rng.standard_normal((N, K2)) / np.sqrt(K2)).astype(np.float32) if K2 else None
+    b = rng.standard_normal(N).astype(np.float32)
+    pro = (rng.uniform(0.5, 1.5, K1).astype(np.float32), rng.standard_normal(K1).astype(np.float32) * 0.2) if relu else None
+    want = ops.conv1x1(a1, w1, b, pro=pro, a2=a2, w2=w2, res=r, relu=relu)
+    want_pool = torch.empty((M // 4, N), device="cuda")
+    _lib.check(_lib.lib().suo_maxpool2(ops.P(want), ops.P(want_pool), L, H, W, N, ops.S()), "suo_maxpool2")
+    torch.cuda.synchronize()
+    ref_pool = want.view(L, H // 2, 2, W // 2, 2, N).amax(dim=(2, 4)).reshape(M // 4, N)
+    assert torch.equal(want_pool, ref_pool)
+    full, pooled = ops.conv1x1_pool(a1, w1, b, H, W, pro=pro, a2=a2, w2=w2, res=r, relu=relu, want_full=want_full)
+    assert torch.equal(pooled, want_pool)
+    if want_full:
+        assert torch.equal(full, want)
+
+
+def test_conv1x1_with_fused_maxpool_refuses_other_shapes(ops):
+    from suo_slam_amd import _lib
+    a1 = torch.zeros((2 * 32 * 32, 64), device="cuda")
+    with pytest.raises(RuntimeError, match="fused max-pool"):
+        ops.conv1x1_pool(a1, np.zeros((128, 64), np.float32), np.zeros(128, np.float32), 32, 32)
+
+
 def test_conv7x7_stride2(ops):
     rng = np.random.default_rng(11)
     L, H, C, N = 2, 64, 44, 64
