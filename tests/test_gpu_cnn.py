@@ -2,6 +2,7 @@
 (oracle/cnn_oracle.py) and the committed golden vectors.  Tolerances are stated per test; fp32 MFMA
 is an exact-fp32 FMA chain, so differences are accumulation-order noise only."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -397,6 +398,28 @@ def test_full_network_golden(ops, cnn_golden, state_dict):
         logits = run_backbone_from_staged(net, xin)
         rel = np.abs(logits - ref).max() / np.abs(ref).max()
         assert rel < 2e-4, rel   # 186 fp32 conv layers deep; observed ~1e-5
+
+
+def test_schedule_options_do_not_change_the_result():
+    """The schedule knobs of csrc/net.hip (side streams for the up1 branch, hipGraph replay, the fused up-sample add, the max-pool
+    fused into the producing GEMM) only move work between launches and streams: the logits are bit-identical under every setting.
+    They are read once per process, hence one child process per setting.  34 crops: the 16x16 maps reach the 256-tile threshold of
+    the fused Winograd tail, so the up-sample fusion is exercised on three levels."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    settings = [({}, 0), ({}, 1), ({"SUO_NET_SIDE_STREAMS": "2"}, 1), ({"SUO_NET_SIDE_STREAMS": "1"}, 0),
+                ({"SUO_FUSE_UPSAMPLE": "0"}, 0), ({"SUO_FUSE_POOL": "0"}, 0)]
+    digests = []
+    for env_extra, graph in settings:
+        env = dict(os.environ)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, os.path.join(here, "gpu_backbone_digest.py"), "34", str(graph)], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [x for x in out.stdout.splitlines() if x.startswith("DIGEST")][-1]
+        digests.append(line.split()[1])
+    assert len(set(digests)) == 1, list(zip(settings, digests))
 
 
 def test_forward_frames_equals_per_frame_calls(ops, state_dict):
