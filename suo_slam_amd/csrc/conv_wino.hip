@@ -32,7 +32,8 @@ constexpr int W_CK = 16, W_PKH = 20, W_PKV = 20, W_TH = 8, W_TW = 16, W_IH = 10,
 constexpr int W_RING = 8;
 
 // host: U[n][c][comp] = (G g G^T)[xi][nu], comp = 4 xi + nu, in fp64; packed as
-//   Up[chunk][comp][s][nb][lane][t] = U[nb*32 + (lane&31)][chunk*16 + s*8 + (lane>>5)*4 + t][comp]        (N, C multiples of 32 / 16)
+//   Up[chunk][comp][s][nb][lane][t] = +-U[nb*32 + (lane&31)][chunk*16 + s*8 + (lane>>5)*4 + t][comp]      (N, C multiples of 32 / 16;
+//   the components of row xi = 3 are stored NEGATED: A^T[.][3] = (0, -1), so their products accumulate straight into Z[1][nu])
 void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float* out_scale, float* out) {
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int nch = Cp / W_CK, NB = Np / 32;
@@ -49,7 +50,7 @@ void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float*
             const int chunk = c / W_CK, cc = c % W_CK, s = cc / 8, half = (cc % 8) / 4, t = cc % 4;
             const int nb = n / 32, lane = half * 32 + (n % 32);
             for (int comp = 0; comp < 16; ++comp)
-                out[((((size_t)(chunk * 16 + comp) * 2 + s) * NB + nb) * 64 + lane) * 4 + t] = (float)U[comp >> 2][comp & 3];
+                out[((((size_t)(chunk * 16 + comp) * 2 + s) * NB + nb) * 64 + lane) * 4 + t] = (float)(comp >= 12 ? -U[comp >> 2][comp & 3] : U[comp >> 2][comp & 3]);      // xi = 3 enters the output transform with -1 only: stored negated
         }
     (void)nch;
 }
@@ -153,15 +154,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     w_f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    w_f32x16 out[4];
+    // Output transform Y = A^T M A in two steps.  128-channel form: the accumulators are Z[i][nu] = sum_xi A^T[i][xi] M(xi,nu), 8 of
+    // them: the components of rows xi = 0 and xi = 3 touch ONE Z each (A^T columns (1,0) and (0,-1), the sign is in the packed
+    // weights), so their MFMAs accumulate into it directly; only rows xi = 1, 2 go through a scratch accumulator and VALU
+    // additions (Z[0] += M1 + M2, Z[1] += M1 - M2): 16 vector additions per chunk instead of 36.  On gfx950 VALU instructions do
+    // NOT overlap with MFMAs of the same SIMD (tools/micro/mfma_valu.hip: every v_add_f32 between MFMAs adds its 2.6-4.7 cycles),
+    // so the fold is paid in MFMA time.  Y = Z A once per tile after the channel loop.  64-channel form: a wave owns 8 components
+    // (rows xi = 2 wc, 2 wc + 1) and one accumulator per component -- no additions in the channel loop at all; the rows meet in the
+    // exchange after it.
+    constexpr int NZ = 8;
+    w_f32x16 out[4], Z[NZ];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[p][r] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NZ; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[p][r] = 0.f;
+    // consumption order of the components: 128-channel form pairs 0-3 = (xi 0, xi 3) of nu = pair (direct), pairs 4-7 = (xi 1, xi 2)
+    // of nu = pair - 4 (scratch); 64-channel form pair p = components 2 p, 2 p + 1 of the wave's half
+    auto comp_of = [&](int pair, int which) -> int {
+        if (NT == 4) return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4));
+        return wc * 8 + 2 * pair + which;
+    };
 
     gload(0);
 #pragma unroll
-    for (int r = 0; r < W_RING - 2; ++r) bload((wc * 8 + (r >> 2) * 2 + (r & 1)) * 2 + ((r >> 1) & 1), bring[r]);      // consumption order, see below
+    for (int r = 0; r < W_RING - 2; ++r) bload(comp_of(r >> 2, r & 1) * 2 + ((r >> 1) & 1), bring[r]);      // consumption order, see below
     sstore(0);
     __syncthreads();
 
@@ -186,48 +206,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         // waits for its own result every time); the first MFMA of a component takes the persistent all-zero accumulator as C.
         // Weight groups are consumed in the order k = 4 pair + 2 s + which <-> (comp = 2 pair + which, s); the ring slot of a
         // group is its consumption index mod W_RING, its address comes from (comp, s).
-        constexpr int At[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
-        auto fold = [&](int comp, const w_f32x16& tmp) {          // out(i,j) += A^T[i][xi] A^T[j][nu] M(xi,nu)
-            const int xi = comp >> 2, nu = comp & 3;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int cf = At[i][xi] * At[j][nu];
-                    if (cf == 1) out[i * 2 + j] += tmp;
-                    else if (cf == -1) out[i * 2 + j] -= tmp;
-                }
-        };
         auto seq_gg = [&](int k) -> int {                         // consumption index (may run into the next chunk) -> packed group
             const int cc = c + k / KSEQ, kk = k % KSEQ;
-            const int comp = wc * 8 + (kk >> 2) * 2 + (kk & 1), sg = (kk >> 1) & 1;
+            const int comp = comp_of(kk >> 2, kk & 1), sg = (kk >> 1) & 1;
             return cc * 32 + comp * 2 + sg;
         };
 #pragma unroll
         for (int pair = 0; pair < NPAIR; ++pair) {
             w_f32x16 ta, tb;
+            const bool direct = NT == 2 || pair < 4;              // accumulate into their own Z, no scratch, no additions
+            const int za = NT == 4 ? pair : 2 * pair, zb = NT == 4 ? 4 + pair : 2 * pair + 1;       // (64-channel form: Z[local component])
+            const int ca = comp_of(pair, 0), cb = comp_of(pair, 1);
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
                 const int k = pair * 4 + sg * 2;
                 bload(seq_gg(k + W_RING - 2), bring[(k + W_RING - 2) % W_RING]);      // the two slots the previous step consumed
                 bload(seq_gg(k + W_RING - 1), bring[(k + W_RING - 1) % W_RING]);
-                const w_f32x4 afa = *(const w_f32x4*)(vs + (wc * 8 + 2 * pair) * 32 * W_PKV + sg * 8);
-                const w_f32x4 afb = *(const w_f32x4*)(vs + (wc * 8 + 2 * pair + 1) * 32 * W_PKV + sg * 8);
+                const w_f32x4 afa = *(const w_f32x4*)(vs + ca * 32 * W_PKV + sg * 8);
+                const w_f32x4 afb = *(const w_f32x4*)(vs + cb * 32 * W_PKV + sg * 8);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    ta = w_mfma32(afa[t], bring[k % W_RING][t], (sg == 0 && t == 0) ? zero16 : ta);
-                    tb = w_mfma32(afb[t], bring[(k + 1) % W_RING][t], (sg == 0 && t == 0) ? zero16 : tb);
+                    if (direct) {
+                        Z[za] = w_mfma32(afa[t], bring[k % W_RING][t], Z[za]);
+                        Z[zb] = w_mfma32(afb[t], bring[(k + 1) % W_RING][t], Z[zb]);
+                    } else {
+                        ta = w_mfma32(afa[t], bring[k % W_RING][t], (sg == 0 && t == 0) ? zero16 : ta);
+                        tb = w_mfma32(afb[t], bring[(k + 1) % W_RING][t], (sg == 0 && t == 0) ? zero16 : tb);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (NT == 4) { fold(2 * pair, ta); fold(2 * pair + 1, tb); }
-            else if (wc == 0) { fold(2 * pair, ta); fold(2 * pair + 1, tb); }          // (wave-uniform: the signs differ per half)
-            else { fold(8 + 2 * pair, ta); fold(8 + 2 * pair + 1, tb); }
+            if (!direct) { Z[pair - 4] += ta; Z[pair - 4] += tb; Z[pair] += ta; Z[pair] -= tb; }      // (pair - 4 = nu: Z[0][nu], Z[1][nu] = Z[4 + nu])
         }
         WPROF(3);
         __syncthreads();
         WPROF(4);
+    }
+    // second step of the output transform: R[h][j] = sum_nu A^T[j][nu] Z[4 h + nu].  128-channel form: h = i, R = Y.
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        out[2 * h] = Z[4 * h] + Z[4 * h + 1] + Z[4 * h + 2];
+        out[2 * h + 1] = Z[4 * h + 1] - Z[4 * h + 2] - Z[4 * h + 3];
     }
 #ifdef SUO_WINO_PROF
     if (blockIdx.x == 1000 && (tid & 63) == 0) printf("wave %d cycles: transform %lld  barrier1 %lld  sstore %lld  mfma+fold %lld  barrier2 %lld\n", w, pt[0], pt[1], pt[2], pt[3], pt[4]);
@@ -350,8 +370,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 
     if constexpr (NT == 2) {
-        // the two component halves of an n-tile meet: wave (wc, wn) keeps output positions {2 wc, 2 wc + 1} and hands the other two
-        // to its partner through LDS ([position][register][lane]: conflict-free), then both run the epilogue on their positions
+        // the two component halves of an n-tile meet.  Wave wc = 0 holds rows xi = 0, 1 (out[0..1] = R of row 0, out[2..3] = R of row 1),
+        // wave wc = 1 rows xi = 2, 3 (row 3 negated in the weights).  Y[0][j] = R0 + R1 + R2, Y[1][j] = R1 - R2 + R3': wave wc keeps
+        // output row i = wc and hands its MIDDLE row (1 or 2) to the partner through LDS ([position][register][lane]: conflict-free).
         float* X = &V[0];
         __syncthreads();                                          // V is free
 #pragma unroll
@@ -364,7 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[q][r] = (wc == 0 ? out[q][r] : out[2 + q][r]) + X[((pw * 2 + q) * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r)
+                mine[q][r] = (wc == 0 ? out[q][r] + out[2 + q][r] : out[2 + q][r] - out[q][r]) + X[((pw * 2 + q) * 16 + r) * 64 + lane];
         __syncthreads();                                          // the exchange area becomes the transposition patches
         float* T = &V[0] + w * (32 * 36);
         const int col = wn * 32 + (lane & 7) * 4;
