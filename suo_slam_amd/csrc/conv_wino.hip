@@ -59,8 +59,11 @@ void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float*
 // n-tile wn and the 8 components [8 wc, 8 wc + 8); the two partial sums are exchanged through LDS before the epilogue).
 template <bool FUSE, int NT = 4, bool UP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float Hin[2][W_NPIX * W_PKH];
-    __shared__ __attribute__((aligned(16))) float V[16 * 32 * W_PKV];
+    // one LDS array: halo double buffer | V; the fused tail re-uses ALL of it for the complete conv2 tile (128 pixels x 128 channels)
+    constexpr int HSZ = W_NPIX * W_PKH, VSZ = 16 * 32 * W_PKV;
+    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VSZ];
+    float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
+    float* V = &S[2 * HSZ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (a.OW + W_TW - 1) / W_TW, tiles_y = (a.OH + W_TH - 1) / W_TH;
@@ -258,114 +261,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         // relu(conv2 + bias2), as in csrc/conv.hip (FUSE): the conv2 tile is complete in `out` (wave w: channels [32 w, 32 w + 32)
         // of the 128 pixels, as 4 output positions x 32 Winograd tiles); slice kc of 32 channels is staged by wave kc through LDS
         // (pixel-major, double-buffered) as the A operand, output channels in two passes of 128 with the waves as a 2 x 2 grid.
-        constexpr int MP = 36, MSZ = 128 * MP;
-        static_assert(2 * MSZ <= 16 * 32 * W_PKV, "mid slices must fit the V buffer");
-        float* M2 = &V[0];
+        // Single pass: every wave stages ITS 32 channels of relu(conv2 + bias2) for all 128 pixels at once (pitch 132: the A-operand
+        // reads of 16 consecutive pixels hit 16 different bank quads), one barrier, then 16 k-groups of MFMAs into 2 x 4 accumulators
+        // (wave grid 2 x 2: 64 pixels x 128 output channels each) with no barrier in between -- `out` is dead from the barrier on, which
+        // is what makes room for the 128 accumulator registers (and for the up-sampled addend of the UP variant without spilling).
+        constexpr int MP = 132;
+        static_assert(128 * MP <= 2 * HSZ + VSZ, "the conv2 tile must fit the workgroup's LDS");
+        float* M2 = &S[0];
         const int wm = w >> 1, wn = w & 1;
         const int NB2 = a.N2 >> 5;
         const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * sizeof(float));
         const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
         const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
         const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
-        constexpr bool has_up = UP;                               // (its own instantiation: the addend costs 16 registers in this tail)
+        constexpr bool has_up = UP;
         const __amdgpu_buffer_rsrc_t up_srd = make_srd(has_up ? a.up + (size_t)l * (crop2 / 4) : a.R, has_up ? crop2 / 4 * sizeof(float) : 0);
         const float b2v = a.bias[w * 32 + (lane & 31)];
-        auto stage = [&](int kc, int buf) {
-            if (w == kc) {
-                float* d = M2 + buf * MSZ;
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int t = w_acc_row(r, lane);                       // Winograd tile -> pixel of the 8 x 16 tile
-                        const int pix = (2 * (t >> 3) + (p >> 1)) * W_TW + 2 * (t & 7) + (p & 1);
-                        d[pix * MP + (lane & 31)] = fmaxf(out[p][r] + b2v, 0.f);
-                    }
-            }
-        };
         const int w3voff = lane * 16;
-        auto b3load = [&](int q, w_f32x4(&b)[2]) {                // q = pass * 16 + k-group of 8 mid channels
-            const int qc = q < 32 ? q : 31;
-            const int kg = qc & 15, nb0 = (qc >> 4) * 4 + wn * 2;
+        auto b3load = [&](int q, w_f32x4(&b)[4]) {                // q = k-group of 8 mid channels; the wave's four 32-channel tiles
+            const int kg = q < 16 ? q : 15;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = buf_load(w3_srd, w3voff, (kg * NB2 + nb0 + j) * 1024);
+            for (int j = 0; j < 4; ++j) b[j] = buf_load(w3_srd, w3voff, (kg * NB2 + wn * 4 + j) * 1024);
         };
-        constexpr int R3 = 2;      // (a 4-slot ring spills 20 registers in this tail: out + acc2 are 128 of the 256)
-        w_f32x4 b3[R3][2];
+        constexpr int R3 = 3;
+        w_f32x4 b3[R3][4];
 #pragma unroll
         for (int r = 0; r < R3 - 1; ++r) b3load(r, b3[r]);
-        stage(0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = w_acc_row(r, lane);                               // Winograd tile -> pixel of the 8 x 16 tile
+                const int pix = (2 * (t >> 3) + (p >> 1)) * W_TW + 2 * (t & 7) + (p & 1);
+                M2[pix * MP + w * 32 + (lane & 31)] = fmaxf(out[p][r] + b2v, 0.f);
+            }
         __syncthreads();
-#pragma unroll 1
-        for (int p = 0; p < 2; ++p) {
-            w_f32x16 acc2[2][2];
+        w_f32x16 acc2[2][4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+        const float* ms = M2 + ((wm * 2) * 32 + (lane & 31)) * MP + (lane >> 5) * 4;
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const int buf = kc & 1;
-                if (kc + 1 < 4) stage(kc + 1, buf ^ 1);
-                const float* ms = M2 + buf * MSZ + ((wm * 2) * 32 + (lane & 31)) * MP + (lane >> 5) * 4;
+        for (int q = 0; q < 16; ++q) {
+            b3load(q + R3 - 1, b3[(q + R3 - 1) % R3]);
+            __builtin_amdgcn_sched_barrier(0);
+            w_f32x4 af[2];
 #pragma unroll
-                for (int sg = 0; sg < 4; ++sg) {
-                    const int q = kc * 4 + sg;
-                    b3load(p * 16 + q + R3 - 1, b3[(q + R3 - 1) % R3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    w_f32x4 af[2];
+            for (int i = 0; i < 2; ++i) af[i] = *(const w_f32x4*)(ms + i * 32 * MP + q * 8);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) af[i] = *(const w_f32x4*)(ms + i * 32 * MP + sg * 8);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc2[i][j] = w_mfma32(af[i][t], b3[q % R3][j][t], acc2[i][j]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float* T = M2 + w * (32 * 36);
-                    const int col = p * 128 + (wn * 2 + j) * 32 + (lane & 7) * 4;
-                    const w_f32x4 bv = *(const w_f32x4*)(a.bias3 + col);
-                    int off[4];
-                    w_f32x4 rv[4], uv[UP ? 4 : 1];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int pp = (wm * 2 + i) * 32 + (lane >> 3) + 8 * k;
-                        const int oy = oy0 + pp / W_TW, ox = ox0 + pp % W_TW;
-                        const bool in = oy < a.OH && ox < a.OW;
-                        off[k] = in ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
-                        rv[k] = buf_load(r_srd, off[k], 0);
-                        // the Hourglass's "up1 + up2(low3)" (hg.py:56-58) folded into this block's output: + low[oy / 2][ox / 2]
-                        // (added LAST, as the separate up-sample kernel would: the fused block stays bit-identical to the two launches;
-                        //  without an addend the descriptor has zero records and the load returns zeros)
-                        if constexpr (UP) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) T[w_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        w_f32x4 o = (*(const w_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
-                        if constexpr (UP) o += uv[k];
-                        buf_store(o, o2_srd, off[k]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            if (p == 0) {
-                __syncthreads();
-                stage(0, 0);
-                __syncthreads();
-            }
+                    for (int j = 0; j < 4; ++j) acc2[i][j] = w_mfma32(af[i][t], b3[q % R3][j][t], acc2[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();                                          // every wave has read the tile: LDS becomes the transposition patches
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* T = M2 + w * (32 * 36);
+                const int col = (wn * 4 + j) * 32 + (lane & 7) * 4;
+                const w_f32x4 bv = *(const w_f32x4*)(a.bias3 + col);
+                int off[4];
+                w_f32x4 rv[4], uv[UP ? 4 : 1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pp = (wm * 2 + i) * 32 + (lane >> 3) + 8 * k;
+                    const int oy = oy0 + pp / W_TW, ox = ox0 + pp % W_TW;
+                    const bool in = oy < a.OH && ox < a.OW;
+                    off[k] = in ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
+                    rv[k] = buf_load(r_srd, off[k], 0);
+                    // the Hourglass's "up1 + up2(low3)" (hg.py:56-58) folded into this block's output: + low[oy / 2][ox / 2]
+                    // (added LAST, as the separate up-sample kernel would: the fused block stays bit-identical to the two launches)
+                    if constexpr (UP) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[w_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w_f32x4 o = (*(const w_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                    if constexpr (UP) o += uv[k];
+                    buf_store(o, o2_srd, off[k]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         return;
     }
 
