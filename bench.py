@@ -237,6 +237,18 @@ def pack_gemm(w, Np, Kp):
     return out
 
 
+def dominant_kernel_traffic(L):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (tools/profile_round.sh -> tools/pmc_to_json.py),
+    or None when the summary is for another launch shape / kernel."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_conv.json")
+    if not os.path.exists(pmc):
+        return None
+    rec = json.load(open(pmc))
+    if rec.get("crops_per_launch") == L and rec.get("kernel", "").replace(" ", "").startswith("wino3x3_kernel<true"):
+        return rec.get("hbm_bytes_per_launch")
+    return None
+
+
 def conv_roofline(L, iters=30):
     """Live HIP-event timing of the dominant kernel at the launch shape of the timed region: the tail of a 256 -> 256 Residual block
     at 64x64 in ONE launch -- conv2 (3x3, 128 -> 128, Winograd F(2x2,3x3)) + ReLU, conv3 (1x1, 128 -> 256) + skip:
@@ -300,12 +312,7 @@ def conv_roofline(L, iters=30):
     tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
     # HBM traffic per launch: rocprofv3 --pmc passes of this same kernel / launch shape (FETCH_SIZE doubled as the
     # microarch guide prescribes for gfx950, WRITE_SIZE as reported), collected by tools/profile_round.sh, stored under profiles/
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_conv.json")
-    if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        if rec.get("crops_per_launch") == L and rec.get("kernel", "").startswith("wino3x3_kernel<true>"):
-            traffic = rec.get("hbm_bytes_per_launch")
+    traffic = dominant_kernel_traffic(L)
     return {"bound": "mfma", "kernel": "wino3x3_kernel<true> fused Residual tail: 3x3 128->128 (Winograd F(2x2,3x3)) + ReLU, 1x1 128->256 + skip @64x64, "
                                        "%d crops/launch" % L,
             "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4),

@@ -36,3 +36,15 @@ def test_winograd_accounting_follows_the_dispatch_threshold():
     assert abs(one - (9 * per(64, 128) + per(128, 64) + per(64, 64))) < 1e-9
     assert bench.winograd_saved_gflop_per_crop(1) < one
     assert bench.GFLOP_PER_CROP - bench.GFLOP_SKIPPED_PER_CROP - full > 0
+
+
+def test_committed_pmc_summary_feeds_roofline_traffic():
+    """roofline.traffic of the default run (256 crops per launch) comes from profiles/pmc_dominant_conv.json: the committed summary
+    must be for that kernel and launch shape, and sane against the algorithmic bytes."""
+    bench, args = _bench([])
+    L = args.objects * args.frames_per_step
+    t = bench.dominant_kernel_traffic(L)
+    assert t is not None
+    algorithmic = 4.0 * L * 64 * 64 * (128 + 256 + 256)
+    assert 0.9 * algorithmic < t < 1.5 * algorithmic
+    assert bench.dominant_kernel_traffic(L + 8) is None
