@@ -38,74 +38,6 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-// the same with LDS reads (ds_read_b128, conflict-free) or L2-resident buffer loads between the MFMAs
-template <int NL, bool VMEM>
-__global__ __launch_bounds__(256) void kl(float* out, const float4* src, int iters) {
-    __shared__ float4 lds[1024];
-    for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = float4{1.f * i, 0.f, 0.f, 0.f};
-    __syncthreads();
-    f32x16 acc[2];
-    for (int i = 0; i < 2; ++i)
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
-    float4 v[8];
-    for (int i = 0; i < 8; ++i) v[i] = float4{0.f, 0.f, 0.f, 0.f};
-    float s = 0;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 1], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < NL; ++q) {
-                const int idx = (threadIdx.x & 63) + 64 * ((u * NL + q) & 15);
-                typedef float vf4 __attribute__((ext_vector_type(4)));
-                vf4 t;
-                if (VMEM) {
-                    const float4* gp = src + idx;
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(t) : "v"(gp) : "memory");
-                } else {
-                    const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)&lds[idx];
-                    asm volatile("ds_read_b128 %0, %1" : "=&v"(t) : "v"(la) : "memory");
-                }
-                if (((u * NL + q) & 7) == 7) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // bound the queue depth
-                v[(u * NL + q) & 7] = float4{t[0], t[1], t[2], t[3]};
-            }
-        }
-        if (it == iters - 1)
-            for (int i = 0; i < 8; ++i) s += v[i].x;
-    }
-    for (int i = 0; i < 2; ++i)
-        for (int r = 0; r < 16; ++r) s += acc[i][r];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
-}
-
-template <int NL, bool VMEM>
-void runl(int wgs_per_cu, int iters) {
-    float* out;
-    float4* src;
-    const int grid = 256 * wgs_per_cu;
-    hipMalloc(&out, grid * 256 * sizeof(float));
-    hipMalloc(&src, 1024 * sizeof(float4));
-    hipMemset(src, 0, 1024 * sizeof(float4));
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    kl<NL, VMEM><<<grid, 256>>>(out, src, 10);
-    hipDeviceSynchronize();
-    float best = 1e9;
-    for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(e0);
-        kl<NL, VMEM><<<grid, 256>>>(out, src, iters);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms;
-        hipEventElapsedTime(&ms, e0, e1);
-        best = ms < best ? ms : best;
-    }
-    const double mfmas = (double)iters * 16 * wgs_per_cu;
-    printf("%s N=%2d waves/SIMD=%d: %.3f ms -> %.1f ns per MFMA per SIMD\n", VMEM ? "buffer/global load x4" : "ds_read_b128         ", NL, wgs_per_cu, best, best * 1e6 / mfmas);
-    hipFree(out); hipFree(src);
-}
-
 template <int NV, bool PK>
 void run(int wgs_per_cu, int iters) {
     float* out;
@@ -143,13 +75,6 @@ int main() {
         run<16, false>(w, 20000);
         run<4, true>(w, 20000);
         run<8, true>(w, 20000);
-    }
-    for (int w = 1; w <= 2; ++w) {
-        runl<1, false>(w, 20000);
-        runl<2, false>(w, 20000);
-        runl<4, false>(w, 20000);
-        runl<1, true>(w, 20000);
-        runl<2, true>(w, 20000);
     }
     return 0;
 }
