@@ -90,7 +90,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     } else {
         t_first = blockIdx.x;
         t_stride = G;
-        n_mine = blockIdx.x < ntiles ? (ntiles - blockIdx.x + G - 1) / G : 0;
+        n_mine = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + G - 1) / G : 0;
     }
     const int nsteps = n_mine * nch;
     if (nsteps == 0) return;

@@ -232,7 +232,6 @@ static int stage_problems(suo_ba_problem* probs, int n_prob, Arena& A, Staged& s
     }
     in_end = L.off;
     // outputs + scratch (device only, but laid out in the same arena; outputs first for one D2H)
-    const size_t out_begin = L.off;
     for (int i = 0; i < n_prob; ++i) {
         suo_ba_problem& q = probs[i];
         size_t* o = prep[i].o;
