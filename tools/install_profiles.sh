@@ -17,7 +17,7 @@ done
   cat $SRC/bench_kernel_stats.txt
 } > profiles/${P}_bench_kernel_stats_final.txt
 {
-  echo "# rocprofv3 --kernel-trace -- python3 tools/bench_dominant.py 30 256   (the dominant kernel (Winograd fused tail), the Winograd 3x3 alone and the two direct-form kernels at the bench launch shape: 256 crops; tools/profile_round.sh $TAG)"
+  echo "# rocprofv3 --kernel-trace -- python3 tools/bench_dominant.py 100 256   (the dominant kernel (Winograd fused tail), the Winograd 3x3 alone and the two direct-form kernels at the bench launch shape: 256 crops; tools/profile_round.sh $TAG)"
   cat $SRC/dominant_kernel_stats.txt
 } > profiles/${P}_dominant_kernel_stats.txt
 {

@@ -12,7 +12,7 @@ python3 $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace -d $OUT/bench_trace -o trace -- python3 $R/bench.py --no-cpu-baseline --no-latency-leg --steps 20 --warmup 5 > $OUT/bench_trace.log 2>&1
 python3 $R/tools/rocpd_stats.py $(find $OUT/bench_trace -name "*.db" | head -1) grid > $OUT/bench_kernel_stats.txt
 # 3. dominant kernel alone at the bench launch shape (256 crops)
-rocprofv3 --kernel-trace -d $OUT/dom_trace -o trace -- python3 $R/tools/bench_dominant.py 30 256 > $OUT/dom.log 2>&1
+rocprofv3 --kernel-trace -d $OUT/dom_trace -o trace -- python3 $R/tools/bench_dominant.py 100 256 > $OUT/dom.log 2>&1
 python3 $R/tools/rocpd_stats.py $(find $OUT/dom_trace -name "*.db" | head -1) grid > $OUT/dominant_kernel_stats.txt
 # 4. PMC passes (separate runs per counter group, no other tracing)
 mkdir -p $R/gpurun_out/pmc && rm -f $R/gpurun_out/pmc/*
