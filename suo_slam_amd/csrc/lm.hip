@@ -83,12 +83,10 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
     size_t off = 0;
     double* S = (double*)lm_lds;            // reduced (object) system / its Cholesky factor, ns x ns
     double* rhs = S;
-    double* colbuf = S;
-    const int sp = ns | 1;                  // odd pitch of S in LDS (lm_device.h: wave_cholesky_solve)
+    const int sp = ns | 1;                  // odd pitch of S in LDS (lm_device.h: wg_cholesky_solve)
     if (schur) {
         off = (((size_t)ns * sp + 8) * sizeof(double) + 15) & ~(size_t)15;
         rhs = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
-        colbuf = (double*)(lm_lds + off); off += ((size_t)ns * sizeof(double) + 15) & ~(size_t)15;
     }
     // Large graphs (the global SLAM adjustment): the [n_edge][29] Jacobians cannot live in LDS.  Instead of writing them
     // to HBM and re-reading each pair's rows 90 times from L2 (47 % of a 7500-edge adjustment), the edges are linearised
@@ -343,12 +341,9 @@ __global__ __launch_bounds__(LM_THREADS) void lm_kernel(const LmProblem* __restr
                     }
                     __syncthreads();
                     LMPROF(6);
-                    // Cholesky S = L L^T (lower, in place), then forward / backward substitution -- by ONE wave: the
-                    // system is at most 96 x 96 and its 5 dependent steps per column need no workgroup barrier this way
-                    // (5 * ns of them otherwise, with up to 16 waves each).  Same arithmetic per element as a
-                    // workgroup-wide version.  LDS operations of a wave complete in issue order; fences + wave barriers
-                    // pin the compiler (lm_device.h: wave_cholesky_solve; odd LDS pitch sp against the 64-way bank conflict).
-                    if (tid < 64) wave_cholesky_solve(S, sp, rhs, colbuf, ns, tid, &sh_ok);
+                    // Cholesky S = L L^T (lower, in place), then forward / backward substitution: blocked by 6 over the whole
+                    // workgroup (lm_device.h: wg_cholesky_solve; odd LDS pitch sp against the 64-way bank conflict)
+                    wg_cholesky_solve(S, sp, rhs, ns, tid, LM_THREADS, &sh_ok);
                     __syncthreads();
                     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
                         const int o = idx / 6;
@@ -462,7 +457,7 @@ int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipSt
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur) {
     size_t b = 0;
     const size_t ns = 6 * (size_t)n_free_obj_schur;
-    b += 8 * (ns * (ns + 1) + 8 + 2 * ns) + 48;
+    b += 8 * (ns * (ns + 1) + 8 + ns) + 48;
     b += 4 * 56 * (size_t)(C + O) / 2 * 2 + 2 * (size_t)(C + O) + 4 * (size_t)O;
     b += 8 * 48 * (size_t)O + 8 * 54 * (size_t)C;
     b += 4 * (3 * (size_t)NP + 1) + 4 * ((size_t)C + 1 + NP) + 4 * ((size_t)O + 1 + NP);

@@ -211,82 +211,139 @@ struct LmProblem {
     int* stats;                  // [4] rounds, LM iterations, LM trials, num_good
 };
 
-// Cholesky factorisation, forward and backward substitution of the ns x ns reduced (object) system by ONE wave; lane l
-// owns rows l, l + 64.  S is row-major with a pitch of `sp` doubles and only its lower triangle is referenced; rhs is
-// overwritten by the solution; colbuf holds ns doubles.  Use an ODD pitch: with sp = ns = 48 every lane of a column
-// access (stride 96 dwords) lands on one LDS bank -- a 64-way conflict that made this step 27 % of a global adjustment.
-// The dot products run on four independent accumulators (the serial fp64 chain was the other half of the cost).
-// *ok is cleared on a non-positive pivot; the factorisation then continues with a unit pivot and the caller rejects the trial.
-// Cross-lane values travel by v_readlane (a few cycles) instead of LDS round trips: the pivot of column j is lane 0's own
-// dot product, and the right-hand side lives in two registers per lane during the substitutions (ns <= 128).
-DEV double wave_bcast(double v, int src_lane) {          // src_lane must be wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-DEV void wave_cholesky_solve(double* S, int sp, double* rhs, double* /*colbuf: no longer needed*/, int ns_, int lane, int* ok) {
-    const int ns = __builtin_amdgcn_readfirstlane(ns_);          // provably wave-uniform loop bounds / readlane selectors
-    for (int j = 0; j < ns; ++j) {                 // column j: lane l owns rows j + l, j + l + 64
-        const double* rj = S + j * sp;
-        // dot product of rows i and j over columns < j, in rounds of 8 terms: 16 LDS reads in flight, four independent fp64
-        // chains; the last round is masked instead of a scalar tail (whose 2 reads + 1 FMA per step were a dependent chain
-        // of LDS round trips).  Masked terms read up to 7 doubles past column j of the two rows -- inside the LDS array or
-        // its 8-double slack, never used.  (Two named results, not an indexed array: that would live in scratch memory.)
-        auto row_dot = [&](int i) -> double {
-            if (i >= ns) return 0.0;
-            const double* ri = S + i * sp;
-            double s0 = ri[j], s1 = 0, s2 = 0, s3 = 0;
-            for (int k = 0; k < j; k += 8) {
-                const double a0 = ri[k], a1 = ri[k + 1], a2 = ri[k + 2], a3 = ri[k + 3], a4 = ri[k + 4], a5 = ri[k + 5], a6 = ri[k + 6], a7 = ri[k + 7];
-                const double b0 = rj[k], b1 = rj[k + 1], b2 = rj[k + 2], b3 = rj[k + 3], b4 = rj[k + 4], b5 = rj[k + 5], b6 = rj[k + 6], b7 = rj[k + 7];
-                const int m = j - k;                 // terms of this round that exist (>= 1)
-                s0 -= a0 * b0;
-                s1 -= m > 1 ? a1 * b1 : 0.0; s2 -= m > 2 ? a2 * b2 : 0.0; s3 -= m > 3 ? a3 * b3 : 0.0;
-                s0 -= m > 4 ? a4 * b4 : 0.0; s1 -= m > 5 ? a5 * b5 : 0.0; s2 -= m > 6 ? a6 * b6 : 0.0; s3 -= m > 7 ? a7 * b7 : 0.0;
+// Cholesky factorisation, forward and backward substitution of the ns x ns reduced (object) system by the WHOLE workgroup, blocked
+// by 6 (one object's pose block; ns is a multiple of 6): right-looking Cholesky of the lower triangle in LDS (row-major, pitch `sp`
+// doubles, only the lower triangle is referenced -- use an ODD pitch: with sp = ns = 48 a column access lands on one LDS bank), then
+// blocked forward / backward substitution; rhs is overwritten by the solution.  Per block step every thread factors the 6 x 6 diagonal
+// block redundantly in registers (broadcast LDS reads, no hand-off), thread t solves panel row t against it, one barrier, the
+// trailing update is tiled 16 x 16 over the threads, one barrier: 2 ns / 6 barriers for the factorisation.  (Until round 2 this was
+// a one-wave column loop -- ns dependent steps, each a dot product of LDS round trips: 161 us for a 96-row system, a third of a
+// bundle-adjustment trial.)  *ok is cleared on a non-positive / non-finite pivot; the factorisation then continues with a unit pivot
+// and the caller rejects the trial.  Call from ALL threads of the workgroup (>= 256); `rhs` holds the solution after the caller's
+// next barrier.
+DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int nthreads, int* ok) {
+    const int ns = __builtin_amdgcn_readfirstlane(ns_);
+    auto load_diag = [&](int k0, double (&L)[6][6]) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) L[r][c] = S[(k0 + r) * sp + k0 + c];
+    };
+    for (int k0 = 0; k0 < ns; k0 += 6) {
+        double L[6][6], rd[6];
+        load_diag(k0, L);
+        bool good = true;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double piv = L[c][c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) piv -= L[c][q] * L[c][q];
+            if (!(piv > 0) || !isfinite(piv)) good = false;
+            const double pp = piv > 0 ? piv : 1.0;
+            rd[c] = rsqrt(pp);
+            L[c][c] = pp * rd[c];
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                double v = L[r][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= L[r][q] * L[c][q];
+                L[r][c] = v * rd[c];
             }
-            return (s0 + s1) + (s2 + s3);
-        };
-        const int ia = j + lane, ib = j + lane + 64;
-        const double sa = row_dot(ia);
-        const double sb = ns > 64 ? row_dot(ib) : 0.0;   // (uniform: systems of <= 64 rows never touch the second row)
-        const double piv = wave_bcast(sa, 0);            // row j itself is lane 0's first row
-        if (!(piv > 0) || !isfinite(piv)) { if (lane == 0) *ok = 0; }
-        // the 48..96 dependent column steps are latency-bound, and an fp64 sqrt followed by an fp64 division is most of a
-        // step: one reciprocal square root serves both (d = piv * rd, L_ij = s_ij * rd; 1-2 ulp from the divided form)
-        const double rd = rsqrt(piv > 0 ? piv : 1.0), d = (piv > 0 ? piv : 1.0) * rd;
-        if (ia < ns) S[ia * sp + j] = (ia == j) ? d : sa * rd;
-        if (ib < ns) S[ib * sp + j] = sb * rd;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // column j is in LDS before any lane's next dot product
-        __builtin_amdgcn_wave_barrier();
+        }
+        if (!good && tid == 0) *ok = 0;
+        // panel row i = k0 + 6 + t:  L21[i][.] = A21[i][.] L11^-T
+        for (int i = k0 + 6 + tid; i < ns; i += nthreads) {
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = S[i * sp + k0 + c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= x[q] * L[c][q];
+                x[c] = v * rd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[i * sp + k0 + c] = x[c];
+        }
+        __syncthreads();                                   // panel complete; every thread has read the diagonal block
+        if (tid < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (c <= tid) {
+                    double v = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) v = r == tid ? L[r][c] : v;      // (static indexing: L stays in registers)
+                    S[(k0 + tid) * sp + k0 + c] = v;
+                }
+        }
+        // trailing update of the lower triangle, 16 x 16 tiles of (row a, column b <= a) over the threads
+        const int m = ns - k0 - 6, base = k0 + 6;
+        const int ty = (tid >> 4) & 15, tx = tid & 15;
+        if (tid < 256) {
+            for (int a0 = 0; a0 < m; a0 += 16) {
+                const int a = a0 + ty;
+                double la[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) la[c] = a < m ? S[(base + a) * sp + k0 + c] : 0.0;
+                for (int b0 = 0; b0 <= a0; b0 += 16) {
+                    const int b = b0 + tx;
+                    if (a < m && b <= a) {
+                        double acc = S[(base + a) * sp + base + b];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) acc -= la[c] * S[(base + b) * sp + k0 + c];
+                        S[(base + a) * sp + base + b] = acc;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    const int i0 = lane, i1 = lane + 64;
-    double r0 = i0 < ns ? rhs[i0] : 0.0, r1 = i1 < ns ? rhs[i1] : 0.0;
-    // reciprocal diagonal of L, one division per lane up front instead of one per (serial) substitution step
-    const double g0 = i0 < ns ? 1.0 / S[i0 * sp + i0] : 1.0, g1 = i1 < ns ? 1.0 / S[i1 * sp + i1] : 1.0;
-    // the element of L a lane needs in step j does not depend on the chain: it is read one step ahead
-    double c0 = i0 < ns ? S[i0 * sp] : 0.0, c1 = i1 < ns ? S[i1 * sp] : 0.0;
-    for (int j = 0; j < ns; ++j) {                 // L y = rhs
-        const int jn = j + 1 < ns ? j + 1 : j;
-        const double n0 = i0 < ns ? S[i0 * sp + jn] : 0.0, n1 = i1 < ns ? S[i1 * sp + jn] : 0.0;
-        const double yj = wave_bcast(j < 64 ? r0 : r1, j & 63) * wave_bcast(j < 64 ? g0 : g1, j & 63);
-        if (i0 == j) r0 = yj;
-        if (i1 == j) r1 = yj;
-        if (i0 > j && i0 < ns) r0 -= c0 * yj;
-        if (i1 > j && i1 < ns) r1 -= c1 * yj;
-        c0 = n0; c1 = n1;
+    // L y = rhs, block by block: every thread solves the 6 x 6 block redundantly, thread t then updates row t below it
+    for (int k0 = 0; k0 < ns; k0 += 6) {
+        double L[6][6], y[6];
+        load_diag(k0, L);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double v = rhs[k0 + c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) v -= L[c][q] * y[q];
+            y[c] = v / L[c][c];
+        }
+        for (int i = k0 + 6 + tid; i < ns; i += nthreads) {
+            double v = rhs[i];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v -= S[i * sp + k0 + c] * y[c];
+            rhs[i] = v;
+        }
+        __syncthreads();                                   // every thread has read rhs[k0 ..]; rows below are updated
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rhs[k0 + c] = y[c];
+        }
     }
-    c0 = i0 < ns ? S[(ns - 1) * sp + i0] : 0.0; c1 = i1 < ns ? S[(ns - 1) * sp + i1] : 0.0;
-    for (int j = ns - 1; j >= 0; --j) {            // L^T x = y
-        const int jn = j > 0 ? j - 1 : 0;
-        const double n0 = i0 < ns ? S[jn * sp + i0] : 0.0, n1 = i1 < ns ? S[jn * sp + i1] : 0.0;
-        const double xj = wave_bcast(j < 64 ? r0 : r1, j & 63) * wave_bcast(j < 64 ? g0 : g1, j & 63);
-        if (i0 == j) r0 = xj;
-        if (i1 == j) r1 = xj;
-        if (i0 < j) r0 -= c0 * xj;
-        if (i1 < j) r1 -= c1 * xj;
-        c0 = n0; c1 = n1;
+    __syncthreads();
+    // L^T x = y, from the last block up
+    for (int k0 = ns - 6; k0 >= 0; k0 -= 6) {
+        double L[6][6], x[6];
+        load_diag(k0, L);
+#pragma unroll
+        for (int c = 5; c >= 0; --c) {
+            double v = rhs[k0 + c];
+#pragma unroll
+            for (int q = c + 1; q < 6; ++q) v -= L[q][c] * x[q];
+            x[c] = v / L[c][c];
+        }
+        for (int i = tid; i < k0; i += nthreads) {
+            double v = rhs[i];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v -= S[(k0 + c) * sp + i] * x[c];
+            rhs[i] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) rhs[k0 + c] = x[c];
+        }
     }
-    if (i0 < ns) rhs[i0] = r0;
-    if (i1 < ns) rhs[i1] = r1;
 }
 
 DEV bool edge_active(const LmProblem& P, int e) {

@@ -192,11 +192,11 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
                                                                const double* __restrict__ HB, const double* __restrict__ St, int expect_ok,
                                                                int* __restrict__ bad) {
     const LmProblem& P = *Pp;
-    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch + slack for the masked dot-product rounds
-    __shared__ double rhs[LM_NS], colbuf[LM_NS];
+    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch (+ slack)
+    __shared__ double rhs[LM_NS];
     __shared__ int sh_ok;
     const int tid = threadIdx.x;
-    const int sp = ns | 1;                          // odd LDS pitch (lm_device.h: wave_cholesky_solve)
+    const int sp = ns | 1;                          // odd LDS pitch (lm_device.h: wg_cholesky_solve)
     const double* rt = St + ns * ns;
     if (tid == 0) sh_ok = 1;
     if (tid == 0 && expect_ok > 0 && (int)(rt[ns] + 0.5) != expect_ok) atomicAdd(bad, 1);      // some rank's camera block was singular
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
         if (P.obj_slot[o] >= 0) rhs[6 * P.obj_slot[o] + r] = HB[27 * o + 21 + r] - rt[6 * P.obj_slot[o] + r];
     }
     __syncthreads();
-    if (tid < 64) wave_cholesky_solve(S, sp, rhs, colbuf, ns, tid, &sh_ok);      // one wave, as in csrc/lm.hip
+    wg_cholesky_solve(S, sp, rhs, ns, tid, LM_THREADS, &sh_ok);                  // blocked by 6, the whole workgroup (lm_device.h)
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
         const int o = idx / 6;

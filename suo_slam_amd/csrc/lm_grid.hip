@@ -125,8 +125,8 @@ DEV void grid_reduce3(double (&v)[LG_RED_N], GridCtx& g, double* red_lds) {
 __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __restrict__ Pp, LmGridScratch sc, int G) {
     if (blockIdx.x & 7) return;                 // workgroup b runs on XCD b % 8 (observed; performance only): keep one XCD
     const LmProblem& P = *Pp;
-    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch + slack for the masked dot-product rounds
-    __shared__ double rhs[LM_NS], colbuf[LM_NS];
+    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch (+ slack)
+    __shared__ double rhs[LM_NS];
     __shared__ double red_lds[LG_RED_N * (LG_THREADS / 64)];
     __shared__ int sh_flag, sh_ok;
     GridCtx g;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
                     LGPROF(5);
                     {   // Cholesky + substitutions by one wave of EVERY workgroup: identical inputs, identical instruction
                         // stream, identical x_o everywhere -- which saves the grid barrier that would publish workgroup 0's
-                        const int sp = ns | 1;                           // odd LDS pitch (lm_device.h: wave_cholesky_solve)
+                        const int sp = ns | 1;                           // odd LDS pitch (lm_device.h: wg_cholesky_solve)
                         // the packed system: all of a thread's loads are issued before the first LDS store (one L2 round trip)
                         constexpr int NCP = (LM_NS * (LM_NS + 1) / 2 + LM_NS + LG_THREADS - 1) / LG_THREADS;
                         double v[NCP];
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
                         if (tid == 0) sh_ok = 1;
                         __syncthreads();
                         LGPROF(10);
-                        if (tid < 64) wave_cholesky_solve(S, sp, rhs, colbuf, ns, tid, &sh_ok);
+                        wg_cholesky_solve(S, sp, rhs, ns, tid, LG_THREADS, &sh_ok);
                         __syncthreads();
                         LGPROF(11);
                         // solution (every workgroup writes the same words)
