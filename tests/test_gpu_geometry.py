@@ -308,7 +308,7 @@ def test_too_few_edges_is_a_noop(ba):
     assert got[4][0] == 0
 
 
-@pytest.mark.parametrize("n_cam,n_obj", [(5, 2), (12, 6), (40, 8), (70, 12), (10, 20)])
+@pytest.mark.parametrize("n_cam,n_obj", [(4, 1), (5, 2), (12, 6), (40, 8), (70, 12), (20, 16), (10, 20)])
 def test_phase_wise_global_ba_matches_oracle_and_single_kernel(ba, n_cam, n_obj):
     """The multi-GPU path's phase kernels (csrc/lm_dist.hip) under the host LM schedule (suo_slam_amd/ba_dist.py),
     here with one rank: must agree with the dense oracle and with the single-kernel path (csrc/lm.hip).  The
