@@ -274,6 +274,12 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
                     for (int r = 0; r < 6; ++r) v = r == tid ? L[r][c] : v;      // (static indexing: L stays in registers)
                     S[(k0 + tid) * sp + k0 + c] = v;
                 }
+            // 1 / L_qq for the substitutions, kept in the never-referenced element right of the diagonal (sp > ns: the last row's is
+            // the pad column) -- six fp64 divisions per block step and thread otherwise
+            double rdv = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) rdv = r == tid ? rd[r] : rdv;
+            S[(k0 + tid) * sp + k0 + tid + 1] = rdv;
         }
         // trailing update of the lower triangle, 16 x 16 tiles of (row a, column b <= a) over the threads
         const int m = ns - k0 - 6, base = k0 + 6;
@@ -306,7 +312,7 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
             double v = rhs[k0 + c];
 #pragma unroll
             for (int q = 0; q < c; ++q) v -= L[c][q] * y[q];
-            y[c] = v / L[c][c];
+            y[c] = v * S[(k0 + c) * sp + k0 + c + 1];
         }
         for (int i = k0 + 6 + tid; i < ns; i += nthreads) {
             double v = rhs[i];
@@ -330,7 +336,7 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
             double v = rhs[k0 + c];
 #pragma unroll
             for (int q = c + 1; q < 6; ++q) v -= L[q][c] * x[q];
-            x[c] = v / L[c][c];
+            x[c] = v * S[(k0 + c) * sp + k0 + c + 1];
         }
         for (int i = tid; i < k0; i += nthreads) {
             double v = rhs[i];

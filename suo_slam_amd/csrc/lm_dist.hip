@@ -151,27 +151,49 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem*
     }
 }
 // out = [S_g (ns x ns) | r_g (ns) | ok]
+// One workgroup per 6 x 6 block (s1, s2) of S (grid-strided), the block's 36 elements x 7 slices of object o1's camera list over 252
+// threads, slices summed in slice order through LDS (deterministic).  (One thread per element walking the whole list: 45 us -- its
+// three dependent index loads per camera are pure latency.)  The right-hand side rows follow, one thread per row.
 __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem* __restrict__ Pp, int ns, const int* __restrict__ bad,
                                                                  double* __restrict__ out) {
     const LmProblem& P = *Pp;
-    for (int idx = GT; idx < ns * ns; idx += GS) {
-        const int row = idx / ns, col = idx - row * ns;
-        const int s1 = row / 6, i = row - s1 * 6, s2 = col / 6, j = col - s2 * 6;
-        int o1 = -1, o2 = -1;
-        for (int o = 0; o < P.n_obj; ++o) { if (P.obj_slot[o] == s1) o1 = o; if (P.obj_slot[o] == s2) o2 = o; }
-        double acc = 0;
-        for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
-            const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
-            const int p2 = P.cam_obj_pair[(size_t)c * P.n_obj + o2];
-            if (P.cam_fixed[c] || p2 < 0) continue;
-            const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
-            const double* Y2 = P.Y + 36 * (size_t)p2;
-            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
+    constexpr int NSL = LM_THREADS / 36;                      // camera slices (7 with 256 threads)
+    __shared__ double part[NSL * 36];
+    __shared__ int sh_o[2];
+    const int tid = threadIdx.x, nb = ns / 6;
+    const int sl = tid / 36, e = tid - sl * 36, i = e / 6, j = e - i * 6;
+    for (int blk = blockIdx.x; blk < nb * nb; blk += gridDim.x) {
+        const int s1 = blk / nb, s2 = blk - s1 * nb;
+        if (tid < 2) {
+            const int want = tid == 0 ? s1 : s2;
+            int oo = -1;
+            for (int o = 0; o < P.n_obj; ++o) if (P.obj_slot[o] == want) oo = o;
+            sh_o[tid] = oo;
         }
-        out[idx] = acc;
+        __syncthreads();
+        const int o1 = sh_o[0], o2 = sh_o[1];
+        if (sl < NSL) {
+            double acc = 0;
+            for (int a = P.obj_pair_ptr[o1] + sl; a < P.obj_pair_ptr[o1 + 1]; a += NSL) {
+                const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
+                const int p2 = P.cam_obj_pair[(size_t)c * P.n_obj + o2];
+                if (P.cam_fixed[c] || p2 < 0) continue;
+                const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
+                const double* Y2 = P.Y + 36 * (size_t)p2;
+                for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
+            }
+            part[sl * 36 + e] = acc;
+        }
+        __syncthreads();
+        if (tid < 36) {
+            double acc = 0;
+            for (int q = 0; q < NSL; ++q) acc += part[q * 36 + tid];
+            out[(6 * s1 + tid / 6) * ns + 6 * s2 + tid % 6] = acc;
+        }
+        __syncthreads();
     }
     for (int row = GT; row < ns; row += GS) {
-        const int s1 = row / 6, i = row - s1 * 6;
+        const int s1 = row / 6, i2 = row - s1 * 6;
         int o1 = -1;
         for (int o = 0; o < P.n_obj; ++o) if (P.obj_slot[o] == s1) o1 = o;
         double acc = 0;
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
             const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
             if (P.cam_fixed[c]) continue;
             const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
-            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * P.yc[6 * c + k];
+            for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i2] * P.yc[6 * c + k];
         }
         out[ns * ns + row] = acc;
     }
@@ -200,7 +222,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
     const double* rt = St + ns * ns;
     if (tid == 0) sh_ok = 1;
     if (tid == 0 && expect_ok > 0 && (int)(rt[ns] + 0.5) != expect_ok) atomicAdd(bad, 1);      // some rank's camera block was singular
-    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) S[(idx / ns) * sp + idx % ns] = -St[idx];
+    for (int row = tid >> 6; row < ns; row += LM_THREADS / 64)          // a wave per row, lanes over the columns of the lower triangle
+        for (int col = tid & 63; col <= row; col += 64) S[row * sp + col] = -St[row * ns + col];
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
         const int o = idx / 36, rc = idx - o * 36, r = rc / 6, cc = rc - r * 6;
@@ -291,23 +314,32 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_big_kernel(const LmProble
     if (tid == 0 && sh_ok == 0) atomicAdd(bad, 1);
 }
 // x_c = y_c - sum_o Y(c,o) x_o for the own cameras, then T <- exp(x) T for cameras and objects (one thread per pose)
+// x_c = y_c - sum_o Y(c,o) x_o and the pose updates.  Six threads per camera (one per row of x_c): the dependent index chain of a
+// camera's pair list runs once per row in parallel instead of six times in a row (one thread per camera: 47 us for 32 cameras).
 __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* __restrict__ Pp, const int* __restrict__ bad) {
     const LmProblem& P = *Pp;
     const bool ok = *bad == 0;
-    for (int c = GT; c < P.n_cam; c += GS) {
-        for (int r = 0; r < 6; ++r) {
+    constexpr int CPW = LM_THREADS / 6;                       // cameras per workgroup and sweep
+    const int tid = threadIdx.x, cl = tid / 6, r = tid - cl * 6;
+    for (int c0 = blockIdx.x * CPW; c0 < P.n_cam; c0 += gridDim.x * CPW) {
+        const int c = c0 + cl;
+        const bool mine = cl < CPW && c < P.n_cam;
+        if (mine) {
             double s = 0;
             if (!P.cam_fixed[c]) {
                 s = P.yc[6 * c + r];
                 for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b) {
                     const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
                     if (P.obj_fixed[o]) continue;
-                    for (int k = 0; k < 6; ++k) s -= P.Y[36 * (size_t)p + r * 6 + k] * P.xo[6 * o + k];
+                    const double* Yr = P.Y + 36 * (size_t)p + r * 6;
+                    const double* xo = P.xo + 6 * o;
+                    for (int k = 0; k < 6; ++k) s -= Yr[k] * xo[k];
                 }
             }
             P.xc[6 * c + r] = s;
         }
-        if (ok && !P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
+        __syncthreads();                                      // the six rows of a camera are written (same workgroup)
+        if (mine && r == 0 && ok && !P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
     }
     if (ok)
         for (int o = GT; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
@@ -374,7 +406,10 @@ int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* s
     SUO_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
     BA_GRID(ba_schur_cams_kernel, lambda, bad);
     BA_GRID(ba_schur_y_kernel);
-    BA_GRID(ba_schur_s_kernel, ns, (const int*)bad, out);
+    {   // one workgroup per 6 x 6 block of S
+        const int nb = ns / 6, g = nb * nb < BA_WGS ? BA_WGS : (nb * nb > 1024 ? 1024 : nb * nb);
+        hipLaunchKernelGGL(ba_schur_s_kernel, dim3(g), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ns, (const int*)bad, out);
+    }
     BA_DONE
 }
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
