@@ -13,7 +13,9 @@ done
 {
   echo "# rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-latency-leg --steps 20 --warmup 5   (MI355X; tools/profile_round.sh $TAG)"
   echo "# one step = 32 frames (256 crops) per network call + their PnP / LM, 2 steps in flight; kernels of the two calls overlap,"
-  echo "# so per-kernel durations here are concurrent-execution times (summarised per kernel x grid with tools/rocpd_stats.py)"
+  echo "# so per-kernel durations here are concurrent-execution times (summarised per kernel x grid with tools/rocpd_stats.py)."
+  echo "# The dominant kernel's 8192-workgroup row mixes the steps' launches (concurrent, longer) with the 41 isolated launches of bench.py's"
+  echo "# roofline loop (its min_us column is the isolated duration); the isolated trace is r02_dominant_kernel_stats.txt."
   cat $SRC/bench_kernel_stats.txt
 } > profiles/${P}_bench_kernel_stats_final.txt
 {
