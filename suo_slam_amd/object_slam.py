@@ -323,6 +323,7 @@ class ObjectSLAM:
             self.optimize()
             self.opt_time_meter.update(time() - t0)
         results = {}
+        n_inl = {}                     # per object, the same for every view: counted once (the reference recounts per view, :199-214)
         assert len(self.view_ids) == len(self.cam_poses)
         for view_id in ([self.view_ids[-1]] if last_only else self.view_ids):
             T_GtoC = to4x4(self.cam_poses[view_id])
@@ -332,7 +333,9 @@ class ObjectSLAM:
                 T_OtoC = None
                 if obj_id in self.obj_poses:
                     T_OtoC = T_GtoC @ to4x4(self.obj_poses[obj_id])
-                results[view_id]["poses"][obj_id] = {"T_OtoC": T_OtoC, "score": 1 + self.obj_num_inliers(obj_id)}
+                if obj_id not in n_inl:
+                    n_inl[obj_id] = self.obj_num_inliers(obj_id)
+                results[view_id]["poses"][obj_id] = {"T_OtoC": T_OtoC, "score": 1 + n_inl[obj_id]}
         return results
 
     # ---------------------------------------------------------------------------------------------
