@@ -453,20 +453,45 @@ DEV void accumulate_pairs_range(const LmProblem& P, int p_begin, int p_end, int 
 }
 DEV void accumulate_pairs(const LmProblem& P) { accumulate_pairs_range(P, 0, P.n_pair); }
 
-// solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if not PD
-__device__ bool spd_solve6(const double* A, const double* b, double* x) {
-    double L[36];
-    for (int i = 0; i < 6; ++i)
+// solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if not PD (x is then unspecified).
+// Fully unrolled with compile-time indices and inlined: as a plain function with runtime loop indices the factor lived in SCRATCH
+// memory (368 bytes per lane in lm_frame_kernel) and every one of its ~100 accesses per call was a memory round trip -- the single
+// largest cost of a frame's LM trial.  One reciprocal per pivot instead of a division per element (1 ulp from the divided form).
+DEV bool spd_solve6(const double* A, const double* b, double* x) {
+    double L[6][6], dinv[6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
         for (int j = 0; j <= i; ++j) {
             double s = A[i * 6 + j];
-            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
-            if (i == j) { if (!(s > 0) || !isfinite(s)) return false; L[i * 6 + i] = sqrt(s); }
-            else L[i * 6 + j] = s / L[j * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 0) || !isfinite(s)) ok = false;
+                L[i][i] = sqrt(ok ? s : 1.0);
+                dinv[i] = 1.0 / L[i][i];
+            } else {
+                L[i][j] = s * dinv[j];
+            }
         }
+    }
     double y[6];
-    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
-    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
-    return true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s * dinv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+        x[i] = s * dinv[i];
+    }
+    return ok;
 }
 
 DEV void unpack_sym21(const double* s, double* A) {

@@ -14,6 +14,8 @@
 //     sum them in object order and take the same accept / reject / lambda decision.
 // Same rounds / robust-kernel schedule / lambda schedule / re-classification as csrc/lm.hip; the summation order of H, b
 // and chi2 differs (rounding level).  Frames run as independent workgroups.
+#include <type_traits>
+
 #include "lm_device.h"
 
 namespace suo {
@@ -138,15 +140,18 @@ __global__ __launch_bounds__(64 * MAXW) void lm_frame_kernel(const LmProblem* __
         return wsum(good);
     };
     // robustified chi2 of the own ACTIVE edges at pose (Ro, to); with h != nullptr also J^T W J (21, packed upper) and J^T W r (6)
-    auto edge_pass = [&](const double* Ro, const double* to, bool robust_on, double* h) -> double {
+    // (WITH_H as a type, h as an array reference: with a nullable pointer the 27 sums lived in scratch memory -- the lambda served both
+    //  call shapes and the array escaped through it -- and every update of them was a memory round trip)
+    auto edge_pass = [&](const double* Ro, const double* to, bool robust_on, auto with_h, double (&h)[27]) -> double {
+        constexpr bool WITH_H = decltype(with_h)::value;
         double c = 0;
         auto one = [&](const LfEdge& E) {
             double er[2], Jo[12];
-            lf_edge(E, Ro, to, er, h ? Jo : nullptr);
+            lf_edge(E, Ro, to, er, WITH_H ? Jo : nullptr);
             const double c2 = lf_chi2(E, er);
             double wgt = 1.0;
             c += robust_on ? huber_rho(c2, P.huber_delta, wgt) : c2;
-            if (h) {
+            if constexpr (WITH_H) {
                 const double i0 = wgt * E.info[0], i1 = wgt * E.info[1], i2 = wgt * E.info[2];
                 const double g0 = -(E.info[0] * er[0] + E.info[1] * er[1]) * wgt, g1 = -(E.info[1] * er[0] + E.info[2] * er[1]) * wgt;
                 double wj0[6], wj1[6];
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(64 * MAXW) void lm_frame_kernel(const LmProblem* __
             q_to_R(pose.q, Ro);
 #pragma unroll
             for (int k = 0; k < 27; ++k) h[k] = 0;
-            const double chi_o = edge_pass(Ro, pose.t, robust_on, h);
+            const double chi_o = edge_pass(Ro, pose.t, robust_on, std::true_type{}, h);
             wsum_many<27>(h);
             double md = 0;
             if (free_obj) {
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(64 * MAXW) void lm_frame_kernel(const LmProblem* __
                 double Rt[9];
                 q_to_R(trial.q, Rt);
                 // (a failed block anywhere rejects the whole trial: the chi2 evaluated here is then discarded)
-                const double temp_o = edge_pass(Rt, trial.t, robust_on, nullptr);
+                const double temp_o = edge_pass(Rt, trial.t, robust_on, std::false_type{}, h);
                 exchange(temp_o, sc_o, ok_o ? 0.0 : 1.0, 0, ex);
                 const bool ok2 = ex[2] == 0.0;
                 const double tempChi = ok2 ? ex[0] : 1.7976931348623157e308;
