@@ -365,7 +365,9 @@ DEV void edge_error(const LmProblem& P, int e, double* err, double* pw_out, doub
     q_to_R(obj.q, Ro);
     q_to_R(cam.q, Rc);
     const double* x = P.edge_p + 3 * e;
+#pragma unroll
     for (int r = 0; r < 3; ++r) pw[r] = Ro[3 * r] * x[0] + Ro[3 * r + 1] * x[1] + Ro[3 * r + 2] * x[2] + obj.t[r];
+#pragma unroll
     for (int r = 0; r < 3; ++r) pc[r] = Rc[3 * r] * pw[0] + Rc[3 * r + 1] * pw[1] + Rc[3 * r + 2] * pw[2] + cam.t[r];
     const double* k = P.edge_k + 4 * e;
     err[0] = P.edge_uv[2 * e] - (k[0] * pc[0] / pc[2] + k[2]);
@@ -399,12 +401,17 @@ DEV double edge_pass_partial(const LmProblem& P, int e_begin, int e_end, bool ro
             const double* k = P.edge_k + 4 * e;
             const double PJ[6] = {-(k[0] / pc[2]), 0, k[0] * pc[0] / (pc[2] * pc[2]), 0, -(k[1] / pc[2]), k[1] * pc[1] / (pc[2] * pc[2])};
             double PR[6];
+            // (every small loop here is unrolled explicitly: left rolled, Dw / Dc were indexed at run time and lived in scratch memory)
+#pragma unroll
             for (int r = 0; r < 2; ++r)
+#pragma unroll
                 for (int cc = 0; cc < 3; ++cc) PR[3 * r + cc] = PJ[3 * r] * Rc[cc] + PJ[3 * r + 1] * Rc[3 + cc] + PJ[3 * r + 2] * Rc[6 + cc];
             const double Dw[18] = {0, pw[2], -pw[1], 1, 0, 0, -pw[2], 0, pw[0], 0, 1, 0, pw[1], -pw[0], 0, 0, 0, 1};
             const double Dc[18] = {0, pc[2], -pc[1], 1, 0, 0, -pc[2], 0, pc[0], 0, 1, 0, pc[1], -pc[0], 0, 0, 0, 1};
             double* J = P.jac + 29 * (size_t)e;
+#pragma unroll
             for (int r = 0; r < 2; ++r)
+#pragma unroll
                 for (int cc = 0; cc < 6; ++cc) {
                     J[6 * r + cc] = PJ[3 * r] * Dc[cc] + PJ[3 * r + 1] * Dc[6 + cc] + PJ[3 * r + 2] * Dc[12 + cc];            // Jc
                     J[12 + 6 * r + cc] = PR[3 * r] * Dw[cc] + PR[3 * r + 1] * Dw[6 + cc] + PR[3 * r + 2] * Dw[12 + cc];       // Jo

@@ -49,6 +49,8 @@ with tempfile.TemporaryDirectory() as root:
             if T is not None:
                 gt = ds.get_obj_pose(scene, v, o)
                 err.append(np.linalg.norm(T[:3, 3] - gt[:3, 3]) / gt[2, 3])
+    print(f"  of which global adjustments (every {slam.global_opt_every} views, graphs of 10 .. {len(samples)} cameras): {1e3 * slam.opt_time_meter.average():.2f} ms each; "
+          f"tracking (PnP, hypotheses, current-view LM) {1e3 * slam.track_time_meter.average():.2f} ms per view")
     print(f"geometry + host logic (debug_gt_kp): {t_geo * 1e3:.2f} ms/view over {len(samples)} views x {n_objs} objects; "
           f"{len(err)} poses, median rel. translation error {np.median(err):.4f}")
 
