@@ -377,7 +377,7 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     // call fall back to the 1024-thread single-workgroup build (csrc/lm_big.hip).
     int max_edges = 0;
     for (int i = 0; i < n_prob; ++i) max_edges = std::max(max_edges, probs[i].n_edge);
-    static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 1024;      // tuning aids
+    static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 512;       // (640 edges: 9.5 vs 12.2 ms, 1000: 10.9 vs 16.0, 350: 8.6 vs 6.1)
     static const int grid_wgs = getenv("SUO_LM_GRID_WGS") ? atoi(getenv("SUO_LM_GRID_WGS")) : 32;          // 0: never use the grid kernel
     // camera tracking (ObjectSLAM.optimize(curr_only=True)): one free camera, every object fixed -> one wave per problem
     static const int cam_kernel = getenv("SUO_LM_CAM") ? atoi(getenv("SUO_LM_CAM")) : 1;                    // 0: general kernel (A/B)
