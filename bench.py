@@ -383,10 +383,10 @@ def cpu_baseline(pool, L):
 
 
 def latency_leg(L, pool, use_graph, seconds=0.6):
-    """The reference's call shape (evaluate.py:338-395: one frame per network call), two calls in flight: not `value`,
-    reported as config.latency_mode_fps."""
+    """The reference's call shape (evaluate.py:338-395: one frame per network call), four calls in flight (470 frames/s with two,
+    484 with four, six or eight; odd depths lose 8 %): not `value`, reported as config.latency_mode_fps."""
     import torch
-    pipe = FramePipeline(L, pool, 1, use_graph=use_graph, depth=2)
+    pipe = FramePipeline(L, pool, 1, use_graph=use_graph, depth=4)
     for i in range(8):
         pipe.step(i)
     pipe.drain(8)
