@@ -247,8 +247,8 @@ def _multi_view_scene(rng, n_cam, n_obj, noise_px=0.5):
 @pytest.mark.parametrize("n_cam,n_obj", [(3, 2), (12, 6), (30, 8), (64, 10), (25, 16)])
 def test_global_bundle_adjustment_matches_oracle(ba, n_cam, n_obj):
     """Global mode: first camera fixed, all other cameras and all objects free (object_slam.py:746-778).
-    HIP eliminates cameras by Schur complement; the oracle solves the full dense system.  Up to 612 edges one
-    workgroup runs the whole adjustment (csrc/lm.hip); the three larger graphs (2000 - 5400 edges) take the
+    HIP eliminates cameras by Schur complement; the oracle solves the full dense system.  Below 512 edges one
+    workgroup runs the whole adjustment (csrc/lm.hip); the larger graphs (612 - 5400 edges) take the
     multi-workgroup kernel with grid barriers (csrc/lm_grid.hip)."""
     rng = np.random.default_rng(n_cam * 7 + n_obj)
     P, obj_gt = _multi_view_scene(rng, n_cam, n_obj)
