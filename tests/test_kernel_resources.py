@@ -1,0 +1,49 @@
+"""Compile-time resource checks of two kernels whose speed hangs on where the compiler puts their data (hipcc cross-compiles without
+a GPU): the fused Winograd tail must not spill registers, and the frame LM kernel must keep its 6x6 solve and its 27 normal-equation
+sums in registers (as stack arrays in scratch memory they cost a third of a frame's LM time)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "suo_slam_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _usage(src, tmp_path):
+    if not os.path.exists(HIPCC) and not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    out = subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                          "-I", os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, src), "-o", str(tmp_path / "x.o"),
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark: .*?\s{2,}([A-Za-z ]+?)(?: \[[^\]]+\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return kernels
+
+
+def test_fused_winograd_tail_does_not_spill(tmp_path):
+    k = _usage("conv_wino.hip", tmp_path)
+    fused = {n: v for n, v in k.items() if "wino3x3_kernelILb1E" in n}
+    assert len(fused) == 2, list(k)
+    for name, v in k.items():
+        assert v["VGPRs Spill"] == 0 and v["ScratchSize"] == 0, (name, v)
+        assert v["Occupancy"] >= 2, (name, v)          # two workgroups per CU
+
+
+def test_frame_lm_kernel_keeps_its_small_systems_in_registers(tmp_path):
+    k = _usage("lm_frame.hip", tmp_path)
+    v = [v for n, v in k.items() if "lm_frame_kernelILi8E" in n]
+    assert len(v) == 1, list(k)
+    # (spilled registers only: 27 VGPRs; with the solve / sums as stack arrays this was 368 bytes and a memory round trip per access)
+    assert v[0]["ScratchSize"] <= 256, v[0]
