@@ -83,8 +83,13 @@ int suo_render_priors(const float* prior_uv_dev, const uint8_t* prior_mask_dev, 
 int suo_net_backbone(suo_net* net, const float* staged_dev, int L, float* prob_logits_dev, void* stream);
 
 /* ---- stand-alone stages (each is also a parity-test entry point) --------------------------------- */
-/* spatial_softmax + post_process_kp (pkpnet.py:13-63): logits [L,41,64,64] -> uv, cov, mean logit */
-int suo_decode_heatmaps(const float* logits_dev, int L, float* uv_dev, float* cov_dev, float* mean_logit_dev, void* stream);
+/* spatial_softmax + post_process_kp (pkpnet.py:13-63): logits [L,41,64,64] -> uv, cov, mean logit.
+ * Optional outputs (NULL = skipped): argmax_idx_dev int32 [L,41] = flat index h*64+w of the first maximum of each heat-map, exactly what
+ * torch.argmax(logits.flatten(2), -1) returns -- the reference decodes with a SOFT arg-max only (pkpnet.py:28-63), this diagnostic hard
+ * arg-max is the bit-exact integer keypoint output; prob_dev float32 [L,41,64,64] = the soft-max itself, ret["prob"]
+ * (pkpnet.py:111). */
+int suo_decode_heatmaps(const float* logits_dev, int L, float* uv_dev, float* cov_dev, float* mean_logit_dev, int32_t* argmax_idx_dev,
+                        float* prob_dev, void* stream);
 /* classifier (pkpnet.py:74-78,116-118): sigmoid(W relu(mean_logit) + b) */
 int suo_classifier(const float* mean_logit_dev, const float* w_dev, const float* b_dev, int L,
                    float* kp_logit_dev, float* kp_prob_dev, void* stream);

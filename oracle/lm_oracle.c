@@ -410,6 +410,68 @@ ORC_API int orc_optimize(int n_cam, int n_obj, int n_edge, double* cam_T, const 
     return 0;
 }
 
+/* ONE SparseOptimizer::initializeOptimization(0) + optimize(iterations) over caller-kept state: poses as g2o keeps them
+ * (SE3Quat = unit quaternion (w,x,y,z) + t, 7 doubles each), per-edge level and robust-kernel flags.  This is what the
+ * recording g2o stub of tests/golden/make_slam_golden.py calls when the REFERENCE's own ObjectSLAM.optimize
+ * (lib/object_slam.py:703-930, imported unmodified) drives the rounds, so that its Python control flow is the thing pinned.
+ * err_out [n_edge][2]: errors of the active edges at the accepted state (others untouched).  Returns LM iterations done. */
+ORC_API int orc_lm_round(int n_cam, int n_obj, int n_edge, double* cam_qt, const uint8_t* cam_fixed, double* obj_qt,
+                         const uint8_t* obj_fixed, const int* edge_cam, const int* edge_obj, const double* edge_camk,
+                         const double* edge_p, const double* edge_uv, const double* edge_info, const uint8_t* level,
+                         const uint8_t* robust, double huber_delta, int iterations, double* err_out, int* lm_trials) {
+    graph_t g;
+    memset(&g, 0, sizeof(g));
+    g.n_cam = n_cam; g.n_obj = n_obj; g.n_edge = n_edge;
+    g.cam = (pose_t*)malloc(sizeof(pose_t) * (n_cam > 0 ? n_cam : 1));
+    g.obj = (pose_t*)malloc(sizeof(pose_t) * (n_obj > 0 ? n_obj : 1));
+    for (int c = 0; c < n_cam; ++c) { memcpy(g.cam[c].q, cam_qt + 7 * c, 4 * sizeof(double)); memcpy(g.cam[c].t, cam_qt + 7 * c + 4, 3 * sizeof(double)); }
+    for (int o = 0; o < n_obj; ++o) { memcpy(g.obj[o].q, obj_qt + 7 * o, 4 * sizeof(double)); memcpy(g.obj[o].t, obj_qt + 7 * o + 4, 3 * sizeof(double)); }
+    g.cam_fixed = cam_fixed; g.obj_fixed = obj_fixed;
+    g.e_cam = edge_cam; g.e_obj = edge_obj; g.e_k = edge_camk; g.e_p = edge_p; g.e_uv = edge_uv; g.e_info = edge_info;
+    g.level = (uint8_t*)malloc(n_edge > 0 ? n_edge : 1);
+    g.robust = (uint8_t*)malloc(n_edge > 0 ? n_edge : 1);
+    memcpy(g.level, level, n_edge);
+    memcpy(g.robust, robust, n_edge);
+    g.active = (uint8_t*)calloc(n_edge > 0 ? n_edge : 1, 1);
+    g.err = (double*)calloc((size_t)(n_edge > 0 ? n_edge : 1) * 2, sizeof(double));
+    g.cam_idx = (int*)malloc(sizeof(int) * (n_cam > 0 ? n_cam : 1));
+    g.obj_idx = (int*)malloc(sizeof(int) * (n_obj > 0 ? n_obj : 1));
+    g.delta = huber_delta;
+    int trials = 0;
+    int r = optimize_round(&g, iterations, &trials);
+    if (r >= 0) {
+        compute_active_errors(&g);
+        for (int e = 0; e < n_edge; ++e) if (g.active[e]) { err_out[2 * e] = g.err[2 * e]; err_out[2 * e + 1] = g.err[2 * e + 1]; }
+    }
+    for (int c = 0; c < n_cam; ++c) { memcpy(cam_qt + 7 * c, g.cam[c].q, 4 * sizeof(double)); memcpy(cam_qt + 7 * c + 4, g.cam[c].t, 3 * sizeof(double)); }
+    for (int o = 0; o < n_obj; ++o) { memcpy(obj_qt + 7 * o, g.obj[o].q, 4 * sizeof(double)); memcpy(obj_qt + 7 * o + 4, g.obj[o].t, 3 * sizeof(double)); }
+    if (lm_trials) *lm_trials = trials;
+    free(g.cam); free(g.obj); free(g.level); free(g.robust); free(g.active); free(g.err); free(g.cam_idx); free(g.obj_idx);
+    return r;
+}
+/* SE3Quat(R, t) construction and SE3Quat::matrix() / to_homogeneous_matrix (se3quat.h:55-60,104-113) for the same stub */
+ORC_API void orc_pose_from_T(const double* T12, double* qt7) {
+    pose_t p;
+    pose_from_T(T12, &p);
+    memcpy(qt7, p.q, 4 * sizeof(double)); memcpy(qt7 + 4, p.t, 3 * sizeof(double));
+}
+ORC_API void orc_pose_to_T(const double* qt7, double* T12) {
+    pose_t p;
+    memcpy(p.q, qt7, 4 * sizeof(double)); memcpy(p.t, qt7 + 4, 3 * sizeof(double));
+    pose_to_T(&p, T12);
+}
+/* computeError of one edge from (q,t) poses (types_object_slam.cpp:45-60) */
+ORC_API void orc_edge_error_qt(const double* cam_qt, const double* obj_qt, const double* k, const double* p, const double* uv, double* err) {
+    graph_t g;
+    memset(&g, 0, sizeof(g));
+    pose_t cam, obj;
+    memcpy(cam.q, cam_qt, 4 * sizeof(double)); memcpy(cam.t, cam_qt + 4, 3 * sizeof(double));
+    memcpy(obj.q, obj_qt, 4 * sizeof(double)); memcpy(obj.t, obj_qt + 4, 3 * sizeof(double));
+    int zero = 0;
+    g.cam = &cam; g.obj = &obj; g.e_cam = &zero; g.e_obj = &zero; g.e_k = k; g.e_p = p; g.e_uv = uv;
+    edge_error(&g, 0, err);
+}
+
 /* small exports for the unit tests */
 ORC_API void orc_pose_oplus(double* T12, const double* u6) {
     pose_t p;

@@ -9,8 +9,10 @@ checked against these.
     maybe_reinit_objects(...)          lib/object_slam.py:595-697    (row a23)
     backup_estimate_camera_pose(...)   lib/object_slam.py:933-973    (row a24)
 
-Parity status: *unpinned* -- lib/object_slam.py cannot be imported here (cv2, g2o, lambdatwist, glumpy are absent,
-SURVEY.md 8c), so no outputs of the reference itself exist for these rows; this is a line-by-line reading.
+Parity status: **pinned** (round 3) -- lib/object_slam.py IS importable here once cv2 / g2o / lambdatwist / torchvision / the
+BOP renderer are stubbed in sys.modules (tests/golden/ref_stubs.py); tests/golden/make_slam_golden.py runs the reference's
+own private methods on 258 seeded states (incl. states searched to sit on every rule's boundary) and records their outputs in
+tests/golden/slam_golden.npz; tests/test_slam_golden.py compares this file AND the product with them.
 A "state" is the reference's own bookkeeping: ``detections[view][obj]`` dicts with keys pose / inliers / model_kp /
 uv_pred / cov_pred / K, ``cam_poses[view]`` ([3,4] or [4,4]), ``obj_poses[obj]``, ``view_ids`` (list), ``cam_K[view]``.
 """

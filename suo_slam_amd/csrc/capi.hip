@@ -88,8 +88,8 @@ int suo_net_backbone(suo_net* net, const float* staged, int L, float* logits, vo
     return net->impl->forward_staged(staged, L, logits, (hipStream_t)stream);
 }
 
-int suo_decode_heatmaps(const float* logits, int L, float* uv, float* cov, float* mean_logit, void* stream) {
-    return suo::launch_decode(logits, L, uv, cov, mean_logit, (hipStream_t)stream);
+int suo_decode_heatmaps(const float* logits, int L, float* uv, float* cov, float* mean_logit, int32_t* argmax_idx, float* prob, void* stream) {
+    return suo::launch_decode(logits, L, uv, cov, mean_logit, argmax_idx, prob, (hipStream_t)stream);
 }
 
 int suo_classifier(const float* mean_logit, const float* w, const float* b, int L, float* kp_logit, float* kp_prob, void* stream) {

@@ -274,8 +274,12 @@ int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float*
 // (16 float4 per lane).  Three in-register passes: max; exp / sum / first moments; centred second
 // moments (two-pass covariance exactly like post_process_kp, no E[x^2]-mu^2 cancellation).
 // Axis convention: u = sum p * r[row],  v = sum p * (-r[col]),  r[i] = (i+0.5)/32 - 1.
+// Optional diagnostics (NULL = not computed): argmax_idx = flat index h*64+w of the FIRST maximum of the heat-map, as torch.argmax
+// over the flattened map returns it (the reference itself has no hard argmax; this one is the bit-exact integer
+// keypoint output north_star asks for); prob = the soft-max itself, the reference's ret["prob"] (pkpnet.py:111).
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ logits, int n_maps, float* __restrict__ uv,
-                                                     float* __restrict__ cov, float* __restrict__ mean_logit) {
+                                                     float* __restrict__ cov, float* __restrict__ mean_logit,
+                                                     int* __restrict__ argmax_idx, float* __restrict__ prob) {
     const int lane = threadIdx.x & 63;
     const int map = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (map >= n_maps) return;
@@ -290,6 +294,15 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ l
         for (int t = 0; t < 4; ++t) { mx = fmaxf(mx, v[j][t]); raw += v[j][t]; }
     mx = wave_max(mx);
     raw = wave_sum(raw);
+    if (argmax_idx) {                     // (uniform branch) smallest flat index holding the maximum: a wave-wide min over the lanes' own
+        int idx = HEAT * HEAT;
+#pragma unroll
+        for (int j = 15; j >= 0; --j)
+#pragma unroll
+            for (int t = 3; t >= 0; --t) idx = (v[j][t] == mx) ? (j * 64 + lane) * 4 + t : idx;
+        idx = -(int)wave_max((float)-idx);          // indices < 2^24 are exact in fp32
+        if (lane == 0) argmax_idx[map] = idx;
+    }
     // row = e / 64 = j*4 + lane/16 ; col = (lane & 15)*4 + t
     const float colbase = (float)((lane & 15) * 4);
     float s0 = 0.f, sx = 0.f, sy = 0.f;
@@ -311,6 +324,11 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ l
     sy = wave_sum(sy);
     const float inv = 1.0f / s0;
     const float mu_x = sx * inv, mu_y = sy * inv;
+    if (prob) {
+        f32x4* dst = (f32x4*)(prob + (size_t)map * HEAT * HEAT);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dst[j * 64 + lane] = v[j] * inv;
+    }
     float cxx = 0.f, cxy = 0.f, cyy = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -338,10 +356,10 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ l
     }
 }
 
-int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, hipStream_t s) {
+int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, int* argmax_idx, float* prob, hipStream_t s) {
     if (L <= 0) { suo_set_error("decode: L<=0"); return SUO_ERR_ARG; }
     const int n_maps = L * NUM_KP;
-    hipLaunchKernelGGL(decode_kernel, dim3((n_maps + 3) / 4), dim3(256), 0, s, logits, n_maps, uv, cov, mean_logit);
+    hipLaunchKernelGGL(decode_kernel, dim3((n_maps + 3) / 4), dim3(256), 0, s, logits, n_maps, uv, cov, mean_logit, argmax_idx, prob);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

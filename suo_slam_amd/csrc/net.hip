@@ -620,7 +620,7 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         const int in_c = (priors || prior_uv) ? IN_C : IMG_C;     // the slab is sized for IN_C; the prior-less layout uses a sixth of it
         SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, in_c, priors, prior_uv, prior_mask, in0, s));
         SUO_TRY(run_backbone(in0, in_c, logits, L, s));
-        SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, s));
+        SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, nullptr, nullptr, s));
         SUO_LAUNCH(launch_classifier(d_mean_logit_, cls_w_, cls_b_, L, kp_logit, kp_prob, s));
         if (logits_out)
             SUO_HIP_CHECK(hipMemcpyAsync(logits_out, logits, (size_t)L * NUM_KP * HEAT * HEAT * sizeof(float), hipMemcpyDeviceToDevice, s));

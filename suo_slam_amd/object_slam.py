@@ -172,8 +172,10 @@ def _det_edges(d):
         assert np.allclose(Kd[[0, 1, 2, 2, 2], [1, 0, 0, 1, 2]], [0, 0, 0, 0, 1]), f"K matrix has off-diagonals!\n\n{Kd}"
         n = c["n"]
         if d["cov_pred"] is not None and n > 0:
-            Om = np.linalg.inv(np.asarray(d["cov_pred"], dtype=np.float64).reshape(n, 2, 2))
-            info = np.stack([Om[:, 0, 0], Om[:, 0, 1], Om[:, 1, 1]], axis=1)
+            # np.linalg.inv(cov_uv[k]) in the covariance's OWN dtype (float32 from the network, :825-828), then g2o's doubles;
+            # the kernels keep Omega as (xx, xy, yy): its symmetric part is all that error^T Omega error sees
+            Om = np.linalg.inv(np.asarray(d["cov_pred"]).reshape(n, 2, 2)).astype(np.float64)
+            info = np.stack([Om[:, 0, 0], 0.5 * (Om[:, 0, 1] + Om[:, 1, 0]), Om[:, 1, 1]], axis=1)
         else:
             info = np.tile(np.array([1.0, 0.0, 1.0]), (n, 1))
         c["info"] = info

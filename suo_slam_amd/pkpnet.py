@@ -135,7 +135,7 @@ class PkpNet:
                                                   _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward")
         ret = {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
         if want_prob:
-            ret["prob"] = torch.softmax(logits.reshape(L, NUM_KP, -1), -1).reshape(logits.shape)
+            ret.update(decode_extras(logits))
         return ret
 
     __call__ = forward
@@ -159,6 +159,23 @@ class PkpNet:
                                                      None, _ptr(uv), _ptr(cov), _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()),
                    "suo_net_forward_frames")
         return {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
+
+
+def decode_extras(logits):
+    """The two optional outputs of the decode kernel (suo_decode_heatmaps) for logits [L,41,64,64] on the device: "prob", the
+    soft-max the reference returns as ret["prob"] (pkpnet.py:111), and "argmax", the diagnostic hard arg-max index per
+    heat-map (int32 [L,41], flat h*64+w, first maximum -- torch.argmax's convention)."""
+    L = int(logits.shape[0])
+    dev = logits.device
+    logits = logits.contiguous()
+    prob = torch.empty_like(logits)
+    idx = torch.empty((L, NUM_KP), dtype=torch.int32, device=dev)
+    uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
+    cov = torch.empty((L, NUM_KP, 2, 2), dtype=torch.float32, device=dev)
+    ml = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().suo_decode_heatmaps(_ptr(logits), L, _ptr(uv), _ptr(cov), _ptr(ml), _ptr(idx), _ptr(prob), _stream()),
+               "suo_decode_heatmaps")
+    return {"prob": prob, "argmax": idx}
 
 
 def render_priors(prior_uv, prior_mask, device="cuda"):

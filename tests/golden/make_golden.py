@@ -103,6 +103,13 @@ def main():
         logit = net.classifier(raw.mean(3).mean(2))
         out["backbone_kp_mask_logits"] = logit.numpy()
         out["backbone_kp_mask"] = torch.sigmoid(logit).numpy()
+        # diagnostic hard arg-max per heat-map (the reference decodes with the soft arg-max only): torch.argmax of
+        # the reference's own logits over the flattened map, and how far the runner-up is below the maximum
+        flat = raw.flatten(2)
+        out["backbone_argmax"] = torch.argmax(flat, -1).numpy().astype(np.int32)
+        top2 = torch.topk(flat, 2, -1).values
+        out["backbone_top2_gap"] = (top2[..., 0] - top2[..., 1]).numpy()
+        out["backbone_prob_sample"] = prob[:, ::5, ::4, ::4].numpy()            # spatial_softmax of the reference (ret["prob"], pkpnet.py:111)
 
         rng = np.random.Generator(np.random.PCG64(303))
         L = 3
@@ -123,6 +130,13 @@ def main():
         logit = net.classifier(ht.mean(3).mean(2))
         out["decode_kp_mask_logits"] = logit.numpy()
         out["decode_kp_mask"] = torch.sigmoid(logit).numpy()
+        out["decode_argmax"] = torch.argmax(ht.flatten(2), -1).numpy().astype(np.int32)
+        out["decode_prob_sample"] = prob[:, ::5, ::4, ::4].numpy()
+        # heat-maps FULL of ties (values quantised to 8 levels): torch.argmax's first-maximum convention
+        rng = np.random.Generator(np.random.PCG64(404))
+        tie = np.floor(rng.uniform(0, 8, (2, 41, 64, 64))).astype(np.float32)
+        out["tie_seed"] = np.int64(404)
+        out["tie_argmax"] = torch.argmax(torch.from_numpy(tie).flatten(2), -1).numpy().astype(np.int32)
         xx, yy = ref_pkpnet.mesh_grid(64, 64)
         out["mesh_xx"] = xx.numpy()
         out["mesh_yy"] = yy.numpy()

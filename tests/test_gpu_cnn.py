@@ -356,7 +356,7 @@ def test_decode_golden_and_masks(ops, cnn_golden, state_dict):
         uv = torch.empty((L, 41, 2), device="cuda")
         cov = torch.empty((L, 41, 2, 2), device="cuda")
         ml = torch.empty((L, 41), device="cuda")
-        _lib.check(lib.suo_decode_heatmaps(ops.P(ld), L, ops.P(uv), ops.P(cov), ops.P(ml), ops.S()))
+        _lib.check(lib.suo_decode_heatmaps(ops.P(ld), L, ops.P(uv), ops.P(cov), ops.P(ml), None, None, ops.S()))
         kl = torch.empty((L, 41), device="cuda")
         kp = torch.empty((L, 41), device="cuda")
         wc, bc = ops.dev(state_dict["classifier.2.weight"]), ops.dev(state_dict["classifier.2.bias"])   # keep alive
@@ -398,6 +398,63 @@ def test_full_network_golden(ops, cnn_golden, state_dict):
         logits = run_backbone_from_staged(net, xin)
         rel = np.abs(logits - ref).max() / np.abs(ref).max()
         assert rel < 2e-4, rel   # 186 fp32 conv layers deep; observed ~1e-5
+
+
+def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict):
+    """The same crop repeated 40 times: every 3x3 layer down to the 16x16 maps now has >= 256 tiles, so the Winograd kernels, the
+    fused Residual tails, the fused up-sample adds and the pooled GEMMs run (test_full_network_golden at L = 1 takes the direct
+    forms only).  Every copy against the REFERENCE's own logits; hard arg-max of the HIP logits = torch.argmax of the reference's
+    wherever the runner-up is more than 1e-4 below the maximum."""
+    from suo_slam_amd.pkpnet import PkpNet, decode_extras
+    L = 40
+    net = PkpNet(state_dict=state_dict, max_crops=L)
+    rng = np.random.Generator(np.random.PCG64(int(cnn_golden["backbone_in_seed"])))
+    x = rng.uniform(0, 1, (1, 44, 256, 256)).astype(np.float32)
+    xin = np.zeros((L, 256, 256, 48), np.float32)
+    xin[..., :44] = x.transpose(0, 2, 3, 1)
+    ref = cnn_golden["backbone_logits"]
+    from tests.gpu_backbone import run_backbone_from_staged
+    logits = run_backbone_from_staged(net, xin)
+    assert logits.shape == (L, 41, 64, 64)
+    rel = np.abs(logits - ref).max() / np.abs(ref).max()
+    assert rel < 2e-4, rel
+    idx = decode_extras(torch.from_numpy(logits).cuda())["argmax"].cpu().numpy()
+    sure = cnn_golden["backbone_top2_gap"][0] > 1e-4
+    assert sure.sum() >= 40
+    for i in (0, 17, L - 1):
+        np.testing.assert_array_equal(idx[i][sure], cnn_golden["backbone_argmax"][0][sure])
+
+
+def test_decode_hard_argmax_is_bit_exact_and_prob_is_the_softmax(ops, cnn_golden):
+    """Optional outputs of suo_decode_heatmaps.  argmax_idx: int32 flat index h*64+w of the FIRST maximum -- bit-exact against
+    torch.argmax of the same logits as the reference computed it (synthetic peaked maps, the reference backbone's own logits, and
+    maps quantised to 8 levels = full of ties).  prob: the reference's spatial_softmax (pkpnet.py:13-17), rel 2e-6."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    tie = np.floor(np.random.Generator(np.random.PCG64(int(cnn_golden["tie_seed"]))).uniform(0, 8, (2, 41, 64, 64))).astype(np.float32)
+    for logits, want, prob_want in ((cnn_golden["decode_in"], cnn_golden["decode_argmax"], cnn_golden["decode_prob_sample"]),
+                                    (cnn_golden["backbone_logits"], cnn_golden["backbone_argmax"], cnn_golden["backbone_prob_sample"]),
+                                    (tie, cnn_golden["tie_argmax"], None)):
+        L = logits.shape[0]
+        ld = ops.dev(logits)
+        uv = torch.empty((L, 41, 2), device="cuda")
+        cov = torch.empty((L, 41, 2, 2), device="cuda")
+        ml = torch.empty((L, 41), device="cuda")
+        idx = torch.full((L, 41), -7, dtype=torch.int32, device="cuda")
+        prob = torch.empty((L, 41, 64, 64), device="cuda")
+        _lib.check(lib.suo_decode_heatmaps(ops.P(ld), L, ops.P(uv), ops.P(cov), ops.P(ml), ops.P(idx), ops.P(prob), ops.S()))
+        uv2, cov2 = torch.empty_like(uv), torch.empty_like(cov)
+        _lib.check(lib.suo_decode_heatmaps(ops.P(ld), L, ops.P(uv2), ops.P(cov2), ops.P(ml), None, None, ops.S()))
+        torch.cuda.synchronize()
+        got = idx.cpu().numpy()
+        assert got.dtype == np.int32
+        np.testing.assert_array_equal(got, want)                                           # bit-exact integer keypoint indices
+        np.testing.assert_array_equal(got, logits.reshape(L, 41, -1).argmax(-1))           # (numpy agrees on the convention)
+        assert torch.equal(uv, uv2) and torch.equal(cov, cov2)                              # the extras do not perturb the decode
+        p = prob.cpu().numpy()
+        np.testing.assert_allclose(p.reshape(L, 41, -1).sum(-1), 1.0, rtol=0, atol=2e-6)
+        if prob_want is not None:
+            np.testing.assert_allclose(p[:, ::5, ::4, ::4], prob_want, rtol=2e-6, atol=1e-12)
 
 
 def test_schedule_options_do_not_change_the_result():
@@ -555,3 +612,54 @@ def test_bench_launch_shape_frames_batched_per_call(ops, state_dict, reps):
     lg = one["prob_logits"]
     assert float((out["prob_logits"][:8] - lg).abs().max() / lg.abs().max()) < 1e-4
     net.close()
+
+
+def test_fused_kernels_on_random_shapes(ops):
+    """39 random shapes (the sweep that used to live in tools/): the max-pool GEMM against GEMM + pool, bit for bit, over random
+    K1 / K2 / N / residual / prologue / map sizes; the Winograd 3x3 against fp64 (5e-6) and the fused Winograd tail (+ the
+    up-sample variant) against its separate launches over ragged maps (H, W not multiples of the 8 x 16 tile)."""
+    rng = np.random.default_rng(123)
+    for it in range(25):
+        W = int(rng.choice([64, 128, 192]))
+        H = int(2 * rng.integers(1, 9))
+        L = int(rng.integers(1, 6))
+        while L * H * W <= 4096:
+            L += 1
+        K1 = int(32 * rng.integers(1, 9))
+        K2 = int(rng.choice([0, 32, 64, 128]))
+        N = int(rng.choice([128, 256]))
+        res, relu, full = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        M = L * H * W
+        a1 = torch.from_numpy(rng.standard_normal((M, K1)).astype(np.float32)).cuda()
+        a2 = torch.from_numpy(rng.standard_normal((M, K2)).astype(np.float32)).cuda() if K2 else None
+        r = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda() if res else None
+        w1 = (rng.standard_normal((N, K1)) / np.sqrt(K1)).astype(np.float32)
+        w2 = (rng.standard_normal((N, K2)) / np.sqrt(K2)).astype(np.float32) if K2 else None
+        b = rng.standard_normal(N).astype(np.float32)
+        pro = (rng.uniform(0.5, 1.5, K1).astype(np.float32), rng.standard_normal(K1).astype(np.float32) * 0.2) if relu else None
+        want = ops.conv1x1(a1, w1, b, pro=pro, a2=a2, w2=w2, res=r, relu=relu)
+        wp = want.view(L, H // 2, 2, W // 2, 2, N).amax(dim=(2, 4)).reshape(M // 4, N)
+        got_full, got_pool = ops.conv1x1_pool(a1, w1, b, H, W, pro=pro, a2=a2, w2=w2, res=r, relu=relu, want_full=full)
+        assert torch.equal(got_pool, wp) and (not full or torch.equal(got_full, want)), ("pool", L, H, W, K1, K2, N, res, relu, full)
+    for it in range(14):
+        H, W, L = int(rng.integers(8, 70)), int(rng.integers(16, 70)), int(rng.integers(1, 12))
+        x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
+        skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
+        w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+        b2 = rng.standard_normal(128).astype(np.float32) * 0.3
+        w3 = (rng.standard_normal((256, 128)) / np.sqrt(128)).astype(np.float32)
+        b3 = rng.standard_normal(256).astype(np.float32)
+        mid = ops.conv3x3_wino(x, w2, b2, relu=True)
+        ref = torch.nn.functional.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), torch.from_numpy(w2).double(),
+                                                                  torch.from_numpy(b2).double(), padding=1)).permute(0, 2, 3, 1)
+        e = float((mid.cpu().double() - ref).abs().max() / ref.abs().max())
+        assert e < 5e-6, ("wino", L, H, W, e)
+        want = ops.conv1x1(mid.reshape(-1, 128), w3, b3, res=skip.reshape(-1, 256)).reshape(L, H, W, 256)
+        got = ops.conv3x3_wino_conv1x1_skip(x, w2, b2, w3, b3, skip)
+        # (<= 4096 pixels: suo_conv1x1 is the split-K kernel, another summation order -- compare by value there)
+        same = torch.equal(got, want) if L * H * W > 4096 else bool(((got - want).abs().max() < 1e-5 * want.abs().max()).item())
+        assert same, ("wino tail", L, H, W)
+        if H % 2 == 0 and W % 2 == 0:
+            low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda()
+            gu = ops.conv3x3_wino_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low)
+            assert torch.equal(gu, got + low.repeat_interleave(2, 1).repeat_interleave(2, 2)), ("wino tail up", L, H, W)
