@@ -152,6 +152,49 @@ int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* y
 /* exact legacy signature: pnp(xs[N,3], ys[N,2], threshold) -> 4x4 */
 int suo_pnp(const double* xs, const double* ys, int n, double threshold, double* T_out);
 
+/* ---- device-resident frame geometry: network outputs -> poses in one stream-ordered chain ----------------------
+ * What the reference does on the host between the network and the poses of a single-view frame -- the three .cpu() synchronisations
+ * and mask logic (lib/object_slam.py:1100-1115), `exp_uv[k][kp_mask]` compaction (:1118-1135), the K^-T normalisation of pnp() (:34-36),
+ * one lambdatwist.pnp per object (:1144), acceptance (:1147-1148), then optimize(): one g2o edge per keypoint with inv(cov) as
+ * information (:795-837) and the robust LM rounds (:842-896) with the camera fixed at identity (:383-385, :774) -- as four kernels on the
+ * caller's stream behind suo_net_forward* + suo_keypoint_masks, and ONE device-to-host copy of everything the host keeps.
+ *   suo_frame_geom_launch: asynchronous.  n_frames frames, frame f = crops [frame_first[f], frame_first[f+1]) of the device arrays
+ *     uv_dev [L,41,2], cov_dev [L,41,2,2], mask_dev [L,41] (the network's outputs and suo_keypoint_masks' result, same stream),
+ *     model_kps_dev float32 [L,41,3].  Host arrays (copied before returning): kinv [L][6] = KinvT[0][0],[1][0],[2][0],[0][1],[1][1],[2][1]
+ *     of inv(K_bbox).T (:34), camk [L][4] = fx, fy, cx, cy of K_bbox (:799), min_depth [L] = 0.5 * diameter (:1147).
+ *     PnP sampler keys as if suo_pnp_batch were called once per frame with that frame's solvable crops (>= 4 keypoints) only and the
+ *     caller advanced `seed` by their number from frame to frame (what ObjectSLAM does between process_view calls).
+ *     do_lm = 0 stops after PnP + acceptance (SLAM tracking continues on the host: camera hypotheses :975-1072).
+ *     At most 16 crops per frame when do_lm (one wave per object, csrc/lm_frame.hip).
+ *   suo_frame_geom_fetch: waits for that launch and points `out` into the context's pinned read-back block (valid until the next launch):
+ *     per crop T_pnp [16] (row-major 4x4; pnp_status 1 = identity = failure), accepted, T_opt [12] (refined T_OtoC, = PnP pose when not
+ *     refined), n_kp, and per keypoint SLOT (crop * 41 + position among the crop's valid keypoints, i.e. the order of the reference's
+ *     boolean indexing) inlier / chi2; uv / cov / mask as the network and suo_keypoint_masks wrote them; lm_stats [n_frames][4]. */
+typedef struct suo_frame_geom suo_frame_geom;
+typedef struct suo_frame_geom_params {
+    double pnp_threshold;          /* 1e-3 (parameters.h:35) */
+    uint64_t seed;
+    int use_cov;                   /* 0: information = identity (no_network_cov, :825) */
+    int do_lm;
+    int its[4]; int n_rounds;      /* {10,10,40,40}, 4 (:843-846) */
+    double chi2_thr;               /* 5.991 */
+    double huber_delta;            /* sqrt(5.991) */
+} suo_frame_geom_params;
+typedef struct suo_frame_geom_result {
+    int n_frames, n_crops;
+    const double* T_pnp; const double* T_opt; const double* chi2;
+    const int* pnp_status; const int* pnp_best_inliers; const int* pnp_iterations; const int* n_kp; const int* lm_stats;
+    const uint8_t* accepted; const uint8_t* inlier;
+    const float* uv; const float* cov; const uint8_t* mask;
+} suo_frame_geom_result;
+int suo_frame_geom_create(int max_crops, int max_frames, suo_frame_geom** out);
+void suo_frame_geom_destroy(suo_frame_geom* g);
+int suo_frame_geom_launch(suo_frame_geom* g, int n_frames, const int* frame_first, const float* uv_dev, const float* cov_dev,
+                          const uint8_t* mask_dev, const float* model_kps_dev, const double* kinv, const double* camk, const double* min_depth,
+                          const suo_frame_geom_params* params, void* stream);
+int suo_frame_geom_fetch(suo_frame_geom* g, suo_frame_geom_result* out);
+int suo_frame_geom_ready(suo_frame_geom* g);      /* 1 when the last launch has completed (or nothing is in flight), 0 otherwise; never blocks */
+
 /* ---- pose refinement / bundle adjustment: replaces the g2o calls of ObjectSLAM.optimize -------------
  * (lib/object_slam.py:703-903; g2o surface listed in SURVEY.md 8b).  A problem is the flat SoA of the graph
  * the reference builds edge by edge (:746-839): vertices = cameras (T_GtoC) and objects (T_OtoG) as

@@ -73,6 +73,11 @@ SIGNATURES = {
     "suo_ba_solve_update_dev": (C.c_int, [VP, C.c_double, C.c_int, C.c_int, VP, VP, VP, VP]),
     "suo_ba_restore_dev": (C.c_int, [VP, VP]),
     "suo_debug_ba_jacobians": (C.c_int, [VP, C.c_int, VP, VP]),
+    "suo_frame_geom_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(VP)]),
+    "suo_frame_geom_destroy": (None, [VP]),
+    "suo_frame_geom_launch": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_frame_geom_fetch": (C.c_int, [VP, VP]),
+    "suo_frame_geom_ready": (C.c_int, [VP]),
     "suo_mesh_db_create": (C.c_int, [C.c_int, VP, VP, C.POINTER(VP)]),
     "suo_mesh_db_destroy": (None, [VP]),
     "suo_pose_errors": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),
@@ -87,6 +92,19 @@ class BaProblem(C.Structure):
                 ("edge_inlier", VP), ("edge_chi2", VP),
                 ("its", C.c_int * 8), ("n_rounds", C.c_int), ("init_with_outliers", C.c_int),
                 ("chi2_thr", C.c_double), ("huber_delta", C.c_double), ("stats", C.c_int * 4)]
+
+
+class FrameGeomParams(C.Structure):
+    """ctypes mirror of suo_frame_geom_params."""
+    _fields_ = [("pnp_threshold", C.c_double), ("seed", C.c_uint64), ("use_cov", C.c_int), ("do_lm", C.c_int), ("its", C.c_int * 4),
+                ("n_rounds", C.c_int), ("chi2_thr", C.c_double), ("huber_delta", C.c_double)]
+
+
+class FrameGeomResult(C.Structure):
+    """ctypes mirror of suo_frame_geom_result."""
+    _fields_ = [("n_frames", C.c_int), ("n_crops", C.c_int), ("T_pnp", VP), ("T_opt", VP), ("chi2", VP), ("pnp_status", VP),
+                ("pnp_best_inliers", VP), ("pnp_iterations", VP), ("n_kp", VP), ("lm_stats", VP), ("accepted", VP), ("inlier", VP),
+                ("uv", VP), ("cov", VP), ("mask", VP)]
 
 
 def register(extra):

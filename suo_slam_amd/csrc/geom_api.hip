@@ -37,7 +37,7 @@ int launch_ba_finalize(const void* P, hipStream_t s);
 
 // PnpParams::get_iterations (thirdparty/lambdatwist/parameters.h:76-102), evaluated on the host so the
 // kernel's adaptive iteration count uses the same libm as the reference would.
-static int get_iterations(double estimated_inliers) {
+int pnp_get_iterations(double estimated_inliers) {
     const double p_meets = 0.9, min_probability = 0.99999;
     const unsigned max_iterations = 1000, min_iterations = 100;
     double p_inlier = std::min(0.9, estimated_inliers * p_meets);
@@ -101,6 +101,7 @@ struct LmProblemHost {
     double* err; double* jac; uint8_t* level; double* pair_part;
     double* Hcc; double* bc; double* Hoo; double* bo; double* Hcc_inv; double* Y; double* yc; double* xc; double* xo;
     int* obj_slot; int* stats;
+    const int* pair_end;
 };
 
 struct Prep {
@@ -130,7 +131,7 @@ int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* y
         if (n_pts[o] < 0) { suo_set_error("suo_pnp_batch: negative point count"); return SUO_ERR_ARG; }
         offsets[o + 1] = offsets[o] + n_pts[o];
         tab_off[o] = (int)tab.size();
-        for (int b = 0; b <= n_pts[o]; ++b) tab.push_back(get_iterations(n_pts[o] > 0 ? b / (double)n_pts[o] : 0.0));
+        for (int b = 0; b <= n_pts[o]; ++b) tab.push_back(pnp_get_iterations(n_pts[o] > 0 ? b / (double)n_pts[o] : 0.0));
     }
     const int total = offsets[n_obj];
     Layout L;

@@ -209,7 +209,11 @@ struct LmProblem {
     double* xc; double* xo;      // [n_cam][6], [n_obj][6]
     int* obj_slot;               // [n_obj] position in the reduced system (free objects only) or -1
     int* stats;                  // [4] rounds, LM iterations, LM trials, num_good
+    // optional (nullptr = pair p's edges end at pair_start[p + 1]): explicit end of each pair's edge range, for problems built ON THE
+    // DEVICE in fixed-stride slots (csrc/frame_geom.hip: 41 slots per object, the first n_keypoints of them used); lm_frame_kernel only
+    const int* pair_end;
 };
+DEV int pair_hi(const LmProblem& P, int p) { return P.pair_end ? P.pair_end[p] : P.pair_start[p + 1]; }
 
 // Cholesky factorisation, forward and backward substitution of the ns x ns reduced (object) system by the WHOLE workgroup, blocked
 // by 6 (one object's pose block; ns is a multiple of 6): right-looking Cholesky of the lower triangle in LDS (row-major, pitch `sp`

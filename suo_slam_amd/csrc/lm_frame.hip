@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * MAXW) void lm_frame_kernel(const LmProblem* __
     if (have)
         for (int a = P.obj_pair_ptr[w]; a < P.obj_pair_ptr[w + 1]; ++a) {
             const int p = P.obj_pair_idx[a];
-            for (int e = P.pair_start[p]; e < P.pair_start[p + 1]; ++e) { if (n_own == lane) e_first = e; ++n_own; }
+            for (int e = P.pair_start[p]; e < pair_hi(P, p); ++e) { if (n_own == lane) e_first = e; ++n_own; }
         }
     LfEdge E0;
     int lvl0 = 0;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * MAXW) void lm_frame_kernel(const LmProblem* __
     auto nth_edge = [&](int j) -> int {
         int n = 0;
         for (int a = P.obj_pair_ptr[w]; a < P.obj_pair_ptr[w + 1]; ++a) {
-            const int p = P.obj_pair_idx[a], cnt = P.pair_start[p + 1] - P.pair_start[p];
+            const int p = P.obj_pair_idx[a], cnt = pair_hi(P, p) - P.pair_start[p];
             if (j < n + cnt) return P.pair_start[p] + (j - n);
             n += cnt;
         }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * MAXW) void lm_frame_kernel(const LmProblem* __
         num_good = (int)ex[0];
         if (round == drop) robust_on = false;
     }
-    if (have && lane == 0) pose_to_T(pose, P.obj_T + 12 * w);
+    if (free_obj && lane == 0) pose_to_T(pose, P.obj_T + 12 * w);      // (a fixed object keeps the bits it came with)
     if (e_first >= 0) P.level[e_first] = (uint8_t)lvl0;
     for (int c = threadIdx.x; c < P.n_cam; c += blockDim.x) {    // cameras are fixed: the same quaternion round trip as csrc/lm.hip
         Pose cam;

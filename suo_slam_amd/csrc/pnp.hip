@@ -493,13 +493,18 @@ DEV unsigned select_inliers(const double* xs, const double* ys, int n, double th
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ offsets, const double* __restrict__ xs_all,
+// counts: nullptr = object o's points are [offsets[o], offsets[o + 1]); else [offsets[o], offsets[o] + counts[o]) -- problems compacted
+// ON THE DEVICE into fixed-stride slots (csrc/frame_geom.hip), whose sizes the host never sees
+// group_first (with counts): first problem of the group (frame) problem o belongs to; sampler keys then continue from group to group the
+// way a caller advances its seed between per-frame launches (by the number of solvable problems of the frame)
+__global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ offsets, const int* __restrict__ counts,
+                                                       const int* __restrict__ group_first, const double* __restrict__ xs_all,
                                                        const double* __restrict__ ys_all, double threshold, uint64_t seed,
                                                        const int* __restrict__ iter_tab, const int* __restrict__ iter_tab_off,
                                                        int do_refine, double* __restrict__ T_out, int* __restrict__ status,
                                                        int* __restrict__ best_out, int* __restrict__ iters_out) {
     const int o = blockIdx.x, lane = threadIdx.x;
-    const int p0 = offsets[o], n = offsets[o + 1] - p0;
+    const int p0 = offsets[o], n = counts ? counts[o] : offsets[o + 1] - p0;
     const double* xs = xs_all + 3 * (size_t)p0;
     const double* ys = ys_all + 2 * (size_t)p0;
     const int* tab = iter_tab + iter_tab_off[o];          // tab[b] = get_iterations(b / n), b = 0..n
@@ -509,7 +514,22 @@ __global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ o
     if (n >= 4 && n <= 64 * PNP_MAX_PER_LANE) {
         const double thr2 = threshold * threshold;
         unsigned iters = (unsigned)tab[0];
-        const uint64_t oseed = seed + (uint64_t)o * 0x9E3779B97F4A7C15ULL;
+        // sampler key: the object's rank among the launch's solvable problems (>= 4 points).  Host-compacted launches hold only
+        // those (rank = o); device-compacted ones (counts) keep a slot per crop, so the rank is counted here -- the same object then
+        // draws the same samples on either route (suo_slam_amd/object_slam.py: the host route skips objects with < 4 keypoints)
+        int rank = o, before = 0;
+        if (counts) {
+            const int g0 = group_first ? group_first[o] : 0;
+            int r = 0, b = 0;
+            for (int i = lane; i < o; i += 64) {
+                const int solvable = counts[i] >= 4 ? 1 : 0;
+                if (i < g0) b += solvable; else r += solvable;
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) { r += __shfl_xor(r, m, 64); b += __shfl_xor(b, m, 64); }
+            rank = r; before = b;
+        }
+        const uint64_t oseed = seed + (uint64_t)before + (uint64_t)rank * 0x9E3779B97F4A7C15ULL;
         for (unsigned base = 0; base < iters; base += 64) {
             const unsigned i = base + lane;
             double q[4], t[3];
@@ -553,14 +573,20 @@ __global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ o
     }
 }
 
-int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, uint64_t seed,
-                     const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
-                     int* iters_out, hipStream_t s) {
+int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, const int* group_first, const double* xs, const double* ys, double threshold, uint64_t seed,
+                            const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
+                            int* iters_out, hipStream_t s) {
     if (n_obj <= 0) return SUO_OK;
-    hipLaunchKernelGGL(pnp_batch_kernel, dim3(n_obj), dim3(64), 0, s, offsets, xs, ys, threshold, seed, iter_tab, iter_tab_off,
+    hipLaunchKernelGGL(pnp_batch_kernel, dim3(n_obj), dim3(64), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
                        do_refine, T_out, status, best_out, iters_out);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
+}
+int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, uint64_t seed,
+                     const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
+                     int* iters_out, hipStream_t s) {
+    return launch_pnp_batch_counts(n_obj, offsets, nullptr, nullptr, xs, ys, threshold, seed, iter_tab, iter_tab_off, do_refine, T_out, status, best_out,
+                                   iters_out, s);
 }
 
 }  // namespace suo

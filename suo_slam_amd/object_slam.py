@@ -242,7 +242,8 @@ class ObjectSLAM:
     def __init__(self, chkpt_path, mesh_db, no_network_cov=False, no_prior_det=False, pred_res=(256, 256),
                  debug_gt_kp=False, sfm_mode=False, single_view_mode=False, viz_cov=False, do_viz_extra=False,
                  global_opt_every=10, kp_var_thresh=0.2, bbox_thresh=0.9, bbox_inflate=0.0, manual_kp_std=0.005,
-                 opt_init_with_outliers=False, give_all_prior=False, state_dict=None, max_crops=16, seed=0, verbose=False):
+                 opt_init_with_outliers=False, give_all_prior=False, state_dict=None, max_crops=16, seed=0, verbose=False,
+                 device_chain=True):
         """Same keyword surface as the reference.  ``chkpt_path`` is a torch checkpoint whose ``['model']`` is the
         PkpNet state_dict (object_slam.py:92-97); ``state_dict`` may be given directly instead."""
         self.mesh_db = mesh_db
@@ -261,6 +262,10 @@ class ObjectSLAM:
         self.opt_init_with_outliers = opt_init_with_outliers
         self.give_all_prior = give_all_prior
         self.verbose = verbose
+        # single-view frames: masks -> compaction -> PnP -> acceptance -> graph -> LM as ONE device chain behind the network
+        # (suo_slam_amd/frame_geom.py); False = the host route that restates the reference's data flow (three read-backs, Python lists)
+        self.device_chain = bool(device_chain)
+        self._fg = None
         self._rng = np.random.default_rng(seed)
         self._pnp_seed = int(seed)
         self.reset()
@@ -375,6 +380,15 @@ class ObjectSLAM:
         self.needs_opt = True
         bboxes[:, [0, 1]] *= 1.0 - self.bbox_inflate
         bboxes[:, [2, 3]] *= 1.0 + self.bbox_inflate
+        if (self.single_view_mode and self.device_chain and self.model is not None and cam_pose is None and len(self.view_ids) == 0
+                and not self.cam_poses and not self.obj_poses and 0 < len(obj_ids) <= 16):
+            self._process_view_single_device(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks)
+            torch.cuda.synchronize()
+            tt1 = time()
+            if self.all_time_num_views > 5:
+                self.track_time_meter.update(tt1 - tt0)        # network + PnP + refinement: one chain, not separable from the host
+            self.needs_opt = False
+            return
 
         def sub(mask):
             return (obj_ids[mask], bboxes[mask], model_kps[mask], model_kps_masks[mask], kp_masks[mask],
@@ -402,6 +416,72 @@ class ObjectSLAM:
             self.optimize()
             self.opt_time_meter.update(time() - t0)
             self.needs_opt = False
+
+    # ---------------------------------------------------------------------------------------------
+    def _process_view_single_device(self, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks):
+        """A single-view frame (evaluate.py --nviews 1: __process_objects(False, ...) :464-593, __run_kp_model :1077-1167, then
+        optimize() :703-930 with the camera fixed at identity) with everything between the network and the poses on the device
+        (csrc/frame_geom.hip): one launch chain, one read-back.  Leaves the same state behind as the host route."""
+        import torch
+        from .frame_geom import FrameGeometry, kbbox_terms
+        from .pkpnet import keypoint_masks
+        L = len(obj_ids)
+        K_bbox = np.stack([fix_K_for_bbox_ndc(K, bboxes[k]) for k in range(L)]).astype(np.float32)     # float32 container (:1082)
+        kinv, camk = kbbox_terms(K_bbox)
+        min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for o in obj_ids], dtype=np.float64)
+        pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None)
+        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+        masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, self.bbox_thresh, vt)
+        kps_dev = torch.as_tensor(np.ascontiguousarray(model_kps, dtype=np.float32)).to(pred["uv"].device)
+        if self._fg is None or self._fg.max_crops < L:
+            self._fg = FrameGeometry(max(16, L), 1)
+        its = (10, 10, 40, 40) if self.sfm_mode else (10, 10, 10, 10)                                    # (:843-846)
+        self._fg.launch([0, L], pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
+                        use_cov=not self.no_network_cov, do_lm=True, its=its)
+        r = self._fg.fetch(copy=True)
+        self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
+        detection = {}
+        for k, obj_id in enumerate(obj_ids):
+            m = r["mask"][k]
+            n = int(r["n_kp"][k])
+            cov_pred = None if self.no_network_cov else r["cov"][k][m]
+            pose = r["T_pnp"][k].copy() if r["accepted"][k] else None
+            if cov_pred is not None and cov_pred.size > 0:
+                std = np.sqrt(cov_pred[..., [0, 1], [0, 1]])
+                self.avg_std_meter.update(std.mean(), std.size)
+            self.obj_num_dets[obj_id] += 1
+            self.obj_num_det_kps[obj_id] += n
+            assert obj_id not in self.obj_poses and obj_id not in detection, f"Object {obj_id} is in detections twice! obj_id must be an instance label."
+            detection[obj_id] = {"bbox": bboxes[k], "model_kp_mask": model_kps_masks[k], "prior_uv": None, "pose": pose,
+                                 "inliers": r["inlier"][k, :n].copy(), "kp_mask": m, "model_kp": model_kps[k][m].astype(np.float64), "uv_gt": None,
+                                 "uv_pred": r["uv"][k][m].astype(np.float64), "cov_pred": cov_pred, "K": K_bbox[k].astype(np.float64),
+                                 "score": 0.0 if n == 0 else 1.0}
+            if pose is not None:
+                self.obj_poses[obj_id] = r["T_opt"][k].copy()
+        self.detections[view_id] = detection
+        self.cam_poses[view_id] = np.eye(4)[:3, :]
+        self.view_ids.append(view_id)
+        self.last_lm_stats = r["lm_stats"][0].copy()
+        t0 = time()
+        self._cull_after_optimize([o for k, o in enumerate(obj_ids) if r["accepted"][k]], False, view_id)
+        self.opt_time_meter.update(time() - t0)
+
+    def _cull_after_optimize(self, graph_objs, curr_only, view_curr):
+        """object_slam.py:904-930: objects whose centre fell behind 0.5 diameter in the current view, then objects with too few inliers."""
+        if not curr_only:
+            for o in graph_objs:
+                if view_curr in self.cam_poses:
+                    p = self.cam_poses[view_curr][:3, :3] @ self.obj_poses[o][:3, 3] + self.cam_poses[view_curr][:3, 3]
+                    if p[2] < 0.5 * self.mesh_db[o]["diameter"]:
+                        self.remove_obj(o)
+        n_inl = defaultdict(int)                                 # obj_num_inliers of every object in one pass over the detections
+        for det in self.detections.values():
+            for o, d in det.items():
+                n_inl[o] += int(np.count_nonzero(d["inliers"]))
+        for o in list(self.obj_poses.keys()):
+            need = 3 if self.obj_num_dets[o] < 3 else 6
+            if n_inl[o] < need:
+                self.remove_obj(o)
 
     # ---------------------------------------------------------------------------------------------
     def _process_objects(self, is_sym, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt=None):
@@ -678,18 +758,7 @@ class ObjectSLAM:
         if not curr_only:
             for o, j in obj_index.items():
                 self.obj_poses[o] = obj_T[j].copy()
-                if view_curr in self.cam_poses:
-                    p = self.cam_poses[view_curr][:3, :3] @ self.obj_poses[o][:3, 3] + self.cam_poses[view_curr][:3, 3]
-                    if p[2] < 0.5 * self.mesh_db[o]["diameter"]:
-                        self.remove_obj(o)
-        n_inl = defaultdict(int)                                 # obj_num_inliers of every object in one pass over the detections
-        for det in self.detections.values():
-            for o, d in det.items():
-                n_inl[o] += int(np.count_nonzero(d["inliers"]))
-        for o in list(self.obj_poses.keys()):
-            need = 3 if self.obj_num_dets[o] < 3 else 6
-            if n_inl[o] < need:
-                self.remove_obj(o)
+        self._cull_after_optimize(list(obj_index.keys()), curr_only, view_curr)
 
     def optimize(self, curr_only=False):
         """object_slam.py:703-930 with the g2o graph replaced by one suo_optimize call."""
