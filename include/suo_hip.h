@@ -82,6 +82,11 @@ int suo_render_priors(const float* prior_uv_dev, const uint8_t* prior_mask_dev, 
  * [L,41,64,64] NCHW (may be NULL).  Test / profiling entry for the conv stack. */
 int suo_net_backbone(suo_net* net, const float* staged_dev, int L, float* prob_logits_dev, void* stream);
 
+/* Frame upload (the H2D of lib/object_slam.py:1096-1098) as a stream-ordered kernel: src is PINNED host memory (hipHostMalloc /
+ * torch pin_memory, i.e. mapped into the device's address space; 16-byte aligned like dst_dev), read over the host link with
+ * coalesced 16-byte loads.  Use instead of hipMemcpyAsync in front of a network call: see csrc/misc.hip for the measured reason. */
+int suo_upload(void* dst_dev, const void* src_pinned_host, size_t bytes, void* stream);
+
 /* ---- stand-alone stages (each is also a parity-test entry point) --------------------------------- */
 /* spatial_softmax + post_process_kp (pkpnet.py:13-63): logits [L,41,64,64] -> uv, cov, mean logit.
  * Optional outputs (NULL = skipped): argmax_idx_dev int32 [L,41] = flat index h*64+w of the first maximum of each heat-map, exactly what

@@ -36,6 +36,7 @@ SIGNATURES = {
     "suo_net_forward_prior_kp": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_render_priors": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "suo_net_backbone": (C.c_int, [VP, VP, C.c_int, VP, VP]),
+    "suo_upload": (C.c_int, [VP, VP, C.c_size_t, VP]),
     "suo_decode_heatmaps": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP, VP]),
     "suo_classifier": (C.c_int, [VP, VP, VP, C.c_int, VP, VP, VP]),
     "suo_keypoint_masks": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_float, C.c_float, VP, VP]),

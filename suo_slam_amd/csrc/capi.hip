@@ -88,6 +88,11 @@ int suo_net_backbone(suo_net* net, const float* staged, int L, float* logits, vo
     return net->impl->forward_staged(staged, L, logits, (hipStream_t)stream);
 }
 
+int suo_upload(void* dst_dev, const void* src_pinned_host, size_t bytes, void* stream) {
+    if (!dst_dev || !src_pinned_host) { suo_set_error("suo_upload: null argument"); return SUO_ERR_ARG; }
+    return suo::launch_upload(dst_dev, src_pinned_host, bytes, (hipStream_t)stream);
+}
+
 int suo_decode_heatmaps(const float* logits, int L, float* uv, float* cov, float* mean_logit, int32_t* argmax_idx, float* prob, void* stream) {
     return suo::launch_decode(logits, L, uv, cov, mean_logit, argmax_idx, prob, (hipStream_t)stream);
 }

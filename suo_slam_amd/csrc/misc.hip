@@ -14,6 +14,8 @@
 
 #include <mutex>
 
+#include <algorithm>
+
 #include "suo_internal.h"
 
 namespace suo {
@@ -408,6 +410,30 @@ int launch_kp_masks(const float* uv, const float* cov, const float* kp_prob, con
     const int n = L * NUM_KP;
     hipLaunchKernelGGL(kp_masks_kernel, dim3((n + 255) / 256), dim3(256), 0, s, uv, cov, kp_prob, model_mask, n,
                        bbox_thresh, 2.0f * kp_var_thresh, out_mask);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host -> device upload by a kernel: the source is PINNED host memory (hipHostMalloc / torch pin_memory: mapped into the device's
+// address space), read with coalesced 16-byte loads over the host link and written to HBM.  Stream-ordered like any kernel.  Why
+// not hipMemcpyAsync: on this stack an asynchronous H2D copy queued in front of kernels makes the NEXT host-side wait on that
+// stream take 10-20 ms (measured, tools/time_frame_chain.py: copy + 2.5 ms of kernels + synchronize = 13-25 ms, the kernels
+// themselves unchanged) -- fatal at one frame per call.  0.92 MB (one 640x480 frame): ~25 us.
+__global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, const uint8_t* __restrict__ src8,
+                                                     uint8_t* __restrict__ dst8, size_t tail0, size_t bytes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    for (size_t i = tail0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += stride) dst8[i] = src8[i];
+}
+
+int launch_upload(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return SUO_OK;
+    if (((uintptr_t)dst_dev | (uintptr_t)src_host) & 15) { suo_set_error("upload: pointers must be 16-byte aligned"); return SUO_ERR_ARG; }
+    const size_t n16 = bytes / 16;
+    const int blocks = (int)std::min<size_t>(1024, (n16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)src_host, (uint4*)dst_dev, n16, (const uint8_t*)src_host,
+                       (uint8_t*)dst_dev, n16 * 16, bytes);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

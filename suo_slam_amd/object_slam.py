@@ -243,7 +243,7 @@ class ObjectSLAM:
                  debug_gt_kp=False, sfm_mode=False, single_view_mode=False, viz_cov=False, do_viz_extra=False,
                  global_opt_every=10, kp_var_thresh=0.2, bbox_thresh=0.9, bbox_inflate=0.0, manual_kp_std=0.005,
                  opt_init_with_outliers=False, give_all_prior=False, state_dict=None, max_crops=16, seed=0, verbose=False,
-                 device_chain=True):
+                 device_chain=True, run_network_in_debug=False):
         """Same keyword surface as the reference.  ``chkpt_path`` is a torch checkpoint whose ``['model']`` is the
         PkpNet state_dict (object_slam.py:92-97); ``state_dict`` may be given directly instead."""
         self.mesh_db = mesh_db
@@ -271,7 +271,11 @@ class ObjectSLAM:
         self.reset()
         self.model = None
         self.model_epoch = -1
-        if not debug_gt_kp:
+        # benchmark aid: in --debug_gt_kp mode ALSO run the network (both passes, device-rendered priors, masks, read-back) on the
+        # frame's pixels and discard what it says in favour of the ground-truth keypoints -- random weights give meaningless
+        # keypoints, a SLAM sequence needs meaningful ones, and the view's time must include the network
+        self.run_network_in_debug = bool(run_network_in_debug and debug_gt_kp and state_dict is not None)
+        if not debug_gt_kp or self.run_network_in_debug:
             from .pkpnet import PkpNet
             if state_dict is None:
                 import torch
@@ -548,7 +552,7 @@ class ObjectSLAM:
         for k in range(L):
             K_bbox[k] = fix_K_for_bbox_ndc(K, bboxes[k])
         cov_uv = None
-        if not self.debug_gt_kp:
+        if not self.debug_gt_kp or self.run_network_in_debug:
             import torch
             from .pkpnet import keypoint_masks
             prior_uv = prior_mask = None
@@ -569,11 +573,12 @@ class ObjectSLAM:
             masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, bt, vt)
             exp_uv = pred["uv"].cpu().numpy()
             kp_masks = masks_dev.cpu().numpy().astype(bool)
-            if not self.no_network_cov:
+            if not self.no_network_cov or self.run_network_in_debug:
                 cov_uv = pred["cov"].cpu().numpy()
-        else:
+        if self.debug_gt_kp:
             assert kp_masks_gt is not None and uv_gt is not None
             kp_masks = np.asarray(kp_masks_gt, dtype=bool)
+            cov_uv = None
         per_obj = []
         for k in range(L):
             m = kp_masks[k]

@@ -181,3 +181,51 @@ def make_pose_graph(rng, n_cam, n_obj, kp_per_obj=10, noise_px=0.5, miss=0.15, o
             "edge_p": np.concatenate(e_p), "edge_uv": np.concatenate(e_uv),
             "edge_info": np.tile([1.0 / noise_px ** 2, 0, 1.0 / noise_px ** 2], (E, 1)), "edge_inlier": np.ones(E, np.uint8),
             "cam_gt": cam_gt, "obj_gt": obj_gt}
+
+
+def make_slam_sequence(rng, n_views=60, n_obj=8, sym_every=3, miss=0.05, vis_drop=0.05, with_image=True):
+    """A synthetic SLAM sequence (BASELINE configs[2]): n_obj objects in the world frame (= first camera), a smooth camera arc,
+    per view the arguments of ObjectSLAM.process_view (object_slam.py:327-328) -- obj_ids, xyxy boxes, model keypoints [L,41,3],
+    class masks, ground-truth visibility and the ground-truth NDC keypoints the reference's --debug_gt_kp mode consumes (:1129-1131).
+    Every sym_every-th object is symmetric, i.e. goes through the second network pass with rendered priors (:486-519)."""
+    K = K_YCBV
+    objs = list(range(1, n_obj + 1))
+    T_OtoG, kps, mmask = {}, {}, {}
+    for o in objs:
+        T = np.eye(4)
+        T[:3, :3] = random_rotation(rng)
+        T[:3, 3] = [rng.uniform(-260, 260), rng.uniform(-160, 160), rng.uniform(850, 1150)]
+        T_OtoG[o] = T
+        mmask[o] = class_mask(int(rng.integers(0, len(YCBV_LIKE))))
+        kps[o] = (rng.uniform(-1, 1, (NUM_KP, 3)) * rng.uniform(35, 70, 3)).astype(np.float32)
+    mesh_db = {o: {"diameter": float(2 * np.abs(kps[o]).max()), "is_symmetric": bool(sym_every and o % sym_every == 0)} for o in objs}
+    image = make_texture(rng) if with_image else None
+    views = []
+    for v in range(n_views):
+        s = v / max(n_views - 1, 1)
+        ang = 0.3 * s
+        T_GtoC = np.eye(4)
+        if v > 0:
+            T_GtoC[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+            T_GtoC[:3, 3] = [-240 * s, rng.uniform(-8, 8), rng.uniform(-8, 8) + 50 * s]
+        ids, boxes, mk, mm, vis, uvg = [], [], [], [], [], []
+        for o in objs:
+            if v > 0 and rng.random() < miss:
+                continue
+            T_OtoC = T_GtoC @ T_OtoG[o]
+            pc = kps[o].astype(np.float64) @ T_OtoC[:3, :3].T + T_OtoC[:3, 3]
+            px = pc @ K.T
+            px = px[:, :2] / px[:, 2:3]
+            sel = px[mmask[o]]
+            bbox = np.array([sel[:, 0].min() - 10, sel[:, 1].min() - 10, sel[:, 0].max() + 10, sel[:, 1].max() + 10])
+            uvw = pc @ fix_K_for_bbox_ndc(K, bbox).T
+            ids.append(o)
+            boxes.append(bbox)
+            mk.append(kps[o])
+            mm.append(mmask[o])
+            vis.append(mmask[o] & (rng.random(NUM_KP) >= vis_drop))
+            uvg.append((uvw[:, :2] / uvw[:, 2:3]).astype(np.float32))
+        views.append({"view_id": v, "K": K.copy(), "image": image, "obj_ids": np.array(ids), "bboxes": np.array(boxes, np.float64),
+                      "model_kps": np.array(mk, np.float32), "model_kps_masks": np.array(mm, bool), "kp_masks": np.array(vis, bool),
+                      "uv_gt": np.array(uvg, np.float32), "T_GtoC_gt": T_GtoC})
+    return {"mesh_db": mesh_db, "views": views, "T_OtoG_gt": T_OtoG}

@@ -48,3 +48,25 @@ def test_committed_pmc_summary_feeds_roofline_traffic():
     algorithmic = 4.0 * L * 64 * 64 * (128 + 256 + 256)
     assert 0.9 * algorithmic < t < 1.5 * algorithmic
     assert bench.dominant_kernel_traffic(L + 8) is None
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must become two ranks (the driver's BENCH command has that shape):
+    the parent starts torch.distributed.run as a child before touching the GPU and relays rank 0's line.  --dry-run stops after
+    the rendezvous; gloo stands in for RCCL on this GPU-less box."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SUO_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(x) for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    assert lines[0]["n_ranks_seen"] == 2 and lines[0]["n_gpus"] == 2 and lines[0]["rccl_backend"] == "gloo"
+
+
+def test_one_gpu_stays_one_process():
+    bench, args = _bench(["--gpus", "1", "--dry-run"])
+    assert args.dry_run and args.gpus == 1
