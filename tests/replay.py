@@ -11,7 +11,7 @@ STRIDE = 0x9E3779B97F4A7C15
 
 class Recording:
     def __init__(self):
-        self.forward, self.masks, self.pnp, self.ba = [], [], [], []
+        self.forward, self.masks, self.pnp, self.ba, self.chain = [], [], [], [], []
 
 
 @contextlib.contextmanager
@@ -51,11 +51,32 @@ def record():
         rec.masks.append({"uv": uv.cpu().numpy(), "cov": cov.cpu().numpy(), "kp": kp.cpu().numpy(), "mm": None if mm is None else np.array(mm),
                           "bt": bt, "vt": vt, "out": out.cpu().numpy().astype(bool)})
         return out
+    # the device-resident frame chain (suo_frame_geom_*): what it was launched on and what it read back
+    from suo_slam_amd import frame_geom as FG
+    orig_launch, orig_fetch = FG.FrameGeometry.launch, FG.FrameGeometry.fetch
+
+    def launch(self, frame_first, uv_dev, cov_dev, mask_dev, model_kps_dev, kinv, camk, min_depth, seed=0, use_cov=True, do_lm=True,
+               its=(10, 10, 40, 40), pnp_threshold=1e-3, stream=None):
+        self._rec = {"frame_first": np.array(frame_first), "uv": uv_dev.cpu().numpy(), "cov": cov_dev.cpu().numpy(),
+                     "mask": mask_dev.cpu().numpy().astype(bool), "model_kps": model_kps_dev.cpu().numpy(), "kinv": np.array(kinv),
+                     "camk": np.array(camk), "min_depth": np.array(min_depth), "seed": int(seed), "use_cov": bool(use_cov), "do_lm": bool(do_lm),
+                     "its": tuple(its), "thr": pnp_threshold}
+        return orig_launch(self, frame_first, uv_dev, cov_dev, mask_dev, model_kps_dev, kinv, camk, min_depth, seed=seed, use_cov=use_cov,
+                           do_lm=do_lm, its=its, pnp_threshold=pnp_threshold, stream=stream)
+
+    def fetch(self, copy=True):
+        out = orig_fetch(self, True)
+        c = dict(self._rec)
+        c["out"] = out
+        rec.chain.append(c)
+        return out
     OS._lt.pnp_batch, OS._ba.optimize_batch, PN.PkpNet.forward, PN.PkpNet.__call__, PN.keypoint_masks = pnp_batch, optimize_batch, forward, forward, keypoint_masks
+    FG.FrameGeometry.launch, FG.FrameGeometry.fetch = launch, fetch
     try:
         yield rec
     finally:
         OS._lt.pnp_batch, OS._ba.optimize_batch, PN.PkpNet.forward, PN.PkpNet.__call__, PN.keypoint_masks = orig_pnp, orig_ba, orig_fwd, orig_fwd, orig_masks
+        FG.FrameGeometry.launch, FG.FrameGeometry.fetch = orig_launch, orig_fetch
 
 
 def _rot_close(a, b, tol_R, tol_t):
@@ -114,3 +135,63 @@ def check_network(rec, sd, max_calls=None, logit_tol=2e-4, uv_tol=2e-4):
         want = O.keypoint_masks(m["uv"], m["cov"], m["kp"], m["mm"], m["bt"], m["vt"])
         assert np.array_equal(m["out"], want)
     return n
+
+
+def check_chain(rec, tol_pnp=1e-8, tol_R=1e-6, tol_t=1e-6):
+    """Every recorded device-chain launch (csrc/frame_geom.hip) vs the CPU oracles on the SAME device inputs: compaction in mask
+    order, K^-T normalisation, PnP per crop with the chain's sampler keys, acceptance, the frame's graph (fp64 inverse of the float32
+    covariance as information) through the dense-Cholesky LM oracle.  Returns (#PnP problems, #frames with an LM) checked."""
+    from oracle import geometry as G
+    n_pnp = n_lm = 0
+    for c in rec.chain:
+        out, ff = c["out"], c["frame_first"]
+        assert np.array_equal(out["mask"], c["mask"]) and np.array_equal(out["uv"], c["uv"]) and np.array_equal(out["cov"], c["cov"])
+        before = 0
+        for f in range(len(ff) - 1):
+            rank, objs, init = 0, [], []
+            for g in range(ff[f], ff[f + 1]):
+                m = c["mask"][g]
+                n = int(m.sum())
+                assert out["n_kp"][g] == n
+                if n < 4:
+                    assert out["pnp_status"][g] == 1 and not out["accepted"][g]
+                    continue
+                xs = c["model_kps"][g][m].astype(np.float64)
+                uv = c["uv"][g][m].astype(np.float64)
+                k = c["kinv"][g]
+                ys = np.stack([(uv[:, 0] * k[0] + uv[:, 1] * k[1]) + k[2], (uv[:, 0] * k[3] + uv[:, 1] * k[4]) + k[5]], 1)
+                T, best, its = G.pnp(xs, ys, c["thr"], seed=(c["seed"] + before + rank * STRIDE) % 2 ** 64)
+                rank += 1
+                assert np.abs(T - out["T_pnp"][g]).max() < tol_pnp * max(1.0, np.abs(T).max()), (g, np.abs(T - out["T_pnp"][g]).max())
+                ident = bool(np.allclose(T, np.eye(4)))
+                assert int(ident) == int(out["pnp_status"][g])
+                acc = (not ident) and T[2, 3] > c["min_depth"][g]
+                assert bool(out["accepted"][g]) == acc
+                n_pnp += 1
+                if acc:
+                    objs.append(g)
+                    init.append(T[:3])
+            before += rank
+            if not c["do_lm"] or not objs:
+                continue
+            cnt = [int(c["mask"][g].sum()) for g in objs]
+            e_obj = np.concatenate([np.full(n, j, np.int32) for j, n in enumerate(cnt)])
+            camk = np.concatenate([np.tile(c["camk"][g], (n, 1)) for g, n in zip(objs, cnt)])
+            p = np.concatenate([c["model_kps"][g][c["mask"][g]].astype(np.float64) for g in objs])
+            uv = np.concatenate([c["uv"][g][c["mask"][g]].astype(np.float64) for g in objs])
+            if c["use_cov"]:
+                cv = np.concatenate([c["cov"][g][c["mask"][g]].astype(np.float64) for g in objs])
+                det = cv[:, 0, 0] * cv[:, 1, 1] - cv[:, 0, 1] * cv[:, 1, 0]
+                info = np.stack([cv[:, 1, 1] / det, 0.5 * (-cv[:, 0, 1] / det + -cv[:, 1, 0] / det), cv[:, 0, 0] / det], 1)
+            else:
+                info = np.tile([1.0, 0.0, 1.0], (len(p), 1))
+            ref = G.optimize(np.eye(4)[None, :3], np.array([1], np.uint8), np.array(init), np.zeros(len(objs), np.uint8), np.zeros(len(p), np.int32),
+                             e_obj, camk, p, uv, info, np.ones(len(p), np.uint8), its=c["its"])
+            k0 = 0
+            for j, g in enumerate(objs):
+                assert _rot_close(out["T_opt"][g], ref[1][j], tol_R, tol_t), (g, np.abs(out["T_opt"][g] - ref[1][j]).max())
+                assert np.array_equal(out["inlier"][g, :cnt[j]], ref[2][k0:k0 + cnt[j]].astype(bool)), g
+                k0 += cnt[j]
+            assert out["lm_stats"][f][0] == ref[4][0] and out["lm_stats"][f][3] == ref[4][3]
+            n_lm += 1
+    return n_pnp, n_lm

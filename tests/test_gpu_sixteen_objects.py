@@ -28,10 +28,20 @@ def test_sixteen_object_frame_network_to_poses_replays_against_the_oracle():
                           fr["model_kps_masks"], fr["model_kps_masks"])
     assert len(rec.forward) == 1 and rec.forward[0]["boxes"].shape == (16, 4) and rec.forward[0]["out"]["uv"].shape == (16, 41, 2)
     assert replay.check_network(rec, sd) == 1
-    assert len(rec.pnp) == 1 and len(rec.pnp[0]["xs"]) >= 12            # one launch for the frame's objects
+    # single-view frames go through the device chain: ONE launch set for the frame's 16 objects, no host-array PnP / LM call
+    assert len(rec.pnp) == 0 and len(rec.ba) == 0 and len(rec.chain) == 1
+    n_pnp, n_lm = replay.check_chain(rec)
+    assert n_pnp >= 12 and n_lm == 1
+    assert set(slam.collect_results()[0]["poses"].keys()) == set(fr["obj_ids"])
+    # ... and the host route (the reference's data flow: three read-backs, suo_pnp_batch / suo_optimize with host arrays) on the same frame
+    slam = ObjectSLAM(None, _mesh_db(fr), sfm_mode=True, single_view_mode=True, state_dict=sd, max_crops=16, kp_var_thresh=0.5, bbox_thresh=1.0,
+                      device_chain=False)
+    with replay.record() as rec:
+        slam.process_view(0, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"],
+                          fr["model_kps_masks"], fr["model_kps_masks"])
+    assert len(rec.chain) == 0 and len(rec.pnp) == 1 and len(rec.pnp[0]["xs"]) >= 12
     assert replay.check_pnp(rec) >= 12
     assert len(rec.ba) == 1 and replay.check_ba(rec) == 1
-    assert set(slam.collect_results()[0]["poses"].keys()) == set(fr["obj_ids"])
 
 
 def test_four_frames_of_sixteen_objects_in_one_network_call():

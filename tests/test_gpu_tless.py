@@ -62,11 +62,12 @@ def test_tless_saved_detections_single_view_replays_against_the_oracle(tmp_path)
     assert seen == {8, 10}
     # --- replay through the oracle ----------------------------------------------------------------------------------
     assert replay.check_network(rec, sd) >= 4
-    n_pnp = replay.check_pnp(rec)
-    n_ba = replay.check_ba(rec)
-    assert n_pnp >= 6 and n_ba >= 3, (n_pnp, n_ba)
-    for b in rec.ba:                                                         # single-view graphs: rounds [10,10,40,40], flag inert
-        assert tuple(b["its"]) == (10, 10, 40, 40) and not b["init_with_outliers"] and b["cam_fixed"].tolist() == [1]
+    # single-view frames run the device chain (csrc/frame_geom.hip): every launch against the PnP / LM oracles on its own device inputs
+    assert len(rec.pnp) == 0 and len(rec.ba) == 0 and len(rec.chain) >= 4
+    n_pnp, n_lm = replay.check_chain(rec)
+    assert n_pnp >= 6 and n_lm >= 3, (n_pnp, n_lm)
+    for c in rec.chain:                                                      # single-view graphs: rounds [10,10,40,40], predicted covariances
+        assert tuple(c["its"]) == (10, 10, 40, 40) and c["use_cov"] and c["do_lm"] and len(c["frame_first"]) == 2
     # --- CSV: one line per target with a pose, BOP format ------------------------------------------------------------
     lines = [ln for ln in open(out["csv_path"]).read().strip().split("\n") if ln]
     for ln in lines:
