@@ -199,8 +199,19 @@ class FramePipeline:
                 S["cov"].copy_(torch.from_numpy(np.concatenate([fr["cov"] for fr in frames])), non_blocking=False)
                 S["mask"].copy_(S["mm"])
         if self.only != "cnn":
+            gs = S["tstream"]
+            mode = os.environ.get("SUO_BENCH_GEOM_STREAM", "0")
+            if mode != "0":
+                if not hasattr(self, "gstreams"):
+                    n = {"1": 1, "2": 2}.get(mode, 1)
+                    self.gstreams = [torch.cuda.Stream(priority=-1) for _ in range(n)]
+                if "nev" not in S:
+                    S["nev"] = torch.cuda.Event()
+                gs = self.gstreams[(i % self.depth) % len(self.gstreams)]
+                S["nev"].record(S["tstream"])
+                gs.wait_event(S["nev"])
             S["fg"].launch(self.first, S["uv"], S["cov"], S["mask"], S["kps"], kinv, camk, min_depth, seed=i, use_cov=True, do_lm=True,
-                           its=(10, 10, 40, 40), stream=S["tstream"].cuda_stream)
+                           its=(10, 10, 40, 40), stream=gs.cuda_stream)
         else:
             S["ev"] = torch.cuda.Event()
             S["ev"].record(S["tstream"])

@@ -14,7 +14,7 @@
 //                       the LmProblem the LM kernels take -- fixed identity camera, one vertex per accepted crop initialised with its PnP
 //                       pose, edges = the crop's compacted keypoints in their slots (41 per crop), rejected crops as fixed vertices
 //                       without edges
-//   lm_frame_kernel     csrc/lm_frame.hip: the robust rounds of ObjectSLAM.optimize (:842-896), a wave per object
+//   lm_frame2_kernel    csrc/lm_frame2.hip: the robust rounds of ObjectSLAM.optimize (:842-896), a wave per frame
 //
 // and ONE device-to-host copy of everything the host keeps (PnP poses, refined poses, inlier flags, chi2, keypoints, covariances, masks,
 // counts, LM statistics).  PnP inputs are bit-identical to the host route's (suo_slam_amd/object_slam.py: _run_kp_model), so the PnP
@@ -35,7 +35,7 @@ int pnp_get_iterations(double estimated_inliers);
 int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, const int* group_first, const double* xs, const double* ys, double threshold, uint64_t seed,
                             const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                             int* iters_out, hipStream_t s);
-int launch_lm_frame(const void* problems_dev, int n_problems, int max_obj, hipStream_t s);
+int launch_lm_frame2(const void* problems_dev, int n_problems, int max_obj, int max_edges, hipStream_t s);
 
 constexpr int FG_MAX_OBJ = 16;          // objects per frame the one-wave-per-object LM kernel takes (csrc/lm_frame.hip: LF_MAX_OBJ)
 
@@ -279,7 +279,7 @@ int suo_frame_geom_launch(suo_frame_geom* c, int n_frames, const int* frame_firs
                        p->huber_delta);
     SUO_HIP_CHECK(hipGetLastError());
     if (p->do_lm) {
-        rc = launch_lm_frame(c->A.problems, n_frames, std::max(max_obj, 1), s);
+        rc = launch_lm_frame2(c->A.problems, n_frames, std::max(max_obj, 1), std::max(max_obj, 1) * NUM_KP, s);
         if (rc != SUO_OK) return rc;
     }
     SUO_HIP_CHECK(hipMemcpyAsync(c->host + c->out_off, c->dev + c->out_off, c->out_bytes, hipMemcpyDeviceToHost, s));

@@ -22,6 +22,8 @@ int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipSt
 int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);
 int launch_lm_cam(const void* problems_dev, int n_problems, hipStream_t s);
 int launch_lm_frame(const void* problems_dev, int n_problems, int max_obj, hipStream_t s);
+int launch_lm_frame2(const void* problems_dev, int n_problems, int max_obj, int max_edges, hipStream_t s);
+int lm_frame2_max_edges();
 size_t lm_grid_scratch_bytes();
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 size_t lm_problem_struct_size();
@@ -396,13 +398,20 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     for (int i = 0; i < n_prob && frame_only; ++i) {
         int nfc = 0;
         for (int c = 0; c < probs[i].n_cam; ++c) nfc += probs[i].cam_fixed[c] ? 0 : 1;
-        frame_only = nfc == 0 && probs[i].n_obj >= 1 && probs[i].n_obj <= frame_kernel && probs[i].n_obj <= 16;
+        // (one wave per object takes <= SUO_LM_FRAME objects: the 16-wave build spills; one wave per frame takes 16)
+        const bool f2 = (getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1) != 0 && probs[i].n_cam == 1 && probs[i].n_edge <= lm_frame2_max_edges();
+        frame_only = nfc == 0 && probs[i].n_obj >= 1 && probs[i].n_obj <= (f2 ? 16 : frame_kernel) && probs[i].n_obj <= 16;
         frame_max_obj = std::max(frame_max_obj, probs[i].n_obj);
     }
     if (cam_only) {
         rc = launch_lm_cam(g_arena.dev + st.o_structs, n_prob, g_arena.stream);
     } else if (frame_only) {
-        rc = launch_lm_frame(g_arena.dev + st.o_structs, n_prob, frame_max_obj, g_arena.stream);
+        // one fixed camera (the single-view frame of evaluate.py): one WAVE per frame, the objects side by side (csrc/lm_frame2.hip)
+        static const int frame2 = getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1;              // 0: one wave per object (A/B)
+        bool one_cam = frame2 != 0;
+        for (int i = 0; i < n_prob && one_cam; ++i) one_cam = probs[i].n_cam == 1 && probs[i].n_edge <= lm_frame2_max_edges();
+        if (one_cam) rc = launch_lm_frame2(g_arena.dev + st.o_structs, n_prob, frame_max_obj, max_edges, g_arena.stream);
+        else rc = launch_lm_frame(g_arena.dev + st.o_structs, n_prob, frame_max_obj, g_arena.stream);
     } else if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {
         static void* grid_scratch = nullptr;
         if (!grid_scratch) SUO_HIP_CHECK(hipMalloc(&grid_scratch, lm_grid_scratch_bytes()));

@@ -497,13 +497,24 @@ DEV unsigned select_inliers(const double* xs, const double* ys, int n, double th
 // ON THE DEVICE into fixed-stride slots (csrc/frame_geom.hip), whose sizes the host never sees
 // group_first (with counts): first problem of the group (frame) problem o belongs to; sampler keys then continue from group to group the
 // way a caller advances its seed between per-frame launches (by the number of solvable problems of the frame)
-__global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ offsets, const int* __restrict__ counts,
-                                                       const int* __restrict__ group_first, const double* __restrict__ xs_all,
-                                                       const double* __restrict__ ys_all, double threshold, uint64_t seed,
-                                                       const int* __restrict__ iter_tab, const int* __restrict__ iter_tab_off,
-                                                       int do_refine, double* __restrict__ T_out, int* __restrict__ status,
-                                                       int* __restrict__ best_out, int* __restrict__ iters_out) {
-    const int o = blockIdx.x, lane = threadIdx.x;
+//
+// One WORKGROUP of PNP_WAVES waves per object.  The RANSAC loop is sequential by definition (PNP::compute accepts hypothesis i only if it
+// beats everything before it, and every acceptance shortens the loop), but hypothesis i itself depends on i alone (counter-based
+// sampler): the waves evaluate PNP_WAVES x 64 consecutive hypotheses at once, the inlier counts meet in LDS and every wave replays the
+// sequential accept rule over them in index order -- hypotheses beyond the (shrinking) iteration count are discarded exactly as the
+// sequential loop would never have drawn them.  1000 iterations (the cap: bad keypoints) are 4 rounds instead of 16, the usual 100-500
+// are 1-2.  The refinement runs on wave 0.
+constexpr int PNP_WAVES = 4;
+__global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __restrict__ offsets, const int* __restrict__ counts,
+                                                                   const int* __restrict__ group_first, const double* __restrict__ xs_all,
+                                                                   const double* __restrict__ ys_all, double threshold, uint64_t seed,
+                                                                   const int* __restrict__ iter_tab, const int* __restrict__ iter_tab_off,
+                                                                   int do_refine, double* __restrict__ T_out, int* __restrict__ status,
+                                                                   int* __restrict__ best_out, int* __restrict__ iters_out) {
+    const int o = blockIdx.x, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ unsigned s_cnt[64 * PNP_WAVES];
+    __shared__ double s_pose[2][8];
     const int p0 = offsets[o], n = counts ? counts[o] : offsets[o + 1] - p0;
     const double* xs = xs_all + 3 * (size_t)p0;
     const double* ys = ys_all + 2 * (size_t)p0;
@@ -511,8 +522,9 @@ __global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ o
     double bq[4] = {1, 0, 0, 0}, bt[3] = {0, 0, 0};
     unsigned best = 0;
     unsigned i_done = 0;
-    if (n >= 4 && n <= 64 * PNP_MAX_PER_LANE) {
-        const double thr2 = threshold * threshold;
+    const bool solvable = n >= 4 && n <= 64 * PNP_MAX_PER_LANE;
+    const double thr2 = threshold * threshold;
+    if (solvable) {
         unsigned iters = (unsigned)tab[0];
         // sampler key: the object's rank among the launch's solvable problems (>= 4 points).  Host-compacted launches hold only
         // those (rank = o); device-compacted ones (counts) keep a slot per crop, so the rank is counted here -- the same object then
@@ -522,42 +534,57 @@ __global__ __launch_bounds__(64) void pnp_batch_kernel(const int* __restrict__ o
             const int g0 = group_first ? group_first[o] : 0;
             int r = 0, b = 0;
             for (int i = lane; i < o; i += 64) {
-                const int solvable = counts[i] >= 4 ? 1 : 0;
-                if (i < g0) b += solvable; else r += solvable;
+                const int sv = counts[i] >= 4 ? 1 : 0;
+                if (i < g0) b += sv; else r += sv;
             }
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) { r += __shfl_xor(r, m, 64); b += __shfl_xor(b, m, 64); }
             rank = r; before = b;
         }
         const uint64_t oseed = seed + (uint64_t)before + (uint64_t)rank * 0x9E3779B97F4A7C15ULL;
-        for (unsigned base = 0; base < iters; base += 64) {
-            const unsigned i = base + lane;
+        int par = 0;
+        for (unsigned base = 0; base < iters; base += 64 * PNP_WAVES) {
+            const unsigned i = base + wv * 64 + lane;
             double q[4], t[3];
-            int idx[4];
-            sample4(oseed, i, n, idx);
-            p4p(xs, ys, idx, q, t);
-            const unsigned cnt = count_inliers(xs, ys, n, thr2, q, t);
-            // replay the sequential accept rule of PNP::compute over this batch of 64
+            unsigned cnt = 0;
+            if (base + wv * 64 < iters) {                  // (wave-uniform: a wave whose 64 hypotheses all lie beyond the loop skips them)
+                int idx[4];
+                sample4(oseed, i, n, idx);
+                p4p(xs, ys, idx, q, t);
+                cnt = count_inliers(xs, ys, n, thr2, q, t);
+            }
+            s_cnt[wv * 64 + lane] = cnt;
+            __syncthreads();
+            // replay the sequential accept rule of PNP::compute over these hypotheses, every wave identically
             int win = -1;
-            for (int j = 0; j < 64; ++j) {
+            for (int j = 0; j < 64 * PNP_WAVES; ++j) {
                 if (base + j >= iters) break;
-                const unsigned cj = __shfl(cnt, j, 64);
+                const unsigned cj = s_cnt[j];
                 if (cj > best) { best = cj; win = j; iters = (unsigned)tab[best]; }
                 i_done = base + j + 1;           // total_iters of PNP::compute = loop counter at exit
             }
             if (win >= 0) {
-                for (int k = 0; k < 4; ++k) bq[k] = bcast_d(q[k], win);
-                for (int k = 0; k < 3; ++k) bt[k] = bcast_d(t[k], win);
+                if (wv == (win >> 6) && lane == (win & 63)) {
+                    for (int k = 0; k < 4; ++k) s_pose[par][k] = q[k];
+                    for (int k = 0; k < 3; ++k) s_pose[par][4 + k] = t[k];
+                }
             }
+            __syncthreads();                               // (also: every wave has read s_cnt before the next round overwrites it)
+            if (win >= 0) {
+                for (int k = 0; k < 4; ++k) bq[k] = s_pose[par][k];
+                for (int k = 0; k < 3; ++k) bt[k] = s_pose[par][4 + k];
+            }
+            par ^= 1;
         }
-        if (best > 3 && do_refine) {
-            int m = 0, deltas = 0;
-            unsigned sel = select_inliers(xs, ys, n, thr2, bq, bt, lane, nullptr, &m, nullptr);
-            refine_pass(xs, ys, n, sel, lane, bq, bt, 5, 1e-6);
-            const unsigned prev = sel;
-            sel = select_inliers(xs, ys, n, thr2, bq, bt, lane, &prev, &m, &deltas);
-            if (!((double)deltas < 0.05 * (double)m)) refine_pass(xs, ys, n, sel, lane, bq, bt, 3, 1e-8);
-        }
+    }
+    if (wv != 0) return;
+    if (solvable && best > 3 && do_refine) {
+        int m = 0, deltas = 0;
+        unsigned sel = select_inliers(xs, ys, n, thr2, bq, bt, lane, nullptr, &m, nullptr);
+        refine_pass(xs, ys, n, sel, lane, bq, bt, 5, 1e-6);
+        const unsigned prev = sel;
+        sel = select_inliers(xs, ys, n, thr2, bq, bt, lane, &prev, &m, &deltas);
+        if (!((double)deltas < 0.05 * (double)m)) refine_pass(xs, ys, n, sel, lane, bq, bt, 3, 1e-8);
     }
     if (lane == 0) {
         double R[9];
@@ -577,7 +604,7 @@ int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, co
                             const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                             int* iters_out, hipStream_t s) {
     if (n_obj <= 0) return SUO_OK;
-    hipLaunchKernelGGL(pnp_batch_kernel, dim3(n_obj), dim3(64), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
+    hipLaunchKernelGGL(pnp_batch_kernel, dim3(n_obj), dim3(64 * PNP_WAVES), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
                        do_refine, T_out, status, best_out, iters_out);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;

@@ -4,7 +4,8 @@ suo_slam_amd/object_slam.py: three read-backs, Python lists, suo_pnp_batch / suo
 
 Parity statement: PnP inputs are bit-identical on both routes (same compaction order, fp64 widening, host-inverted K_bbox, same sampler
 keys) => PnP poses bit-identical; the graph handed to the LM kernel is bit-identical when the information matrices are (the chain inverts
-the float32 covariance in fp64 closed form; fed the same matrices, suo_optimize returns the same bits); against the host route's
+the float32 covariance in fp64 closed form; fed the same matrices, suo_optimize returns the same bits when every crop is accepted and
+agrees to 1e-8 when rejected crops leave the accepted ones in other lanes of the one-wave-per-frame kernel); against the host route's
 float32-rounded np.linalg.inv (what the reference hands g2o) refined poses agree to the LM tolerance 1e-6 and every inlier flag whose
 chi2 is not within 1e-5 of the gate."""
 import numpy as np
@@ -108,11 +109,15 @@ def test_chain_equals_the_host_array_entry_points_bit_for_bit(n_obj, use_cov):
             assert not r["accepted"][o] and r["pnp_status"][o] == 1
         for o in far:
             assert not r["accepted"][o] and r["pnp_status"][o] == 0
-        if n_obj <= 8:           # the host-array route launches the same one-wave-per-object kernel for <= 8 objects: same bits
+        if r["accepted"].all():
+            # same kernel (csrc/lm_frame2.hip), same graph, same lanes: same bits.  With rejected crops the chain keeps their (empty)
+            # slots, so the accepted objects sit in other lane groups than in the host route's compacted graph and the frame-wide sums
+            # pair up differently: rounding-level differences, which ~100 non-converged LM iterations carry up to ~1e-9 relative
             assert np.array_equal(r["T_opt"], h["T_opt"]), np.abs(r["T_opt"] - h["T_opt"]).max()
             assert np.array_equal(r["lm_stats"][0], h["stats"])
         else:
-            np.testing.assert_allclose(r["T_opt"], h["T_opt"], rtol=0, atol=1e-6 * np.abs(h["T_opt"]).max())
+            np.testing.assert_allclose(r["T_opt"], h["T_opt"], rtol=0, atol=1e-8 * np.abs(h["T_opt"]).max())
+            assert r["lm_stats"][0][0] == h["stats"][0] and r["lm_stats"][0][3] == h["stats"][3]
         for o, inl in h["inlier"].items():
             assert np.array_equal(r["inlier"][o, :len(inl)], inl)
         if "oracle" in h:                                                 # and the CPU oracle on the same graph
