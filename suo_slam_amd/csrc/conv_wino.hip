@@ -66,6 +66,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     float* V = &S[2 * HSZ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(SUO_WINO_PRIO)
+    // experiment: asymmetric issue priority between the two workgroups of a CU.  A workgroup has one wave per SIMD, so the two
+    // co-resident ones sit in two wave slots of every SIMD; the slot number (HW_ID[3:0]) is inherited by whoever replaces a finished
+    // workgroup: odd slots always win the MFMA pipe, even slots fill the gaps (the symmetric default lets the two fall into lock-step)
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
+#if SUO_WINO_PRIO == 1
+        if (hw & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#elif SUO_WINO_PRIO == 2
+        if (hw & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+#elif SUO_WINO_PRIO == 3
+        if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+#endif
     const int tiles_x = (a.OW + W_TW - 1) / W_TW, tiles_y = (a.OH + W_TH - 1) / W_TH;
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
@@ -94,10 +109,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
     w_f32x4 areg[NLD];
     auto gload = [&](int c) {
+#ifdef SUO_WINO_EXP_NOGLOAD
+        return;                                                   // timing experiment (wrong results): no halo fetch at all
+#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) areg[i] = buf_load(in_srd, avoff[i], c * W_CK * 4);
     };
     auto sstore = [&](int buf) {
+#ifdef SUO_WINO_EXP_NOSSTORE
+        return;                                                   // timing experiment (wrong results): what would LDS-DMA staging of the halo save at most?
+#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
@@ -133,6 +154,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             L1[c] = *(const w_f32x4*)(hs + (W_IW + c) * W_PKH);
             L2[c] = *(const w_f32x4*)(hs + (2 * W_IW + c) * W_PKH);
         }
+#ifdef SUO_WINO_EXP_NOXFORM
+        {   // timing experiment (wrong results): the transform's LDS traffic without its 64 additions per thread -- the most that doing
+            // the B^T d B arithmetic on the matrix pipe could take off the VALU
+            float* va0 = &V[((th ? 3 : 0) * 4) * 32 * W_PKV + vbase];
+            float* vb0 = &V[((th ? 2 : 1) * 4) * 32 * W_PKV + vbase];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { *(w_f32x4*)(va0 + c * 32 * W_PKV) = L0[c]; *(w_f32x4*)(vb0 + c * 32 * W_PKV) = c & 1 ? L1[c] : L2[c]; }
+            return;
+        }
+#endif
         // rows of B^T d:  half 0 (input rows 0,1,2): xi0 = r0 - r2, xi1 = r1 + r2;  half 1 (rows 1,2,3): xi3 = r1 - r3, xi2 = r2 - r1
         w_f32x4 eA[4], eB[4];
 #pragma unroll

@@ -1,40 +1,25 @@
 #!/bin/bash
-# Copy the artifacts of one tools/profile_round.sh run (gpurun_out/round_<tag>/, optionally gpurun_out/bench_serial_F32/)
-# into profiles/ under the round's names, each with a header saying which command produced it.
-#   bash tools/install_profiles.sh <tag> [round-prefix, default r01]
+# Copy the artifacts of one tools/profile_round.sh run (gpurun_out/round_<tag>/) into profiles/ under the round's names; every
+# installed file starts with the command that produced it, taken from the cmd_*.txt the profiling script wrote (not retyped here).
+#   bash tools/install_profiles.sh <tag> [round-prefix, default r03]
 set -eu
-TAG=$1; P=${2:-r02}
+TAG=$1; P=${2:-r03}
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/round_$TAG
-tail -1 $SRC/bench_line.json > profiles/${P}_bench_line.json
-for extra in driver_flags objects16; do
-  if [ -s $SRC/bench_line_$extra.json ]; then tail -1 $SRC/bench_line_$extra.json > profiles/${P}_bench_line_$extra.json; fi
+for extra in "" _driver_flags _objects16; do
+  if [ -s $SRC/bench_line$extra.json ]; then tail -1 $SRC/bench_line$extra.json > profiles/${P}_bench_line$extra.json; fi
 done
-{
-  echo "# rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-latency-leg --steps 20 --warmup 5   (MI355X; tools/profile_round.sh $TAG)"
-  echo "# one step = 32 frames (256 crops) per network call + their PnP / LM, 2 steps in flight; kernels of the two calls overlap,"
-  echo "# so per-kernel durations here are concurrent-execution times (summarised per kernel x grid with tools/rocpd_stats.py)."
-  echo "# The dominant kernel's 8192-workgroup row mixes the steps' launches (concurrent, longer) with the 41 isolated launches of bench.py's"
-  echo "# roofline loop (its min_us column is the isolated duration); the isolated trace is r02_dominant_kernel_stats.txt."
-  cat $SRC/bench_kernel_stats.txt
-} > profiles/${P}_bench_kernel_stats_final.txt
-{
-  echo "# rocprofv3 --kernel-trace -- python3 tools/bench_dominant.py 100 256   (the dominant kernel (Winograd fused tail), the Winograd 3x3 alone and the two direct-form kernels at the bench launch shape: 256 crops; tools/profile_round.sh $TAG)"
-  cat $SRC/dominant_kernel_stats.txt
-} > profiles/${P}_dominant_kernel_stats.txt
-{
-  echo "# rocprofv3 --pmc <counter group> --kernel-trace -- python3 tools/bench_dominant.py 20 256   (tools/profile_round.sh $TAG; one pass per counter group)"
-  echo "# dominant kernel: fused Residual tail wino3x3_kernel<true> (3x3 128->128 in Winograd F(2x2,3x3) form + ReLU, 1x1 128->256 + skip) @64x64, 256 crops per launch"
+for name in bench cnn_serial dominant dominant_latency latency slam; do
+  if [ -s $SRC/${name}_kernel_stats.txt ]; then
+    { echo "# $(cat $SRC/cmd_$name.txt)   (1x MI355X; tools/profile_round.sh $TAG; per kernel x grid, tools/rocpd_stats.py)"; cat $SRC/${name}_kernel_stats.txt; } > profiles/${P}_${name}_kernel_stats.txt
+  fi
+done
+{ echo "# rocprofv3 --pmc <counter group> --kernel-trace -- python3 tools/bench_dominant.py 20 256   (one pass per counter group; tools/profile_round.sh $TAG)"
   echo "# FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as reported"
-  cat $SRC/pmc.txt
-} > profiles/${P}_pmc_dominant_conv.txt
+  cat $SRC/pmc.txt; } > profiles/${P}_pmc_dominant_conv.txt
+{ echo "# SUO_PMC_GEMM_M=1048576 bash tools/profile_gemm_pmc.sh conv1   (rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_gemm.py run conv1 10, one pass per group)"
+  cat $SRC/pmc_gemm.txt; } > profiles/${P}_pmc_gemm.txt
 cp $SRC/pmc_dominant_conv.json profiles/pmc_dominant_conv.json
-if [ -f gpurun_out/bench_serial_F32/stats.txt ]; then
-  {
-    echo "# SUO_SERIAL=1 rocprofv3 --kernel-trace -- python3 bench.py --no-cpu-baseline --no-graph --only cnn --depth 1 --frames-per-step 32 --steps 6 --warmup 2   (tools/profile_bench_serial.sh)"
-    echo "# one network call at a time, one stream, no graph: per-kernel NON-overlapped durations at 256 crops per call (8 calls;"
-    echo "# the dominant-kernel row also contains the launches of bench.py's roofline loop)."
-    cat gpurun_out/bench_serial_F32/stats.txt
-  } > profiles/${P}_cnn_serial_kernel_stats.txt
-fi
+[ -s $SRC/pmc_gemm.json ] && cp $SRC/pmc_gemm.json profiles/pmc_gemm.json
+for f in latency.log slam.log; do [ -s $SRC/$f ] && grep -v "amdgpu.ids\|rocprofv3\|simple_timer\|^W2026" $SRC/$f > profiles/${P}_${f%.log}_run.txt || true; done
 ls -la profiles/

@@ -14,7 +14,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-M = 524288
+M = int(os.environ.get("SUO_PMC_GEMM_M", 524288))          # 1048576 = the bench's launch shape (256 crops @64x64)
 SHAPES = {   # K1, N, kwargs, algorithmic bytes (activations + output (+ residual) + weights), flop
     "residual": (128, 256, dict(res=True), 4 * (M * 128 + 2 * M * 256 + 128 * 256)),
     "conv1": (256, 128, dict(pro=True, relu=True), 4 * (M * 256 + M * 128 + 256 * 128)),
@@ -63,6 +63,9 @@ def report(shape):
            "mfma_util": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles), 3),
            "l2_hit_rate": round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 3)}
     print(json.dumps(rec, indent=1))
+    if shape == "conv1" and M == 1048576:                 # bench.py's roofline_all.largest_gemm reads `traffic` from here
+        out = {"kernel": "gemm_persist_kernel", "crops_per_launch": M // 4096, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "detail": rec}
+        json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_gemm.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -1,20 +1,35 @@
 #!/bin/bash
-# Round profiles on the GPU box (one gpurun call): bench line, bench kernel stats, dominant-kernel stats, PMC passes.
-#   bash tools/profile_round.sh <round-tag>      -> gpurun_out/round_<tag>/...
-TAG=${1:-r02}
+# Round profiles on the GPU box (one gpurun call): bench lines, kernel traces, dominant-kernel stats, PMC passes.
+#   bash tools/profile_round.sh <round-tag>      -> gpurun_out/round_<tag>/...   (then: bash tools/install_profiles.sh <tag> <prefix>)
+# Every rocprofv3 command is written next to its output (cmd_*.txt) so that the installed files carry the command that made them.
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. the bench line itself (with the CPU baseline)
+run_traced() {   # name, then the program and its arguments
+  local name=$1; shift
+  echo "rocprofv3 --kernel-trace -- python3 $*" | sed "s#$R/##g" > $OUT/cmd_$name.txt
+  rocprofv3 --kernel-trace -d $OUT/${name}_trace -o trace -- python3 "$@" > $OUT/$name.log 2>&1
+  python3 $R/tools/rocpd_stats.py $(find $OUT/${name}_trace -name "*.db" | head -1) grid > $OUT/${name}_kernel_stats.txt
+  rm -rf $OUT/${name}_trace
+}
+# 1. the bench line itself (all legs), and at the driver's flags
 python3 $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-# 2. kernel trace of the same command (shorter run)
-rocprofv3 --kernel-trace -d $OUT/bench_trace -o trace -- python3 $R/bench.py --no-cpu-baseline --no-latency-leg --steps 20 --warmup 5 > $OUT/bench_trace.log 2>&1
-python3 $R/tools/rocpd_stats.py $(find $OUT/bench_trace -name "*.db" | head -1) grid > $OUT/bench_kernel_stats.txt
-# 3. dominant kernel alone at the bench launch shape (256 crops)
-rocprofv3 --kernel-trace -d $OUT/dom_trace -o trace -- python3 $R/tools/bench_dominant.py 100 256 > $OUT/dom.log 2>&1
-python3 $R/tools/rocpd_stats.py $(find $OUT/dom_trace -name "*.db" | head -1) grid > $OUT/dominant_kernel_stats.txt
-# 4. PMC passes (separate runs per counter group, no other tracing)
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line_driver_flags.json 2>> $OUT/bench.err
+python3 $R/bench.py --no-cpu-baseline --no-slam-leg --no-latency-leg --objects 16 --frames-per-step 16 > $OUT/bench_line_objects16.json 2>> $OUT/bench.err
+# 2. kernel trace of the timed region (two steps in flight: per-kernel durations are concurrent-execution times)
+run_traced bench $R/bench.py --no-legs --steps 20 --warmup 5
+# 3. the same network calls one at a time (one stream, no graph): non-overlapped per-kernel durations at 256 crops per call
+SUO_SERIAL=1 run_traced cnn_serial $R/bench.py --no-legs --no-graph --only cnn --depth 1 --steps 6 --warmup 2
+# 4. dominant kernel alone at the bench launch shape (256 crops) and at the latency-mode shape (8 crops)
+run_traced dominant $R/tools/bench_dominant.py 100 256
+run_traced dominant_latency $R/tools/bench_dominant.py 100 8
+# 5. one frame per call, one in flight: every kernel of a frame (network + device geometry chain)
+run_traced latency $R/tools/time_frame_chain.py
+# 6. one SLAM sequence through ObjectSLAM.process_view (BASELINE configs[2])
+run_traced slam $R/tools/profile_slam_view.py
+# 7. PMC passes (separate runs per counter group, nothing but --kernel-trace beside --pmc)
 mkdir -p $R/gpurun_out/pmc && rm -f $R/gpurun_out/pmc/*
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d" " -f1)
@@ -22,5 +37,6 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
 done
 python3 $R/tools/pmc_to_json.py 256 > $OUT/pmc.txt 2>&1
 cp $R/profiles/pmc_dominant_conv.json $OUT/ 2>/dev/null
-rm -rf $OUT/bench_trace $OUT/dom_trace
+SUO_PMC_GEMM_M=1048576 bash $R/tools/profile_gemm_pmc.sh conv1 > $OUT/pmc_gemm.txt 2>&1
+cp $R/profiles/pmc_gemm.json $OUT/ 2>/dev/null
 ls $OUT
