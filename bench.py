@@ -386,6 +386,43 @@ def gemm_roofline(L, iters=30):
             "avg_launch_us": round(us, 2), "flop_per_launch": flop, "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N) + 4.0 * N * K}
 
 
+def bf16x3_leg(L, iters=30):
+    """EXPERIMENTAL, beside the f32 line and never instead of it (`dtype` of `value` stays f32): the largest 1x1 convolution of a call
+    (as gemm_roofline) at fp32 accuracy on the bf16 matrix pipe -- both operands split into three bf16 terms, 6 of the 9 cross products
+    accumulated in fp32 (csrc/gemm_bf16x3.hip) -- against the fp32 MFMA kernel: error of both against fp64 on the same inputs, and time."""
+    import torch
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(1)
+    M, K, N = L * 4096, 256, 128
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+    w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), (rng.standard_normal(K) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    wp = torch.from_numpy(pack_gemm(w, N, K)).cuda()
+    w3 = np.empty(3 * N * K, np.uint16)
+    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data), "pack_bf16x3")
+    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+    scd, shd, bd = torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda(), torch.from_numpy(b).cuda()
+    o32, o3 = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    st = torch.cuda.current_stream()
+    s = C.c_void_p(st.cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    f32 = lambda: _lib.check(lib.suo_conv1x1(P(a), K, K, P(scd), P(shd), None, 0, 0, P(wp), P(bd), None, 0, P(o32), N, M, N, N, 1, 0, s), "suo_conv1x1")  # noqa: E731
+    x3 = lambda: _lib.check(lib.suo_conv1x1_bf16x3(P(a), K, K, P(scd), P(shd), P(w3d), P(bd), P(o3), N, M, N, 1, s), "suo_conv1x1_bf16x3")  # noqa: E731
+    us32, us3 = _timed(f32, st, iters), _timed(x3, st, iters)
+    rows = slice(0, 4096)
+    pre = np.maximum(a[rows].cpu().numpy() * sc + sh, 0).astype(np.float32).astype(np.float64)      # the prologue is float32 in both kernels
+    ref = np.maximum(pre @ w.astype(np.float64).T + b, 0)
+    e32, e3 = np.abs(o32[rows].cpu().numpy() - ref).max(), np.abs(o3[rows].cpu().numpy() - ref).max()
+    flop = 2.0 * M * N * K
+    return {"kernel": "gemm_bf16x3_kernel vs gemm_persist_kernel: 1x1 conv K256->N128, BN+ReLU prologue, + ReLU, M = %d" % M, "dtype": "f32 via bf16x3",
+            "f32_mfma_us": round(us32, 1), "bf16x3_us": round(us3, 1), "speedup": round(us32 / us3, 3),
+            "bf16x3_tflops_f32_equivalent": round(flop / us3 / 1e6, 1), "bf16x3_over_f32_mfma_peak": round(flop / us3 / 1e6 / FP32_MFMA_PEAK_TF, 3),
+            "max_abs_err_vs_fp64": {"f32_mfma": float(f"{e32:.3e}"), "bf16x3": float(f"{e3:.3e}")}, "output_range": round(float(np.abs(ref).max()), 3),
+            "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N), "note": "fp32 accuracy holds; the shape is HBM-heavy (42 FLOP/B): see DESIGN.md section 4"}
+
+
 def latency_roofline(L=8, iters=50):
     """The dominant kernel of the reference's call shape (one frame = 8 crops per network call): the same fused Winograd tail at
     256 tiles -- one workgroup per CU, a quarter of the chip's wave slots."""
@@ -772,6 +809,7 @@ def main():
                     extra["roofline"] = extra["roofline_all"]["dominant_conv"]
             leg("largest_gemm", gemm_roofline, L * F, into="roofline_all")
             leg("latency_mode_dominant_conv", latency_roofline, 8, into="roofline_all")
+            leg("experimental_bf16x3_gemm", bf16x3_leg, L * F)
             if world == 1:
                 leg("pose_check", pose_check_leg, L, pool, not args.no_graph)
                 if not args.no_latency_leg:

@@ -123,6 +123,12 @@ int suo_conv1x1_pool(const float* a1_dev, int lda1, int K1, const float* pro_sca
                      const float* a2_dev, int lda2, int K2, const float* wp_dev, const float* bias_dev,
                      const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, int H, int W,
                      float* pool_out_dev, void* stream);
+/* EXPERIMENTAL, not used by suo_net_forward: the same 1x1 convolution (N = 128, K a multiple of 32, optional BN + ReLU prologue,
+ * bias, optional ReLU) at fp32 accuracy on the bf16 matrix pipe: both operands are split into three bf16 terms and 6 of the 9 cross
+ * products are accumulated in fp32 (csrc/gemm_bf16x3.hip).  wp3 = suo_pack_gemm_weight_bf16x3(W[N][K]) -> 3*N*K uint16. */
+int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out);
+int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* wp3_dev,
+                       const float* bias_dev, float* out_dev, int ldo, int M, int N, int relu, void* stream);
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);

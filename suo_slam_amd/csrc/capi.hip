@@ -88,6 +88,18 @@ int suo_net_backbone(suo_net* net, const float* staged, int L, float* logits, vo
     return net->impl->forward_staged(staged, L, logits, (hipStream_t)stream);
 }
 
+int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out) {
+    if (!w || !out || N <= 0 || K <= 0 || (K % 32)) { suo_set_error("suo_pack_gemm_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_gemm_weight_bf16x3(w, N, K, out);
+    return SUO_OK;
+}
+
+int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* wp3_dev,
+                       const float* bias_dev, float* out_dev, int ldo, int M, int N, int relu, void* stream) {
+    if (!a_dev || !wp3_dev || !out_dev) { suo_set_error("suo_conv1x1_bf16x3: null argument"); return SUO_ERR_ARG; }
+    return suo::launch_gemm_bf16x3(a_dev, lda, K, pro_scale_dev, pro_shift_dev, wp3_dev, bias_dev, out_dev, ldo, M, N, relu, (hipStream_t)stream);
+}
+
 int suo_upload(void* dst_dev, const void* src_pinned_host, size_t bytes, void* stream) {
     if (!dst_dev || !src_pinned_host) { suo_set_error("suo_upload: null argument"); return SUO_ERR_ARG; }
     return suo::launch_upload(dst_dev, src_pinned_host, bytes, (hipStream_t)stream);

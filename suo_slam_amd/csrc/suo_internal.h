@@ -86,6 +86,10 @@ int launch_upsample2_add(const float* up1, const float* low, float* out, int L, 
 int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, int out_c,
                             const float* priors, const float* prior_uv, const uint8_t* prior_mask, float* out, hipStream_t s);
 int launch_render_priors(const float* uv, const uint8_t* mask, int L, float* out, hipStream_t s);
+// experimental: fp32-accurate 1x1 convolution on the bf16 matrix pipe (csrc/gemm_bf16x3.hip)
+void pack_gemm_weight_bf16x3(const float* W, int N, int K, uint16_t* out);
+int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
+                       float* out, int ldo, int M, int N, int relu, hipStream_t s);
 int launch_upload(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
 int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, int* argmax_idx, float* prob, hipStream_t s);
 int launch_classifier(const float* mean_logit, const float* Wc, const float* bc, int L,

@@ -663,3 +663,42 @@ def test_fused_kernels_on_random_shapes(ops):
             low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda()
             gu = ops.conv3x3_wino_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low)
             assert torch.equal(gu, got + low.repeat_interleave(2, 1).repeat_interleave(2, 2)), ("wino tail up", L, H, W)
+
+
+def test_experimental_bf16x3_gemm_is_fp32_accurate(ops):
+    """csrc/gemm_bf16x3.hip (experimental, not on the product path): the 1x1 convolution on the bf16 matrix pipe with both operands
+    split into three bf16 terms and 6 of 9 cross products accumulated in fp32 must be as accurate as the fp32 MFMA kernel: same
+    bound against fp64 (rel 5e-6 of the output range, the bound every fp32 conv kernel is held to), with and without the BN + ReLU
+    prologue, ragged M (rows beyond the last full 128-row tile), and the truncation split of the weights exact (w0 + w1 + w2 == w)."""
+    import ctypes as C
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(77)
+    K, N = 256, 128
+    w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
+    w3 = np.empty(3 * N * K, np.uint16)
+    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
+    planes = (w3.reshape(K // 16, 3, N, 16).astype(np.uint32) << 16).view(np.float32)                 # [ks][plane][n][16]
+    back = planes.astype(np.float64).sum(1).transpose(1, 0, 2).reshape(N, K)
+    assert np.abs(back - w).max() <= np.abs(w).max() * 2.0 ** -23                                       # three bf16 terms carry the 24 bits
+    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    bd = ops.dev(b)
+    for M, pro, relu in ((4096, True, 1), (1000, False, 0), (128 * 513 + 5, True, 1)):
+        a = rng.standard_normal((M, K)).astype(np.float32) * 3
+        sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), (rng.standard_normal(K) * 0.1).astype(np.float32)
+        ad, scd, shd = ops.dev(a), ops.dev(sc), ops.dev(sh)
+        out = torch.full((M + 7, N), -5.0, device="cuda")
+        _lib.check(lib.suo_conv1x1_bf16x3(ops.P(ad), K, K, ops.P(scd) if pro else None, ops.P(shd) if pro else None, ops.P(w3d), ops.P(bd),
+                                          ops.P(out), N, M, N, relu, ops.S()))
+        torch.cuda.synchronize()
+        x = np.maximum(a * sc + sh, 0).astype(np.float32).astype(np.float64) if pro else a.astype(np.float64)
+        ref = x @ w.astype(np.float64).T + b
+        if relu:
+            ref = np.maximum(ref, 0)
+        got = out.cpu().numpy()
+        assert np.abs(got[:M] - ref).max() < 5e-6 * np.abs(ref).max(), (M, np.abs(got[:M] - ref).max() / np.abs(ref).max())
+        assert (got[M:] == -5.0).all()                                                                  # nothing written past M
+    from suo_slam_amd._lib import SuoError
+    with pytest.raises(SuoError):
+        _lib.check(lib.suo_conv1x1_bf16x3(ops.P(ad), K, 48, None, None, ops.P(w3d), ops.P(bd), ops.P(out), N, 128, N, 0, ops.S()))
