@@ -73,7 +73,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pool", type=int, default=0, help="number of distinct synthetic frames cycled through (0 = 2 steps' worth)")
-    ap.add_argument("--depth", type=int, default=2, help="steps in flight (independent network instances / streams / geometry contexts)")
+    ap.add_argument("--depth", type=int, default=4, help="steps in flight (independent network instances / streams / geometry contexts; "
+                                                          "measured 773 / 786 / 795 frames/s at 2 / 3 / 4: 5.4 GB of workspace each)")
     ap.add_argument("--frames-per-step", "--frames-per-forward", dest="frames_per_step", type=int, default=32,
                     help="frames of the stream batched into one network call = one step (--objects crops each)")
     ap.add_argument("--only", choices=["all", "cnn"], default="all", help="diagnostic: network half of the step only")

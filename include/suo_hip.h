@@ -132,7 +132,7 @@ int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scal
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);
-/* 3x3 convolution (stride 1, pad 1, N = 128 output channels, C a multiple of 16) in Winograd F(2x2,3x3) form: weight W[N][C][3][3] ->
+/* 3x3 convolution (stride 1, pad 1, N = 128 or 64 output channels, C a multiple of 16) in Winograd F(2x2,3x3) form: weight W[N][C][3][3] ->
  * out[16 * Np * Cp] floats (U = G g G^T per channel pair, computed in fp64, MFMA B-operand order); same tensors as suo_conv_kxk. */
 int suo_pack_wino_weight(const float* w, int N, int C, int Np, int Cp, float* out);
 int suo_conv3x3_wino(const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev, float* out_dev, int N,

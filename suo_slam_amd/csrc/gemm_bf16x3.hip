@@ -89,7 +89,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + 64 * i + ar;
             arow_ok[set][i] = row < M;
+#ifdef SUO_X3_EXP_NOLOAD
+            areg[set][i] = x3_f32x4{(float)(row + ks), 1.f, 2.f, (float)aq};          // timing experiment: no HBM reads
+#else
             areg[set][i] = *(const x3_f32x4*)(A + (size_t)(arow_ok[set][i] ? row : m0) * lda + ks * X3_BK + 4 * aq);
+#endif
         }
         if (pro_scale) {
             sreg[set] = *(const x3_f32x4*)(pro_scale + ks * X3_BK + 4 * aq);

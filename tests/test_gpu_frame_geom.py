@@ -219,3 +219,39 @@ def test_object_slam_single_view_both_routes_leave_the_same_state(n_obj, no_cov)
             np.testing.assert_allclose(np.asarray(map_a[o])[:3], np.asarray(map_b[o])[:3], rtol=0, atol=1e-6 * np.abs(map_b[o]).max())
         assert {o: r["score"] for o, r in res_a.items()} == {o: r["score"] for o, r in res_b.items()}
     assert n_poses >= n_obj
+
+
+def test_upload_kernel_copies_pinned_host_memory_bit_for_bit():
+    """suo_upload (the frame H2D of the timed region): any size incl. a tail that is not a multiple of 16 bytes; misaligned pointers refused."""
+    import ctypes as C
+    from suo_slam_amd import _lib
+    from suo_slam_amd._lib import SuoError
+    lib = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (921600, 32 * 921600, 1000, 16, 33, 4096 + 7):
+        h = torch.from_numpy(np.random.default_rng(n).integers(0, 255, n).astype(np.uint8)).pin_memory()
+        d = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.suo_upload(C.c_void_p(d.data_ptr()), C.c_void_p(h.data_ptr()), n, st))
+        torch.cuda.synchronize()
+        got = d.cpu()
+        assert torch.equal(got[:n], h) and int(got[n:].sum()) == 0
+    with pytest.raises(SuoError):
+        _lib.check(lib.suo_upload(C.c_void_p(d.data_ptr() + 4), C.c_void_p(h.data_ptr()), 64, st))
+
+
+def test_more_than_sixteen_objects_take_the_host_route():
+    """The device chain refines frames of <= 16 crops; ObjectSLAM sends larger frames (T-LESS scenes can have more) through the host
+    route instead of failing -- same interface, same kind of result."""
+    from suo_slam_amd import weights
+    from suo_slam_amd.object_slam import ObjectSLAM
+    from tests import replay
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    sd["classifier.2.bias"] = (np.asarray(sd["classifier.2.bias"]) + 4.0).astype(np.float32)
+    fr = S.make_frame(np.random.default_rng(61), 18, noise=0.0)
+    slam = ObjectSLAM(None, _mesh_db(fr), sfm_mode=True, single_view_mode=True, state_dict=sd, max_crops=18, kp_var_thresh=0.5, bbox_thresh=1.0)
+    with replay.record() as rec:
+        slam.process_view(0, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
+                          fr["model_kps_masks"])
+    assert len(rec.chain) == 0 and len(rec.pnp) == 1 and len(rec.ba) == 1
+    assert replay.check_pnp(rec) >= 12 and replay.check_ba(rec) == 1
+    assert len(slam.collect_results()[0]["poses"]) == 18
