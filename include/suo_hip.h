@@ -142,6 +142,18 @@ int suo_conv3x3_wino(const float* in_dev, int L, int H, int W, int C, const floa
  * launches only (>= 1024 tiles of 128 pixels, the shapes the network uses it for); bit-identical to suo_conv_kxk + suo_conv1x1. */
 int suo_conv3x3_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wp2_dev, const float* bias2_dev, const float* wp3_dev,
                              const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);
+/* EXPERIMENTAL (csrc/conv_wino_x3.hip): the Winograd 3x3 convolution (128 -> 128 channels) with its element-wise products on the bf16
+ * matrix pipe at fp32 accuracy (3-way split of both operands, 6 of 9 cross terms, fp32 accumulate).
+ * wq3 = suo_pack_wino_weight_bf16x3(W[128][128][3][3]) -> 3 * 16 * N * C uint16; same tensors as suo_conv3x3_wino / .._conv1x1_skip_up. */
+int suo_pack_wino_weight_bf16x3(const float* w, int N, int C, uint16_t* out);
+int suo_conv3x3_wino_x3(const float* in_dev, int L, int H, int W, const uint16_t* wq3_dev, const float* bias_dev, float* out_dev, int relu,
+                        void* stream);
+/* wp3_dev: conv3 weight packed by suo_pack_gemm_weight (tail_bf16x3 = 0: conv3 on the fp32 pipe) or by suo_pack_tail_weight_bf16x3
+ * (tail_bf16x3 = 1: W3[256][128] -> 3 * 256 * 128 uint16, conv3 on the bf16 pipe as well). */
+int suo_pack_tail_weight_bf16x3(const float* w3, int N2, int K, uint16_t* out);
+int suo_conv3x3_wino_x3_conv1x1_skip_up(const float* in_dev, int L, int H, int W, const uint16_t* wq3_dev, const float* bias2_dev,
+                                        const void* wp3_dev, int tail_bf16x3, const float* bias3_dev, const float* skip_dev,
+                                        const float* up_dev, float* out_dev, void* stream);
 /* The same with the 3x3 convolution in Winograd form (wq2 from suo_pack_wino_weight): what the network launches for its 256 -> 256 blocks */
 int suo_conv3x3_wino_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wq2_dev, const float* bias2_dev, const float* wp3_dev,
                                   const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);

@@ -188,6 +188,34 @@ int suo_conv3x3_wino_conv1x1_skip_up(const float* in, int L, int H, int W, const
     return suo::launch_conv3x3_wino_fused(c, (hipStream_t)stream);
 }
 
+int suo_pack_wino_weight_bf16x3(const float* w, int N, int C, uint16_t* out) {
+    if (!w || !out || N % 32 || C % 16) { suo_set_error("suo_pack_wino_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_wino_weight_bf16x3(w, N, C, N, C, nullptr, out);
+    return SUO_OK;
+}
+
+int suo_conv3x3_wino_x3(const float* in, int L, int H, int W, const uint16_t* wq3, const float* bias, float* out, int relu, void* stream) {
+    suo::ConvArgs c = {};
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = 128; c.Wp = (const float*)wq3; c.bias = bias; c.out = out; c.OH = H; c.OW = W; c.N = 128; c.relu = relu;
+    return suo::launch_conv3x3_wino_x3(c, (hipStream_t)stream);
+}
+
+int suo_pack_tail_weight_bf16x3(const float* w3, int N2, int K, uint16_t* out) {
+    if (!w3 || !out || N2 % 32 || K % 16) { suo_set_error("suo_pack_tail_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_tail_weight_bf16x3(w3, N2, K, out);
+    return SUO_OK;
+}
+
+int suo_conv3x3_wino_x3_conv1x1_skip_up(const float* in, int L, int H, int W, const uint16_t* wq3, const float* bias2, const void* wp3, int tail_bf16x3,
+                                        const float* bias3, const float* skip, const float* up, float* out, void* stream) {
+    suo::ConvArgs c = {};
+    c.w3_bf16x3 = tail_bf16x3;
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = 128; c.Wp = (const float*)wq3; c.bias = bias2; c.out = nullptr; c.OH = H; c.OW = W; c.N = 128; c.relu = 1;
+    c.W3p = (const float*)wp3; c.bias3 = bias3; c.R = skip; c.out2 = out; c.N2 = 256; c.up = up;
+    if (up && ((H | W) & 1)) { suo_set_error("suo_conv3x3_wino_x3_conv1x1_skip_up: odd map size"); return SUO_ERR_ARG; }
+    return suo::launch_conv3x3_wino_x3_fused(c, (hipStream_t)stream);
+}
+
 int suo_conv3x3_wino_conv1x1_skip(const float* in, int L, int H, int W, const float* wq2, const float* bias2, const float* wp3, const float* bias3,
                                   const float* skip, float* out, void* stream) {
     return suo_conv3x3_wino_conv1x1_skip_up(in, L, H, W, wq2, bias2, wp3, bias3, skip, nullptr, out, stream);

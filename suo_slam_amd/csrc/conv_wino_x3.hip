@@ -1,0 +1,579 @@
+// EXPERIMENTAL: the Winograd F(2x2,3x3) convolution of csrc/conv_wino.hip with its element-wise products on the BF16 matrix pipe at
+// fp32 accuracy (3-way operand split, 6 of 9 cross terms, fp32 accumulate: see csrc/gemm_bf16x3.hip for the arithmetic).
+//
+//   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A
+// Per 16-channel chunk and Winograd component the product V_xi,nu (32 tiles x 16 channels) * U_xi,nu (16 channels x 32 outputs) is
+// EIGHT v_mfma_f32_32x32x2_f32 (8 x 64 = 512 pipe cycles) in the fp32 kernel and SIX v_mfma_f32_32x32x16_bf16 (6 x 32 = 192 cycles)
+// here: U is split on the host (fp64 transform, rounded once to fp32, then three truncated bf16 terms), V = B^T d B is computed in fp32
+// exactly as before and split by the transforming thread on its way to LDS (three bf16 planes, 49 KB).  Same workgroup tile (8 x 16
+// output pixels = 32 Winograd tiles x 128 output channels, 4 waves, wave w owns output channels [32 w, 32 w + 32)), same halo
+// staging, same two-step output transform (rows xi = 0, 3 accumulate straight into Z, rows 1, 2 through a scratch accumulator and 16
+// vector additions per chunk), same epilogues -- the accumulator layout of the bf16 MFMA is that of the fp32 one, so the fused
+// Residual tail (conv3 1x1 + skip [+ up-sampled addend], kept on the fp32 pipe) is taken over unchanged.
+#include <string.h>
+
+#include "buffer_ops.h"
+#include "suo_internal.h"
+
+namespace suo {
+
+typedef float x_f32x4 __attribute__((ext_vector_type(4)));
+typedef float x_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned x_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned x_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 x_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ x_f32x16 x_mfma32(float a, float b, x_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int x_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ unsigned x_pack_hi(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
+__device__ __forceinline__ float x_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// (Tried and dropped, tools/bench_wino_x3.py: forcing the transform / fold additions into v_pk_add_f32 (-30 % VALU instructions) or into
+// plain v_add_f32 changes nothing measurable; inline-asm VALU on MFMA results is unsafe -- hipcc's hazard recogniser does not see through it.)
+__device__ __forceinline__ x_f32x4 x_sub4(x_f32x4 a, x_f32x4 b) { return a - b; }
+__device__ __forceinline__ x_f32x4 x_add4(x_f32x4 a, x_f32x4 b) { return a + b; }
+__device__ __forceinline__ void x_add16(x_f32x16& z, const x_f32x16& t) { z += t; }
+__device__ __forceinline__ void x_sub16(x_f32x16& z, const x_f32x16& t) { z -= t; }
+
+constexpr int X_CK = 16, X_PKH = 20, X_TH = 8, X_TW = 16, X_IH = 10, X_IW = 18, X_NPIX = X_IH * X_IW;
+
+// host: U[n][c][comp] = (G g G^T)[xi][nu] in fp64 (BN scale folded in), rounded once to fp32, split into three truncated bf16 terms;
+//   Up3[chunk][comp][nb][plane][lane][e] = term `plane` of +-U[nb*32 + (lane&31)][chunk*16 + 8*(lane>>5) + e][comp]     (B operand of
+//   v_mfma_f32_32x32x16_bf16: lane l supplies k = 8 (l >> 5) .. + 7 of column l & 31); the components of row xi = 3 are stored negated
+void pack_wino_weight_bf16x3(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int NB = Np / 32;
+    memset(out, 0, (size_t)Np * Cp * 16 * 3 * sizeof(uint16_t));
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            const float* g = W + ((size_t)n * C + c) * 9;
+            const double sc = out_scale ? (double)out_scale[n] : 1.0;
+            double Gg[4][3], U[4][4];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 3; ++j) Gg[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) U[i][j] = (Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2]) * sc;
+            const int chunk = c / X_CK, cc = c % X_CK, nb = n / 32, lane = (cc / 8) * 32 + (n % 32), e = cc % 8;
+            for (int comp = 0; comp < 16; ++comp) {
+                float x = (float)(comp >= 12 ? -U[comp >> 2][comp & 3] : U[comp >> 2][comp & 3]);
+                for (int p = 0; p < 3; ++p) {
+                    uint32_t u;
+                    memcpy(&u, &x, 4);
+                    u &= 0xffff0000u;
+                    float hi;
+                    memcpy(&hi, &u, 4);
+                    out[((((size_t)(chunk * 16 + comp) * NB + nb) * 3 + p) * 64 + lane) * 8 + e] = (uint16_t)(u >> 16);
+                    x -= hi;
+                }
+            }
+        }
+}
+
+// host: conv3 weight W3[N2][K] (1x1) -> three truncated bf16 terms in B-operand order of v_mfma_f32_32x32x16_bf16:
+//   W3x[(ks * NB + nb) * 3 + plane][lane][e] = term `plane` of W3[nb*32 + (lane&31)][ks*16 + 8*(lane>>5) + e]
+void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out) {
+    const int NB = N2 / 32;
+    for (int n = 0; n < N2; ++n)
+        for (int k = 0; k < K; ++k) {
+            const int ks = k / 16, kk = k % 16, lane = (kk / 8) * 32 + (n % 32), e = kk % 8, nb = n / 32;
+            float x = W3[(size_t)n * K + k];
+            for (int p = 0; p < 3; ++p) {
+                uint32_t u;
+                memcpy(&u, &x, 4);
+                u &= 0xffff0000u;
+                float hi;
+                memcpy(&hi, &u, 4);
+                out[((((size_t)(ks * NB + nb) * 3 + p) * 64 + lane) * 8) + e] = (uint16_t)(u >> 16);
+                x -= hi;
+            }
+        }
+}
+
+template <bool FUSE, bool UP = false, bool TX3 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
+    // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
+    constexpr int HSZ = X_NPIX * X_PKH;                       // floats per halo buffer
+    constexpr int VROW = 16;                                  // bf16 per (tile, chunk) row = 32 bytes; the two 16-byte halves swap for tiles 8-15 / 24-31
+    constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
+    constexpr int VFLOATS = 3 * VPL / 2;
+    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
+    float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
+    uint16_t* V = reinterpret_cast<uint16_t*>(&S[2 * HSZ]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (a.OW + X_TW - 1) / X_TW, tiles_y = (a.OH + X_TH - 1) / X_TH;
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
+    const int l = bid / (tiles_x * tiles_y);
+    bid -= l * tiles_x * tiles_y;
+    const int ty0 = bid / tiles_x, tx0 = bid - ty0 * tiles_x;
+    const int oy0 = ty0 * X_TH, ox0 = tx0 * X_TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int nch = a.C / X_CK, NB = a.N >> 5;
+    const float* in_l = a.in + (size_t)l * a.H * a.W * a.C;
+    const __amdgpu_buffer_rsrc_t in_srd = make_srd(in_l, (size_t)a.H * a.W * a.C * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * 16 * 3 * sizeof(uint16_t));
+    const __amdgpu_buffer_rsrc_t out_srd = make_srd(a.out + (size_t)l * a.OH * a.OW * a.N, (size_t)a.OH * a.OW * a.N * sizeof(float));
+
+    // ---- halo staging (as csrc/conv_wino.hip): 180 pixels x 4 float4 per chunk over 256 threads -----------------------------
+    constexpr int NF4 = X_NPIX * 4, NLD = (NF4 + 255) / 256;
+    int avoff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int pix = idx >> 2, cc = idx & 3;
+        const int py = pix / X_IW, px = pix - py * X_IW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool ok = idx < NF4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        avoff[i] = ok ? ((iy * a.W + ix) * a.C + cc * 4) * 4 : BUF_OOB;
+    }
+    x_f32x4 areg[NLD];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) areg[i] = buf_load(in_srd, avoff[i], c * X_CK * 4);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < NF4) *(x_f32x4*)&Hin[buf][(idx >> 2) * X_PKH + (idx & 3) * 4] = areg[i];
+        }
+    };
+    // ---- weights: Up3[(chunk * 16 + comp)][nb][plane][lane][8 bf16]: 3 KB per (component, n-tile), three 16-byte loads per lane -----
+    const int wvoff = lane * 16;
+    const int gtot = nch * 16;
+    auto bload = [&](int gc, x_u32x4 (&b)[3]) {               // gc = chunk * 16 + comp (clamped: the stream runs on past the last chunk)
+#ifdef SUO_WX3_EXP_W0
+        const int g = gc & 1;                                 // timing experiment (wrong results): weights from two cache-resident groups
+#else
+        const int g = gc < gtot ? gc : gtot - 1;
+#endif
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff, ((g * NB + w) * 3 + p) * 1024));
+    };
+    // ---- transform: thread = (tile tt, channel quad tq, half th) as in csrc/conv_wino.hip; every result vector is split on its way to LDS ----
+    const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;
+    const int t_ty = tt >> 3, t_tx = tt & 7;
+    const int hbase = ((2 * t_ty + th) * X_IW + 2 * t_tx) * X_PKH + tq * 4;
+    // V element offset of (component 0, tile tt, channels 4 tq ..): row tt, half (tq >> 1) swapped for tiles 8-15 / 24-31, 4 bf16 = 8 bytes
+    const int vbase = tt * VROW + ((((tq >> 1) ^ ((tt >> 3) & 1)) * 8) + (tq & 1) * 4);
+    auto vstore = [&](int comp, x_f32x4 v) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + vbase] = x_u32x2{x_pack_hi(v[0], v[1]), x_pack_hi(v[2], v[3])};
+#ifndef SUO_WX3_EXP_NOSPLIT                                   // (timing experiment, wrong results: the three planes hold the same term)
+            if (p < 2) {
+                v = x_sub4(v, x_f32x4{x_hi(v[0]), x_hi(v[1]), x_hi(v[2]), x_hi(v[3])});      // exact residual
+            }
+#endif
+        }
+    };
+    // rows of B^T d:  half 0 (input rows 0,1,2): xi0 = r0 - r2, xi1 = r1 + r2;  half 1 (rows 1,2,3): xi3 = r1 - r3, xi2 = r2 - r1
+    // = (first - third, second +- other) with `other` = third / first row of the half's three: the row is picked by address, the sign is a scalar
+    const int hother = th ? 0 : 2 * X_IW * X_PKH;
+    const float hsign = th ? -1.f : 1.f;
+    auto transform = [&](int buf) {
+        const float* hs = &Hin[buf][hbase];
+        x_f32x4 L0[4], L1[4], L2[4], Lx[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            L0[c] = *(const x_f32x4*)(hs + c * X_PKH);
+            L1[c] = *(const x_f32x4*)(hs + (X_IW + c) * X_PKH);
+            L2[c] = *(const x_f32x4*)(hs + (2 * X_IW + c) * X_PKH);
+            Lx[c] = *(const x_f32x4*)(hs + hother + c * X_PKH);
+        }
+#ifdef SUO_WX3_EXP_NOXFORM                                    // timing experiment (wrong results): the transform's LDS traffic without its arithmetic
+        {
+            const int xa = th ? 3 : 0, xb = th ? 2 : 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    *(x_u32x2*)&V[p * VPL + (xa * 4 + c) * 32 * VROW + vbase] = x_u32x2{__float_as_uint(L0[c][p]), __float_as_uint(L2[c][p])};
+                    *(x_u32x2*)&V[p * VPL + (xb * 4 + c) * 32 * VROW + vbase] = x_u32x2{__float_as_uint(L1[c][p]), __float_as_uint(Lx[c][p])};
+                }
+            return;
+        }
+#endif
+        x_f32x4 eA[4], eB[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            eA[c] = x_sub4(L0[c], L2[c]);
+            eB[c] = x_f32x4{__builtin_fmaf(Lx[c][0], hsign, L1[c][0]), __builtin_fmaf(Lx[c][1], hsign, L1[c][1]), __builtin_fmaf(Lx[c][2], hsign, L1[c][2]),
+                            __builtin_fmaf(Lx[c][3], hsign, L1[c][3])};                      // (a product by +-1 is exact: with or without contraction the same value)
+        }
+        const int xiA = th ? 3 : 0, xiB = th ? 2 : 1;
+        // columns: nu0 = c0 - c2, nu1 = c1 + c2, nu2 = c2 - c1, nu3 = c1 - c3
+        vstore(xiA * 4 + 0, x_sub4(eA[0], eA[2]));
+        vstore(xiA * 4 + 1, x_add4(eA[1], eA[2]));
+        vstore(xiA * 4 + 2, x_sub4(eA[2], eA[1]));
+        vstore(xiA * 4 + 3, x_sub4(eA[1], eA[3]));
+        vstore(xiB * 4 + 0, x_sub4(eB[0], eB[2]));
+        vstore(xiB * 4 + 1, x_add4(eB[1], eB[2]));
+        vstore(xiB * 4 + 2, x_sub4(eB[2], eB[1]));
+        vstore(xiB * 4 + 3, x_sub4(eB[1], eB[3]));
+    };
+
+    x_f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    x_f32x16 out[4], Z[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[p][r] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[p][r] = 0.f;
+    // Consumption order of the components, in pairs: pairs 0-3 = (xi 0, xi 3) of nu = pair, accumulated straight into their Z; pairs 4-7 =
+    // (xi 1, xi 2) of nu = pair - 4, through two scratch accumulators that are folded into Z[0][nu], Z[1][nu].  The weights of pair p + 1
+    // are requested before pair p's MFMAs.  Measured alternatives, all slower (tools/bench_wino_x3.py, 256 crops, plain / fused, us):
+    // this schedule 920 / 1620; the two accumulation chains of a pair interleaved 1030 / 1800; one component at a time with the A
+    // fragments one and the weights one / three components ahead 943 / 1690 and 1052 / 1825.
+    auto comp_of = [&](int pair, int which) -> int { return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4)); };
+    // A operand of component comp: tile = lane & 31, channels 8 (lane >> 5) .. + 7 (the half, swapped for tiles 8-15 / 24-31)
+    const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ ((lane >> 3) & 1)) * 8);
+    // the six cross terms of a component, smallest first
+    auto mac6 = [&](x_f32x16& acc, const x_bf16x8 (&f)[3], const x_u32x4 (&bw)[3], bool from_zero) {
+        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+#ifdef SUO_WX3_EXP_MFMA3                                      // timing experiment (wrong results): half of the cross terms
+        for (int t = 0; t < 3; ++t)
+#else
+        for (int t = 0; t < 6; ++t)
+#endif
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[TI[t]], __builtin_bit_cast(x_bf16x8, bw[TJ[t]]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
+    };
+    x_u32x4 bring[2][2][3];                                   // [slot][which][plane]
+    gload(0);
+    bload(comp_of(0, 0), bring[0][0]);
+    bload(comp_of(0, 1), bring[0][1]);
+    sstore(0);
+    __syncthreads();
+
+#ifdef SUO_WX3_PROF
+    long long pt[5] = {0, 0, 0, 0, 0}, p0 = clock64();
+#define XPROF(i) do { const long long _t = clock64(); pt[i] += _t - p0; p0 = _t; } while (0)
+#else
+#define XPROF(i) do { } while (0)
+#endif
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nch;
+        if (more) gload(c + 1);
+        transform(buf);
+        XPROF(0);
+        __syncthreads();
+        XPROF(1);
+        if (more) sstore(buf ^ 1);
+        XPROF(2);
+#ifdef SUO_WX3_EXP_NOAREAD
+        x_u32x4 keepa[3];
+#endif
+#pragma unroll
+        for (int pair = 0; pair < 8; ++pair) {
+            const int slot = pair & 1;
+            {   // next pair (of this chunk, or pair 0 of the next one)
+                const int np = pair + 1 < 8 ? pair + 1 : 0, nc = pair + 1 < 8 ? c : c + 1;
+                bload(nc * 16 + comp_of(np, 0), bring[slot ^ 1][0]);
+                bload(nc * 16 + comp_of(np, 1), bring[slot ^ 1][1]);
+            }
+            const int ca = comp_of(pair, 0), cb = comp_of(pair, 1);
+            x_bf16x8 afa[3], afb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#ifdef SUO_WX3_EXP_NOAREAD                                    // timing experiment (wrong results): A fragments read once per chunk
+                if (pair > 0) { afa[p] = __builtin_bit_cast(x_bf16x8, keepa[p]); afb[p] = __builtin_bit_cast(x_bf16x8, keepa[p]); continue; }
+#endif
+                afa[p] = *(const x_bf16x8*)&V[p * VPL + ca * 32 * VROW + afoff];
+                afb[p] = *(const x_bf16x8*)&V[p * VPL + cb * 32 * VROW + afoff];
+#ifdef SUO_WX3_EXP_NOAREAD
+                keepa[p] = __builtin_bit_cast(x_u32x4, afa[p]);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pair < 4) {                                   // accumulate into their own Z, no scratch, no additions
+                mac6(Z[pair], afa, bring[slot][0], false);
+                mac6(Z[4 + pair], afb, bring[slot][1], false);
+            } else {
+                x_f32x16 ta, tb;
+                mac6(ta, afa, bring[slot][0], true);
+                mac6(tb, afb, bring[slot][1], true);
+#ifdef SUO_WX3_EXP_NOFOLD                                     // (timing experiment, wrong results)
+                Z[pair - 4][0] += ta[0] + tb[0];
+#else
+                x_add16(Z[pair - 4], ta); x_add16(Z[pair - 4], tb); x_add16(Z[pair], ta); x_sub16(Z[pair], tb);      // Z[0][nu] += M1 + M2, Z[1][nu] += M1 - M2
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        XPROF(3);
+        __syncthreads();
+        XPROF(4);
+    }
+#ifdef SUO_WX3_PROF
+    if (blockIdx.x == 1000 && (tid & 63) == 0) printf("wave %d cycles: transform %lld  barrier1 %lld  sstore %lld  mfma+fold %lld  barrier2 %lld\n", w, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
+    // second step of the output transform: Y[i][j] = sum_nu A^T[j][nu] Z[4 i + nu]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        out[2 * h] = Z[4 * h] + Z[4 * h + 1] + Z[4 * h + 2];
+        out[2 * h + 1] = Z[4 * h + 1] - Z[4 * h + 2] - Z[4 * h + 3];
+    }
+
+    if constexpr (FUSE && TX3) {
+        // ---- tail of the Residual block (layers/Residual.py:27-35) on the bf16 pipe as well: out2 = W3 relu(conv2 + bias2) + bias3 + skip [+ up],
+        // conv3 = 1x1, 128 -> 256.  The conv2 tile (128 pixels x 128 channels, in `out`: wave w holds channels [32 w, 32 w + 32) as 4 output
+        // positions x 32 Winograd tiles) is the A operand; split into three bf16 planes it is 96 KB, so it goes through LDS in two halves of
+        // 64 pixels: pass h = the output positions of pixel row parity h (image rows oy0 + 2 ty + h).  Per pass: every lane splits its 32
+        // values and stores the bf16 terms (the upper halves of the fp32 value and of its two exact residuals: ds_write_b16_d16_hi) into
+        // AP[plane][k-step][pixel m = 16 ty + x][16 channels] (A-operand order: 32-byte rows, the 16-byte halves swapped for pixels 8-15 of
+        // every 16); barrier; wave w computes the 64 pixels x output channels [64 w, 64 w + 64) (2 x 2 accumulators, 8 k-steps x 24 MFMAs),
+        // then its epilogue (transposition through a wave-private patch, + bias3 + skip [+ up], 16-byte stores).
+        constexpr int KS_STRIDE = 64 * 32 + 32;                 // bytes per k-step image (+ 32: the two k-steps a wave stores to hit different banks)
+        constexpr int PL_STRIDE = 8 * KS_STRIDE;
+        static_assert(3 * PL_STRIDE + 4 * 32 * 36 * 4 <= (2 * HSZ + VFLOATS) * 4, "tail staging must fit the workgroup's LDS");
+        unsigned char* AP = reinterpret_cast<unsigned char*>(&S[0]);
+        float* T = &S[3 * PL_STRIDE / 4] + w * (32 * 36);
+        const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * 3 * sizeof(uint16_t));
+        const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
+        const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
+        constexpr bool has_up = UP;
+        const __amdgpu_buffer_rsrc_t up_srd = make_srd(has_up ? a.up + (size_t)l * (crop2 / 4) : a.R, has_up ? crop2 / 4 * sizeof(float) : 0);
+        const float b2v = a.bias[w * 32 + (lane & 31)];
+        // store address of the lane's channel n = 32 w + (lane & 31): k-step n >> 4, half (n >> 3) & 1 (swapped for pixels 8-15: = lane >> 5, see m below),
+        // element n & 7; pixel m = 16 (r >> 2) + 2 (r & 3) + 8 (lane >> 5) + pj for accumulator row r (tile (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+        const int sbase = (2 * w + ((lane >> 4) & 1)) * KS_STRIDE + (lane >> 5) * (8 * 32) + ((((lane >> 3) & 1) ^ (lane >> 5)) * 16) + (lane & 7) * 2;
+        // A operand: pixel m = 32 i + (lane & 31), channels 8 (lane >> 5) .. + 7 of the k-step
+        const int aoff = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
+        // weights: W3x[(ks * 8 + nb) * 3 + plane][lane][8 bf16], 1 KB each (pack_tail_weight_bf16x3); the wave's n-tiles are 2 w, 2 w + 1
+        const int w3voff = lane * 16;
+        auto b3load = [&](int ks, x_u32x4 (&b)[2][3]) {
+            const int k = ks < 8 ? ks : 7;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + 2 * w + j) * 3) + p) * 1024));
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            x_u32x4 b3[2][2][3];
+            b3load(0, b3[0]);
+#pragma unroll
+            for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = fmaxf(out[2 * h + pj][r] + b2v, 0.f);
+                    const int off = sbase + (16 * (r >> 2) + 2 * (r & 3) + pj) * 32;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        *reinterpret_cast<uint16_t*>(AP + p * PL_STRIDE + off) = (uint16_t)(__float_as_uint(v) >> 16);
+                        if (p < 2) v -= x_hi(v);
+                    }
+                }
+            __syncthreads();
+            x_f32x16 acc2[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                b3load(ks + 1, b3[(ks + 1) & 1]);
+                x_bf16x8 af[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[i][p] = *(const x_bf16x8*)(AP + p * PL_STRIDE + ks * KS_STRIDE + i * 1024 + aoff);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mac6(acc2[i][j], af[i], b3[ks & 1][j], false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = (2 * w + j) * 32 + (lane & 7) * 4;
+                    const x_f32x4 bv = *(const x_f32x4*)(a.bias3 + col);
+                    int off[4];
+                    x_f32x4 rv[4], uv[UP ? 4 : 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = 32 * i + (lane >> 3) + 8 * k;
+                        const int oy = oy0 + 2 * (m >> 4) + h, ox = ox0 + (m & 15);
+                        const bool in = oy < a.OH && ox < a.OW;
+                        off[k] = in ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
+                        rv[k] = buf_load(r_srd, off[k], 0);
+                        if constexpr (UP) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) T[x_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x_f32x4 o = (*(const x_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                        if constexpr (UP) o += uv[k];
+                        buf_store(o, o2_srd, off[k]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            if (h == 0) __syncthreads();                      // every wave is done with the A planes of pass 0
+        }
+        return;
+    }
+
+    if constexpr (FUSE && !TX3) {
+        // ---- tail of the Residual block (layers/Residual.py:27-35) exactly as in csrc/conv_wino.hip: conv3 (1x1, 128 -> 256) + bias + skip
+        // on relu(conv2 + bias2), on the fp32 pipe: the conv2 tile goes through LDS (pitch 132) as the A operand, 2 x 4 accumulators
+        constexpr int MP = 132;
+        static_assert(128 * MP <= 2 * HSZ + VFLOATS, "the conv2 tile must fit the workgroup's LDS");
+        float* M2 = &S[0];
+        const int wm = w >> 1, wn = w & 1;
+        const int NB2 = a.N2 >> 5;
+        const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * sizeof(float));
+        const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
+        const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
+        const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
+        constexpr bool has_up = UP;
+        const __amdgpu_buffer_rsrc_t up_srd = make_srd(has_up ? a.up + (size_t)l * (crop2 / 4) : a.R, has_up ? crop2 / 4 * sizeof(float) : 0);
+        const float b2v = a.bias[w * 32 + (lane & 31)];
+        const int w3voff = lane * 16;
+        auto b3load = [&](int q, x_f32x4(&b)[4]) {
+            const int kg = q < 16 ? q : 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = buf_load(w3_srd, w3voff, (kg * NB2 + wn * 4 + j) * 1024);
+        };
+        constexpr int R3 = 3;
+        x_f32x4 b3[R3][4];
+#pragma unroll
+        for (int r = 0; r < R3 - 1; ++r) b3load(r, b3[r]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = x_acc_row(r, lane);
+                const int pix = (2 * (t >> 3) + (p >> 1)) * X_TW + 2 * (t & 7) + (p & 1);
+                M2[pix * MP + w * 32 + (lane & 31)] = fmaxf(out[p][r] + b2v, 0.f);
+            }
+        __syncthreads();
+        x_f32x16 acc2[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+        const float* ms = M2 + ((wm * 2) * 32 + (lane & 31)) * MP + (lane >> 5) * 4;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            b3load(q + R3 - 1, b3[(q + R3 - 1) % R3]);
+            __builtin_amdgcn_sched_barrier(0);
+            x_f32x4 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const x_f32x4*)(ms + i * 32 * MP + q * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#ifdef SUO_WX3_EXP_TAIL38                                     // timing experiment (wrong results): 3/8 of the tail's MFMA time = what the bf16x3 form would take
+                if ((q * 4 + t) % 8 < 3)
+#endif
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc2[i][j] = x_mfma32(af[i][t], b3[q % R3][j][t], acc2[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* T = M2 + w * (32 * 36);
+                const int col = (wn * 4 + j) * 32 + (lane & 7) * 4;
+                const x_f32x4 bv = *(const x_f32x4*)(a.bias3 + col);
+                int off[4];
+                x_f32x4 rv[4], uv[UP ? 4 : 1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pp = (wm * 2 + i) * 32 + (lane >> 3) + 8 * k;
+                    const int oy = oy0 + pp / X_TW, ox = ox0 + pp % X_TW;
+                    const bool in = oy < a.OH && ox < a.OW;
+                    off[k] = in ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
+                    rv[k] = buf_load(r_srd, off[k], 0);
+                    if constexpr (UP) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[x_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    x_f32x4 o = (*(const x_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                    if constexpr (UP) o += uv[k];
+                    buf_store(o, o2_srd, off[k]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
+
+    // ---- epilogue (plain convolution): per output position transpose the 32 tiles x 32 channels through a wave-private patch -> 16-byte stores
+    float* T = &S[2 * HSZ] + w * (32 * 36);
+    const int col = w * 32 + (lane & 7) * 4;
+    const x_f32x4 bv = *(const x_f32x4*)(a.bias + col);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int pi = p >> 1, pj = p & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[x_acc_row(r, lane) * 36 + (lane & 31)] = out[p][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = (lane >> 3) + 8 * k;
+            const int oy = oy0 + 2 * (t >> 3) + pi, ox = ox0 + 2 * (t & 7) + pj;
+            x_f32x4 o = *(const x_f32x4*)&T[t * 36 + (lane & 7) * 4] + bv;
+            if (a.relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
+            }
+            buf_store(o, out_srd, (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N + col) * 4 : BUF_OOB);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// a.Wp = weights packed by pack_wino_weight_bf16x3 (uint16 under a float pointer); 128 -> 128 channels only
+int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
+    if (a.OH != a.H || a.OW != a.W || a.N != 128 || a.C != 128) {
+        suo_set_error("conv3x3_wino_x3: unsupported shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
+        return SUO_ERR_ARG;
+    }
+    const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
+    hipLaunchKernelGGL((wino3x3_x3_kernel<false>), dim3(tiles), dim3(256), 0, s, a);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+int launch_conv3x3_wino_x3_fused(const ConvArgs& a, hipStream_t s) {
+    if (a.OH != a.H || a.OW != a.W || a.N != 128 || a.C != 128 || a.N2 != 256 || !a.W3p || !a.bias3 || !a.R || !a.out2) {
+        suo_set_error("conv3x3_wino_x3_fused: unsupported shape C=%d N=%d N2=%d", a.C, a.N, a.N2);
+        return SUO_ERR_ARG;
+    }
+    const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
+    if (a.w3_bf16x3) {                                        // W3p packed by pack_tail_weight_bf16x3: the tail on the bf16 pipe too
+        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true>), dim3(tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true>), dim3(tiles), dim3(256), 0, s, a);
+    } else {
+        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, false>), dim3(tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, false>), dim3(tiles), dim3(256), 0, s, a);
+    }
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+}  // namespace suo

@@ -67,6 +67,7 @@ struct ConvArgs {
     // fused Residual tail (launch_conv3x3_fused only): out2 = W3 relu(conv + bias) + bias3 + R, [L,OH,OW,N2]; `out` is not written
     const float* W3p; const float* bias3; const float* R; float* out2; int N2;
     const float* up;                                     // optional [L,OH/2,OW/2,N2]: out2 += nearest-neighbour 2x up-sampling of it (hg.py:56-58)
+    int w3_bf16x3;                                       // csrc/conv_wino_x3.hip only: W3p holds pack_tail_weight_bf16x3's uint16 planes
 };
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 bool conv3x3_fusable(const ConvArgs& a);
@@ -90,6 +91,11 @@ int launch_render_priors(const float* uv, const uint8_t* mask, int L, float* out
 void pack_gemm_weight_bf16x3(const float* W, int N, int K, uint16_t* out);
 int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
                        float* out, int ldo, int M, int N, int relu, hipStream_t s);
+// experimental: Winograd 3x3 with its products on the bf16 matrix pipe at fp32 accuracy (csrc/conv_wino_x3.hip); ConvArgs.Wp = packed uint16
+void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out);
+void pack_wino_weight_bf16x3(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out);
+int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_wino_x3_fused(const ConvArgs& a, hipStream_t s);
 int launch_upload(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
 int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, int* argmax_idx, float* prob, hipStream_t s);
 int launch_classifier(const float* mean_logit, const float* Wc, const float* bc, int L,
