@@ -17,11 +17,12 @@ struct HostTensor {
 };
 
 struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; };
-struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; float* Wq = nullptr; };   // Wq: Winograd-packed (3x3, 128 -> 128 only)
+struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; float* Wq = nullptr; float* Wq3 = nullptr; };   // Wq: Winograd-packed (3x3, 128 -> 128 / 64 -> 64); Wq3: its bf16x3 planes (128 -> 128, csrc/conv_wino_x3.hip)
 struct ResidualW {
     float* pro_scale = nullptr; float* pro_shift = nullptr;
     GemmW c1; ConvW c2; GemmW c3;
     int cin = 0, cout = 0; bool has_skip_conv = false;
+    float* c3x = nullptr;                                // conv3 as bf16x3 planes for the fused Winograd tail on the bf16 pipe (256 <- 128 only)
 };
 struct HourglassW {
     int n = 0;

@@ -122,7 +122,17 @@ float* Net::upload(const std::vector<float>& v) {
     return d;
 }
 
+#ifndef SUO_WINO_BF16X3_DEFAULT
+#define SUO_WINO_BF16X3_DEFAULT 0
+#endif
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// SUO_WINO_BF16X3=0: the Residual blocks' 3x3 convolution + fused tail on the fp32 matrix pipe (csrc/conv_wino.hip) instead of the bf16 pipe
+// with 3-way split operands (csrc/conv_wino_x3.hip: same accuracy, ~1.2x faster)
+static bool wino_bf16x3() {
+    static const int on = getenv("SUO_WINO_BF16X3") ? atoi(getenv("SUO_WINO_BF16X3")) : SUO_WINO_BF16X3_DEFAULT;
+    return on != 0;
+}
 
 // 1x1 conv W[N][K] with optional per-output scale (BN folded) -> device packed weight + bias
 void Net::make_gemm(const std::string& conv, const std::string& bn_after, const std::string& conv2, GemmW& g) {
@@ -183,6 +193,11 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
         std::vector<float> wq((size_t)16 * N * C);
         pack_wino_weight(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), wq.data());
         c.Wq = upload(wq);
+        if (N == 128 && wino_bf16x3()) {                      // the same on the bf16 pipe at fp32 accuracy (csrc/conv_wino_x3.hip)
+            std::vector<float> wq3((size_t)3 * 16 * N * C / 2);                  // uint16 planes
+            pack_wino_weight_bf16x3(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), reinterpret_cast<uint16_t*>(wq3.data()));
+            c.Wq3 = upload(wq3);
+        }
     }
 }
 
@@ -210,6 +225,14 @@ void Net::make_residual(const std::string& p, ResidualW& r) {
     // conv3 (+ conv4 on the raw input as a second K segment: out = W3*mid + W4*x + b3 + b4)
     make_gemm(p + ".conv3", "", r.has_skip_conv ? p + ".conv4" : "", r.c3);
     r.cout = r.c3.n_valid;
+    if (r.c2.Wq3 && !r.has_skip_conv) {
+        const HostTensor& w3 = T(p + ".conv3.weight");
+        if (w3.shape[0] == 256 && w3.shape[1] == 128) {
+            std::vector<float> x3((size_t)3 * 256 * 128 / 2);
+            pack_tail_weight_bf16x3(w3.data, 256, 128, reinterpret_cast<uint16_t*>(x3.data()));
+            r.c3x = upload(x3);
+        }
+    }
 }
 
 void Net::make_hourglass(const std::string& p, int n, HourglassW& h) {
@@ -410,6 +433,10 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
             // conv2 -> conv3 + skip in one launch (933 vs 713 + 346 us at 64x64 / 128 crops, 257 vs 195 + 91 at 32x32)
             if (!out) out = alloc((size_t)M * 256);
             c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256; c2.up = up;
+            if (r.c2.Wq3 && r.c3x) {                          // both products on the bf16 pipe, 3-way split operands
+                c2.Wp = r.c2.Wq3; c2.W3p = r.c3x; c2.w3_bf16x3 = 1;
+                SUO_LAUNCH(launch_conv3x3_wino_x3_fused(c2, s));
+            } else
             SUO_LAUNCH(launch_conv3x3_wino_fused(c2, s));
             if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
             return SUO_OK;
