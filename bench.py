@@ -45,6 +45,7 @@ GFLOP_PER_CROP = 31.495          # conv FLOPs, hook-counted on the reference mod
 # channels are structural zeros and their MACs are never issued (csrc/net.hip: stem_img_): 2*128*128*64*49*41 per crop.
 GFLOP_SKIPPED_PER_CROP = 2 * 128 * 128 * 64 * 49 * 41 / 1e9
 FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
+BF16_MFMA_PEAK_TF = 2500.0       # dense, same table (the fp32 pipe is 1/16 of it)
 BBOX_THRESH, KP_VAR_THRESH = 1.0, 0.5      # evaluate.py:66-74 (the T-LESS pair): with random weights the YCB-V pair masks everything
 
 
@@ -277,8 +278,13 @@ def committed_traffic(name, L, kernel_prefix):
     return None
 
 
+def wino_bf16x3_enabled():
+    """csrc/net.hip: the Residual blocks' 3x3 convolution + fused tail run on the bf16 matrix pipe with 3-way split operands unless SUO_WINO_BF16X3=0."""
+    return os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
+
+
 def dominant_kernel_traffic(L):
-    return committed_traffic("pmc_dominant_conv.json", L, "wino3x3_kernel<true")
+    return committed_traffic("pmc_dominant_conv.json", L, "wino3x3_x3_kernel<true" if wino_bf16x3_enabled() else "wino3x3_kernel<true")
 
 
 def _timed(f, st, iters):
@@ -300,11 +306,16 @@ def _timed(f, st, iters):
 
 def conv_roofline(L, iters=30):
     """Live HIP-event timing of the dominant kernel at the launch shape of the timed region: the tail of a 256 -> 256 Residual block
-    at 64x64 in ONE launch -- conv2 (3x3, 128 -> 128, Winograd F(2x2,3x3)) + ReLU, conv3 (1x1, 128 -> 256) + skip:
-    wino3x3_kernel<true> (8 launches per network call, about a third of its kernel time).
-    `achieved` / `frac` count the FLOPs the kernel EXECUTES on the MFMA pipe (the Winograd form issues 16 products per 2x2 tile and
-    channel pair where the direct form issues 36) -- that is the roofline fraction.  The reference-counted (algorithmic) rate, which
-    exceeds the peak because 2.25x fewer MACs are issued, is reported beside it as `algorithmic_tflops` / `algorithmic_over_peak`."""
+    at 64x64 in ONE launch -- conv2 (3x3, 128 -> 128, Winograd F(2x2,3x3)) + ReLU, conv3 (1x1, 128 -> 256) + skip (8 launches per network
+    call, about a third of its kernel time).  What the network launches (csrc/net.hip):
+      * default: wino3x3_x3_kernel<true,*,true> (csrc/conv_wino_x3.hip) -- every product on the BF16 matrix pipe, both operands split into
+        three bf16 terms, 6 of the 9 cross terms accumulated in fp32 (fp32 accuracy: tests/test_gpu_cnn.py).  `achieved` / `frac` count
+        the bf16 FLOPs the kernel EXECUTES (6 MFMAs of 32x32x16 per component / k-step) against the dense bf16 MFMA peak; the fp32-equivalent
+        rates (what an fp32 kernel would have to sustain for the same launch time) are beside it: `f32_equivalent_executed_tflops` (Winograd-
+        counted, / 157.3 = `f32_equivalent_over_f32_peak`) and the reference-counted `algorithmic_tflops`;
+      * SUO_WINO_BF16X3=0: wino3x3_kernel<true> (csrc/conv_wino.hip) on the fp32 pipe: `achieved` / `frac` = executed fp32 FLOPs (16 products
+        per 2x2 tile and channel pair where the direct form issues 36) against the fp32 MFMA peak.
+    The other kernel of the pair, the 3x3 alone and the direct forms are timed in the same process under `same_process`."""
     import torch
     from suo_slam_amd import _lib
     rng = np.random.default_rng(0)
@@ -316,6 +327,12 @@ def conv_roofline(L, iters=30):
     wq = np.empty(16 * 128 * 128, np.float32)
     _lib.check(lib.suo_pack_wino_weight(np.ascontiguousarray(w2).ctypes.data, 128, 128, 128, 128, wq.ctypes.data), "pack_wino")
     wq2 = torch.from_numpy(wq).cuda()
+    wq3h = np.empty(3 * 16 * 128 * 128, np.uint16)
+    _lib.check(lib.suo_pack_wino_weight_bf16x3(np.ascontiguousarray(w2).ctypes.data, 128, 128, wq3h.ctypes.data), "pack_wino_x3")
+    wq3 = torch.from_numpy(wq3h.view(np.int16)).cuda()
+    w3xh = np.empty(3 * 256 * 128, np.uint16)
+    _lib.check(lib.suo_pack_tail_weight_bf16x3(np.ascontiguousarray(w3).ctypes.data, 256, 128, w3xh.ctypes.data), "pack_tail_x3")
+    w3x = torch.from_numpy(w3xh.view(np.int16)).cuda()
     wp2 = torch.from_numpy(pack_conv(w2, 128, 128, 32)).cuda()
     wp3 = torch.from_numpy(pack_gemm(w3, 256, 128)).cuda()
     b2 = torch.zeros(128, device="cuda")
@@ -325,6 +342,12 @@ def conv_roofline(L, iters=30):
     st = torch.cuda.current_stream()
     s = C.c_void_p(st.cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def x3_fused():
+        _lib.check(lib.suo_conv3x3_wino_x3_conv1x1_skip_up(P(x), L, 64, 64, P(wq3), P(b2), P(w3x), 1, P(b3), P(skip), None, P(out), s), "suo_conv3x3_wino_x3_conv1x1_skip_up")
+
+    def x3_plain():
+        _lib.check(lib.suo_conv3x3_wino_x3(P(x), L, 64, 64, P(wq3), P(b2), P(mid), 1, s), "suo_conv3x3_wino_x3")
 
     def wino_fused():
         _lib.check(lib.suo_conv3x3_wino_conv1x1_skip(P(x), L, 64, 64, P(wq2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "suo_conv3x3_wino_conv1x1_skip")
@@ -337,24 +360,39 @@ def conv_roofline(L, iters=30):
 
     def direct_plain():
         _lib.check(lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp2), P(b2), P(mid), 128, 1, s), "suo_conv_kxk")
-    us, us_wp, us_df, us_dp = (_timed(f, st, iters) for f in (wino_fused, wino_plain, direct_fused, direct_plain))
+    us_x, us_xp, us_w, us_wp, us_df, us_dp = (_timed(f, st, iters) for f in (x3_fused, x3_plain, wino_fused, wino_plain, direct_fused, direct_plain))
     px = float(L) * 64 * 64
     flop3, flop1 = 2.0 * px * 128 * 128 * 9, 2.0 * px * 128 * 256
     flop = flop3 + flop1
     flop_exec = flop3 / 2.25 + flop1                               # 16 products per 2x2 tile and channel pair instead of 36
+    flop_exec_bf16 = 6.0 * flop_exec                               # every product as 6 bf16 cross terms
     tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
-    fr = lambda f, t: round(f / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4) if t == t else None  # noqa: E731
-    return {"bound": "mfma", "kernel": "wino3x3_kernel<true> fused Residual tail: 3x3 128->128 (Winograd F(2x2,3x3)) + ReLU, 1x1 128->256 + skip @64x64, "
-                                       "%d crops/launch" % L,
-            "achieved": tf(flop_exec, us), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fr(flop_exec, us),
-            "traffic": dominant_kernel_traffic(L), "avg_launch_us": round(us, 2),
-            "flop_basis": "executed on the MFMA pipe: 2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1)", "executed_flop_per_launch": flop_exec,
-            "algorithmic_flop_per_launch": flop, "algorithmic_tflops": tf(flop, us), "algorithmic_over_peak": fr(flop, us),
-            "algorithmic_bytes_per_launch": 4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 16 + 128 * 256),
-            "same_process": {"wino3x3_kernel<false> (3x3 alone)": {"avg_launch_us": round(us_wp, 2), "frac": fr(flop3 / 2.25, us_wp), "algorithmic_tflops": tf(flop3, us_wp)},
-                             "convk_kernel<3,1,32,8,16,2,2,2,2,true> (direct, fused tail)": {"avg_launch_us": round(us_df, 2) if us_df == us_df else None,
-                                                                                            "frac": fr(flop, us_df)},
-                             "convk_kernel<3,1,32,8,16,2,2,2,2,false> (direct 3x3 alone)": {"avg_launch_us": round(us_dp, 2), "frac": fr(flop3, us_dp)}}}
+    fr = lambda f, t, pk=FP32_MFMA_PEAK_TF: round(f / (t * 1e-6) / 1e12 / pk, 4) if t == t else None  # noqa: E731
+    f32_entry = {"avg_launch_us": round(us_w, 2), "frac": fr(flop_exec, us_w), "achieved_tflops": tf(flop_exec, us_w), "peak": FP32_MFMA_PEAK_TF,
+                 "algorithmic_tflops": tf(flop, us_w), "algorithmic_over_peak": fr(flop, us_w)}
+    x3_entry = {"avg_launch_us": round(us_x, 2), "frac": fr(flop_exec_bf16, us_x, BF16_MFMA_PEAK_TF), "achieved_tflops": tf(flop_exec_bf16, us_x),
+                "peak": BF16_MFMA_PEAK_TF, "f32_equivalent_executed_tflops": tf(flop_exec, us_x), "f32_equivalent_over_f32_peak": fr(flop_exec, us_x),
+                "algorithmic_tflops": tf(flop, us_x)}
+    same = {"wino3x3_kernel<false> (fp32 pipe, 3x3 alone)": {"avg_launch_us": round(us_wp, 2), "frac": fr(flop3 / 2.25, us_wp), "algorithmic_tflops": tf(flop3, us_wp)},
+            "wino3x3_x3_kernel<false> (bf16x3, 3x3 alone)": {"avg_launch_us": round(us_xp, 2), "frac": fr(6.0 * flop3 / 2.25, us_xp, BF16_MFMA_PEAK_TF),
+                                                             "f32_equivalent_over_f32_peak": fr(flop3 / 2.25, us_xp), "algorithmic_tflops": tf(flop3, us_xp)},
+            "convk_kernel<3,1,32,8,16,2,2,2,2,true> (direct, fused tail)": {"avg_launch_us": round(us_df, 2) if us_df == us_df else None, "frac": fr(flop, us_df)},
+            "convk_kernel<3,1,32,8,16,2,2,2,2,false> (direct 3x3 alone)": {"avg_launch_us": round(us_dp, 2), "frac": fr(flop3, us_dp)}}
+    common = {"bound": "mfma", "unit": "TFLOP/s", "traffic": dominant_kernel_traffic(L), "algorithmic_flop_per_launch": flop,
+              "algorithmic_bytes_per_launch": 4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 16 + 128 * 256)}
+    shape = "fused Residual tail: 3x3 128->128 (Winograd F(2x2,3x3)) + ReLU, 1x1 128->256 + skip @64x64, %d crops/launch" % L
+    if wino_bf16x3_enabled():
+        same["wino3x3_kernel<true> (fp32 pipe, SUO_WINO_BF16X3=0)"] = f32_entry
+        return dict(common, kernel="wino3x3_x3_kernel<true,false,true> " + shape, dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)",
+                    achieved=x3_entry["achieved_tflops"], peak=BF16_MFMA_PEAK_TF, frac=x3_entry["frac"], avg_launch_us=x3_entry["avg_launch_us"],
+                    flop_basis="bf16 FLOPs executed on the MFMA pipe: 6 * (2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1))",
+                    executed_flop_per_launch=flop_exec_bf16, f32_equivalent_executed_tflops=x3_entry["f32_equivalent_executed_tflops"],
+                    f32_equivalent_over_f32_peak=x3_entry["f32_equivalent_over_f32_peak"], algorithmic_tflops=x3_entry["algorithmic_tflops"],
+                    algorithmic_over_f32_peak=fr(flop, us_x), same_process=same)
+    same["wino3x3_x3_kernel<true,false,true> (bf16x3, default)"] = x3_entry
+    return dict(common, kernel="wino3x3_kernel<true> " + shape, dtype="f32", achieved=tf(flop_exec, us_w), peak=FP32_MFMA_PEAK_TF, frac=fr(flop_exec, us_w),
+                avg_launch_us=round(us_w, 2), flop_basis="executed on the MFMA pipe: 2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1)",
+                executed_flop_per_launch=flop_exec, algorithmic_tflops=tf(flop, us_w), algorithmic_over_peak=fr(flop, us_w), same_process=same)
 
 
 def gemm_roofline(L, iters=30):
@@ -428,8 +466,11 @@ def latency_roofline(L=8, iters=50):
     """The dominant kernel of the reference's call shape (one frame = 8 crops per network call): the same fused Winograd tail at
     256 tiles -- one workgroup per CU, a quarter of the chip's wave slots."""
     r = conv_roofline(L, iters)
-    return {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "executed_flop_per_launch",
-                              "algorithmic_over_peak")}
+    keep = ("bound", "kernel", "dtype", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "executed_flop_per_launch", "algorithmic_over_peak",
+            "f32_equivalent_executed_tflops", "f32_equivalent_over_f32_peak", "algorithmic_over_f32_peak")
+    out = {k: r[k] for k in keep if k in r}
+    out["same_process"] = {k: v for k, v in r["same_process"].items() if k.startswith("wino3x3_kernel<true>") or k.startswith("wino3x3_x3_kernel<true")}
+    return out
 
 
 def cpu_baseline(pool, L):
@@ -742,7 +783,9 @@ def main():
                        "weights": "seeded random, classifier bias + 4, thresholds bbox %.1f / var %.1f so the masks pass: the geometry runs on "
                                   "whatever the network emitted (worst case: RANSAC at its iteration cap)" % (BBOX_THRESH, KP_VAR_THRESH),
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
-            "cnn_tflops_executed": round(fps * L * exec_gflop / 1e3, 2),                  # zero-prior MACs not issued, Winograd 3x3 at 16/36
+            # fp32-equivalent rates of the whole network (zero-prior MACs not issued, Winograd 3x3 at 16/36; with the default bf16x3 form of the
+            # Residual 3x3 + tail, part of these products runs on the bf16 pipe: see roofline for the per-kernel accounting)
+            "cnn_tflops_executed": round(fps * L * exec_gflop / 1e3, 2),
             "cnn_executed_frac_of_fp32_mfma_peak": round(fps / world * L * exec_gflop / 1e3 / FP32_MFMA_PEAK_TF, 4),
             "cnn_tflops_algorithmic": round(fps * L * GFLOP_PER_CROP / 1e3, 2),           # reference-counted FLOPs per crop x crops/s
             "cnn_algorithmic_over_fp32_mfma_peak": round(fps / world * L * GFLOP_PER_CROP / 1e3 / FP32_MFMA_PEAK_TF, 4),

@@ -10,7 +10,6 @@
 // staging, same two-step output transform (rows xi = 0, 3 accumulate straight into Z, rows 1, 2 through a scratch accumulator and 16
 // vector additions per chunk), same epilogues -- the accumulator layout of the bf16 MFMA is that of the fp32 one, so the fused
 // Residual tail (conv3 1x1 + skip [+ up-sampled addend], kept on the fp32 pipe) is taken over unchanged.
-#include <stdlib.h>
 #include <string.h>
 
 #include "buffer_ops.h"
@@ -36,9 +35,6 @@ __device__ __forceinline__ x_f32x4 x_add4(x_f32x4 a, x_f32x4 b) { return a + b; 
 __device__ __forceinline__ void x_add16(x_f32x16& z, const x_f32x16& t) { z += t; }
 __device__ __forceinline__ void x_sub16(x_f32x16& z, const x_f32x16& t) { z -= t; }
 
-#ifndef SUO_WX3_SGB
-#define SUO_WX3_SGB 1
-#endif
 constexpr int X_CK = 16, X_PKH = 20, X_TH = 8, X_TW = 16, X_IH = 10, X_IW = 18, X_NPIX = X_IH * X_IW;
 
 // host: U[n][c][comp] = (G g G^T)[xi][nu] in fp64 (BN scale folded in), rounded once to fp32, split into three truncated bf16 terms;
@@ -93,18 +89,14 @@ void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out) {
         }
 }
 
-// W1: ONE workgroup per CU (one wave per SIMD, up to 512 registers each): all 16 component accumulators stay in registers (no fold in the
-// channel loop), V is double-buffered and the input transform of chunk c + 1 is interleaved with the MFMAs of chunk c in the same instruction
-// stream -- on gfx950 the two waves that share a SIMD do not hide each other's VALU / LDS work under MFMAs, one wave's own stream does
-// (MI355X_MICROARCH.md, "Two waves per SIMD: what they share").
-template <bool FUSE, bool UP = false, bool TX3 = false, bool W1 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W1 ? 1 : 2, W1 ? 1 : 2))) void wino3x3_x3_kernel(const ConvArgs a) {
+template <bool FUSE, bool UP = false, bool TX3 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
     // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
     constexpr int HSZ = X_NPIX * X_PKH;                       // floats per halo buffer
     constexpr int VROW = 16;                                  // bf16 per (tile, chunk) row = 32 bytes; the two 16-byte halves swap for tiles 8-15 / 24-31
     constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
     constexpr int VFLOATS = 3 * VPL / 2;
-    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + (W1 ? 2 : 1) * VFLOATS];
+    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
     float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
     uint16_t* V = reinterpret_cast<uint16_t*>(&S[2 * HSZ]);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -165,10 +157,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W1 ? 1 : 2,
     const int hbase = ((2 * t_ty + th) * X_IW + 2 * t_tx) * X_PKH + tq * 4;
     // V element offset of (component 0, tile tt, channels 4 tq ..): row tt, half (tq >> 1) swapped for tiles 8-15 / 24-31, 4 bf16 = 8 bytes
     const int vbase = tt * VROW + ((((tq >> 1) ^ ((tt >> 3) & 1)) * 8) + (tq & 1) * 4);
-    auto vstore = [&](int comp, x_f32x4 v, int vb = 0) {       // vb: V buffer (W1)
+    auto vstore = [&](int comp, x_f32x4 v) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            *(x_u32x2*)&V[vb * 3 * VPL + p * VPL + comp * 32 * VROW + vbase] = x_u32x2{x_pack_hi(v[0], v[1]), x_pack_hi(v[2], v[3])};
+            *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + vbase] = x_u32x2{x_pack_hi(v[0], v[1]), x_pack_hi(v[2], v[3])};
 #ifndef SUO_WX3_EXP_NOSPLIT                                   // (timing experiment, wrong results: the three planes hold the same term)
             if (p < 2) {
                 v = x_sub4(v, x_f32x4{x_hi(v[0]), x_hi(v[1]), x_hi(v[2]), x_hi(v[3])});      // exact residual
@@ -245,191 +237,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W1 ? 1 : 2,
 #endif
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[TI[t]], __builtin_bit_cast(x_bf16x8, bw[TJ[t]]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
     };
-    if constexpr (W1) {
-        // ---- one workgroup per CU: 16 accumulators M[comp], pair p = components 2 p, 2 p + 1; per pair step 12 MFMAs (the two chains alternate)
-        // with, in their gaps: the weight loads of pair p + WR - 1, the A-fragment reads of pair p + 1, one eighth of the transform of
-        // chunk c + 1 (halo buffer (c + 1) & 1 -> V buffer (c + 1) & 1); one barrier per chunk.
-        constexpr int WR = 4;                                 // weight ring, in pairs
-        x_f32x16 M[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) M[q][r] = 0.f;
-        x_u32x4 bring[WR][2][3];
-        x_bf16x8 af[2][2][3];
-        const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ ((lane >> 3) & 1)) * 8);
-        auto aread = [&](int vb, int pair, x_bf16x8 (&f)[2][3]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) f[i][p] = *(const x_bf16x8*)&V[vb * 3 * VPL + p * VPL + (2 * pair + i) * 32 * VROW + afoff];
-        };
-        x_f32x4 eA[4], eB[4];
-        const int xiA = th ? 3 : 0, xiB = th ? 2 : 1;
-        auto xf_eA = [&](int hb) {
-            const float* hs = &Hin[hb][hbase];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) eA[c] = x_sub4(*(const x_f32x4*)(hs + c * X_PKH), *(const x_f32x4*)(hs + (2 * X_IW + c) * X_PKH));
-        };
-        auto xf_eB = [&](int hb) {
-            const float* hs = &Hin[hb][hbase];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const x_f32x4 l1 = *(const x_f32x4*)(hs + (X_IW + c) * X_PKH), lx = *(const x_f32x4*)(hs + hother + c * X_PKH);
-                eB[c] = x_f32x4{__builtin_fmaf(lx[0], hsign, l1[0]), __builtin_fmaf(lx[1], hsign, l1[1]), __builtin_fmaf(lx[2], hsign, l1[2]), __builtin_fmaf(lx[3], hsign, l1[3])};
-            }
-        };
-        auto xf_comp = [&](int j, int vb) {                    // j = 0..3: row xiA, nu = j; 4..7: row xiB, nu = j - 4
-            const x_f32x4 (&e)[4] = j < 4 ? eA : eB;
-            const int nu = j & 3, comp = (j < 4 ? xiA : xiB) * 4 + nu;
-            vstore(comp, nu == 0 ? x_sub4(e[0], e[2]) : nu == 1 ? x_add4(e[1], e[2]) : nu == 2 ? x_sub4(e[2], e[1]) : x_sub4(e[1], e[3]), vb);
-        };
-        constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
-
-        // prologue: chunk 0 staged and transformed, chunk 1 staged, the first weights on their way.  Every 128-byte line of the tile's input
-        // (all chunks) is touched once first: vmcnt retires in order, so a halo load that went to HBM inside the channel loop would hold up
-        // every weight load (L2) issued after it -- from here on the halo comes from L2 / MALL like the weights.
-        unsigned touch = 0;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            const int pix = idx >> 2, ln = idx & 3;
-            const int py = pix / X_IW, px = pix - py * X_IW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = idx < NF4 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            touch |= __builtin_amdgcn_raw_buffer_load_b32(in_srd, ok ? ((iy * a.W + ix) * a.C + ln * 32) * 4 : BUF_OOB, 0, 0);
-        }
-        gload(0);
-#pragma unroll
-        for (int r = 0; r < WR - 1; ++r) { bload(2 * r, bring[r][0]); bload(2 * r + 1, bring[r][1]); }
-        sstore(0);
-        asm volatile("" :: "v"(touch));                       // (keeps the touching loads alive)
-        gload(1);
-        __syncthreads();
-        xf_eA(0); xf_eB(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf_comp(j, 0);
-        sstore(1);
-        __syncthreads();
-
-#ifdef SUO_WX3_PROF
-        long long qt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, q0 = clock64();
-        const long long qstart = q0;
-#define QPROF(i) do { const long long _t = clock64(); qt[i] += _t - q0; q0 = _t; } while (0)
-#else
-#define QPROF(i) do { } while (0)
-#endif
-        for (int c = 0; c < nch; ++c) {
-            const int vb = c & 1, nb_ = vb ^ 1;               // V buffer of this chunk / of the next one = halo buffer of the next one
-            gload(c + 2);                                     // (beyond the last chunk: harmless, never used)
-            aread(vb, 0, af[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            QPROF(8);
-#pragma unroll
-            for (int pair = 0; pair < 8; ++pair) {
-                // -- requests first: weights WR - 1 pairs ahead (this chunk's, or the next one's), A fragments one pair ahead, (step 0) the halo
-#ifndef SUO_WX3_EXP_NOLOADS
-                {
-                    const int np = (pair + WR - 1) & 7, nc = c + ((pair + WR - 1) >> 3);
-                    bload(nc * 16 + 2 * np, bring[(pair + WR - 1) % WR][0]);
-                    bload(nc * 16 + 2 * np + 1, bring[(pair + WR - 1) % WR][1]);
-                }
-                if (pair < 7) aread(vb, pair + 1, af[(pair + 1) & 1]);
-#endif
-                x_f32x4 hl[16];
-                if (pair == 0) {
-                    const float* hs = &Hin[nb_][hbase];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        hl[q] = *(const x_f32x4*)(hs + q * X_PKH);
-                        hl[4 + q] = *(const x_f32x4*)(hs + (2 * X_IW + q) * X_PKH);
-                        hl[8 + q] = *(const x_f32x4*)(hs + (X_IW + q) * X_PKH);
-                        hl[12 + q] = *(const x_f32x4*)(hs + hother + q * X_PKH);
-                    }
-                }
-                // -- 12 MFMAs (the two chains alternate); in their gaps: the requests above and one slice of the next chunk's transform
-                const x_bf16x8 (&fa)[3] = af[pair & 1][0];
-                const x_bf16x8 (&fb)[3] = af[pair & 1][1];
-                const x_u32x4 (&wa)[3] = bring[pair % WR][0];
-                const x_u32x4 (&wb)[3] = bring[pair % WR][1];
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    M[2 * pair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TI[t]], __builtin_bit_cast(x_bf16x8, wa[TJ[t]]), M[2 * pair], 0, 0, 0);
-                    M[2 * pair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[TI[t]], __builtin_bit_cast(x_bf16x8, wb[TJ[t]]), M[2 * pair + 1], 0, 0, 0);
-                }
-#ifndef SUO_WX3_EXP_NOXF
-                if (pair == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        eA[q] = x_sub4(hl[q], hl[4 + q]);
-                        eB[q] = x_f32x4{__builtin_fmaf(hl[12 + q][0], hsign, hl[8 + q][0]), __builtin_fmaf(hl[12 + q][1], hsign, hl[8 + q][1]),
-                                        __builtin_fmaf(hl[12 + q][2], hsign, hl[8 + q][2]), __builtin_fmaf(hl[12 + q][3], hsign, hl[8 + q][3])};
-                    }
-                } else {
-                    xf_comp(pair - 1, nb_);
-                    if (pair == 7) xf_comp(7, nb_);
-                }
-#endif
-#if SUO_WX3_SGB
-                // issue order: an MFMA, then at most one memory instruction and a few VALU (MI355X_MICROARCH.md: one wave per SIMD hides
-                // about five single-issue instructions per 32-cycle MFMA)
-                if (pair == 0) {                              // + 16 halo reads; the transform arithmetic on them waits for the second half
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    }
-                } else if (pair < 7) {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                        if (i == 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        if (i == 5 || i == 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                QPROF(pair);
-            }
-            sstore(c & 1);                                    // halo of chunk c + 2 -> the buffer chunk c's transform read one iteration ago
-            QPROF(9);
-            __syncthreads();
-            QPROF(10);
-        }
-#ifdef SUO_WX3_PROF
-        if (blockIdx.x == 1000 && (tid & 63) == 0)
-            printf("wave %d cycles per WG: steps %lld %lld %lld %lld %lld %lld %lld %lld  top %lld  sstore %lld  barrier %lld  loop %lld\n", w, qt[0], qt[1], qt[2], qt[3], qt[4],
-                   qt[5], qt[6], qt[7], qt[8], qt[9], qt[10], q0 - qstart);
-#endif
-        // output transform Y = A^T M A (row xi = 3 was packed negated)
-        x_f32x16 Z[8];
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            Z[nu] = M[nu] + M[4 + nu] + M[8 + nu];
-            Z[4 + nu] = M[4 + nu] - M[8 + nu] + M[12 + nu];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            out[2 * h] = Z[4 * h] + Z[4 * h + 1] + Z[4 * h + 2];
-            out[2 * h + 1] = Z[4 * h + 1] - Z[4 * h + 2] - Z[4 * h + 3];
-        }
-    } else {
     // Consumption order of the components, in pairs: pairs 0-3 = (xi 0, xi 3) of nu = pair, accumulated straight into their Z; pairs 4-7 =
     // (xi 1, xi 2) of nu = pair - 4, through two scratch accumulators that are folded into Z[0][nu], Z[1][nu].  The weights of pair p + 1
     // are requested before pair p's MFMAs.  Measured alternatives, all slower (tools/bench_wino_x3.py, 256 crops, plain / fused, us):
@@ -513,7 +320,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W1 ? 1 : 2,
     for (int h = 0; h < 2; ++h) {
         out[2 * h] = Z[4 * h] + Z[4 * h + 1] + Z[4 * h + 2];
         out[2 * h + 1] = Z[4 * h + 1] - Z[4 * h + 2] - Z[4 * h + 3];
-    }
     }
 
     if constexpr (FUSE && TX3) {
@@ -741,13 +547,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W1 ? 1 : 2,
     }
 }
 
-// SUO_WX3_W1=1 (experiment, slower today): one workgroup per CU (512 registers per wave, no fold, transform interleaved with the MFMAs)
-// instead of two (256 registers per wave, fold in the channel loop)
-static bool x3_one_wg_per_cu() {
-    static const int on = getenv("SUO_WX3_W1") ? atoi(getenv("SUO_WX3_W1")) : 0;
-    return on != 0;
-}
-
 // a.Wp = weights packed by pack_wino_weight_bf16x3 (uint16 under a float pointer); 128 -> 128 channels only
 int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
     if (a.OH != a.H || a.OW != a.W || a.N != 128 || a.C != 128) {
@@ -755,8 +554,7 @@ int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-    if (x3_one_wg_per_cu()) hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, true>), dim3(tiles), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wino3x3_x3_kernel<false>), dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wino3x3_x3_kernel<false>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -767,10 +565,7 @@ int launch_conv3x3_wino_x3_fused(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-    if (a.w3_bf16x3 && x3_one_wg_per_cu()) {
-        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, true>), dim3(tiles), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, true>), dim3(tiles), dim3(256), 0, s, a);
-    } else if (a.w3_bf16x3) {                                 // W3p packed by pack_tail_weight_bf16x3: the tail on the bf16 pipe too
+    if (a.w3_bf16x3) {                                 // W3p packed by pack_tail_weight_bf16x3: the tail on the bf16 pipe too
         if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true>), dim3(tiles), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true>), dim3(tiles), dim3(256), 0, s, a);
     } else {

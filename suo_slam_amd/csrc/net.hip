@@ -123,15 +123,16 @@ float* Net::upload(const std::vector<float>& v) {
 }
 
 #ifndef SUO_WINO_BF16X3_DEFAULT
-#define SUO_WINO_BF16X3_DEFAULT 0
+#define SUO_WINO_BF16X3_DEFAULT 1
 #endif
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // SUO_WINO_BF16X3=0: the Residual blocks' 3x3 convolution + fused tail on the fp32 matrix pipe (csrc/conv_wino.hip) instead of the bf16 pipe
 // with 3-way split operands (csrc/conv_wino_x3.hip: same accuracy, ~1.2x faster)
+// (read when a network is built, not cached: one process can hold networks of both kinds)
 static bool wino_bf16x3() {
-    static const int on = getenv("SUO_WINO_BF16X3") ? atoi(getenv("SUO_WINO_BF16X3")) : SUO_WINO_BF16X3_DEFAULT;
-    return on != 0;
+    const char* e = getenv("SUO_WINO_BF16X3");
+    return (e ? atoi(e) : SUO_WINO_BF16X3_DEFAULT) != 0;
 }
 
 // 1x1 conv W[N][K] with optional per-output scale (BN folded) -> device packed weight + bias
@@ -441,7 +442,8 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
             if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
             return SUO_OK;
         }
-        SUO_LAUNCH(launch_conv3x3_wino(c2, s));
+        if (r.c2.Wq3) { c2.Wp = r.c2.Wq3; SUO_LAUNCH(launch_conv3x3_wino_x3(c2, s)); }
+        else SUO_LAUNCH(launch_conv3x3_wino(c2, s));
     } else {
         SUO_LAUNCH(launch_conv3x3(c2, s));
     }

@@ -170,3 +170,41 @@ def conv3x3_wino_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc):
                "suo_conv3x3_wino_conv1x1_skip_up")
     torch.cuda.synchronize()
     return out
+
+
+def _pack_x3(w2, w3=None):
+    lib = _lib.lib()
+    w2 = np.ascontiguousarray(w2, np.float32)
+    q = np.empty(3 * 16 * 128 * 128, np.uint16)
+    _lib.check(lib.suo_pack_wino_weight_bf16x3(w2.ctypes.data, 128, 128, q.ctypes.data), "pack_wino_x3")
+    wq3 = torch.from_numpy(q.view(np.int16)).cuda()
+    if w3 is None:
+        return wq3
+    w3 = np.ascontiguousarray(w3, np.float32)
+    t = np.empty(3 * 256 * 128, np.uint16)
+    _lib.check(lib.suo_pack_tail_weight_bf16x3(w3.ctypes.data, 256, 128, t.ctypes.data), "pack_tail_x3")
+    return wq3, torch.from_numpy(t.view(np.int16)).cuda()
+
+
+def conv3x3_wino_x3(x_nhwc, w, bias, relu=False):
+    """csrc/conv_wino_x3.hip: the Winograd 3x3 convolution (128 -> 128) on the bf16 matrix pipe with 3-way split operands."""
+    L, H, W, C = x_nhwc.shape
+    assert C == 128 and w.shape == (128, 128, 3, 3)
+    wq3, b = _pack_x3(w), dev(bias)
+    out = torch.empty((L, H, W, 128), device="cuda")
+    _lib.check(_lib.lib().suo_conv3x3_wino_x3(P(x_nhwc), L, H, W, P(wq3), P(b), P(out), int(relu), S()), "suo_conv3x3_wino_x3")
+    torch.cuda.synchronize()
+    return out
+
+
+def conv3x3_wino_x3_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc=None, tail_x3=True):
+    """The fused Residual tail of csrc/conv_wino_x3.hip: conv3 on the bf16 pipe as well (tail_x3, what the network launches) or on the fp32 pipe."""
+    L, H, W, C = x_nhwc.shape
+    wq3, w3x = _pack_x3(w2, w3)
+    wp3 = w3x if tail_x3 else dev(pack_gemm(np.ascontiguousarray(w3, np.float32), 256, 128))
+    out = torch.empty((L, H, W, 256), device="cuda")
+    b2d, b3d = dev(b2), dev(b3)
+    _lib.check(_lib.lib().suo_conv3x3_wino_x3_conv1x1_skip_up(P(x_nhwc), L, H, W, P(wq3), P(b2d), P(wp3), int(tail_x3), P(b3d), P(skip_nhwc), P(up_nhwc), P(out), S()),
+               "suo_conv3x3_wino_x3_conv1x1_skip_up")
+    torch.cuda.synchronize()
+    return out

@@ -211,6 +211,54 @@ def test_fused_winograd_residual_tail_equals_the_separate_launches(ops, L, H, W)
         assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("L,H,W,scale", [(2, 64, 64, 1.0), (3, 40, 40, 1.0), (128, 16, 16, 1.0), (5, 24, 56, 1.0), (1, 8, 16, 1.0), (2, 64, 64, 1e-12), (2, 32, 32, 1e9)])
+def test_conv3x3_winograd_bf16x3_is_fp32_accurate(ops, L, H, W, scale):
+    """csrc/conv_wino_x3.hip (what the network launches for its 128 -> 128 3x3 convolutions): the Winograd products on the BF16 matrix pipe,
+    both operands split into three bf16 terms (truncation, exact residuals), 6 of the 9 cross terms accumulated in fp32.  Same bound as the
+    fp32-pipe kernel (5e-6 of the output range against fp64; observed 4e-7), ragged maps, a single tile, tiny and huge magnitudes (bf16 has
+    fp32's exponent range: the split must not lose the small terms), per-crop check against stray stores."""
+    rng = np.random.default_rng(L * H + W)
+    x = (rng.standard_normal((L, 128, H, W)) * scale).astype(np.float32)
+    w = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    b = (rng.standard_normal(128) * scale).astype(np.float32)
+    out = ops.nchw(ops.conv3x3_wino_x3(ops.nhwc(x), w, b, relu=True))
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)).numpy()
+    assert _rel(out, ref) < 5e-6
+    bad = np.abs(out - ref).reshape(L, -1).max(1) > 1e-3 * np.abs(ref).max()
+    assert not bad.any(), np.flatnonzero(bad)[:8]
+    f32 = ops.nchw(ops.conv3x3_wino(ops.nhwc(x), w, b, relu=True))
+    assert _rel(out, f32) < 5e-6                              # and no worse than the fp32-pipe kernel
+    assert _rel(out, ref) < 2.0 * _rel(f32, ref) + 1e-7
+
+
+@pytest.mark.parametrize("L,H,W,up,tail_x3", [(128, 64, 64, False, True), (20, 60, 60, False, True), (7, 64, 72, True, True), (128, 16, 16, True, True),
+                                               (9, 40, 56, True, False), (3, 8, 16, False, False)])
+def test_fused_winograd_bf16x3_residual_tail(ops, L, H, W, up, tail_x3):
+    """conv2 (3x3, Winograd, bf16x3) -> ReLU -> conv3 (1x1, on the bf16 pipe too, or on the fp32 one) + bias + skip [+ up-sampled addend] in one
+    launch: within 5e-6 of fp64 on the first and last crop, and within 1e-5 of the fp32-pipe fused kernel on EVERY crop (stray stores, the
+    two pixel-row passes of the tail, ragged edges)."""
+    rng = np.random.default_rng(L + H)
+    x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
+    skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
+    low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda() if up else None
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    b2 = rng.standard_normal(128).astype(np.float32) * 0.3
+    w3 = (rng.standard_normal((256, 128)) / np.sqrt(128)).astype(np.float32)
+    b3 = rng.standard_normal(256).astype(np.float32)
+    out = ops.conv3x3_wino_x3_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low, tail_x3=tail_x3)
+    f32 = ops.conv3x3_wino_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low) if up else ops.conv3x3_wino_conv1x1_skip(x, w2, b2, w3, b3, skip)
+    scale = float(f32.abs().max())
+    per_crop = (out - f32).abs().reshape(L, -1).amax(1) / scale
+    assert float(per_crop.max()) < 1e-5, int(per_crop.argmax())
+    for l in (0, L - 1):
+        xm = x[l:l + 1].permute(0, 3, 1, 2).double().cpu()
+        m = F.relu(F.conv2d(xm, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1))
+        ref = F.conv2d(m, torch.from_numpy(w3).double()[:, :, None, None], torch.from_numpy(b3).double()) + skip[l:l + 1].permute(0, 3, 1, 2).double().cpu()
+        if up:
+            ref = ref + low[l:l + 1].permute(0, 3, 1, 2).double().cpu().repeat_interleave(2, 2).repeat_interleave(2, 3)
+        assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
+
+
 @pytest.mark.parametrize("L,H,W", [(64, 64, 64), (9, 40, 56), (128, 16, 16)])
 def test_fused_tail_with_upsampled_addend_equals_tail_then_upsample_add(ops, L, H, W):
     """Hourglass "up1 + up2(low3)" (hg.py:56-58) folded into the last up1 block's fused tail: bit-identical to the fused tail
@@ -400,13 +448,16 @@ def test_full_network_golden(ops, cnn_golden, state_dict):
         assert rel < 2e-4, rel   # 186 fp32 conv layers deep; observed ~1e-5
 
 
-def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict):
-    """The same crop repeated 40 times: every 3x3 layer down to the 16x16 maps now has >= 256 tiles, so the Winograd kernels, the
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
+def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict, monkeypatch, bf16x3):
+    """Both forms of the Residual blocks' 3x3 + tail: on the bf16 matrix pipe with 3-way split operands (default) and on the fp32 pipe
+    (SUO_WINO_BF16X3=0, read when the network is built).  The same crop repeated 40 times: every 3x3 layer down to the 16x16 maps now has >= 256 tiles, so the Winograd kernels, the
     fused Residual tails, the fused up-sample adds and the pooled GEMMs run (test_full_network_golden at L = 1 takes the direct
     forms only).  Every copy against the REFERENCE's own logits; hard arg-max of the HIP logits = torch.argmax of the reference's
     wherever the runner-up is more than 1e-4 below the maximum."""
     from suo_slam_amd.pkpnet import PkpNet, decode_extras
     L = 40
+    monkeypatch.setenv("SUO_WINO_BF16X3", bf16x3)
     net = PkpNet(state_dict=state_dict, max_crops=L)
     rng = np.random.Generator(np.random.PCG64(int(cnn_golden["backbone_in_seed"])))
     x = rng.uniform(0, 1, (1, 44, 256, 256)).astype(np.float32)
@@ -423,6 +474,26 @@ def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict):
     assert sure.sum() >= 40
     for i in (0, 17, L - 1):
         np.testing.assert_array_equal(idx[i][sure], cnn_golden["backbone_argmax"][0][sure])
+
+
+def test_the_two_matrix_pipe_forms_are_both_reachable_and_agree(ops, state_dict, monkeypatch):
+    """SUO_WINO_BF16X3 selects the form when a network is built; the default is the bf16x3 one.  The two networks' logits on the same
+    input agree to fp32-rounding level but are not bit-identical (= different kernels really ran)."""
+    from suo_slam_amd.pkpnet import PkpNet
+    from tests.gpu_backbone import run_backbone_from_staged
+    L = 40
+    xin = np.zeros((L, 256, 256, 48), np.float32)
+    xin[..., :44] = np.random.default_rng(5).uniform(0, 1, (L, 256, 256, 44)).astype(np.float32)
+    outs = {}
+    for mode in (None, "0", "1"):
+        if mode is None:
+            monkeypatch.delenv("SUO_WINO_BF16X3", raising=False)
+        else:
+            monkeypatch.setenv("SUO_WINO_BF16X3", mode)
+        outs[mode] = run_backbone_from_staged(PkpNet(state_dict=state_dict, max_crops=L), xin)
+    assert np.array_equal(outs[None], outs["1"])
+    assert not np.array_equal(outs["0"], outs["1"])
+    assert np.abs(outs["0"] - outs["1"]).max() / np.abs(outs["0"]).max() < 5e-5
 
 
 def test_decode_hard_argmax_is_bit_exact_and_prob_is_the_softmax(ops, cnn_golden):

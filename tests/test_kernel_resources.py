@@ -32,13 +32,16 @@ def _usage(src, tmp_path):
     return kernels
 
 
-def test_fused_winograd_tail_does_not_spill(tmp_path):
-    k = _usage("conv_wino.hip", tmp_path)
-    fused = {n: v for n, v in k.items() if "wino3x3_kernelILb1E" in n}
-    assert len(fused) == 2, list(k)
+@pytest.mark.parametrize("src,fused_tag,n_fused", [("conv_wino.hip", "wino3x3_kernelILb1E", 2), ("conv_wino_x3.hip", "wino3x3_x3_kernelILb1E", 4)])
+def test_fused_winograd_tail_does_not_spill(tmp_path, src, fused_tag, n_fused):
+    """Both forms (fp32 pipe / bf16 pipe with split operands; the latter sits at 252-254 of its 256 registers)."""
+    k = _usage(src, tmp_path)
+    fused = {n: v for n, v in k.items() if fused_tag in n}
+    assert len(fused) == n_fused, list(k)
     for name, v in k.items():
         assert v["VGPRs Spill"] == 0 and v["ScratchSize"] == 0, (name, v)
         assert v["Occupancy"] >= 2, (name, v)          # two workgroups per CU
+        assert 2 * v["LDS Size"] <= 160 * 1024, (name, v)
 
 
 def test_frame_lm_kernel_keeps_its_small_systems_in_registers(tmp_path):
