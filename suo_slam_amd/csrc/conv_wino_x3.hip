@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int ty0 = bid / tiles_x, tx0 = bid - ty0 * tiles_x;
     const int oy0 = ty0 * X_TH, ox0 = tx0 * X_TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int nch = a.C / X_CK, NB = a.N >> 5;
+    const int nch = a.C / X_CK;
     const float* in_l = a.in + (size_t)l * a.H * a.W * a.C;
     const __amdgpu_buffer_rsrc_t in_srd = make_srd(in_l, (size_t)a.H * a.W * a.C * sizeof(float));
     const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * 16 * 3 * sizeof(uint16_t));
@@ -140,16 +140,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         }
     };
     // ---- weights: Up3[(chunk * 16 + comp)][nb][plane][lane][8 bf16]: 3 KB per (component, n-tile), three 16-byte loads per lane -----
+    // (128 output channels: NB = 4 n-tiles; the plane offset rides in the instruction's immediate field, one scalar addition per component;
+    // past the last chunk the descriptor's range check returns zeros -- those prefetches are never consumed)
     const int wvoff = lane * 16;
-    const int gtot = nch * 16;
-    auto bload = [&](int gc, x_u32x4 (&b)[3]) {               // gc = chunk * 16 + comp (clamped: the stream runs on past the last chunk)
+    const int wsbase = w * 3 * 1024;
+    auto bload = [&](int gc, x_u32x4 (&b)[3]) {               // gc = chunk * 16 + comp
 #ifdef SUO_WX3_EXP_W0
         const int g = gc & 1;                                 // timing experiment (wrong results): weights from two cache-resident groups
 #else
-        const int g = gc < gtot ? gc : gtot - 1;
+        const int g = gc;
 #endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff, ((g * NB + w) * 3 + p) * 1024));
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (4 * 3 * 1024) + wsbase));
     };
     // ---- transform: thread = (tile tt, channel quad tq, half th) as in csrc/conv_wino.hip; every result vector is split on its way to LDS ----
     const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;

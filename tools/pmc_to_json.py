@@ -6,6 +6,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+# the fused Residual tail in Winograd form as the network launches it: bf16 pipe with 3-way split operands (default), or the fp32 pipe
+X3 = os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
+KERNEL = "wino3x3_x3_kernel<true,false,true>" if X3 else "wino3x3_kernel<true,4,false>"
 vals = {}
 for f in os.listdir(os.path.join(ROOT, "gpurun_out", "pmc")):
     if not f.endswith(".db"):
@@ -14,14 +17,14 @@ for f in os.listdir(os.path.join(ROOT, "gpurun_out", "pmc")):
     cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
     namec = "kernel_name" if "kernel_name" in cols else "name"
     for name, cnt, n, avg in c.execute(f"select {namec}, counter_name, count(*), avg(value) from counters_collection group by {namec}, counter_name"):
-        if "wino3x3_kernel<true,4,false>" in name.replace(" ", ""):      # the fused Residual tail in Winograd form
+        if KERNEL in name.replace(" ", ""):
             vals[cnt] = avg
 fetch = vals["FETCH_SIZE"] * 1024 * 2          # KB -> B; gfx950: FETCH_SIZE reads 1/2 of wide coalesced reads (microarch guide, HBM section)
 write = vals["WRITE_SIZE"] * 1024
 cycles = vals["GRBM_GUI_ACTIVE"] / 8            # summed over the 8 XCDs
-rec = {"kernel": "wino3x3_kernel<true,4,false>", "crops_per_launch": L, "hbm_bytes_per_launch": round(fetch + write),
+rec = {"kernel": KERNEL, "crops_per_launch": L, "hbm_bytes_per_launch": round(fetch + write),
        "fetch_bytes_corrected": round(fetch), "write_bytes": round(write),
-       "algorithmic_bytes": L * 64 * 64 * (128 + 256 + 256) * 4 + (128 * 128 * 16 + 128 * 256) * 4,      # in 128 ch + skip 256 ch + out 256 ch + weights
+       "algorithmic_bytes": L * 64 * 64 * (128 + 256 + 256) * 4 + (128 * 128 * 16 + 128 * 256) * (6 if X3 else 4),      # in 128 ch + skip 256 ch + out 256 ch + weights
        "mfma_busy_cycles": vals["SQ_VALU_MFMA_BUSY_CYCLES"], "kernel_cycles": cycles,
        "mfma_util": vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles),      # busy SIMD-cycles / (256 CUs x 4 SIMDs x kernel cycles)
        "l2_hit_rate": vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]),

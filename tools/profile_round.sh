@@ -31,7 +31,8 @@ run_traced latency $R/tools/time_frame_chain.py
 run_traced slam $R/tools/profile_slam_view.py
 # 7. PMC passes (separate runs per counter group, nothing but --kernel-trace beside --pmc)
 mkdir -p $R/gpurun_out/pmc && rm -f $R/gpurun_out/pmc/*
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
   n=$(echo $c | cut -d" " -f1)
   rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc -o $n -- python3 $R/tools/bench_dominant.py 20 256 > /dev/null 2>&1
 done
