@@ -397,8 +397,11 @@ def conv_roofline(L, iters=30):
 
 def gemm_roofline(L, iters=30):
     """The largest 1x1 convolution of a network call: conv1 of a 256 -> 256 Residual block at 64x64 -- BN + ReLU prologue (the
-    pre-activation, layers/Residual.py:22-24), K = 256 -> N = 128, M = L * 4096 pixels -- through the persistent GEMM
-    (gemm_persist_kernel, csrc/gemm_persist.hip).  2*M*N*K FLOPs against 4*(M*K + M*N) bytes = 42 FLOP/B: MFMA-bound."""
+    pre-activation, layers/Residual.py:22-24), K = 256 -> N = 128, M = L * 4096 pixels.  2*M*N*K FLOPs against 4*(M*K + M*N) bytes = 42 FLOP/B.
+    What the network launches (csrc/net.hip: residual): by default gemm_bf16x3_kernel (csrc/gemm_bf16x3.hip: bf16 matrix pipe, both operands
+    split into three bf16 terms, 6 cross terms, fp32 accumulate) -- `achieved` / `frac` = executed bf16 FLOPs (6 x 2*M*N*K) against the dense
+    bf16 peak, with the fp32-equivalent rate beside it; with SUO_WINO_BF16X3=0 the persistent fp32 GEMM (gemm_persist_kernel) against the
+    fp32 MFMA peak.  The other form is timed in the same process."""
     import torch
     from suo_slam_amd import _lib
     rng = np.random.default_rng(1)
@@ -407,28 +410,45 @@ def gemm_roofline(L, iters=30):
     out = torch.empty((M, N), device="cuda")
     w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
     wp = torch.from_numpy(pack_gemm(w, N, K)).cuda()
+    lib = _lib.lib()
+    w3 = np.empty(3 * N * K, np.uint16)
+    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data), "pack_bf16x3")
+    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
     sc = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32)).cuda()
     sh = torch.from_numpy((rng.standard_normal(K) * 0.1).astype(np.float32)).cuda()
     b = torch.zeros(N, device="cuda")
     st = torch.cuda.current_stream()
     s = C.c_void_p(st.cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    lib = _lib.lib()
 
     def gemm():
         _lib.check(lib.suo_conv1x1(P(a), K, K, P(sc), P(sh), None, 0, 0, P(wp), P(b), None, 0, P(out), N, M, N, N, 1, 0, s), "suo_conv1x1")
-    us = _timed(gemm, st, iters)
+
+    def gemm_x3():
+        _lib.check(lib.suo_conv1x1_bf16x3(P(a), K, K, P(sc), P(sh), P(w3d), P(b), P(out), N, M, N, 1, s), "suo_conv1x1_bf16x3")
+    us, us3 = _timed(gemm, st, iters), _timed(gemm_x3, st, iters)
     flop = 2.0 * M * N * K
-    return {"bound": "mfma", "kernel": "gemm_persist_kernel: 1x1 conv K256->N128 with BN+ReLU prologue, + ReLU, M = %d pixels (%d crops @64x64)" % (M, L),
-            "achieved": round(flop / (us * 1e-6) / 1e12, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4), "traffic": committed_traffic("pmc_gemm.json", L, "gemm_persist_kernel"),
-            "avg_launch_us": round(us, 2), "flop_per_launch": flop, "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N) + 4.0 * N * K}
+    tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
+    shape = "1x1 conv K256->N128 with BN+ReLU prologue, + ReLU, M = %d pixels (%d crops @64x64)" % (M, L)
+    f32 = {"kernel": "gemm_persist_kernel: " + shape, "avg_launch_us": round(us, 2), "achieved_tflops": tf(flop, us), "peak": FP32_MFMA_PEAK_TF,
+           "frac": round(flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+    x3 = {"kernel": "gemm_bf16x3_kernel: " + shape, "avg_launch_us": round(us3, 2), "achieved_tflops": tf(6.0 * flop, us3), "peak": BF16_MFMA_PEAK_TF,
+          "frac": round(6.0 * flop / (us3 * 1e-6) / 1e12 / BF16_MFMA_PEAK_TF, 4), "f32_equivalent_tflops": tf(flop, us3),
+          "f32_equivalent_over_f32_peak": round(flop / (us3 * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+    common = {"bound": "mfma", "unit": "TFLOP/s", "flop_per_launch": flop, "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N) + 4.0 * N * K}
+    if wino_bf16x3_enabled():
+        return dict(common, kernel=x3["kernel"], dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)", achieved=x3["achieved_tflops"], peak=BF16_MFMA_PEAK_TF,
+                    frac=x3["frac"], avg_launch_us=x3["avg_launch_us"], executed_flop_per_launch=6.0 * flop, f32_equivalent_tflops=x3["f32_equivalent_tflops"],
+                    f32_equivalent_over_f32_peak=x3["f32_equivalent_over_f32_peak"], traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"),
+                    hbm_gbps_algorithmic=round(common["algorithmic_bytes_per_launch"] / us3 / 1e3, 1), same_process={"fp32 pipe (SUO_WINO_BF16X3=0)": f32})
+    return dict(common, kernel=f32["kernel"], dtype="f32", achieved=f32["achieved_tflops"], peak=FP32_MFMA_PEAK_TF, frac=f32["frac"], avg_launch_us=f32["avg_launch_us"],
+                traffic=committed_traffic("pmc_gemm.json", L, "gemm_persist_kernel"), same_process={"bf16x3 (default)": x3})
 
 
 def bf16x3_leg(L, iters=30):
-    """EXPERIMENTAL, beside the f32 line and never instead of it (`dtype` of `value` stays f32): the largest 1x1 convolution of a call
-    (as gemm_roofline) at fp32 accuracy on the bf16 matrix pipe -- both operands split into three bf16 terms, 6 of the 9 cross products
-    accumulated in fp32 (csrc/gemm_bf16x3.hip) -- against the fp32 MFMA kernel: error of both against fp64 on the same inputs, and time."""
+    """Accuracy of the bf16x3 form next to its speed: the largest 1x1 convolution of a call (as gemm_roofline) on the bf16 matrix pipe -- both
+    operands split into three bf16 terms, 6 of the 9 cross products accumulated in fp32 (csrc/gemm_bf16x3.hip, what the network launches
+    for conv1 of its Residual blocks) -- against the fp32 MFMA kernel: error of both against fp64 on the same inputs, and time."""
     import torch
     from suo_slam_amd import _lib
     lib = _lib.lib()
@@ -459,7 +479,7 @@ def bf16x3_leg(L, iters=30):
             "f32_mfma_us": round(us32, 1), "bf16x3_us": round(us3, 1), "speedup": round(us32 / us3, 3),
             "bf16x3_tflops_f32_equivalent": round(flop / us3 / 1e6, 1), "bf16x3_over_f32_mfma_peak": round(flop / us3 / 1e6 / FP32_MFMA_PEAK_TF, 3),
             "max_abs_err_vs_fp64": {"f32_mfma": float(f"{e32:.3e}"), "bf16x3": float(f"{e3:.3e}")}, "output_range": round(float(np.abs(ref).max()), 3),
-            "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N), "note": "fp32 accuracy holds; the shape is HBM-heavy (42 FLOP/B): see DESIGN.md section 4"}
+            "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N), "note": "fp32 accuracy holds (tests/test_gpu_cnn.py); see DESIGN.md section 4"}
 
 
 def latency_roofline(L=8, iters=50):
@@ -853,7 +873,7 @@ def main():
                     extra["roofline"] = extra["roofline_all"]["dominant_conv"]
             leg("largest_gemm", gemm_roofline, L * F, into="roofline_all")
             leg("latency_mode_dominant_conv", latency_roofline, 8, into="roofline_all")
-            leg("experimental_bf16x3_gemm", bf16x3_leg, L * F)
+            leg("bf16x3_vs_f32_gemm", bf16x3_leg, L * F)
             if world == 1:
                 leg("pose_check", pose_check_leg, L, pool, not args.no_graph)
                 if not args.no_latency_leg:

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "buffer_ops.h"
 #include "suo_internal.h"
 
 namespace suo {
@@ -30,201 +31,221 @@ typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 16, X3_PITCH = 24;      // LDS row pitch in bf16 (48 bytes: conflict-free 16-byte fragment reads)
+#ifndef SUO_X3_SGB
+#define SUO_X3_SGB 0
+#endif
+#ifndef SUO_X3_LEAD
+#define SUO_X3_LEAD 3
+#endif
+constexpr int X3_LEAD = SUO_X3_LEAD;                                                // k-steps between a request and its use, for BOTH global streams
 
-// host: W[N][K] fp32 -> out[K/16][3][N][16] bf16 (as uint16), split by truncation like the device does
+// host: W[N][K] fp32 -> B-operand order of v_mfma_f32_32x32x16_bf16, split by truncation like the device does:
+//   out[((ks * NB + nb) * 3 + plane) * 64 + lane][e] = term `plane` of W[nb*32 + (lane&31)][ks*16 + 8*(lane>>5) + e]
 void pack_gemm_weight_bf16x3(const float* W, int N, int K, uint16_t* out) {
-    for (int ks = 0; ks < K / X3_BK; ++ks)
-        for (int n = 0; n < N; ++n)
-            for (int kk = 0; kk < X3_BK; ++kk) {
-                float x = W[(size_t)n * K + ks * X3_BK + kk];
-                for (int p = 0; p < 3; ++p) {
-                    uint32_t u;
-                    memcpy(&u, &x, 4);
-                    u &= 0xffff0000u;
-                    float hi;
-                    memcpy(&hi, &u, 4);
-                    out[(((size_t)ks * 3 + p) * N + n) * X3_BK + kk] = (uint16_t)(u >> 16);
-                    x -= hi;                                                   // exact
-                }
+    const int NB = N / 32;
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const int ks = k / 16, kk = k % 16, lane = (kk / 8) * 32 + (n % 32), e = kk % 8, nb = n / 32;
+            float x = W[(size_t)n * K + k];
+            for (int p = 0; p < 3; ++p) {
+                uint32_t u;
+                memcpy(&u, &x, 4);
+                u &= 0xffff0000u;
+                float hi;
+                memcpy(&hi, &u, 4);
+                out[((((size_t)(ks * NB + nb) * 3 + p) * 64 + lane) * 8) + e] = (uint16_t)(u >> 16);
+                x -= hi;                                                       // exact
             }
+        }
 }
 
 __device__ __forceinline__ unsigned x3_pack_hi(float a, float b) {          // the leading bf16 of a (low half) and of b (high half)
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
 __device__ __forceinline__ float x3_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Workgroup = 128 rows x 128 columns, four waves as 2 x 2 (64 x 64 each = 2 x 2 accumulators), one 16-wide k-step per barrier.
+//   * activations: global fp32 (four adjacent lanes fetch the 64 contiguous bytes a row contributes to a k-step) -> registers -> prologue ->
+//     truncation split -> three bf16 planes in LDS (two stages) -> A fragments by ds_read_b128;
+//   * weights: host-split, B-operand order, straight from L2 into registers (the two waves of a column half read the same lines: L1);
+//   * vmcnt retires in order, so a request can only be waited for once everything issued before it has landed: both streams are requested
+//     the same X3_LEAD k-steps ahead (an activation load from HBM issued just before a "nearer" weight load would stall that one);
+//   * epilogue: accumulators transposed through a wave-private LDS patch, bias (+ ReLU) and stores on 16-byte vectors.
+template <bool PRO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(
     const float* __restrict__ A, int lda, int K, const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
     const uint16_t* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int relu) {
-    // two stages of {A planes, B planes}: stage s is written (split of step k) while the MFMAs of step k - 1 read stage s ^ 1
     constexpr int PLANE = X3_BM * X3_PITCH;                                   // bf16 elements of one plane
-    __shared__ __attribute__((aligned(16))) uint16_t S[2][2][3 * PLANE];      // [stage][A / B][plane][row][pitch]  = 73 728 bytes
+    __shared__ __attribute__((aligned(16))) uint16_t S[2][3 * PLANE];         // [stage][plane][row][pitch] = 36 864 bytes (the epilogue re-uses it)
+    __shared__ __attribute__((aligned(16))) float P[2][512];                  // prologue scale / shift (K <= 512)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
-    // PERSISTENT workgroups walk the tile list (tile = 128 rows), two per CU: a tile's stores drain under the next tile's first steps
-    const int ntiles = (M + X3_BM - 1) / X3_BM;
+    if (PRO) {
+        for (int k = tid; k < K; k += 256) { P[0][k] = pro_scale[k]; P[1][k] = pro_shift[k]; }
+    }
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order
+    const int m0 = bid * X3_BM;
     const int nsteps = K / X3_BK;
-    // staging roles per 16-wide K step: A -- rows tid / 4 and 64 + tid / 4, the 4 floats at k = 4 (tid & 3): four adjacent lanes read
-    // the 64 contiguous bytes a row contributes to the step (with two lanes per row and 32 bytes each, every 64-byte segment was
-    // requested by two separate instructions); B -- three 16-byte chunks (one per plane)
+    const __amdgpu_buffer_rsrc_t a_srd = make_srd(A, (size_t)M * lda * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(Wp, (size_t)X3_BN * K * 3 * sizeof(uint16_t));
+    // staging roles per k-step: rows tid / 4 and 64 + tid / 4, the 4 floats at k = 4 (tid & 3)
     const int ar = tid >> 2, aq = tid & 3;
-    x3_f32x4 areg[4][2], sreg[4], hreg[4];
-    x3_u32x4 breg[2][3];
-    bool arow_ok[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
-    const int nwg = gridDim.x;
-    auto tile_of = [&](int it) -> int {                                       // XCD-aware: workgroup b lives on XCD b % 8
-        const int g = it * nwg + blockIdx.x;
-        if (g >= ntiles) return ntiles;
-        if ((nwg & 7) == 0 && (ntiles & 7) == 0) { const int per = ntiles >> 3; return (g & 7) * per + (g >> 3); }
-        return g;
-    };
-    // activations come from HBM (1 GB per launch: the kernel is read-bound long before it is MFMA-bound), weights from L2: A is
-    // prefetched FOUR steps ahead (4 register sets: 64 KB in flight per CU -- with two steps the chip had 8 MB in flight, about
-    // half of what the HBM latency x bandwidth product asks for, and nothing overlapped), B two steps ahead
-    auto gloadA = [&](int set, int tile, int ks) {
-        const int m0 = tile * X3_BM;
+    int avoff[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = m0 + 64 * i + ar;
-            arow_ok[set][i] = row < M;
-#ifdef SUO_X3_EXP_NOLOAD
-            areg[set][i] = x3_f32x4{(float)(row + ks), 1.f, 2.f, (float)aq};          // timing experiment: no HBM reads
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + 64 * i + ar;
+        avoff[i] = row < M ? (row * lda + 4 * aq) * 4 : BUF_OOB;              // rows past M read zeros (and the prologue's result is zeroed below)
+    }
+    const bool rok[2] = {m0 + ar < M, m0 + 64 + ar < M};
+    const int wvoff = lane * 16;
+    x3_f32x4 araw[X3_LEAD + 1][2];
+    x3_u32x4 braw[X3_LEAD + 1][2][3];
+    auto requestA = [&](int ks, int slot) {
+#pragma unroll
+#ifdef SUO_X3_EXP_NOLOADA
+        for (int i = 0; i < 2; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
 #else
-            areg[set][i] = *(const x3_f32x4*)(A + (size_t)(arow_ok[set][i] ? row : m0) * lda + ks * X3_BK + 4 * aq);
+        for (int i = 0; i < 2; ++i) araw[slot][i] = buf_load(a_srd, avoff[i], ks * X3_BK * 4);
 #endif
-        }
-        if (pro_scale) {
-            sreg[set] = *(const x3_f32x4*)(pro_scale + ks * X3_BK + 4 * aq);
-            hreg[set] = *(const x3_f32x4*)(pro_shift + ks * X3_BK + 4 * aq);
-        }
     };
-    auto gloadB = [&](int set, int ks) {
-        const x3_u32x4* bp = (const x3_u32x4*)(Wp + (size_t)ks * 3 * X3_BN * X3_BK);      // [plane][n][16] bf16: 2 chunks per row
+    auto requestB = [&](int ks, int slot) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) breg[set][j] = bp[tid + 256 * j];
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((ks * 4 + 2 * wn + cb) * 3) * 1024));
     };
-    auto sstore = [&](int set, int bset, int stage) {
+    auto split_store = [&](int ks, int slot, int stage) {
         float x[8];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float v = areg[set][i][t];
-                if (pro_scale) v = fmaxf(fmaf(v, sreg[set][t], hreg[set][t]), 0.f);
-                x[4 * i + t] = arow_ok[set][i] ? v : 0.f;
-            }
-        uint16_t* As = &S[stage][0][0];
-        uint16_t* Bs = &S[stage][1][0];
+            for (int t = 0; t < 4; ++t) x[4 * i + t] = araw[slot][i][t];
+        if (PRO) {
+            const x3_f32x4 sc = *(const x3_f32x4*)&P[0][ks * X3_BK + 4 * aq], sh = *(const x3_f32x4*)&P[1][ks * X3_BK + 4 * aq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[4 * i + t] = rok[i] ? fmaxf(fmaf(x[4 * i + t], sc[t], sh[t]), 0.f) : 0.f;
+        }
+        uint16_t* As = &S[stage][0];
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            for (int i = 0; i < 2; ++i)
                 *(u32x2*)&As[p * PLANE + (64 * i + ar) * X3_PITCH + 4 * aq] = u32x2{x3_pack_hi(x[4 * i], x[4 * i + 1]), x3_pack_hi(x[4 * i + 2], x[4 * i + 3])};
-            }
             if (p < 2) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] -= x3_hi(x[e]);              // exact residual
             }
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c = tid + 256 * j;                                      // chunk = ((plane * 128 + n) * 2 + half)
-            *(x3_u32x4*)&Bs[(c >> 1) * X3_PITCH + (c & 1) * 8] = breg[bset][j];
-        }
     };
-
-    int it = 0, tile = tile_of(0);
-    if (tile >= ntiles) return;
-    int next_tile = tile_of(1);
-    // prologue: A steps 0..3 and B steps 0, 1 in flight (the step sequence runs on into the next tile)
-    auto stepA = [&](int set, int q) {                                          // q = step number counted from the current tile's step 0
-        if (q < nsteps) gloadA(set, tile, q);
-        else if (next_tile < ntiles) gloadA(set, next_tile, q - nsteps);
-    };
-    auto stepB = [&](int set, int q) {
-        if (q < nsteps || next_tile < ntiles) gloadB(set, q < nsteps ? q : q - nsteps);
-    };
+    x3_f32x16 acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) stepA(u, u);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) stepB(u, u);
-    while (tile < ntiles) {
-        const int m0 = tile * X3_BM;
-        x3_f32x16 acc[2][2];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // prologue: steps 0 .. LEAD in flight (slot = step % (LEAD + 1)), step 0 split into stage 0
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+    for (int u = 0; u <= X3_LEAD; ++u) { requestA(u < nsteps ? u : nsteps - 1, u); requestB(u < nsteps ? u : nsteps - 1, u); }
+    __syncthreads();                                                          // (scale / shift staged)
+    split_store(0, 0, 0);
+    constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // six cross terms, smallest first
+    const int ko = 8 * (lane >> 5);
+    for (int ks0 = 0; ks0 < nsteps; ks0 += X3_LEAD + 1) {                      // (K a multiple of 64: slots and stages are compile-time indices)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int ks = 0; ks < nsteps; ks += 4) {
-            // four steps per trip so that register sets and LDS stages are compile-time indices (K a multiple of 64)
+        for (int u = 0; u <= X3_LEAD; ++u) {
+            const int ks = ks0 + u;
+            __syncthreads();                                                  // stage u & 1 complete; every wave is past its reads of the other stage
+            // this step's A fragments are requested first: their LDS latency passes under the split of the next step's activations
+            const uint16_t* As = &S[u & 1][0];
+            x3_bf16x8 af[2][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) af[rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (64 * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko];
+            __builtin_amdgcn_sched_barrier(0);
+            // weights of this step out of their slot, then the slot's next requests; the next step's activations -> the other stage
+            x3_u32x4 bw[2][3];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bw[cb][p] = braw[u][cb][p];
 #ifndef SUO_X3_EXP_NOSPLIT
-                sstore(u, u & 1, u & 1);                                      // step ks + u: registers -> split -> LDS stage u & 1
+            if (ks + 1 < nsteps) split_store(ks + 1, (u + 1) % (X3_LEAD + 1), (u + 1) & 1);
 #endif
-                stepA(u, ks + u + 4);                                         // its register sets are free for later steps
-                stepB(u & 1, ks + u + 2);
-                __syncthreads();                                              // stage u complete; every wave is past its reads of stage u (two steps ago)
-                const uint16_t* As = &S[u & 1][0][0];
-                const uint16_t* Bs = &S[u & 1][1][0];
-                x3_bf16x8 af[2][3], bf[2][3];
-                const int ko = 8 * (lane >> 5);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) af[rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (64 * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko];
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) bf[cb][p] = *(const x3_bf16x8*)&Bs[p * PLANE + (64 * wn + 32 * cb + (lane & 31)) * X3_PITCH + ko];
-                }
-                constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // six cross terms, smallest first
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
-                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][TI[t]], bf[cb][TJ[t]], acc[rb][cb], 0, 0, 0);
+            {
+                const int kn = ks + X3_LEAD + 1 < nsteps ? ks + X3_LEAD + 1 : nsteps - 1;
+                requestB(kn, u);
+                requestA(kn, u);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
+#if SUO_X3_SGB
+            // issue order: the split's VALU / LDS instructions and the requests in the gaps of the MFMA stream
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue: bias (+ ReLU), straight from the accumulator layout (for a fixed register, 32 lanes hold 32 consecutive columns of one row)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int col = 64 * wn + 32 * cb + (lane & 31);
-                const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + 64 * wm + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = acc[rb][cb][r] + bv;
-                    if (relu) v = fmaxf(v, 0.f);
-#ifdef SUO_X3_EXP_NOSTORE
-                    if (row < M && v == 123456.f) out[(size_t)row * ldo + col] = v;      // timing experiment: (almost) no stores
-#else
-                    if (row < M) out[(size_t)row * ldo + col] = v;
-#endif
-                }
-            }
-        ++it;
-        tile = next_tile;
-        next_tile = tile_of(it + 1);
     }
+    __syncthreads();                                                          // the stages are free: the epilogue's patches live there
+    float* T = reinterpret_cast<float*>(&S[0][0]) + w * (32 * 36);
+    const __amdgpu_buffer_rsrc_t o_srd = make_srd(out, (size_t)M * ldo * sizeof(float));
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = 64 * wn + 32 * cb + (lane & 7) * 4;
+            x3_f32x4 bv = x3_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *(const x3_f32x4*)(bias + col);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[x3_acc_row(r, lane) * 36 + (lane & 31)] = acc[rb][cb][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = m0 + 64 * wm + 32 * rb + (lane >> 3) + 8 * k;
+                x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv;
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
+                }
+#ifdef SUO_X3_EXP_NOSTORE
+                if (o[0] == 123456.f)
+#endif
+                buf_store(o, o_srd, row < M ? (row * ldo + col) * 4 : BUF_OOB);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
 }
 
 int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
                        float* out, int ldo, int M, int N, int relu, hipStream_t s) {
-    if (N != X3_BN || K <= 0 || (K % 64) || M <= 0 || (lda % 4) || ((pro_scale == nullptr) != (pro_shift == nullptr))) {
-        suo_set_error("gemm_bf16x3 (prototype): N must be 128 and K a multiple of 64 (N=%d K=%d)", N, K);
+    if (N != X3_BN || K <= 0 || (K % 64) || K > 512 || M <= 0 || (lda % 4) || (ldo % 4) || ((pro_scale == nullptr) != (pro_shift == nullptr)) ||
+        (size_t)M * lda * sizeof(float) >= ((size_t)1 << 31) || (size_t)M * ldo * sizeof(float) >= ((size_t)1 << 31)) {
+        suo_set_error("gemm_bf16x3: N must be 128, K a multiple of 64 up to 512, the tensors below 2 GB (N=%d K=%d M=%d)", N, K, M);
         return SUO_ERR_ARG;
     }
     const int tiles = (M + X3_BM - 1) / X3_BM;
-    static const int wgs = getenv("SUO_X3_WGS") ? atoi(getenv("SUO_X3_WGS")) : 512;        // two resident workgroups per CU
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(tiles < wgs ? tiles : wgs), dim3(256), 0, s, A, lda, K, pro_scale, pro_shift, Wp, bias, out, ldo, M, relu);
+    if (pro_scale) hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3(tiles), dim3(256), 0, s, A, lda, K, pro_scale, pro_shift, Wp, bias, out, ldo, M, relu);
+    else hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, dim3(tiles), dim3(256), 0, s, A, lda, K, pro_scale, pro_shift, Wp, bias, out, ldo, M, relu);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

@@ -16,7 +16,7 @@ struct HostTensor {
     size_t numel = 0;
 };
 
-struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; };
+struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; float* Wx3 = nullptr; };   // Wx3: bf16x3 planes (N = 128, one K segment of a multiple of 64; csrc/gemm_bf16x3.hip)
 struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; float* Wq = nullptr; float* Wq3 = nullptr; };   // Wq: Winograd-packed (3x3, 128 -> 128 / 64 -> 64); Wq3: its bf16x3 planes (128 -> 128, csrc/conv_wino_x3.hip)
 struct ResidualW {
     float* pro_scale = nullptr; float* pro_shift = nullptr;

@@ -165,6 +165,11 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
     g.Wp = upload(packed);
     g.bias = upload(bias);
     g.N = Np; g.n_valid = N; g.K1 = K1p; g.K2 = K2p;
+    if (N == 128 && Np == 128 && !K2 && K1 == K1p && K1 % 64 == 0 && K1 <= 512 && wino_bf16x3()) {      // the same operator on the bf16 pipe at fp32 accuracy
+        std::vector<float> x3((size_t)3 * 128 * K1 / 2);                       // uint16 planes
+        pack_gemm_weight_bf16x3(full.data(), 128, K1, reinterpret_cast<uint16_t*>(x3.data()));
+        g.Wx3 = upload(x3);
+    }
 }
 
 // c_used > 0: keep only the first c_used input channels of the filter (the others multiply structural zeros)
@@ -413,6 +418,11 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     GemmArgs g1 = {};
     g1.A1 = x; g1.lda1 = r.cin; g1.K1 = r.c1.K1; g1.pro_scale = r.pro_scale; g1.pro_shift = r.pro_shift;
     g1.Wp = r.c1.Wp; g1.bias = r.c1.bias; g1.out = mid1; g1.ldo = r.c1.N; g1.M = M; g1.N = r.c1.N; g1.n_valid = r.c1.n_valid; g1.relu = 1;
+    // large launches: on the bf16 pipe with 3-way split operands (464 vs 595 us at 256 crops / 64 x 64; below ~256 tiles the fp32 kernels' smaller tiles win)
+    static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+    if (r.c1.Wx3 && M >= x3_min_rows && (size_t)M * r.cin * sizeof(float) < ((size_t)1 << 31))
+        SUO_LAUNCH(launch_gemm_bf16x3(x, r.cin, r.c1.K1, r.pro_scale, r.pro_shift, reinterpret_cast<const uint16_t*>(r.c1.Wx3), r.c1.bias, mid1, r.c1.N, M, 128, 1, s));
+    else
     SUO_LAUNCH(launch_gemm1x1(g1, s));
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;

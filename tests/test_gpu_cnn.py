@@ -736,8 +736,9 @@ def test_fused_kernels_on_random_shapes(ops):
             assert torch.equal(gu, got + low.repeat_interleave(2, 1).repeat_interleave(2, 2)), ("wino tail up", L, H, W)
 
 
-def test_experimental_bf16x3_gemm_is_fp32_accurate(ops):
-    """csrc/gemm_bf16x3.hip (experimental, not on the product path): the 1x1 convolution on the bf16 matrix pipe with both operands
+@pytest.mark.parametrize("K", [256, 128, 64])
+def test_bf16x3_gemm_is_fp32_accurate(ops, K):
+    """csrc/gemm_bf16x3.hip (what the network launches for conv1 of its Residual blocks at >= 32768 pixels): the 1x1 convolution on the bf16 matrix pipe with both operands
     split into three bf16 terms and 6 of 9 cross products accumulated in fp32 must be as accurate as the fp32 MFMA kernel: same
     bound against fp64 (rel 5e-6 of the output range, the bound every fp32 conv kernel is held to), with and without the BN + ReLU
     prologue, ragged M (rows beyond the last full 128-row tile), and the truncation split of the weights exact (w0 + w1 + w2 == w)."""
@@ -745,12 +746,12 @@ def test_experimental_bf16x3_gemm_is_fp32_accurate(ops):
     from suo_slam_amd import _lib
     lib = _lib.lib()
     rng = np.random.default_rng(77)
-    K, N = 256, 128
+    N = 128
     w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
     w3 = np.empty(3 * N * K, np.uint16)
     _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
-    planes = (w3.reshape(K // 16, 3, N, 16).astype(np.uint32) << 16).view(np.float32)                 # [ks][plane][n][16]
-    back = planes.astype(np.float64).sum(1).transpose(1, 0, 2).reshape(N, K)
+    planes = (w3.reshape(K // 16, N // 32, 3, 2, 32, 8).astype(np.uint32) << 16).view(np.float32)      # [ks][nb][plane][k half][n % 32][8]: B-operand order
+    back = planes.astype(np.float64).sum(2).transpose(1, 3, 0, 2, 4).reshape(N, K)
     assert np.abs(back - w).max() <= np.abs(w).max() * 2.0 ** -23                                       # three bf16 terms carry the 24 bits
     w3d = torch.from_numpy(w3.view(np.int16)).cuda()
     b = (rng.standard_normal(N) * 0.1).astype(np.float32)

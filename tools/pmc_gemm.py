@@ -6,6 +6,7 @@ Two roles:
 Shapes: residual  (K 128 -> N 256 + identity skip, M = 524288: Residual.conv3 at 64x64, 128 crops)
         conv1     (K 256 -> N 128, BN-ReLU prologue + ReLU, M = 524288: Residual.conv1)
         lin       (K 256 -> N 256 + ReLU, M = 524288: the lin_ head)
+        conv1_x3  (conv1 through gemm_bf16x3_kernel, the form the network launches by default: csrc/gemm_bf16x3.hip)
 Driver: tools/profile_gemm_pmc.sh (one rocprofv3 process per counter group, no other tracing, as the micro-architecture
 guide prescribes)."""
 import json
@@ -19,6 +20,7 @@ SHAPES = {   # K1, N, kwargs, algorithmic bytes (activations + output (+ residua
     "residual": (128, 256, dict(res=True), 4 * (M * 128 + 2 * M * 256 + 128 * 256)),
     "conv1": (256, 128, dict(pro=True, relu=True), 4 * (M * 256 + M * 128 + 256 * 128)),
     "lin": (256, 256, dict(relu=True), 4 * (M * 256 + M * 256 + 256 * 256)),
+    "conv1_x3": (256, 128, dict(pro=True, relu=True, x3=True), 4 * (M * 256 + M * 128) + 6 * 256 * 128),
 }
 
 
@@ -28,12 +30,38 @@ def run(shape, iters):
     import torch
     K, N, kw, _ = SHAPES[shape]
     bo.timeit.__defaults__ = (iters,)
-    bo.gemm(M, K, N, **kw)
+    if kw.get("x3"):
+        import ctypes as C
+        import numpy as np
+        from suo_slam_amd import _lib
+        lib = _lib.lib()
+        rng = np.random.default_rng(0)
+        w = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+        w3 = np.empty(3 * N * K, np.uint16)
+        _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
+        w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+        rot = 8                                                # distinct buffers: inputs are not L2-resident between launches
+        a = [torch.randn((M, K), device="cuda") for _ in range(rot)]
+        o = [torch.empty((M, N), device="cuda") for _ in range(rot)]
+        sc, sh, b = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(N, device="cuda")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        i = [0]
+
+        def fn():
+            k = i[0] % rot
+            i[0] += 1
+            _lib.check(lib.suo_conv1x1_bf16x3(P(a[k]), K, K, P(sc), P(sh), P(w3d), P(b), P(o[k]), N, M, N, 1, s))
+        us = bo.timeit(fn)
+        print(f"gemm_bf16x3 M={M} K={K} N={N}: {us:8.2f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF (fp32-equivalent)")
+    else:
+        bo.gemm(M, K, N, **{k: v for k, v in kw.items() if k != "x3"})
     torch.cuda.synchronize()
 
 
 def report(shape):
     K, N, kw, alg = SHAPES[shape]
+    kname = "gemm_bf16x3_kernel" if kw.get("x3") else "gemm_persist_kernel"
     d = os.path.join(ROOT, "gpurun_out", f"pmc_gemm_{shape}")
     vals, dur = {}, None
     for f in sorted(os.listdir(d)):
@@ -45,26 +73,28 @@ def report(shape):
             cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
             namec = "kernel_name" if "kernel_name" in cols else "name"
             for name, cnt, n, avg in c.execute(f"select {namec}, counter_name, count(*), avg(value) from counters_collection group by {namec}, counter_name"):
-                if "gemm_persist_kernel" in name:
+                if kname in name:
                     vals[cnt] = avg
         if f.startswith("trace") and "kernels" in tabs:
-            rows = c.execute("select avg(end-start), min(end-start), count(*) from kernels where name like '%gemm_persist_kernel%'").fetchall()
+            rows = c.execute(f"select avg(end-start), min(end-start), count(*) from kernels where name like '%{kname}%'").fetchall()
             dur = rows[0]
     fetch = vals["FETCH_SIZE"] * 1024 * 2          # KB -> B; gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section)
     write = vals["WRITE_SIZE"] * 1024
     cycles = vals["GRBM_GUI_ACTIVE"] / 8           # summed over the 8 XCDs
     flop = 2.0 * M * K * N
-    rec = {"kernel": "gemm_persist_kernel<2,2,2,2,%s>" % ("true" if kw.get("res") else "false"), "shape": f"M={M} K={K} N={N} {kw}",
+    rec = {"kernel": "gemm_bf16x3_kernel<true>" if kw.get("x3") else "gemm_persist_kernel<2,2,2,2,%s>" % ("true" if kw.get("res") else "false"),
+           "shape": f"M={M} K={K} N={N} {kw}",
            "avg_launch_us": round(dur[0] / 1e3, 2), "min_launch_us": round(dur[1] / 1e3, 2), "launches_timed": dur[2],
-           "tflops": round(flop / dur[0] / 1e3, 1),
+           "tflops": round(flop / dur[0] / 1e3, 1), "mfma_flop_per_busy_cycle": 1024 if kw.get("x3") else 64,
            "hbm_bytes_per_launch": round(fetch + write), "fetch_bytes_corrected": round(fetch), "write_bytes": round(write),
            "algorithmic_bytes": alg, "traffic_over_algorithmic": round((fetch + write) / alg, 3),
            "hbm_GBps": round((fetch + write) / dur[0], 1), "hbm_frac_of_8TBps": round((fetch + write) / dur[0] / 8000, 3),
            "mfma_util": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles), 3),
            "l2_hit_rate": round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 3)}
     print(json.dumps(rec, indent=1))
-    if shape == "conv1" and M == 1048576:                 # bench.py's roofline_all.largest_gemm reads `traffic` from here
-        out = {"kernel": "gemm_persist_kernel", "crops_per_launch": M // 4096, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "detail": rec}
+    want = "conv1_x3" if os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "") else "conv1"
+    if shape == want and M == 1048576:                    # bench.py's roofline_all.largest_gemm reads `traffic` from here
+        out = {"kernel": kname, "crops_per_launch": M // 4096, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "detail": rec}
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_gemm.json"), "w"), indent=1)
 
 
