@@ -123,9 +123,10 @@ int suo_conv1x1_pool(const float* a1_dev, int lda1, int K1, const float* pro_sca
                      const float* a2_dev, int lda2, int K2, const float* wp_dev, const float* bias_dev,
                      const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, int H, int W,
                      float* pool_out_dev, void* stream);
-/* EXPERIMENTAL, not used by suo_net_forward: the same 1x1 convolution (N = 128, K a multiple of 32, optional BN + ReLU prologue,
- * bias, optional ReLU) at fp32 accuracy on the bf16 matrix pipe: both operands are split into three bf16 terms and 6 of the 9 cross
- * products are accumulated in fp32 (csrc/gemm_bf16x3.hip).  wp3 = suo_pack_gemm_weight_bf16x3(W[N][K]) -> 3*N*K uint16. */
+/* The same 1x1 convolution (N = 128, K a multiple of 64 up to 512, optional BN + ReLU prologue, bias, optional ReLU) at fp32 accuracy on the
+ * bf16 matrix pipe: both operands are split into three bf16 terms and 6 of the 9 cross products are accumulated in fp32
+ * (csrc/gemm_bf16x3.hip; what suo_net_forward launches for conv1 of its Residual blocks at >= 32768 pixels unless SUO_WINO_BF16X3=0).
+ * wp3 = suo_pack_gemm_weight_bf16x3(W[N][K]) -> 3*N*K uint16 (MFMA B-operand order). */
 int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out);
 int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* wp3_dev,
                        const float* bias_dev, float* out_dev, int ldo, int M, int N, int relu, void* stream);
@@ -142,8 +143,9 @@ int suo_conv3x3_wino(const float* in_dev, int L, int H, int W, int C, const floa
  * launches only (>= 1024 tiles of 128 pixels, the shapes the network uses it for); bit-identical to suo_conv_kxk + suo_conv1x1. */
 int suo_conv3x3_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wp2_dev, const float* bias2_dev, const float* wp3_dev,
                              const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);
-/* EXPERIMENTAL (csrc/conv_wino_x3.hip): the Winograd 3x3 convolution (128 -> 128 channels) with its element-wise products on the bf16
- * matrix pipe at fp32 accuracy (3-way split of both operands, 6 of 9 cross terms, fp32 accumulate).
+/* csrc/conv_wino_x3.hip (what suo_net_forward launches for the Residual blocks' 3x3 + tail unless SUO_WINO_BF16X3=0): the Winograd 3x3
+ * convolution (128 -> 128 channels) with its element-wise products on the bf16 matrix pipe at fp32 accuracy (3-way split of both operands,
+ * 6 of 9 cross terms, fp32 accumulate).
  * wq3 = suo_pack_wino_weight_bf16x3(W[128][128][3][3]) -> 3 * 16 * N * C uint16; same tensors as suo_conv3x3_wino / .._conv1x1_skip_up. */
 int suo_pack_wino_weight_bf16x3(const float* w, int N, int C, uint16_t* out);
 int suo_conv3x3_wino_x3(const float* in_dev, int L, int H, int W, const uint16_t* wq3_dev, const float* bias_dev, float* out_dev, int relu,

@@ -1,4 +1,4 @@
-"""The experimental bf16x3 Winograd 3x3 convolution (csrc/conv_wino_x3.hip) against the fp32 MFMA Winograd kernel (csrc/conv_wino.hip) on
+"""The bf16x3 Winograd 3x3 convolution (csrc/conv_wino_x3.hip, the network's default) against the fp32 MFMA Winograd kernel (csrc/conv_wino.hip) on
 the Residual block's shape (128 -> 128 channels, 64 x 64 maps): error of both against fp64, and time, plain and with the fused Residual tail.
 python tools/bench_wino_x3.py [crops]"""
 import ctypes as C, os, sys

@@ -17,7 +17,7 @@ done
 { echo "# rocprofv3 --pmc <counter group> --kernel-trace -- python3 tools/bench_dominant.py 20 256   (one pass per counter group; tools/profile_round.sh $TAG)"
   echo "# FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as reported"
   cat $SRC/pmc.txt; } > profiles/${P}_pmc_dominant_conv.txt
-{ echo "# SUO_PMC_GEMM_M=1048576 bash tools/profile_gemm_pmc.sh conv1   (rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_gemm.py run conv1 10, one pass per group)"
+{ echo "# SUO_PMC_GEMM_M=1048576 bash tools/profile_gemm_pmc.sh conv1_x3 conv1   (rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_gemm.py run <shape> 10, one pass per group; conv1_x3 = gemm_bf16x3_kernel, what the network launches; conv1 = the fp32-pipe kernel)"
   cat $SRC/pmc_gemm.txt; } > profiles/${P}_pmc_gemm.txt
 cp $SRC/pmc_dominant_conv.json profiles/pmc_dominant_conv.json
 [ -s $SRC/pmc_gemm.json ] && cp $SRC/pmc_gemm.json profiles/pmc_gemm.json

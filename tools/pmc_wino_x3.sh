@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over tools/bench_wino_x3.py (the experimental bf16x3 Winograd kernels next to the fp32 ones): one counter group per run,
+# PMC passes over tools/bench_wino_x3.py (the bf16x3 Winograd kernels next to the fp32-pipe ones; the TCP_* / TA_* groups hang rocprofv3 on this pool: left out): one counter group per run,
 # nothing but --kernel-trace beside --pmc.   tools/pmc_wino_x3.sh [crops]   -> gpurun_out/pmc_wx3/summary.txt
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
@@ -12,9 +12,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_I
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL" \
          "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_IFETCH_LEVEL" \
-         "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
-         "TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+         "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $c --kernel-trace -d $O -o g$i -- python3 $R/tools/bench_wino_x3.py $L > $O/g$i.log 2>&1
 done
