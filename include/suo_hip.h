@@ -130,6 +130,12 @@ int suo_conv1x1_pool(const float* a1_dev, int lda1, int K1, const float* pro_sca
 int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out);
 int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* wp3_dev,
                        const float* bias_dev, float* out_dev, int ldo, int M, int N, int relu, void* stream);
+/* The general form: N a multiple of 128, an optional second K segment (a2, K2: the skip conv of a Residual block; then no prologue), an optional
+ * residual operand r_dev [M, ldr] added after the bias; K1, K2 multiples of 64; wp3 = suo_pack_gemm_weight_bf16x3 of the row-wise concatenation
+ * [W1 | W2] (N rows, K1 + K2 columns).  What suo_net_forward launches for its N = 256 1x1 convolutions at 64x64 (lin, re-injection, conv3 + conv4). */
+int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev,
+                          int lda2, int K2, const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo,
+                          int M, int N, int relu, void* stream);
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);

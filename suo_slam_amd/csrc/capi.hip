@@ -89,7 +89,7 @@ int suo_net_backbone(suo_net* net, const float* staged, int L, float* logits, vo
 }
 
 int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out) {
-    if (!w || !out || N <= 0 || K <= 0 || (K % 32)) { suo_set_error("suo_pack_gemm_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
+    if (!w || !out || N <= 0 || (N % 32) || K <= 0 || (K % 16)) { suo_set_error("suo_pack_gemm_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
     suo::pack_gemm_weight_bf16x3(w, N, K, out);
     return SUO_OK;
 }
@@ -98,6 +98,15 @@ int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scal
                        const float* bias_dev, float* out_dev, int ldo, int M, int N, int relu, void* stream) {
     if (!a_dev || !wp3_dev || !out_dev) { suo_set_error("suo_conv1x1_bf16x3: null argument"); return SUO_ERR_ARG; }
     return suo::launch_gemm_bf16x3(a_dev, lda, K, pro_scale_dev, pro_shift_dev, wp3_dev, bias_dev, out_dev, ldo, M, N, relu, (hipStream_t)stream);
+}
+
+int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                          const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, void* stream) {
+    if (!a1_dev || !wp3_dev || !out_dev) { suo_set_error("suo_conv1x1_bf16x3_ex: null argument"); return SUO_ERR_ARG; }
+    suo::GemmArgs g = {};
+    g.A1 = a1_dev; g.lda1 = lda1; g.K1 = K1; g.pro_scale = pro_scale_dev; g.pro_shift = pro_shift_dev; g.A2 = a2_dev; g.lda2 = lda2; g.K2 = K2;
+    g.bias = bias_dev; g.R = r_dev; g.ldr = ldr; g.out = out_dev; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = N; g.relu = relu;
+    return suo::launch_gemm_bf16x3_args(g, wp3_dev, (hipStream_t)stream);
 }
 
 int suo_upload(void* dst_dev, const void* src_pinned_host, size_t bytes, void* stream) {

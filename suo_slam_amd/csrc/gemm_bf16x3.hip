@@ -72,50 +72,59 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 //   * vmcnt retires in order, so a request can only be waited for once everything issued before it has landed: both streams are requested
 //     the same X3_LEAD k-steps ahead (an activation load from HBM issued just before a "nearer" weight load would stall that one);
 //   * epilogue: accumulators transposed through a wave-private LDS patch, bias (+ ReLU) and stores on 16-byte vectors.
-template <bool PRO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(
-    const float* __restrict__ A, int lda, int K, const float* __restrict__ pro_scale, const float* __restrict__ pro_shift,
-    const uint16_t* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, int ldo, int M, int relu) {
+template <bool PRO, bool DUAL, bool RES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
     constexpr int PLANE = X3_BM * X3_PITCH;                                   // bf16 elements of one plane
     __shared__ __attribute__((aligned(16))) uint16_t S[2][3 * PLANE];         // [stage][plane][row][pitch] = 36 864 bytes (the epilogue re-uses it)
-    __shared__ __attribute__((aligned(16))) float P[2][512];                  // prologue scale / shift (K <= 512)
+    __shared__ __attribute__((aligned(16))) float P[2][512];                  // prologue scale / shift (K1 <= 512)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
+    const int M = g.M, K = g.K1 + (DUAL ? g.K2 : 0), ldo = g.ldo;
     if (PRO) {
-        for (int k = tid; k < K; k += 256) { P[0][k] = pro_scale[k]; P[1][k] = pro_shift[k]; }
+        for (int k = tid; k < g.K1; k += 256) { P[0][k] = g.pro_scale[k]; P[1][k] = g.pro_shift[k]; }
     }
+    // tile = (row tile, column tile of 128); the column tiles of a row tile are neighbours (the second one finds the activations in L2)
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order
-    const int m0 = bid * X3_BM;
-    const int nsteps = K / X3_BK;
-    const __amdgpu_buffer_rsrc_t a_srd = make_srd(A, (size_t)M * lda * sizeof(float));
-    const __amdgpu_buffer_rsrc_t w_srd = make_srd(Wp, (size_t)X3_BN * K * 3 * sizeof(uint16_t));
+    const int ntn = g.N >> 7, NBT = g.N >> 5;
+    const int tn = bid % ntn, m0 = (bid / ntn) * X3_BM;
+    const int ns1 = g.K1 / X3_BK, nsteps = K / X3_BK;
+    const __amdgpu_buffer_rsrc_t a1_srd = make_srd(g.A1, (size_t)M * g.lda1 * sizeof(float));
+    const __amdgpu_buffer_rsrc_t a2_srd = make_srd(DUAL ? g.A2 : g.A1, DUAL ? (size_t)M * g.lda2 * sizeof(float) : 0);
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(Wp, (size_t)g.N * K * 3 * sizeof(uint16_t));
     // staging roles per k-step: rows tid / 4 and 64 + tid / 4, the 4 floats at k = 4 (tid & 3)
     const int ar = tid >> 2, aq = tid & 3;
-    int avoff[2];
+    int avoff1[2], avoff2[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = m0 + 64 * i + ar;
-        avoff[i] = row < M ? (row * lda + 4 * aq) * 4 : BUF_OOB;              // rows past M read zeros (and the prologue's result is zeroed below)
+        avoff1[i] = row < M ? (row * g.lda1 + 4 * aq) * 4 : BUF_OOB;          // rows past M read zeros (and the prologue's result is zeroed below)
+        avoff2[i] = DUAL && row < M ? (row * g.lda2 + 4 * aq) * 4 : BUF_OOB;
     }
     const bool rok[2] = {m0 + ar < M, m0 + 64 + ar < M};
     const int wvoff = lane * 16;
     x3_f32x4 araw[X3_LEAD + 1][2];
     x3_u32x4 braw[X3_LEAD + 1][2][3];
     auto requestA = [&](int ks, int slot) {
-#pragma unroll
 #ifdef SUO_X3_EXP_NOLOADA
         for (int i = 0; i < 2; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
 #else
-        for (int i = 0; i < 2; ++i) araw[slot][i] = buf_load(a_srd, avoff[i], ks * X3_BK * 4);
+        if (!DUAL || ks < ns1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) araw[slot][i] = buf_load(a1_srd, avoff1[i], ks * X3_BK * 4);
+        } else {                                                              // second K segment (conv4 on the block's input)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) araw[slot][i] = buf_load(a2_srd, avoff2[i], (ks - ns1) * X3_BK * 4);
+        }
 #endif
     };
     auto requestB = [&](int ks, int slot) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((ks * 4 + 2 * wn + cb) * 3) * 1024));
+            for (int p = 0; p < 3; ++p)
+                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((ks * NBT + 4 * tn + 2 * wn + cb) * 3) * 1024));
     };
     auto split_store = [&](int ks, int slot, int stage) {
         float x[8];
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) x[4 * i + t] = araw[slot][i][t];
-        if (PRO) {
+        if (PRO) {                                                            // (single K segment only: checked by the launcher)
             const x3_f32x4 sc = *(const x3_f32x4*)&P[0][ks * X3_BK + 4 * aq], sh = *(const x3_f32x4*)&P[1][ks * X3_BK + 4 * aq];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     split_store(0, 0, 0);
     constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // six cross terms, smallest first
     const int ko = 8 * (lane >> 5);
-    for (int ks0 = 0; ks0 < nsteps; ks0 += X3_LEAD + 1) {                      // (K a multiple of 64: slots and stages are compile-time indices)
+    for (int ks0 = 0; ks0 < nsteps; ks0 += X3_LEAD + 1) {                      // (K1, K2 multiples of 64: slots and stages are compile-time indices)
 #pragma unroll
         for (int u = 0; u <= X3_LEAD; ++u) {
             const int ks = ks0 + u;
@@ -208,14 +217,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     __syncthreads();                                                          // the stages are free: the epilogue's patches live there
     float* T = reinterpret_cast<float*>(&S[0][0]) + w * (32 * 36);
-    const __amdgpu_buffer_rsrc_t o_srd = make_srd(out, (size_t)M * ldo * sizeof(float));
+    const __amdgpu_buffer_rsrc_t o_srd = make_srd(g.out, (size_t)M * ldo * sizeof(float));
+    const __amdgpu_buffer_rsrc_t r_srd = make_srd(RES ? g.R : g.out, RES ? (size_t)M * g.ldr * sizeof(float) : 0);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const int col = 64 * wn + 32 * cb + (lane & 7) * 4;
+            const int col = 128 * tn + 64 * wn + 32 * cb + (lane & 7) * 4;
             x3_f32x4 bv = x3_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (bias) bv = *(const x3_f32x4*)(bias + col);
+            if (g.bias) bv = *(const x3_f32x4*)(g.bias + col);
+            x3_f32x4 rv[RES ? 4 : 1];
+            if (RES) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = m0 + 64 * wm + 32 * rb + (lane >> 3) + 8 * k;
+                    rv[k] = buf_load(r_srd, row < M ? (row * g.ldr + col) * 4 : BUF_OOB, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[x3_acc_row(r, lane) * 36 + (lane & 31)] = acc[rb][cb][r];
             __builtin_amdgcn_wave_barrier();
@@ -223,7 +241,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int k = 0; k < 4; ++k) {
                 const int row = m0 + 64 * wm + 32 * rb + (lane >> 3) + 8 * k;
                 x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv;
-                if (relu) {
+                if (RES) o += rv[k];                                          // (bias, then the residual: the order of the fp32 kernels)
+                if (g.relu) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
                 }
@@ -236,18 +255,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         }
 }
 
-int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
-                       float* out, int ldo, int M, int N, int relu, hipStream_t s) {
-    if (N != X3_BN || K <= 0 || (K % 64) || K > 512 || M <= 0 || (lda % 4) || (ldo % 4) || ((pro_scale == nullptr) != (pro_shift == nullptr)) ||
-        (size_t)M * lda * sizeof(float) >= ((size_t)1 << 31) || (size_t)M * ldo * sizeof(float) >= ((size_t)1 << 31)) {
-        suo_set_error("gemm_bf16x3: N must be 128, K a multiple of 64 up to 512, the tensors below 2 GB (N=%d K=%d M=%d)", N, K, M);
+// out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R ): N a multiple of 128, K1 and K2 multiples of 64 (K2 may be 0),
+// the prologue only without a second segment; Wx3 = pack_gemm_weight_bf16x3 of the row-concatenated [W1 | W2] (N rows, K1 + K2 columns)
+bool gemm_bf16x3_takes(const GemmArgs& g) {
+    const size_t lim = (size_t)1 << 31;
+    return g.N > 0 && g.N % 128 == 0 && g.n_valid == g.N && g.K1 > 0 && g.K1 % 64 == 0 && g.K2 % 64 == 0 && g.K1 <= 512 && !g.nchw_hw && !g.pool_out && g.out &&
+           (!g.K2 || (!g.pro_scale && g.A2 && g.lda2 % 4 == 0)) && g.lda1 % 4 == 0 && g.ldo % 4 == 0 && (!g.R || g.ldr % 4 == 0) &&
+           ((g.pro_scale == nullptr) == (g.pro_shift == nullptr)) && (size_t)g.M * g.lda1 * 4 < lim && (size_t)g.M * g.ldo * 4 < lim &&
+           (!g.K2 || (size_t)g.M * g.lda2 * 4 < lim) && (!g.R || (size_t)g.M * g.ldr * 4 < lim);
+}
+
+int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t s) {
+    if (!gemm_bf16x3_takes(g) || !Wx3) {
+        suo_set_error("gemm_bf16x3: unsupported shape (N=%d K=%d+%d M=%d)", g.N, g.K1, g.K2, g.M);
         return SUO_ERR_ARG;
     }
-    const int tiles = (M + X3_BM - 1) / X3_BM;
-    if (pro_scale) hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, dim3(tiles), dim3(256), 0, s, A, lda, K, pro_scale, pro_shift, Wp, bias, out, ldo, M, relu);
-    else hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, dim3(tiles), dim3(256), 0, s, A, lda, K, pro_scale, pro_shift, Wp, bias, out, ldo, M, relu);
+    const int tiles = ((g.M + X3_BM - 1) / X3_BM) * (g.N / 128);
+#define X3_LAUNCH(P_, D_, R_) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_>), dim3(tiles), dim3(256), 0, s, g, Wx3)
+    const bool res = g.R != nullptr;
+    if (g.pro_scale) { if (res) X3_LAUNCH(true, false, true); else X3_LAUNCH(true, false, false); }
+    else if (g.K2) { if (res) X3_LAUNCH(false, true, true); else X3_LAUNCH(false, true, false); }
+    else { if (res) X3_LAUNCH(false, false, true); else X3_LAUNCH(false, false, false); }
+#undef X3_LAUNCH
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
+}
+
+int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
+                       float* out, int ldo, int M, int N, int relu, hipStream_t s) {
+    GemmArgs g = {};
+    g.A1 = A; g.lda1 = lda; g.K1 = K; g.pro_scale = pro_scale; g.pro_shift = pro_shift; g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = N;
+    g.relu = relu;
+    return launch_gemm_bf16x3_args(g, Wp, s);
 }
 
 }  // namespace suo

@@ -57,7 +57,7 @@ private:
     float* alloc(size_t floats);
     // pool_out: also produce max_pool2d(out, 2, 2) (fused into the last GEMM where it can be, else a separate launch); `out` may then be nullptr
     int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr, float* pool_out = nullptr);
-    int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s);
+    int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const float* Wx3 = nullptr);
     bool residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const;
     int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx, const float* x_pooled = nullptr);
     int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s);

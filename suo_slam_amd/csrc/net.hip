@@ -165,9 +165,9 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
     g.Wp = upload(packed);
     g.bias = upload(bias);
     g.N = Np; g.n_valid = N; g.K1 = K1p; g.K2 = K2p;
-    if (N == 128 && Np == 128 && !K2 && K1 == K1p && K1 % 64 == 0 && K1 <= 512 && wino_bf16x3()) {      // the same operator on the bf16 pipe at fp32 accuracy
-        std::vector<float> x3((size_t)3 * 128 * K1 / 2);                       // uint16 planes
-        pack_gemm_weight_bf16x3(full.data(), 128, K1, reinterpret_cast<uint16_t*>(x3.data()));
+    if (N % 128 == 0 && Np == N && K1 == K1p && K2 == K2p && K1 % 64 == 0 && K2 % 64 == 0 && K1 <= 512 && wino_bf16x3()) {      // the same operator on the bf16 pipe at fp32 accuracy
+        std::vector<float> x3((size_t)3 * N * Kp / 2);                         // uint16 planes
+        pack_gemm_weight_bf16x3(full.data(), N, Kp, reinterpret_cast<uint16_t*>(x3.data()));
         g.Wx3 = upload(x3);
     }
 }
@@ -331,6 +331,11 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
         reinject_.Wp = upload(packed);
         reinject_.bias = upload(bias);
         reinject_.N = N; reinject_.n_valid = N; reinject_.K1 = K; reinject_.K2 = 0;
+        if (N % 128 == 0 && K % 64 == 0 && K <= 512 && wino_bf16x3()) {
+            std::vector<float> x3((size_t)3 * N * K / 2);                     // uint16 planes
+            pack_gemm_weight_bf16x3(full.data(), N, K, reinterpret_cast<uint16_t*>(x3.data()));
+            reinject_.Wx3 = upload(x3);
+        }
     }
     {
         const HostTensor& w = T("classifier.2.weight");
@@ -398,8 +403,20 @@ bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const 
 // A 1x1 convolution whose result is also wanted max-pooled (nn.MaxPool2d(2, 2)): pooled in the GEMM's epilogue when the launch
 // would use the persistent 128x128 kernel anyway (csrc/gemm_persist.hip: POOL), else GEMM + max-pool kernel.  g.out may be nullptr
 // when only the pooled tensor is wanted.
-int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s) {
+int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const float* Wx3) {
     static const int fuse_pool = getenv("SUO_FUSE_POOL") ? atoi(getenv("SUO_FUSE_POOL")) : 1;                    // 0: A/B
+    // large launches with a bf16x3 form of the weights: on the bf16 pipe (csrc/gemm_bf16x3.hip), the pool as its own kernel (928 + 60 vs 1250-1280 us
+    // for N = 256 at 256 crops / 64 x 64)
+    static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+    if (Wx3 && g.M >= x3_min_rows && (g.out || !pool_out)) {
+        GemmArgs gx = g;
+        gx.pool_out = nullptr;
+        if (gemm_bf16x3_takes(gx)) {
+            SUO_LAUNCH(launch_gemm_bf16x3_args(gx, reinterpret_cast<const uint16_t*>(Wx3), s));
+            if (pool_out) SUO_LAUNCH(launch_maxpool2(g.out, pool_out, L, H, W, g.N, s));
+            return SUO_OK;
+        }
+    }
     if (!pool_out) { SUO_LAUNCH(launch_gemm1x1(g, s)); return SUO_OK; }
     GemmArgs gp = g;
     gp.pool_out = pool_out; gp.pool_H = H; gp.pool_W = W;
@@ -419,11 +436,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     g1.A1 = x; g1.lda1 = r.cin; g1.K1 = r.c1.K1; g1.pro_scale = r.pro_scale; g1.pro_shift = r.pro_shift;
     g1.Wp = r.c1.Wp; g1.bias = r.c1.bias; g1.out = mid1; g1.ldo = r.c1.N; g1.M = M; g1.N = r.c1.N; g1.n_valid = r.c1.n_valid; g1.relu = 1;
     // large launches: on the bf16 pipe with 3-way split operands (464 vs 595 us at 256 crops / 64 x 64; below ~256 tiles the fp32 kernels' smaller tiles win)
-    static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
-    if (r.c1.Wx3 && M >= x3_min_rows && (size_t)M * r.cin * sizeof(float) < ((size_t)1 << 31))
-        SUO_LAUNCH(launch_gemm_bf16x3(x, r.cin, r.c1.K1, r.pro_scale, r.pro_shift, reinterpret_cast<const uint16_t*>(r.c1.Wx3), r.c1.bias, mid1, r.c1.N, M, 128, 1, s));
-    else
-    SUO_LAUNCH(launch_gemm1x1(g1, s));
+    SUO_TRY(gemm_maybe_pooled(g1, L, H, W, nullptr, s, r.c1.Wx3));
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
     c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
@@ -463,7 +476,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     if (r.has_skip_conv) { g3.A2 = x; g3.lda2 = r.cin; g3.K2 = r.c3.K2; }
     else { g3.R = x; g3.ldr = r.cin; }
     g3.Wp = r.c3.Wp; g3.bias = r.c3.bias; g3.out = out; g3.ldo = r.cout; g3.M = M; g3.N = r.c3.N; g3.n_valid = r.c3.n_valid;
-    return gemm_maybe_pooled(g3, L, H, W, pool_out, s);
+    return gemm_maybe_pooled(g3, L, H, W, pool_out, s, r.c3.Wx3);
 }
 
 // Hourglass.forward (hg.py:37-58).  The up1 branch is independent of the low branch until the
@@ -552,7 +565,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         GemmArgs gl = {};
         gl.A1 = rb; gl.lda1 = 256; gl.K1 = 256; gl.Wp = lin_[i].Wp; gl.bias = lin_[i].bias; gl.out = ll; gl.ldo = 256;
         gl.M = M; gl.N = 256; gl.n_valid = 256; gl.relu = 1;
-        SUO_LAUNCH(launch_gemm1x1(gl, s));
+        SUO_TRY(gemm_maybe_pooled(gl, L, 64, 64, nullptr, s, lin_[i].Wx3));
         GemmArgs gh = {};
         gh.A1 = ll; gh.lda1 = 256; gh.K1 = 256; gh.Wp = head_[i].Wp; gh.bias = head_[i].bias; gh.M = M; gh.N = 64;
         if (i == 0) {
@@ -563,7 +576,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
             gr.Wp = reinject_.Wp; gr.bias = reinject_.bias; gr.R = x; gr.ldr = 256; gr.out = xn; gr.ldo = 256;
             gr.M = M; gr.N = 256; gr.n_valid = 256;
             xp = alloc((size_t)L * 32 * 32 * 256);
-            SUO_TRY(gemm_maybe_pooled(gr, L, 64, 64, xp, s));
+            SUO_TRY(gemm_maybe_pooled(gr, L, 64, 64, xp, s, reinject_.Wx3));
             x = xn;
         } else {
             gh.out = logits; gh.n_valid = NUM_KP; gh.nchw_hw = HEAT * HEAT;

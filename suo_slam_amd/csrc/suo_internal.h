@@ -89,6 +89,8 @@ int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float*
 int launch_render_priors(const float* uv, const uint8_t* mask, int L, float* out, hipStream_t s);
 // experimental: fp32-accurate 1x1 convolution on the bf16 matrix pipe (csrc/gemm_bf16x3.hip)
 void pack_gemm_weight_bf16x3(const float* W, int N, int K, uint16_t* out);
+bool gemm_bf16x3_takes(const GemmArgs& g);
+int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t s);
 int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
                        float* out, int ldo, int M, int N, int relu, hipStream_t s);
 // experimental: Winograd 3x3 with its products on the bf16 matrix pipe at fp32 accuracy (csrc/conv_wino_x3.hip); ConvArgs.Wp = packed uint16

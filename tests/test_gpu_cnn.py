@@ -736,6 +736,43 @@ def test_fused_kernels_on_random_shapes(ops):
             assert torch.equal(gu, got + low.repeat_interleave(2, 1).repeat_interleave(2, 2)), ("wino tail up", L, H, W)
 
 
+@pytest.mark.parametrize("M,K1,K2,N,res,relu", [(4096, 256, 0, 256, False, 1), (128 * 9 + 77, 128, 128, 256, False, 0), (5000, 256, 0, 256, True, 0),
+                                                 (1000, 64, 64, 128, False, 0), (4096, 128, 128, 256, True, 1)])
+def test_bf16x3_gemm_general_form(ops, M, K1, K2, N, res, relu):
+    """suo_conv1x1_bf16x3_ex (csrc/gemm_bf16x3.hip; what the network launches for lin, the re-injection and conv3 + conv4 at 64x64): N = 256 as two
+    column tiles, a second K segment on a second operand, the residual operand; within 5e-6 of fp64 and of the fp32-pipe kernel on the same inputs."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(M + K1 + N)
+    K = K1 + K2
+    w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
+    w3 = np.empty(3 * N * K, np.uint16)
+    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
+    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    a1 = rng.standard_normal((M, K1)).astype(np.float32) * 2
+    a2 = rng.standard_normal((M, K2)).astype(np.float32) if K2 else None
+    r = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    a1d, bd = ops.dev(a1), ops.dev(b)
+    a2d = ops.dev(a2) if K2 else None
+    rd = ops.dev(r) if res else None
+    out = torch.full((M + 3, N), -5.0, device="cuda")
+    _lib.check(lib.suo_conv1x1_bf16x3_ex(ops.P(a1d), K1, K1, None, None, ops.P(a2d), K2, K2, ops.P(w3d), ops.P(bd), ops.P(rd), N, ops.P(out), N, M, N, relu, ops.S()))
+    torch.cuda.synchronize()
+    ref = a1.astype(np.float64) @ w[:, :K1].astype(np.float64).T + b
+    if K2:
+        ref = ref + a2.astype(np.float64) @ w[:, K1:].astype(np.float64).T
+    if res:
+        ref = ref + r
+    if relu:
+        ref = np.maximum(ref, 0)
+    got = out.cpu().numpy()
+    assert np.abs(got[:M] - ref).max() < 5e-6 * np.abs(ref).max()
+    assert (got[M:] == -5.0).all()
+    f32 = ops.conv1x1(a1d, w[:, :K1], b, a2=a2d, w2=w[:, K1:] if K2 else None, res=rd, relu=bool(relu)).cpu().numpy()
+    assert np.abs(got[:M] - f32).max() < 5e-6 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("K", [256, 128, 64])
 def test_bf16x3_gemm_is_fp32_accurate(ops, K):
     """csrc/gemm_bf16x3.hip (what the network launches for conv1 of its Residual blocks at >= 32768 pixels): the 1x1 convolution on the bf16 matrix pipe with both operands
