@@ -10,7 +10,6 @@
 // staging, same two-step output transform (rows xi = 0, 3 accumulate straight into Z, rows 1, 2 through a scratch accumulator and 16
 // vector additions per chunk), same epilogues -- the accumulator layout of the bf16 MFMA is that of the fp32 one, so the fused
 // Residual tail (conv3 1x1 + skip [+ up-sampled addend], kept on the fp32 pipe) is taken over unchanged.
-#include <stdlib.h>
 #include <string.h>
 
 #include "buffer_ops.h"
@@ -556,8 +555,6 @@ int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
         suo_set_error("conv3x3_wino_x3: unsupported shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;
     }
-    static const int persist = getenv("SUO_WX3_PERSIST") ? atoi(getenv("SUO_WX3_PERSIST")) : 0;      // experiment: csrc/conv_wino_x3p.hip
-    if (persist) return launch_conv3x3_wino_x3p(a, s);
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
     hipLaunchKernelGGL((wino3x3_x3_kernel<false>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
