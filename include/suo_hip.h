@@ -156,6 +156,9 @@ int suo_conv3x3_conv1x1_skip(const float* in_dev, int L, int H, int W, const flo
 int suo_pack_wino_weight_bf16x3(const float* w, int N, int C, uint16_t* out);
 int suo_conv3x3_wino_x3(const float* in_dev, int L, int H, int W, const uint16_t* wq3_dev, const float* bias_dev, float* out_dev, int relu,
                         void* stream);
+/* the same with channels = 128 or 64 (64 -> 64: the first two Residual blocks; wq3 = suo_pack_wino_weight_bf16x3(w, 64, 64, ...)) */
+int suo_conv3x3_wino_x3_n(const float* in_dev, int L, int H, int W, int channels, const uint16_t* wq3_dev, const float* bias_dev, float* out_dev,
+                          int relu, void* stream);
 /* wp3_dev: conv3 weight packed by suo_pack_gemm_weight (tail_bf16x3 = 0: conv3 on the fp32 pipe) or by suo_pack_tail_weight_bf16x3
  * (tail_bf16x3 = 1: W3[256][128] -> 3 * 256 * 128 uint16, conv3 on the bf16 pipe as well). */
 int suo_pack_tail_weight_bf16x3(const float* w3, int N2, int K, uint16_t* out);

@@ -203,10 +203,14 @@ int suo_pack_wino_weight_bf16x3(const float* w, int N, int C, uint16_t* out) {
     return SUO_OK;
 }
 
-int suo_conv3x3_wino_x3(const float* in, int L, int H, int W, const uint16_t* wq3, const float* bias, float* out, int relu, void* stream) {
+int suo_conv3x3_wino_x3_n(const float* in, int L, int H, int W, int channels, const uint16_t* wq3, const float* bias, float* out, int relu, void* stream) {
     suo::ConvArgs c = {};
-    c.in = in; c.L = L; c.H = H; c.W = W; c.C = 128; c.Wp = (const float*)wq3; c.bias = bias; c.out = out; c.OH = H; c.OW = W; c.N = 128; c.relu = relu;
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = channels; c.Wp = (const float*)wq3; c.bias = bias; c.out = out; c.OH = H; c.OW = W; c.N = channels; c.relu = relu;
     return suo::launch_conv3x3_wino_x3(c, (hipStream_t)stream);
+}
+
+int suo_conv3x3_wino_x3(const float* in, int L, int H, int W, const uint16_t* wq3, const float* bias, float* out, int relu, void* stream) {
+    return suo_conv3x3_wino_x3_n(in, L, H, W, 128, wq3, bias, out, relu, stream);
 }
 
 int suo_pack_tail_weight_bf16x3(const float* w3, int N2, int K, uint16_t* out) {

@@ -89,8 +89,12 @@ void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out) {
         }
 }
 
-template <bool FUSE, bool UP = false, bool TX3 = false>
+// NT = output channels / 32: 4 (128 channels: wave w owns n-tile w and all 16 components) or 2 (64 -> 64 channels: wave (wc, wn) owns n-tile wn and
+// the 8 components of rows xi = 2 wc, 2 wc + 1 -- one accumulator each, no fold; the two halves meet through LDS before the epilogue, as in
+// csrc/conv_wino.hip).
+template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
+    static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
     // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
     constexpr int HSZ = X_NPIX * X_PKH;                       // floats per halo buffer
     constexpr int VROW = 16;                                  // bf16 per (tile, chunk) row = 32 bytes; the two 16-byte halves swap for tiles 8-15 / 24-31
@@ -143,7 +147,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     // (128 output channels: NB = 4 n-tiles; the plane offset rides in the instruction's immediate field, one scalar addition per component;
     // past the last chunk the descriptor's range check returns zeros -- those prefetches are never consumed)
     const int wvoff = lane * 16;
-    const int wsbase = w * 3 * 1024;
+    const int wn = NT == 4 ? w : (w & 1), wc = NT == 4 ? 0 : (w >> 1);      // n-tile, component half
+    constexpr int NPAIR = NT == 4 ? 8 : 4;                      // component pairs per chunk and wave
+    const int wsbase = wn * 3 * 1024;
     auto bload = [&](int gc, x_u32x4 (&b)[3]) {               // gc = chunk * 16 + comp
 #ifdef SUO_WX3_EXP_W0
         const int g = gc & 1;                                 // timing experiment (wrong results): weights from two cache-resident groups
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int g = gc;
 #endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (4 * 3 * 1024) + wsbase));
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (NT * 3 * 1024) + wsbase));
     };
     // ---- transform: thread = (tile tt, channel quad tq, half th) as in csrc/conv_wino.hip; every result vector is split on its way to LDS ----
     const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;
@@ -244,7 +250,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     // are requested before pair p's MFMAs.  Measured alternatives, all slower (tools/bench_wino_x3.py, 256 crops, plain / fused, us):
     // this schedule 920 / 1620; the two accumulation chains of a pair interleaved 1030 / 1800; one component at a time with the A
     // fragments one and the weights one / three components ahead 943 / 1690 and 1052 / 1825.
-    auto comp_of = [&](int pair, int which) -> int { return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4)); };
+    auto comp_of = [&](int pair, int which) -> int {
+        if (NT == 4) return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4));
+        return wc * 8 + 2 * pair + which;                     // (64-channel form: the wave's own half, in order)
+    };
     // A operand of component comp: tile = lane & 31, channels 8 (lane >> 5) .. + 7 (the half, swapped for tiles 8-15 / 24-31)
     const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ ((lane >> 3) & 1)) * 8);
     x_u32x4 bring[2][2][3];                                   // [slot][which][plane]
@@ -274,10 +283,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         x_u32x4 keepa[3];
 #endif
 #pragma unroll
-        for (int pair = 0; pair < 8; ++pair) {
+        for (int pair = 0; pair < NPAIR; ++pair) {
             const int slot = pair & 1;
             {   // next pair (of this chunk, or pair 0 of the next one)
-                const int np = pair + 1 < 8 ? pair + 1 : 0, nc = pair + 1 < 8 ? c : c + 1;
+                const int np = pair + 1 < NPAIR ? pair + 1 : 0, nc = pair + 1 < NPAIR ? c : c + 1;
                 bload(nc * 16 + comp_of(np, 0), bring[slot ^ 1][0]);
                 bload(nc * 16 + comp_of(np, 1), bring[slot ^ 1][1]);
             }
@@ -295,7 +304,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (pair < 4) {                                   // accumulate into their own Z, no scratch, no additions
+            if (NT == 2) {                                    // Z[local component]
+                mac6(Z[2 * pair], afa, bring[slot][0], false);
+                mac6(Z[2 * pair + 1], afb, bring[slot][1], false);
+            } else if (pair < 4) {                            // accumulate into their own Z, no scratch, no additions
                 mac6(Z[pair], afa, bring[slot][0], false);
                 mac6(Z[4 + pair], afb, bring[slot][1], false);
             } else {
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #ifdef SUO_WX3_PROF
     if (blockIdx.x == 1000 && (tid & 63) == 0) printf("wave %d cycles: transform %lld  barrier1 %lld  sstore %lld  mfma+fold %lld  barrier2 %lld\n", w, pt[0], pt[1], pt[2], pt[3], pt[4]);
 #endif
-    // second step of the output transform: Y[i][j] = sum_nu A^T[j][nu] Z[4 i + nu]
+    // second step of the output transform: R[h][j] = sum_nu A^T[j][nu] Z[4 h + nu].  128-channel form: h = i, R = Y; 64-channel form: h = the wave's local row
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         out[2 * h] = Z[4 * h] + Z[4 * h + 1] + Z[4 * h + 2];
@@ -524,6 +536,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         return;
     }
 
+    if constexpr (NT == 2) {
+        // the two component halves of an n-tile meet.  Wave wc = 0 holds rows xi = 0, 1 (out[0..1] = R of row 0, out[2..3] = R of row 1), wave wc = 1
+        // rows xi = 2, 3 (row 3 negated in the weights).  Y[0][j] = R0 + R1 + R2, Y[1][j] = R1 - R2 + R3': wave wc keeps output row i = wc and
+        // hands its MIDDLE row (1 or 2) to the partner through LDS ([position][register][lane]: conflict-free).
+        float* X = &S[2 * HSZ];                                // (the last chunk's closing barrier has passed: V is free)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[((w * 2 + q) * 16 + r) * 64 + lane] = wc == 0 ? out[2 + q][r] : out[q][r];
+        __syncthreads();
+        const int pw = (1 - wc) * 2 + wn;
+        x_f32x16 mine[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[q][r] = (wc == 0 ? out[q][r] + out[2 + q][r] : out[2 + q][r] - out[q][r]) + X[((pw * 2 + q) * 16 + r) * 64 + lane];
+        __syncthreads();                                      // the exchange area becomes the transposition patches
+        float* T = &S[2 * HSZ] + w * (32 * 36);
+        const int col = wn * 32 + (lane & 7) * 4;
+        const x_f32x4 bv = *(const x_f32x4*)(a.bias + col);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = 2 * wc + q, pi = p >> 1, pj = p & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[x_acc_row(r, lane) * 36 + (lane & 31)] = mine[q][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = (lane >> 3) + 8 * k;
+                const int oy = oy0 + 2 * (t >> 3) + pi, ox = ox0 + 2 * (t & 7) + pj;
+                x_f32x4 o = *(const x_f32x4*)&T[t * 36 + (lane & 7) * 4] + bv;
+                if (a.relu) {
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) o[z] = fmaxf(o[z], 0.f);
+                }
+                buf_store(o, out_srd, (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * a.N + col) * 4 : BUF_OOB);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+
     // ---- epilogue (plain convolution): per output position transpose the 32 tiles x 32 channels through a wave-private patch -> 16-byte stores
     float* T = &S[2 * HSZ] + w * (32 * 36);
     const int col = w * 32 + (lane & 7) * 4;
@@ -551,6 +606,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 
 // a.Wp = weights packed by pack_wino_weight_bf16x3 (uint16 under a float pointer); 128 -> 128 channels only
 int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
+    if (a.OH == a.H && a.OW == a.W && a.N == 64 && a.C == 64) {
+        const int tiles64 = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
+        hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2>), dim3(tiles64), dim3(256), 0, s, a);
+        SUO_HIP_CHECK(hipGetLastError());
+        return SUO_OK;
+    }
     if (a.OH != a.H || a.OW != a.W || a.N != 128 || a.C != 128) {
         suo_set_error("conv3x3_wino_x3: unsupported shape H=%d W=%d C=%d N=%d", a.H, a.W, a.C, a.N);
         return SUO_ERR_ARG;

@@ -199,7 +199,7 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
         std::vector<float> wq((size_t)16 * N * C);
         pack_wino_weight(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), wq.data());
         c.Wq = upload(wq);
-        if (N == 128 && wino_bf16x3()) {                      // the same on the bf16 pipe at fp32 accuracy (csrc/conv_wino_x3.hip)
+        if (wino_bf16x3()) {                                  // the same on the bf16 pipe at fp32 accuracy (csrc/conv_wino_x3.hip; 128 -> 128 and 64 -> 64)
             std::vector<float> wq3((size_t)3 * 16 * N * C / 2);                  // uint16 planes
             pack_wino_weight_bf16x3(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), reinterpret_cast<uint16_t*>(wq3.data()));
             c.Wq3 = upload(wq3);

@@ -175,8 +175,9 @@ def conv3x3_wino_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc):
 def _pack_x3(w2, w3=None):
     lib = _lib.lib()
     w2 = np.ascontiguousarray(w2, np.float32)
-    q = np.empty(3 * 16 * 128 * 128, np.uint16)
-    _lib.check(lib.suo_pack_wino_weight_bf16x3(w2.ctypes.data, 128, 128, q.ctypes.data), "pack_wino_x3")
+    n = w2.shape[0]
+    q = np.empty(3 * 16 * n * n, np.uint16)
+    _lib.check(lib.suo_pack_wino_weight_bf16x3(w2.ctypes.data, n, n, q.ctypes.data), "pack_wino_x3")
     wq3 = torch.from_numpy(q.view(np.int16)).cuda()
     if w3 is None:
         return wq3
@@ -189,10 +190,10 @@ def _pack_x3(w2, w3=None):
 def conv3x3_wino_x3(x_nhwc, w, bias, relu=False):
     """csrc/conv_wino_x3.hip: the Winograd 3x3 convolution (128 -> 128) on the bf16 matrix pipe with 3-way split operands."""
     L, H, W, C = x_nhwc.shape
-    assert C == 128 and w.shape == (128, 128, 3, 3)
+    assert C in (128, 64) and w.shape == (C, C, 3, 3)
     wq3, b = _pack_x3(w), dev(bias)
-    out = torch.empty((L, H, W, 128), device="cuda")
-    _lib.check(_lib.lib().suo_conv3x3_wino_x3(P(x_nhwc), L, H, W, P(wq3), P(b), P(out), int(relu), S()), "suo_conv3x3_wino_x3")
+    out = torch.empty((L, H, W, C), device="cuda")
+    _lib.check(_lib.lib().suo_conv3x3_wino_x3_n(P(x_nhwc), L, H, W, C, P(wq3), P(b), P(out), int(relu), S()), "suo_conv3x3_wino_x3_n")
     torch.cuda.synchronize()
     return out
 

@@ -211,16 +211,19 @@ def test_fused_winograd_residual_tail_equals_the_separate_launches(ops, L, H, W)
         assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
 
 
-@pytest.mark.parametrize("L,H,W,scale", [(2, 64, 64, 1.0), (3, 40, 40, 1.0), (128, 16, 16, 1.0), (5, 24, 56, 1.0), (1, 8, 16, 1.0), (2, 64, 64, 1e-12), (2, 32, 32, 1e9)])
-def test_conv3x3_winograd_bf16x3_is_fp32_accurate(ops, L, H, W, scale):
+@pytest.mark.parametrize("L,H,W,scale,C", [(2, 64, 64, 1.0, 128), (3, 40, 40, 1.0, 128), (128, 16, 16, 1.0, 128), (5, 24, 56, 1.0, 128), (1, 8, 16, 1.0, 128),
+                                            (2, 64, 64, 1e-12, 128), (2, 32, 32, 1e9, 128), (2, 128, 128, 1.0, 64), (3, 40, 72, 1.0, 64), (1, 8, 16, 1.0, 64),
+                                            (40, 64, 64, 1.0, 64)])
+def test_conv3x3_winograd_bf16x3_is_fp32_accurate(ops, L, H, W, scale, C):
     """csrc/conv_wino_x3.hip (what the network launches for its 128 -> 128 3x3 convolutions): the Winograd products on the BF16 matrix pipe,
     both operands split into three bf16 terms (truncation, exact residuals), 6 of the 9 cross terms accumulated in fp32.  Same bound as the
-    fp32-pipe kernel (5e-6 of the output range against fp64; observed 4e-7), ragged maps, a single tile, tiny and huge magnitudes (bf16 has
+    fp32-pipe kernel (5e-6 of the output range against fp64; observed 4e-7), ragged maps, a single tile, the 64 -> 64 form (components split over wave
+    pairs), tiny and huge magnitudes (bf16 has
     fp32's exponent range: the split must not lose the small terms), per-crop check against stray stores."""
     rng = np.random.default_rng(L * H + W)
-    x = (rng.standard_normal((L, 128, H, W)) * scale).astype(np.float32)
-    w = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
-    b = (rng.standard_normal(128) * scale).astype(np.float32)
+    x = (rng.standard_normal((L, C, H, W)) * scale).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    b = (rng.standard_normal(C) * scale).astype(np.float32)
     out = ops.nchw(ops.conv3x3_wino_x3(ops.nhwc(x), w, b, relu=True))
     ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)).numpy()
     assert _rel(out, ref) < 5e-6
