@@ -136,6 +136,11 @@ int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scal
 int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev,
                           int lda2, int K2, const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo,
                           int M, int N, int relu, void* stream);
+/* ... with the 2x2 max-pool of the result written as well (suo_conv1x1_pool's contract: the M pixels are images of H x W, W a multiple of 64, H even;
+ * pool_out_dev is [M/4, ldo]; out_dev may be NULL when only the pooled tensor is wanted). */
+int suo_conv1x1_bf16x3_pool(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev,
+                            int lda2, int K2, const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo,
+                            int M, int N, int relu, int H, int W, float* pool_out_dev, void* stream);
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);

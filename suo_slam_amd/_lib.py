@@ -47,6 +47,7 @@ SIGNATURES = {
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_pack_gemm_weight_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "suo_conv1x1_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "suo_conv1x1_bf16x3_pool": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "suo_conv1x1_bf16x3_ex": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_conv_kxk": (C.c_int, [C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, C.c_int, VP]),
     "suo_pack_wino_weight_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, VP]),

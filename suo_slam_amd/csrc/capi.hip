@@ -100,13 +100,21 @@ int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scal
     return suo::launch_gemm_bf16x3(a_dev, lda, K, pro_scale_dev, pro_shift_dev, wp3_dev, bias_dev, out_dev, ldo, M, N, relu, (hipStream_t)stream);
 }
 
-int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
-                          const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, void* stream) {
-    if (!a1_dev || !wp3_dev || !out_dev) { suo_set_error("suo_conv1x1_bf16x3_ex: null argument"); return SUO_ERR_ARG; }
+int suo_conv1x1_bf16x3_pool(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                            const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu,
+                            int H, int W, float* pool_out_dev, void* stream) {
+    if (!a1_dev || !wp3_dev || (!out_dev && !pool_out_dev)) { suo_set_error("suo_conv1x1_bf16x3: null argument"); return SUO_ERR_ARG; }
     suo::GemmArgs g = {};
     g.A1 = a1_dev; g.lda1 = lda1; g.K1 = K1; g.pro_scale = pro_scale_dev; g.pro_shift = pro_shift_dev; g.A2 = a2_dev; g.lda2 = lda2; g.K2 = K2;
     g.bias = bias_dev; g.R = r_dev; g.ldr = ldr; g.out = out_dev; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = N; g.relu = relu;
+    g.pool_out = pool_out_dev; g.pool_H = H; g.pool_W = W;
     return suo::launch_gemm_bf16x3_args(g, wp3_dev, (hipStream_t)stream);
+}
+
+int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                          const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, void* stream) {
+    return suo_conv1x1_bf16x3_pool(a1_dev, lda1, K1, pro_scale_dev, pro_shift_dev, a2_dev, lda2, K2, wp3_dev, bias_dev, r_dev, ldr, out_dev, ldo, M, N, relu, 0, 0,
+                                   nullptr, stream);
 }
 
 int suo_upload(void* dst_dev, const void* src_pinned_host, size_t bytes, void* stream) {

@@ -72,7 +72,10 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 //   * vmcnt retires in order, so a request can only be waited for once everything issued before it has landed: both streams are requested
 //     the same X3_LEAD k-steps ahead (an activation load from HBM issued just before a "nearer" weight load would stall that one);
 //   * epilogue: accumulators transposed through a wave-private LDS patch, bias (+ ReLU) and stores on 16-byte vectors.
-template <bool PRO, bool DUAL, bool RES>
+// POOL: the result's 2x2 max-pool (nn.MaxPool2d(2, 2)) written as well (or only: g.out may be null).  The tile is then two image rows x 64 columns
+// (row r of the tile = pixel (y0 + (r >> 6), x0 + (r & 63))): the horizontal maximum is a lane exchange (rows j, j + 1 sit 8 lanes apart), the vertical
+// one meets through LDS (image row 0 belongs to the waves wm = 0, row 1 to wm = 1).
+template <bool PRO, bool DUAL, bool RES, bool POOL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
     constexpr int PLANE = X3_BM * X3_PITCH;                                   // bf16 elements of one plane
     __shared__ __attribute__((aligned(16))) uint16_t S[2][3 * PLANE];         // [stage][plane][row][pitch] = 36 864 bytes (the epilogue re-uses it)
@@ -88,7 +91,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order
     const int ntn = g.N >> 7, NBT = g.N >> 5;
-    const int tn = bid % ntn, m0 = (bid / ntn) * X3_BM;
+    const int tn = bid % ntn, mt = bid / ntn, m0 = mt * X3_BM;
+    // pixel (row of the operands) of tile row r
+    int pool_base = 0;                                                        // POOL: pixel of tile row 0; tile row r -> pool_base + (r >> 6) * W + (r & 63)
+    if (POOL) {
+        const int tpr = g.pool_W >> 6, tpc = (g.pool_H >> 1) * tpr;           // tiles per image row pair, per crop
+        const int l = mt / tpc, rr = mt - l * tpc, yp = rr / tpr, xb = rr - yp * tpr;
+        pool_base = (l * g.pool_H + 2 * yp) * g.pool_W + 64 * xb;
+    }
+    auto pixel_of = [&](int r) -> int { return POOL ? pool_base + (r >> 6) * g.pool_W + (r & 63) : m0 + r; };
     const int ns1 = g.K1 / X3_BK, nsteps = K / X3_BK;
     const __amdgpu_buffer_rsrc_t a1_srd = make_srd(g.A1, (size_t)M * g.lda1 * sizeof(float));
     const __amdgpu_buffer_rsrc_t a2_srd = make_srd(DUAL ? g.A2 : g.A1, DUAL ? (size_t)M * g.lda2 * sizeof(float) : 0);
@@ -98,11 +109,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     int avoff1[2], avoff2[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = m0 + 64 * i + ar;
+        const int row = pixel_of(64 * i + ar);
         avoff1[i] = row < M ? (row * g.lda1 + 4 * aq) * 4 : BUF_OOB;          // rows past M read zeros (and the prologue's result is zeroed below)
         avoff2[i] = DUAL && row < M ? (row * g.lda2 + 4 * aq) * 4 : BUF_OOB;
     }
-    const bool rok[2] = {m0 + ar < M, m0 + 64 + ar < M};
+    const bool rok[2] = {pixel_of(ar) < M, pixel_of(64 + ar) < M};
     const int wvoff = lane * 16;
     x3_f32x4 araw[X3_LEAD + 1][2];
     x3_u32x4 braw[X3_LEAD + 1][2][3];
@@ -217,7 +228,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     __syncthreads();                                                          // the stages are free: the epilogue's patches live there
     float* T = reinterpret_cast<float*>(&S[0][0]) + w * (32 * 36);
-    const __amdgpu_buffer_rsrc_t o_srd = make_srd(g.out, (size_t)M * ldo * sizeof(float));
+    x3_f32x4* PX = reinterpret_cast<x3_f32x4*>(reinterpret_cast<float*>(&S[0][0]) + 4 * 32 * 36);      // POOL: 16 KB behind the four patches
+    x3_f32x4 hold[POOL ? 2 : 1][POOL ? 2 : 1][POOL ? 4 : 1];
+    const __amdgpu_buffer_rsrc_t o_srd = make_srd((POOL && !g.out) ? (float*)g.pool_out : g.out, (POOL && !g.out) ? 0 : (size_t)M * ldo * sizeof(float));
     const __amdgpu_buffer_rsrc_t r_srd = make_srd(RES ? g.R : g.out, RES ? (size_t)M * g.ldr * sizeof(float) : 0);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             if (RES) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int row = m0 + 64 * wm + 32 * rb + (lane >> 3) + 8 * k;
+                    const int row = pixel_of(64 * wm + 32 * rb + (lane >> 3) + 8 * k);
                     rv[k] = buf_load(r_srd, row < M ? (row * g.ldr + col) * 4 : BUF_OOB, 0);
                 }
             }
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int row = m0 + 64 * wm + 32 * rb + (lane >> 3) + 8 * k;
+                const int row = pixel_of(64 * wm + 32 * rb + (lane >> 3) + 8 * k);
                 x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv;
                 if (RES) o += rv[k];                                          // (bias, then the residual: the order of the fp32 kernels)
                 if (g.relu) {
@@ -249,19 +262,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #ifdef SUO_X3_EXP_NOSTORE
                 if (o[0] == 123456.f)
 #endif
-                buf_store(o, o_srd, row < M ? (row * ldo + col) * 4 : BUF_OOB);
+                if (!POOL || g.out) buf_store(o, o_srd, row < M ? (row * ldo + col) * 4 : BUF_OOB);
+                if (POOL) {
+                    x3_f32x4 hm;                                              // max over image columns j, j ^ 1 (8 lanes apart within a row of 16: row_ror:8)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        hm[q] = fmaxf(o[q], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(o[q]), 0x128, 0xf, 0xf, false)));
+                    if (wm == 0) hold[rb][cb][k] = hm;
+                    else if (!(lane & 8)) PX[(((wn * 2 + rb) * 2 + cb) * 4 + k) * 32 + (lane >> 4) * 8 + (lane & 7)] = hm;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
+    if (POOL) {
+        __syncthreads();
+        if (wm == 0 && !(lane & 8)) {
+            const __amdgpu_buffer_rsrc_t p_srd = make_srd(g.pool_out, (size_t)(M >> 2) * ldo * sizeof(float));
+            const int pw = g.pool_W >> 1;
+            const int prow0 = (pool_base / g.pool_W >> 1) * pw + ((pool_base % g.pool_W) >> 1);      // pooled pixel of tile row 0 (l * H / 2 + yp folded: H even)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = 32 * rb + (lane >> 3) + 8 * k;          // even: the pair (j, j + 1)
+                        const int col = 128 * tn + 64 * wn + 32 * cb + (lane & 7) * 4;
+                        const x3_f32x4 other = PX[(((wn * 2 + rb) * 2 + cb) * 4 + k) * 32 + (lane >> 4) * 8 + (lane & 7)];
+                        x3_f32x4 v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(hold[rb][cb][k][q], other[q]);
+                        buf_store(v, p_srd, ((prow0 + (j >> 1)) * ldo + col) * 4);
+                    }
+        }
+    }
 }
 
 // out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R ): N a multiple of 128, K1 and K2 multiples of 64 (K2 may be 0),
 // the prologue only without a second segment; Wx3 = pack_gemm_weight_bf16x3 of the row-concatenated [W1 | W2] (N rows, K1 + K2 columns)
 bool gemm_bf16x3_takes(const GemmArgs& g) {
     const size_t lim = (size_t)1 << 31;
-    return g.N > 0 && g.N % 128 == 0 && g.n_valid == g.N && g.K1 > 0 && g.K1 % 64 == 0 && g.K2 % 64 == 0 && g.K1 <= 512 && !g.nchw_hw && !g.pool_out && g.out &&
+    return g.N > 0 && g.N % 128 == 0 && g.n_valid == g.N && g.K1 > 0 && g.K1 % 64 == 0 && g.K2 % 64 == 0 && g.K1 <= 512 && !g.nchw_hw && (g.pool_out ? (g.pool_W % 64 == 0 && g.pool_H % 2 == 0 && g.M % (g.pool_H * g.pool_W) == 0) : g.out != nullptr) &&
            (!g.K2 || (!g.pro_scale && g.A2 && g.lda2 % 4 == 0)) && g.lda1 % 4 == 0 && g.ldo % 4 == 0 && (!g.R || g.ldr % 4 == 0) &&
-           ((g.pro_scale == nullptr) == (g.pro_shift == nullptr)) && (size_t)g.M * g.lda1 * 4 < lim && (size_t)g.M * g.ldo * 4 < lim &&
+           ((g.pro_scale == nullptr) == (g.pro_shift == nullptr)) && (size_t)g.M * g.lda1 * 4 < lim && (!g.out || (size_t)g.M * g.ldo * 4 < lim) &&
            (!g.K2 || (size_t)g.M * g.lda2 * 4 < lim) && (!g.R || (size_t)g.M * g.ldr * 4 < lim);
 }
 
@@ -271,7 +314,8 @@ int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t 
         return SUO_ERR_ARG;
     }
     const int tiles = ((g.M + X3_BM - 1) / X3_BM) * (g.N / 128);
-#define X3_LAUNCH(P_, D_, R_) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_>), dim3(tiles), dim3(256), 0, s, g, Wx3)
+#define X3_LAUNCH(P_, D_, R_) do { if (g.pool_out) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, true>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
+                                   else hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false>), dim3(tiles), dim3(256), 0, s, g, Wx3); } while (0)
     const bool res = g.R != nullptr;
     if (g.pro_scale) { if (res) X3_LAUNCH(true, false, true); else X3_LAUNCH(true, false, false); }
     else if (g.K2) { if (res) X3_LAUNCH(false, true, true); else X3_LAUNCH(false, true, false); }

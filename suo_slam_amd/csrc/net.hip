@@ -405,13 +405,14 @@ bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const 
 // when only the pooled tensor is wanted.
 int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const float* Wx3) {
     static const int fuse_pool = getenv("SUO_FUSE_POOL") ? atoi(getenv("SUO_FUSE_POOL")) : 1;                    // 0: A/B
-    // large launches with a bf16x3 form of the weights: on the bf16 pipe (csrc/gemm_bf16x3.hip), the pool as its own kernel (928 + 60 vs 1250-1280 us
-    // for N = 256 at 256 crops / 64 x 64)
+    // large launches with a bf16x3 form of the weights: on the bf16 pipe (csrc/gemm_bf16x3.hip)
     static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
-    if (Wx3 && g.M >= x3_min_rows && (g.out || !pool_out)) {
+    if (Wx3 && g.M >= x3_min_rows) {
         GemmArgs gx = g;
-        gx.pool_out = nullptr;
-        if (gemm_bf16x3_takes(gx)) {
+        gx.pool_out = pool_out; gx.pool_H = H; gx.pool_W = W;                  // the pool in the epilogue (maps of 64-column multiples), `out` optional
+        if (gemm_bf16x3_takes(gx)) { SUO_LAUNCH(launch_gemm_bf16x3_args(gx, reinterpret_cast<const uint16_t*>(Wx3), s)); return SUO_OK; }
+        gx.pool_out = nullptr;                                                // else the pool as its own launch
+        if (g.out && gemm_bf16x3_takes(gx)) {
             SUO_LAUNCH(launch_gemm_bf16x3_args(gx, reinterpret_cast<const uint16_t*>(Wx3), s));
             if (pool_out) SUO_LAUNCH(launch_maxpool2(g.out, pool_out, L, H, W, g.N, s));
             return SUO_OK;

@@ -776,6 +776,47 @@ def test_bf16x3_gemm_general_form(ops, M, K1, K2, N, res, relu):
     assert np.abs(got[:M] - f32).max() < 5e-6 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("L,H,W,K1,K2,N,res,want_full", [(3, 64, 64, 256, 0, 256, True, True), (2, 64, 64, 128, 128, 256, False, True), (1, 128, 128, 64, 64, 128, False, False),
+                                                          (2, 16, 64, 256, 0, 128, False, True)])
+def test_bf16x3_gemm_with_the_pool_in_its_epilogue(ops, L, H, W, K1, K2, N, res, want_full):
+    """suo_conv1x1_bf16x3_pool: tiles of two image rows x 64 columns, the 2x2 maximum taken in the epilogue (lane exchange + LDS) -- the full result (when asked
+    for) and the pooled one against fp64, the pooled one exactly the 2x2 maximum of the full one, nothing written elsewhere."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(H + K1 + N)
+    M, K = L * H * W, K1 + K2
+    w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
+    w3 = np.empty(3 * N * K, np.uint16)
+    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
+    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    a1 = rng.standard_normal((M, K1)).astype(np.float32)
+    a2 = rng.standard_normal((M, K2)).astype(np.float32) if K2 else None
+    r = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    a1d, bd = ops.dev(a1), ops.dev(b)
+    a2d = ops.dev(a2) if K2 else None
+    rd = ops.dev(r) if res else None
+    out = torch.full((M + 2, N), -5.0, device="cuda") if want_full else None
+    pooled = torch.full((M // 4 + 2, N), -7.0, device="cuda")
+    _lib.check(lib.suo_conv1x1_bf16x3_pool(ops.P(a1d), K1, K1, None, None, ops.P(a2d), K2, K2, ops.P(w3d), ops.P(bd), ops.P(rd), N, ops.P(out), N, M, N, 0,
+                                           H, W, ops.P(pooled), ops.S()))
+    torch.cuda.synchronize()
+    ref = a1.astype(np.float64) @ w[:, :K1].astype(np.float64).T + b
+    if K2:
+        ref = ref + a2.astype(np.float64) @ w[:, K1:].astype(np.float64).T
+    if res:
+        ref = ref + r
+    refp = ref.reshape(L, H // 2, 2, W // 2, 2, N).max(axis=(2, 4)).reshape(M // 4, N)
+    gp = pooled.cpu().numpy()
+    assert np.abs(gp[:M // 4] - refp).max() < 5e-6 * np.abs(ref).max()
+    assert (gp[M // 4:] == -7.0).all()
+    if want_full:
+        go = out.cpu().numpy()
+        assert np.abs(go[:M] - ref).max() < 5e-6 * np.abs(ref).max()
+        assert (go[M:] == -5.0).all()
+        np.testing.assert_array_equal(gp[:M // 4], go[:M].reshape(L, H // 2, 2, W // 2, 2, N).max(axis=(2, 4)).reshape(M // 4, N))
+
+
 @pytest.mark.parametrize("K", [256, 128, 64])
 def test_bf16x3_gemm_is_fp32_accurate(ops, K):
     """csrc/gemm_bf16x3.hip (what the network launches for conv1 of its Residual blocks at >= 32768 pixels): the 1x1 convolution on the bf16 matrix pipe with both operands
