@@ -1,4 +1,4 @@
-"""The experimental bf16x3 1x1 convolution (csrc/gemm_bf16x3.hip) against the fp32 MFMA kernel on the network's largest 1x1 shape
+"""The bf16x3 1x1 convolution (csrc/gemm_bf16x3.hip, what the network launches) against the fp32 MFMA kernel on the network's largest 1x1 shape
 (Residual.conv1: K 256 -> N 128, BN + ReLU prologue, + ReLU): error of both against fp64, and time.  python tools/bench_bf16x3.py [crops]"""
 import ctypes as C, os, sys
 import numpy as np, torch

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 # the fused Residual tail in Winograd form as the network launches it: bf16 pipe with 3-way split operands (default), or the fp32 pipe
 X3 = os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
-KERNEL = "wino3x3_x3_kernel<true,false,true>" if X3 else "wino3x3_kernel<true,4,false>"
+KERNEL = "wino3x3_x3_kernel<true,false,true,4>" if X3 else "wino3x3_kernel<true,4,false>"
 vals = {}
 for f in os.listdir(os.path.join(ROOT, "gpurun_out", "pmc")):
     if not f.endswith(".db"):
