@@ -262,6 +262,47 @@ def test_fused_winograd_bf16x3_residual_tail(ops, L, H, W, up, tail_x3):
         assert _rel(out[l:l + 1].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy()) < 5e-6
 
 
+def test_bf16x3_kernels_at_the_bench_launch_shape_size_independent_properties(ops):
+    """The bench's launch shape (256 crops x 64 x 64: 8192 workgroups, 1 M GEMM rows) is too big to check against fp64 on the host, so two
+    properties that hold EXACTLY stand in: (1) homogeneity under powers of two -- truncation splits commute with a scaling by 2^k, every
+    product and sum scales exactly, ReLU commutes with a positive factor: f(4 x; 4 b, 4 skip) == 4 f(x; b, skip) bit for bit; (2) crops are
+    independent -- the same crop at every position of the batch gives the same output at every position (stray indexing, tile order)."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(2026)
+    L, H, W = 256, 64, 64
+    one = rng.standard_normal((1, H, W, 128)).astype(np.float32)
+    skip1 = rng.standard_normal((1, H, W, 256)).astype(np.float32)
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    b2 = (rng.standard_normal(128) * 0.25).astype(np.float32)
+    w3 = (rng.standard_normal((256, 128)) / np.sqrt(128)).astype(np.float32)
+    b3 = rng.standard_normal(256).astype(np.float32)
+    x = torch.from_numpy(one).cuda().expand(L, H, W, 128).contiguous()
+    skip = torch.from_numpy(skip1).cuda().expand(L, H, W, 256).contiguous()
+    out = ops.conv3x3_wino_x3_conv1x1_skip_up(x, w2, b2, w3, b3, skip, None, tail_x3=True)
+    assert bool((out == out[0:1]).all())                                     # (2)
+    out4 = ops.conv3x3_wino_x3_conv1x1_skip_up(x * 4, w2, b2 * 4, w3, b3 * 4, skip * 4, None, tail_x3=True)
+    assert torch.equal(out4, out * 4)                                        # (1)
+    del out4, skip
+    # the conv1 GEMM at M = 1 048 576 with its prologue (scale a power of two too: the BN shift scales with the input)
+    K, N, M = 256, 128, L * H * W
+    w1 = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
+    w1x = np.empty(3 * N * K, np.uint16)
+    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w1.ctypes.data, N, K, w1x.ctypes.data))
+    w1d = torch.from_numpy(w1x.view(np.int16)).cuda()
+    a = out.reshape(M, 256)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32)).cuda()
+    sh = torch.from_numpy((rng.standard_normal(K) * 0.1).astype(np.float32)).cuda()
+    bias = torch.from_numpy((rng.standard_normal(N) * 0.1).astype(np.float32)).cuda()
+    o1, o2 = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+    _lib.check(lib.suo_conv1x1_bf16x3(ops.P(a), K, K, ops.P(sc), ops.P(sh), ops.P(w1d), ops.P(bias), ops.P(o1), N, M, N, 1, ops.S()))
+    a8, sh8, bias8 = a * 8, sh * 8, bias * 8
+    _lib.check(lib.suo_conv1x1_bf16x3(ops.P(a8), K, K, ops.P(sc), ops.P(sh8), ops.P(w1d), ops.P(bias8), ops.P(o2), N, M, N, 1, ops.S()))
+    torch.cuda.synchronize()
+    assert torch.equal(o2, o1 * 8)
+    assert bool((o1.reshape(L, H * W, N) == o1.reshape(L, H * W, N)[0:1]).all())
+
+
 @pytest.mark.parametrize("L,H,W", [(64, 64, 64), (9, 40, 56), (128, 16, 16)])
 def test_fused_tail_with_upsampled_addend_equals_tail_then_upsample_add(ops, L, H, W):
     """Hourglass "up1 + up2(low3)" (hg.py:56-58) folded into the last up1 block's fused tail: bit-identical to the fused tail
