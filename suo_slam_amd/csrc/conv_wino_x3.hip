@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
     // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
     constexpr int HSZ = X_NPIX * X_PKH;                       // floats per halo buffer
-    constexpr int VROW = 16;                                  // bf16 per (tile, chunk) row = 32 bytes; the two 16-byte halves swap for tiles 8-15 / 24-31
+    constexpr int VROW = 16;                                  // bf16 per (tile, chunk) row = 32 bytes; the two 16-byte halves swap where bits 2 and 3 of the tile differ (4-7, 8-11, 20-23, 24-27):
+                                                              // conflict-free A-fragment ds_read_b128, 2-way instead of 4-way on the transform's ds_write_b64
     constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
     constexpr int VFLOATS = 3 * VPL / 2;
     __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;
     const int t_ty = tt >> 3, t_tx = tt & 7;
     const int hbase = ((2 * t_ty + th) * X_IW + 2 * t_tx) * X_PKH + tq * 4;
-    // V element offset of (component 0, tile tt, channels 4 tq ..): row tt, half (tq >> 1) swapped for tiles 8-15 / 24-31, 4 bf16 = 8 bytes
-    const int vbase = tt * VROW + ((((tq >> 1) ^ ((tt >> 3) & 1)) * 8) + (tq & 1) * 4);
+    // V element offset of (component 0, tile tt, channels 4 tq ..): row tt, half (tq >> 1) swapped where bits 2, 3 of tt differ, 4 bf16 = 8 bytes
+    const int vbase = tt * VROW + ((((tq >> 1) ^ (((tt >> 2) ^ (tt >> 3)) & 1)) * 8) + (tq & 1) * 4);
     auto vstore = [&](int comp, x_f32x4 v) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -254,8 +255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if (NT == 4) return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4));
         return wc * 8 + 2 * pair + which;                     // (64-channel form: the wave's own half, in order)
     };
-    // A operand of component comp: tile = lane & 31, channels 8 (lane >> 5) .. + 7 (the half, swapped for tiles 8-15 / 24-31)
-    const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ ((lane >> 3) & 1)) * 8);
+    // A operand of component comp: tile = lane & 31, channels 8 (lane >> 5) .. + 7 (the half, swapped as the rows were written)
+    const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ (((lane >> 2) ^ (lane >> 3)) & 1)) * 8);
     x_u32x4 bring[2][2][3];                                   // [slot][which][plane]
     gload(0);
     bload(comp_of(0, 0), bring[0][0]);
