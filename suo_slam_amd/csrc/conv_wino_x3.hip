@@ -1,5 +1,6 @@
-// EXPERIMENTAL: the Winograd F(2x2,3x3) convolution of csrc/conv_wino.hip with its element-wise products on the BF16 matrix pipe at
-// fp32 accuracy (3-way operand split, 6 of 9 cross terms, fp32 accumulate: see csrc/gemm_bf16x3.hip for the arithmetic).
+// The Winograd F(2x2,3x3) convolution of csrc/conv_wino.hip with its element-wise products on the BF16 matrix pipe at fp32 accuracy (3-way
+// operand split, 6 of 9 cross terms, fp32 accumulate: see csrc/gemm_bf16x3.hip for the arithmetic) -- what the network launches for the
+// Residual blocks' 3x3 convolutions and fused tails (csrc/net.hip; SUO_WINO_BF16X3=0 keeps the fp32-pipe kernels).
 //
 //   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A
 // Per 16-channel chunk and Winograd component the product V_xi,nu (32 tiles x 16 channels) * U_xi,nu (16 channels x 32 outputs) is
@@ -9,7 +10,8 @@
 // output pixels = 32 Winograd tiles x 128 output channels, 4 waves, wave w owns output channels [32 w, 32 w + 32)), same halo
 // staging, same two-step output transform (rows xi = 0, 3 accumulate straight into Z, rows 1, 2 through a scratch accumulator and 16
 // vector additions per chunk), same epilogues -- the accumulator layout of the bf16 MFMA is that of the fp32 one, so the fused
-// Residual tail (conv3 1x1 + skip [+ up-sampled addend], kept on the fp32 pipe) is taken over unchanged.
+// Residual tail (conv3 1x1 + skip [+ up-sampled addend]) could be taken over unchanged (TX3 = false: conv3 on the fp32 pipe); the network uses
+// TX3 = true, conv3 on the bf16 pipe as well (two passes of 64 pixels: see the tail's comment).
 #include <string.h>
 
 #include "buffer_ops.h"

@@ -1,22 +1,14 @@
-// EXPERIMENTAL (not on the product path; bench.py reports it beside the fp32 line, never instead of it):
-// fp32-accurate 1x1 convolution on the bf16 matrix pipe by 3-way operand splitting.
+// fp32-accurate 1x1 convolution on the bf16 matrix pipe by 3-way operand splitting: what the network launches for its 1x1 convolutions with
+// 128 / 256 output channels at >= 32768 pixels (csrc/net.hip: gemm_maybe_pooled; SUO_WINO_BF16X3=0 keeps the fp32-pipe kernels).
 //
 // gfx950 runs fp32 MFMAs at the vector rate (157 TFLOP/s) and bf16 MFMAs 16x faster (2.5 PFLOP/s dense).  An fp32 number is exactly
 // the sum of three bf16 numbers (8 significand bits each: x0 = hi(x), x1 = hi(x - x0), x2 = hi(x - x0 - x1), every subtraction exact),
 // a bf16 x bf16 product is exact in fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32.  So
 //     x * w  =  sum over i + j <= 2 of x_i * w_j   +   O(2^-24 |x w|)            (6 of the 9 cross terms)
 // costs 6 bf16 MFMAs of K = 16 (6 x 32 = 192 cycles per SIMD) where the fp32 form needs 8 MFMAs of K = 2 (8 x 64 = 512 cycles): 2.67x
-// fewer matrix-pipe cycles per MAC at fp32 accuracy -- the only lever above the fp32-MFMA roof (DESIGN.md section 7).
-//
-// This file is the prototype VERDICT round 2 asked for, on the largest 1x1 shape of the network (Residual.conv1: BN + ReLU prologue,
-// K = 256 -> N = 128, + ReLU):  out[M, N] = relu( relu(A * scale + shift) W^T + bias ).
-//   * weights are split on the host (pack_gemm_weight_bf16x3) and packed per 32-wide K step as [plane][n][32] bf16;
-//   * activations are split while they are staged: global fp32 -> registers (prefetched one K step ahead) -> prologue -> truncation
-//     split (x & 0xffff0000 is the exact leading bf16 of x toward zero; the residuals keep the sign) -> three bf16 planes in LDS;
-//   * workgroup tile 128 x 128, four waves as 2 x 2 (64 x 64 each = 2 x 2 accumulators), K step 32 = 2 MFMA k-steps; the six terms
-//     of a k-step are issued smallest first;
-//   * 61 KB of LDS and < 256 registers: two workgroups per CU, so one workgroup's split phase (VALU + LDS writes, which cannot
-//     overlap its own MFMAs on this part) runs under the other's MFMA phase.
+// fewer matrix-pipe cycles per MAC at fp32 accuracy -- the only lever above the fp32-MFMA roof.
+//   out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R )  [and / or its 2x2 max-pool]
+// Kernel layout and the measurements behind it: the comment at gemm_bf16x3_kernel and DESIGN.md section 4 ("Measured, bf16 pipe").
 #include <stdlib.h>
 #include <string.h>
 
