@@ -790,7 +790,10 @@ def main():
             "metric": "frames/sec (obj-crops/sec) YCB-V 640x480 8-obj; ADD(-S) vs ref",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "n_ranks_seen": n_ranks_seen, "rccl_backend": rccl_backend,
+            "dtype": "f32", "dtype_note": ("fp32 tensors and fp32 accuracy end to end; the Residual blocks' 3x3 + tail and the large 1x1 convolutions form their products on "
+                                           "the bf16 matrix pipe from operands split into three bf16 terms (6 cross terms, fp32 accumulate): DESIGN.md section 4"
+                                           if wino_bf16x3_enabled() else "fp32 MFMA throughout (SUO_WINO_BF16X3=0)"),
+            "data": "synthetic", "n_ranks_seen": n_ranks_seen, "rccl_backend": rccl_backend,
             "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> H2D, RoI crop, hourglass keypoint "
                                    "CNN fp32, decode, masks, device-resident compaction -> batched PnP -> acceptance -> LM rounds [10,10,40,40], "
                                    "one read-back" % L,
