@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -103,11 +104,19 @@ def _world():
     return 0, 1
 
 
+def _collectives_forced():
+    """SUO_FORCE_COLLECTIVES=1: issue every collective even in a process group of ONE rank (where a SUM all-reduce is the identity and
+    is otherwise skipped) -- so that a single-GPU box executes the very calls an 8-GPU node will make: the RCCL communicator bring-up,
+    the in-place all-reduce of `lin` / `sch` / the `red[:3]` view, and their stream ordering against the phase kernels
+    (tests/test_gpu_rccl.py; bench.py's global_ba leg)."""
+    return os.environ.get("SUO_FORCE_COLLECTIVES", "0") not in ("", "0") and dist.is_available() and dist.is_initialized()
+
+
 def _reduce_(t):
     """In-place SUM all-reduce of an exchange buffer.  RCCL ("nccl") reduces the device tensor where it lies; with gloo (CPU
     tests; rehearsals with several ranks on one GPU) a device tensor is staged through the host."""
     rank, world = _world()
-    if world == 1:
+    if world == 1 and not _collectives_forced():
         return t
     if t.is_cuda and dist.get_backend() != "nccl":
         h = t.cpu()
@@ -122,7 +131,7 @@ def _allreduce(arr):
     """SUM all-reduce of a small host array (result assembly after the last round only)."""
     rank, world = _world()
     a = np.ascontiguousarray(arr, np.float64)
-    if world == 1:
+    if world == 1 and not _collectives_forced():
         return a.copy()
     t = torch.from_numpy(a.copy())
     if dist.get_backend() == "nccl":

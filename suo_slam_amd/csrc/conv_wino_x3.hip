@@ -5,7 +5,7 @@
 //   Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A
 // Per 16-channel chunk and Winograd component the product V_xi,nu (32 tiles x 16 channels) * U_xi,nu (16 channels x 32 outputs) is
 // EIGHT v_mfma_f32_32x32x2_f32 (8 x 64 = 512 pipe cycles) in the fp32 kernel and SIX v_mfma_f32_32x32x16_bf16 (6 x 32 = 192 cycles)
-// here: U is split on the host (fp64 transform, rounded once to fp32, then three truncated bf16 terms), V = B^T d B is computed in fp32
+// here: U is split on the host (fp64 transform, rounded once to fp32, then three round-to-nearest bf16 terms: csrc/bf16x3.h), V = B^T d B is computed in fp32
 // exactly as before and split by the transforming thread on its way to LDS (three bf16 planes, 49 KB).  Same workgroup tile (8 x 16
 // output pixels = 32 Winograd tiles x 128 output channels, 4 waves, wave w owns output channels [32 w, 32 w + 32)), same halo
 // staging, same two-step output transform (rows xi = 0, 3 accumulate straight into Z, rows 1, 2 through a scratch accumulator and 16
@@ -14,6 +14,7 @@
 // TX3 = true, conv3 on the bf16 pipe as well (two passes of 64 pixels: see the tail's comment).
 #include <string.h>
 
+#include "bf16x3.h"
 #include "buffer_ops.h"
 #include "suo_internal.h"
 
@@ -27,8 +28,6 @@ typedef __bf16 x_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ x_f32x16 x_mfma32(float a, float b, x_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int x_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-__device__ __forceinline__ unsigned x_pack_hi(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
-__device__ __forceinline__ float x_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
 // (Tried and dropped, tools/bench_wino_x3.py: forcing the transform / fold additions into v_pk_add_f32 (-30 % VALU instructions) or into
 // plain v_add_f32 changes nothing measurable; inline-asm VALU on MFMA results is unsafe -- hipcc's hazard recogniser does not see through it.)
@@ -39,7 +38,7 @@ __device__ __forceinline__ void x_sub16(x_f32x16& z, const x_f32x16& t) { z -= t
 
 constexpr int X_CK = 16, X_PKH = 20, X_TH = 8, X_TW = 16, X_IH = 10, X_IW = 18, X_NPIX = X_IH * X_IW;
 
-// host: U[n][c][comp] = (G g G^T)[xi][nu] in fp64 (BN scale folded in), rounded once to fp32, split into three truncated bf16 terms;
+// host: U[n][c][comp] = (G g G^T)[xi][nu] in fp64 (BN scale folded in), rounded once to fp32, split into three bf16 terms (csrc/bf16x3.h);
 //   Up3[chunk][comp][nb][plane][lane][e] = term `plane` of +-U[nb*32 + (lane&31)][chunk*16 + 8*(lane>>5) + e][comp]     (B operand of
 //   v_mfma_f32_32x32x16_bf16: lane l supplies k = 8 (l >> 5) .. + 7 of column l & 31); the components of row xi = 3 are stored negated
 void pack_wino_weight_bf16x3(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out) {
@@ -57,37 +56,23 @@ void pack_wino_weight_bf16x3(const float* W, int N, int C, int Np, int Cp, const
                 for (int j = 0; j < 4; ++j) U[i][j] = (Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2]) * sc;
             const int chunk = c / X_CK, cc = c % X_CK, nb = n / 32, lane = (cc / 8) * 32 + (n % 32), e = cc % 8;
             for (int comp = 0; comp < 16; ++comp) {
-                float x = (float)(comp >= 12 ? -U[comp >> 2][comp & 3] : U[comp >> 2][comp & 3]);
-                for (int p = 0; p < 3; ++p) {
-                    uint32_t u;
-                    memcpy(&u, &x, 4);
-                    u &= 0xffff0000u;
-                    float hi;
-                    memcpy(&hi, &u, 4);
-                    out[((((size_t)(chunk * 16 + comp) * NB + nb) * 3 + p) * 64 + lane) * 8 + e] = (uint16_t)(u >> 16);
-                    x -= hi;
-                }
+                uint16_t t[3];
+                s3_split_host((float)(comp >= 12 ? -U[comp >> 2][comp & 3] : U[comp >> 2][comp & 3]), t);
+                for (int p = 0; p < 3; ++p) out[((((size_t)(chunk * 16 + comp) * NB + nb) * 3 + p) * 64 + lane) * 8 + e] = t[p];
             }
         }
 }
 
-// host: conv3 weight W3[N2][K] (1x1) -> three truncated bf16 terms in B-operand order of v_mfma_f32_32x32x16_bf16:
+// host: conv3 weight W3[N2][K] (1x1) -> three bf16 terms (csrc/bf16x3.h) in B-operand order of v_mfma_f32_32x32x16_bf16:
 //   W3x[(ks * NB + nb) * 3 + plane][lane][e] = term `plane` of W3[nb*32 + (lane&31)][ks*16 + 8*(lane>>5) + e]
 void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out) {
     const int NB = N2 / 32;
     for (int n = 0; n < N2; ++n)
         for (int k = 0; k < K; ++k) {
             const int ks = k / 16, kk = k % 16, lane = (kk / 8) * 32 + (n % 32), e = kk % 8, nb = n / 32;
-            float x = W3[(size_t)n * K + k];
-            for (int p = 0; p < 3; ++p) {
-                uint32_t u;
-                memcpy(&u, &x, 4);
-                u &= 0xffff0000u;
-                float hi;
-                memcpy(&hi, &u, 4);
-                out[((((size_t)(ks * NB + nb) * 3 + p) * 64 + lane) * 8) + e] = (uint16_t)(u >> 16);
-                x -= hi;
-            }
+            uint16_t t[3];
+            s3_split_host(W3[(size_t)n * K + k], t);
+            for (int p = 0; p < 3; ++p) out[((((size_t)(ks * NB + nb) * 3 + p) * 64 + lane) * 8) + e] = t[p];
         }
 }
 
@@ -147,8 +132,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         }
     };
     // ---- weights: Up3[(chunk * 16 + comp)][nb][plane][lane][8 bf16]: 3 KB per (component, n-tile), three 16-byte loads per lane -----
-    // (128 output channels: NB = 4 n-tiles; the plane offset rides in the instruction's immediate field, one scalar addition per component;
-    // past the last chunk the descriptor's range check returns zeros -- those prefetches are never consumed)
+    // (128 output channels: NB = 4 n-tiles; the plane offset rides in the instruction's immediate field, one scalar addition per component.
+    // The group offset is the instruction's SCALAR offset, which raw buffer loads do not range-check: every prefetch must name a group
+    // inside Wq3 -- the loop below re-requests the last chunk's first pair instead of running past the end.)
     const int wvoff = lane * 16;
     const int wn = NT == 4 ? w : (w & 1), wc = NT == 4 ? 0 : (w >> 1);      // n-tile, component half
     constexpr int NPAIR = NT == 4 ? 8 : 4;                      // component pairs per chunk and wave
@@ -171,10 +157,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     auto vstore = [&](int comp, x_f32x4 v) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + vbase] = x_u32x2{x_pack_hi(v[0], v[1]), x_pack_hi(v[2], v[3])};
+            const unsigned q0 = s3_pack_rn(v[0], v[1]), q1 = s3_pack_rn(v[2], v[3]);       // round-to-nearest terms (csrc/bf16x3.h); p == 2: exact
+            *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + vbase] = x_u32x2{q0, q1};
 #ifndef SUO_WX3_EXP_NOSPLIT                                   // (timing experiment, wrong results: the three planes hold the same term)
             if (p < 2) {
-                v = x_sub4(v, x_f32x4{x_hi(v[0]), x_hi(v[1]), x_hi(v[2]), x_hi(v[3])});      // exact residual
+                v = x_sub4(v, x_f32x4{s3_lo(q0), s3_hi(q0), s3_lo(q1), s3_hi(q1)});        // exact residual
             }
 #endif
         }
@@ -288,8 +275,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
         for (int pair = 0; pair < NPAIR; ++pair) {
             const int slot = pair & 1;
-            {   // next pair (of this chunk, or pair 0 of the next one)
-                const int np = pair + 1 < NPAIR ? pair + 1 : 0, nc = pair + 1 < NPAIR ? c : c + 1;
+            {   // next pair (of this chunk, or pair 0 of the next one; after the last chunk pair 0 of that chunk again -- never consumed, but in range)
+                const int np = pair + 1 < NPAIR ? pair + 1 : 0, nc = pair + 1 < NPAIR ? c : (more ? c + 1 : c);
                 bload(nc * 16 + comp_of(np, 0), bring[slot ^ 1][0]);
                 bload(nc * 16 + comp_of(np, 1), bring[slot ^ 1][1]);
             }
@@ -344,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         // conv3 = 1x1, 128 -> 256.  The conv2 tile (128 pixels x 128 channels, in `out`: wave w holds channels [32 w, 32 w + 32) as 4 output
         // positions x 32 Winograd tiles) is the A operand; split into three bf16 planes it is 96 KB, so it goes through LDS in two halves of
         // 64 pixels: pass h = the output positions of pixel row parity h (image rows oy0 + 2 ty + h).  Per pass: every lane splits its 32
-        // values and stores the bf16 terms (the upper halves of the fp32 value and of its two exact residuals: ds_write_b16_d16_hi) into
+        // values and stores the bf16 terms (round-to-nearest of the value and of its two exact residuals: ds_write_b16_d16_hi) into
         // AP[plane][k-step][pixel m = 16 ty + x][16 channels] (A-operand order: 32-byte rows, the 16-byte halves swapped for pixels 8-15 of
         // every 16); barrier; wave w computes the 64 pixels x output channels [64 w, 64 w + 64) (2 x 2 accumulators, 8 k-steps x 24 MFMAs),
         // then its epilogue (transposition through a wave-private patch, + bias3 + skip [+ up], 16-byte stores).
@@ -386,8 +373,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                     const int off = sbase + (16 * (r >> 2) + 2 * (r & 3) + pj) * 32;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
-                        *reinterpret_cast<uint16_t*>(AP + p * PL_STRIDE + off) = (uint16_t)(__float_as_uint(v) >> 16);
-                        if (p < 2) v -= x_hi(v);
+                        const unsigned q = s3_pack_rn(v, v);              // both halves = rn(v): the store takes the upper one (ds_write_b16_d16_hi)
+                        *reinterpret_cast<uint16_t*>(AP + p * PL_STRIDE + off) = (uint16_t)(q >> 16);
+                        if (p < 2) v -= s3_hi(q);
                     }
                 }
             __syncthreads();

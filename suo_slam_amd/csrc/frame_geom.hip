@@ -258,6 +258,8 @@ int suo_frame_geom_launch(suo_frame_geom* c, int n_frames, const int* frame_firs
         max_obj = std::max(max_obj, m);
     }
     if (L <= 0 || L > c->max_crops) { suo_set_error("suo_frame_geom_launch: %d crops (context holds %d)", L, c->max_crops); return SUO_ERR_ARG; }
+    // fg_build_kernel is one wave per frame, a lane per crop: beyond 64 crops of one frame nothing would be written
+    if (max_obj > 64) { suo_set_error("suo_frame_geom_launch: %d objects in one frame (the chain takes 64 without LM, %d with)", max_obj, FG_MAX_OBJ); return SUO_ERR_ARG; }
     if (p->do_lm && max_obj > FG_MAX_OBJ) { suo_set_error("suo_frame_geom_launch: %d objects in one frame (the frame LM kernel takes %d)", max_obj, FG_MAX_OBJ); return SUO_ERR_ARG; }
     if (p->n_rounds < 0 || p->n_rounds > 4) { suo_set_error("suo_frame_geom_launch: n_rounds %d", p->n_rounds); return SUO_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;

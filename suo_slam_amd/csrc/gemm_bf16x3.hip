@@ -2,9 +2,9 @@
 // 128 / 256 output channels at >= 32768 pixels (csrc/net.hip: gemm_maybe_pooled; SUO_WINO_BF16X3=0 keeps the fp32-pipe kernels).
 //
 // gfx950 runs fp32 MFMAs at the vector rate (157 TFLOP/s) and bf16 MFMAs 16x faster (2.5 PFLOP/s dense).  An fp32 number is exactly
-// the sum of three bf16 numbers (8 significand bits each: x0 = hi(x), x1 = hi(x - x0), x2 = hi(x - x0 - x1), every subtraction exact),
+// the sum of three bf16 numbers (8 significand bits each: x0 = rn(x), x1 = rn(x - x0), x2 = x - x0 - x1, every subtraction exact: csrc/bf16x3.h),
 // a bf16 x bf16 product is exact in fp32, and v_mfma_f32_32x32x16_bf16 accumulates in fp32.  So
-//     x * w  =  sum over i + j <= 2 of x_i * w_j   +   O(2^-24 |x w|)            (6 of the 9 cross terms)
+//     x * w  =  sum over i + j <= 2 of x_i * w_j   +   O(2^-24 |x w|), either sign  (6 of the 9 cross terms)
 // costs 6 bf16 MFMAs of K = 16 (6 x 32 = 192 cycles per SIMD) where the fp32 form needs 8 MFMAs of K = 2 (8 x 64 = 512 cycles): 2.67x
 // fewer matrix-pipe cycles per MAC at fp32 accuracy -- the only lever above the fp32-MFMA roof.
 //   out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R )  [and / or its 2x2 max-pool]
@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "bf16x3.h"
 #include "buffer_ops.h"
 #include "suo_internal.h"
 
@@ -31,35 +32,24 @@ constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 16, X3_PITCH = 24;      // LDS r
 #endif
 constexpr int X3_LEAD = SUO_X3_LEAD;                                                // k-steps between a request and its use, for BOTH global streams
 
-// host: W[N][K] fp32 -> B-operand order of v_mfma_f32_32x32x16_bf16, split by truncation like the device does:
+// host: W[N][K] fp32 -> B-operand order of v_mfma_f32_32x32x16_bf16, split like the device does (csrc/bf16x3.h: round-to-nearest terms):
 //   out[((ks * NB + nb) * 3 + plane) * 64 + lane][e] = term `plane` of W[nb*32 + (lane&31)][ks*16 + 8*(lane>>5) + e]
 void pack_gemm_weight_bf16x3(const float* W, int N, int K, uint16_t* out) {
     const int NB = N / 32;
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
             const int ks = k / 16, kk = k % 16, lane = (kk / 8) * 32 + (n % 32), e = kk % 8, nb = n / 32;
-            float x = W[(size_t)n * K + k];
-            for (int p = 0; p < 3; ++p) {
-                uint32_t u;
-                memcpy(&u, &x, 4);
-                u &= 0xffff0000u;
-                float hi;
-                memcpy(&hi, &u, 4);
-                out[((((size_t)(ks * NB + nb) * 3 + p) * 64 + lane) * 8) + e] = (uint16_t)(u >> 16);
-                x -= hi;                                                       // exact
-            }
+            uint16_t t[3];
+            s3_split_host(W[(size_t)n * K + k], t);
+            for (int p = 0; p < 3; ++p) out[((((size_t)(ks * NB + nb) * 3 + p) * 64 + lane) * 8) + e] = t[p];
         }
 }
 
-__device__ __forceinline__ unsigned x3_pack_hi(float a, float b) {          // the leading bf16 of a (low half) and of b (high half)
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-__device__ __forceinline__ float x3_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // Workgroup = 128 rows x 128 columns, four waves as 2 x 2 (64 x 64 each = 2 x 2 accumulators), one 16-wide k-step per barrier.
 //   * activations: global fp32 (four adjacent lanes fetch the 64 contiguous bytes a row contributes to a k-step) -> registers -> prologue ->
-//     truncation split -> three bf16 planes in LDS (two stages) -> A fragments by ds_read_b128;
+//     round-to-nearest split (csrc/bf16x3.h) -> three bf16 planes in LDS (two stages) -> A fragments by ds_read_b128;
 //   * weights: host-split, B-operand order, straight from L2 into registers (the two waves of a column half read the same lines: L1);
 //   * vmcnt retires in order, so a request can only be waited for once everything issued before it has landed: both streams are requested
 //     the same X3_LEAD k-steps ahead (an activation load from HBM issued just before a "nearer" weight load would stall that one);
@@ -146,12 +136,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
+            unsigned q[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                *(u32x2*)&As[p * PLANE + (64 * i + ar) * X3_PITCH + 4 * aq] = u32x2{x3_pack_hi(x[4 * i], x[4 * i + 1]), x3_pack_hi(x[4 * i + 2], x[4 * i + 3])};
+            for (int j = 0; j < 4; ++j) q[j] = s3_pack_rn(x[2 * j], x[2 * j + 1]);      // (p == 2: the conversion is exact)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *(u32x2*)&As[p * PLANE + (64 * i + ar) * X3_PITCH + 4 * aq] = u32x2{q[2 * i], q[2 * i + 1]};
             if (p < 2) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] -= x3_hi(x[e]);              // exact residual
+                for (int j = 0; j < 4; ++j) { x[2 * j] -= s3_lo(q[j]); x[2 * j + 1] -= s3_hi(q[j]); }      // exact residuals
             }
         }
     };

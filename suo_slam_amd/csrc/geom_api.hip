@@ -349,6 +349,21 @@ static int fetch_results(suo_ba_problem* probs, int n_prob, Arena& A, Staged& st
 
 static int optimize_phasewise(suo_ba_problem* q);
 
+// csrc/lm_frame2.hip takes one fixed camera, <= 16 objects, the edges that fit its LDS allotment, and -- its lanes keep their own edges'
+// outlier flags in a 32-bit mask -- at most 32 edges per lane: 32 * G per object, G = 8 lanes (<= 8 objects) or 4 (9-16)
+static bool frame2_takes(const suo_ba_problem& q) {
+    if (q.n_cam != 1 || q.n_obj < 1 || q.n_obj > 16 || q.n_edge > lm_frame2_max_edges()) return false;
+    int per_obj[16] = {0};
+    for (int e = 0; e < q.n_edge; ++e) {
+        const int o = q.edge_obj[e];
+        if (o < 0 || o >= q.n_obj) return false;
+        ++per_obj[o];
+    }
+    const int cap = 32 * (q.n_obj <= 8 ? 8 : 4);
+    for (int o = 0; o < q.n_obj; ++o) if (per_obj[o] > cap) return false;
+    return true;
+}
+
 int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     if (n_prob <= 0) return SUO_OK;
     if (!probs) { suo_set_error("suo_optimize_batch: null argument"); return SUO_ERR_ARG; }
@@ -399,7 +414,7 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         int nfc = 0;
         for (int c = 0; c < probs[i].n_cam; ++c) nfc += probs[i].cam_fixed[c] ? 0 : 1;
         // (one wave per object takes <= SUO_LM_FRAME objects: the 16-wave build spills; one wave per frame takes 16)
-        const bool f2 = (getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1) != 0 && probs[i].n_cam == 1 && probs[i].n_edge <= lm_frame2_max_edges();
+        const bool f2 = (getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1) != 0 && frame2_takes(probs[i]);
         frame_only = nfc == 0 && probs[i].n_obj >= 1 && probs[i].n_obj <= (f2 ? 16 : frame_kernel) && probs[i].n_obj <= 16;
         frame_max_obj = std::max(frame_max_obj, probs[i].n_obj);
     }
@@ -409,7 +424,7 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         // one fixed camera (the single-view frame of evaluate.py): one WAVE per frame, the objects side by side (csrc/lm_frame2.hip)
         static const int frame2 = getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1;              // 0: one wave per object (A/B)
         bool one_cam = frame2 != 0;
-        for (int i = 0; i < n_prob && one_cam; ++i) one_cam = probs[i].n_cam == 1 && probs[i].n_edge <= lm_frame2_max_edges();
+        for (int i = 0; i < n_prob && one_cam; ++i) one_cam = frame2_takes(probs[i]);
         if (one_cam) rc = launch_lm_frame2(g_arena.dev + st.o_structs, n_prob, frame_max_obj, max_edges, g_arena.stream);
         else rc = launch_lm_frame(g_arena.dev + st.o_structs, n_prob, frame_max_obj, g_arena.stream);
     } else if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {

@@ -384,7 +384,8 @@ class ObjectSLAM:
         self.needs_opt = True
         bboxes[:, [0, 1]] *= 1.0 - self.bbox_inflate
         bboxes[:, [2, 3]] *= 1.0 + self.bbox_inflate
-        if (self.single_view_mode and self.device_chain and self.model is not None and cam_pose is None and len(self.view_ids) == 0
+        # (debug_gt_kp replaces the network's keypoints by the ground truth, :1129-1131: that substitution lives on the host route)
+        if (self.single_view_mode and self.device_chain and self.model is not None and not self.debug_gt_kp and cam_pose is None and len(self.view_ids) == 0
                 and not self.cam_poses and not self.obj_poses and 0 < len(obj_ids) <= 16):
             self._process_view_single_device(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks)
             torch.cuda.synchronize()

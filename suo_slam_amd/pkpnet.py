@@ -183,7 +183,8 @@ class PkpNet:
 
 
 def decode_extras(logits):
-    """The two optional outputs of the decode kernel (suo_decode_heatmaps) for logits [L,41,64,64] on the device: "prob", the
+    """The decode kernel (suo_decode_heatmaps) on logits [L,41,64,64] given on the device -- "uv", "cov", "mean_logit" as the forward
+    pass computes them -- with its two optional outputs: "prob", the
     soft-max the reference returns as ret["prob"] (pkpnet.py:111), and "argmax", the diagnostic hard arg-max index per
     heat-map (int32 [L,41], flat h*64+w, first maximum -- torch.argmax's convention)."""
     L = int(logits.shape[0])
@@ -196,7 +197,7 @@ def decode_extras(logits):
     ml = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().suo_decode_heatmaps(_ptr(logits), L, _ptr(uv), _ptr(cov), _ptr(ml), _ptr(idx), _ptr(prob), _stream()),
                "suo_decode_heatmaps")
-    return {"prob": prob, "argmax": idx}
+    return {"prob": prob, "argmax": idx, "uv": uv, "cov": cov, "mean_logit": ml}
 
 
 def render_priors(prior_uv, prior_mask, device="cuda"):

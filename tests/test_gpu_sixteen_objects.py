@@ -64,8 +64,9 @@ def test_four_frames_of_sixteen_objects_in_one_network_call():
             assert float((out[k][16 * i:16 * (i + 1)] - one[k]).abs().max()) < 1e-5, (i, k)
     ref = O.pkpnet_forward(frames[0]["image"], frames[0]["boxes"], None, sd)
     lr = ref["prob_logits"].numpy()
-    assert np.abs(out["prob_logits"][:16].cpu().numpy() - lr).max() < 2e-4 * np.abs(lr).max()
-    assert np.abs(out["uv"][:16].cpu().numpy() - ref["uv"].numpy()).max() < 2e-4
+    assert np.abs(out["prob_logits"][:16].cpu().numpy() - lr).max() < 1e-5 * np.abs(lr).max()
+    for k in ("uv", "cov", "kp_mask"):
+        assert np.abs(out[k][:16].cpu().numpy() - ref[k].numpy()).max() < 1e-5, k
 
 
 def test_sixteen_object_frame_debug_keypoints_recovers_every_pose():

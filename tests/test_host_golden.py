@@ -97,15 +97,24 @@ def _rects(x):
     return r
 
 
+def _patch_values_match(got, gold):
+    """The fixture's patch comes from a cv2 stand-in WITHOUT OpenCV's border reflection, stored as float16: inside the patch the values agree
+    to float16 resolution; the outermost ring (<= 1.2e-2 of the peak) carries the doubled BORDER_REFLECT_101 samples, which
+    tests/test_oracle_cnn.py pins against F.conv2d + reflect padding to 1e-6."""
+    d = np.abs(got - gold)
+    assert d[gold > 1.2e-2].max() < 5e-4
+    assert d.max() < 1.3e-2
+
+
 def test_prior_stamp_windows_match_reference_index_logic():
     got = OS.make_prior_kp_input(GOLD["prior_kp"], GOLD["prior_mask"], (256, 256), ndc=True)
     assert np.array_equal(_rects(got), GOLD["prior_ndc_rect"])
     # values: float16 fixture + the doubled outer ring of BORDER_REFLECT_101 (max 2 * 5.7e-3), see object_slam._gaussian_patch
-    assert np.abs(got - GOLD["prior_ndc"].astype(np.float32)).max() < 1.3e-2
+    _patch_values_match(got, GOLD["prior_ndc"].astype(np.float32))
     px = GOLD["prior_px"]
     got = OS.make_prior_kp_input(px, np.ones(len(px), bool), (480, 640), ndc=False)
     assert np.array_equal(_rects(got), GOLD["prior_px_rect"])
-    assert np.abs(got - GOLD["prior_px_out"].astype(np.float32)).max() < 1.3e-2
+    _patch_values_match(got, GOLD["prior_px_out"].astype(np.float32))
 
 
 # ---- N3 ----------------------------------------------------------------------------------------------

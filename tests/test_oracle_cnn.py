@@ -2,6 +2,7 @@
 modules (tests/golden/make_golden.py -> cnn_golden.npz).  CPU only."""
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from oracle import cnn_oracle as O
 from suo_slam_amd import weights as W
@@ -69,3 +70,80 @@ def test_roi_align_identity_box():
     # 2x downsample: grid 2x2 per bin
     out = O.roi_align(img, np.array([[0, 0, 32, 32]], np.float32), (16, 16))
     assert out.shape == (1, 3, 16, 16) and np.isfinite(out).all()
+
+
+# ---- independent cross-checks of the two "builder's reading only" pieces -----------------------------------------
+def test_roi_align_equals_grid_sample_for_boxes_up_to_256_px():
+    """For boxes of at most 256 px a side torchvision's RoIAlign (aligned=False, sampling_ratio=-1 -> one sample per bin,
+    lib/models/pkpnet.py:93) is a plain bilinear resample at the bin centres x1 + (pw + .5) w / 256 in the pixel-centres-at-integers
+    convention -- exactly F.grid_sample(align_corners=True) at g = 2 x / (W - 1) - 1.  torch's grid_sample is an implementation the
+    builder did not write: 200 random in-image boxes of the synthetic stream's range (w, h ~ U[60, 240]), coordinates
+    formed independently in float64."""
+    from suo_slam_amd import synthetic as S
+    rng = np.random.default_rng(2024)
+    img = S.make_frame(rng, 1, noise=0.0)["image"]                       # uint8 [480,640,3], low-pass texture
+    chw = O.image_to_chw(img)                                            # float32 [3,480,640] / 255
+    H, W = chw.shape[1:]
+    n = 200
+    w = rng.uniform(60, 240, n)
+    h = rng.uniform(60, 240, n)
+    h[:20] = rng.uniform(1.5, 60, 20)                                    # a few small boxes too (> 1 px: the min-size clamp is not grid_sample's business)
+    w[10:30] = rng.uniform(1.5, 60, 20)
+    w[30], h[30] = 256.0, 256.0                                          # the largest one-sample-per-bin box
+    x1 = rng.uniform(0, W - 1 - w)
+    y1 = rng.uniform(0, H - 1 - h)
+    boxes = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    got = O.roi_align(chw, boxes, (256, 256))
+    src = torch.from_numpy(chw).double()[None]
+
+    def resample(xs, ys):                                                # xs, ys: float64 [n,256] sample coordinates in pixels
+        ref = np.empty_like(got)
+        grid = np.stack(np.broadcast_arrays((2 * xs / (W - 1) - 1)[:, None, :], (2 * ys / (H - 1) - 1)[:, :, None]), -1)      # [n,256,256,(x,y)]
+        for i in range(0, n, 25):
+            g = torch.from_numpy(grid[i:i + 25])
+            ref[i:i + 25] = F.grid_sample(src.expand(g.shape[0], -1, -1, -1), g, mode="bilinear", padding_mode="zeros", align_corners=True).float().numpy()
+        return ref
+
+    # (A) the interpolation: sample coordinates rounded as RoIAlign's float32 arithmetic rounds them (SURVEY.md B1: start + ph * bin +
+    #     .5 * bin), the interpolation itself by grid_sample in float64 -- atol 1e-6, the bound the HIP kernel is held to against this oracle
+    f32 = np.float32
+    bw = ((boxes[:, 2] - boxes[:, 0]) / f32(256)).astype(f32)
+    bh = ((boxes[:, 3] - boxes[:, 1]) / f32(256)).astype(f32)
+    p = np.arange(256, dtype=f32)
+    xs32 = (boxes[:, 0:1] + p[None] * bw[:, None] + (f32(0.5) * bw)[:, None]).astype(f32)
+    ys32 = (boxes[:, 1:2] + p[None] * bh[:, None] + (f32(0.5) * bh)[:, None]).astype(f32)
+    ref = resample(xs32.astype(np.float64), ys32.astype(np.float64))
+    assert np.abs(got - ref).max() < 1e-6, np.abs(got - ref).max()
+    # (B) the sampling positions: bin centres x1 + (pw + .5) w / 256 formed in float64 from the definition.  float32 places a sample
+    #     within 640 * 2^-23 = 8e-5 px of that; times the steepest gradient of the texture
+    b = boxes.astype(np.float64)
+    centres = (np.arange(256) + 0.5) / 256.0
+    ref = resample(b[:, 0:1] + centres[None] * (b[:, 2:3] - b[:, 0:1]), b[:, 1:2] + centres[None] * (b[:, 3:4] - b[:, 1:2]))
+    grad = max(np.abs(np.diff(chw, axis=1)).max(), np.abs(np.diff(chw, axis=2)).max())
+    assert np.abs(got - ref).max() < 1e-6 + 2 * 8e-5 * grad, (np.abs(got - ref).max(), grad)
+
+
+def test_prior_stamp_equals_conv2d_of_an_impulse_with_opencvs_kernel():
+    """gaussian_2d(91) (lib/utils/utils.py:356-361) = cv2.GaussianBlur(impulse, (91, 91), 0) / max.  OpenCV's documented pieces --
+    getGaussianKernel(91, sigma <= 0 -> 0.3 ((91 - 1) / 2 - 1) + 0.8 = 14, float32 coefficients normalised to sum 1), a separable
+    filter, BORDER_REFLECT_101 -- assembled from torch's own reflect padding and F.conv2d (machinery the builder did not write)
+    against the closed form the product and the device kernel evaluate (object_slam._gaussian_patch; csrc/misc.hip prior_value)."""
+    from suo_slam_amd import object_slam as OS
+    n = 91
+    sigma = 0.3 * ((n - 1) * 0.5 - 1) + 0.8
+    assert sigma == 14.0
+    x = np.arange(n, dtype=np.float64) - (n - 1) * 0.5
+    cf = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)       # getGaussianKernel, CV_32F
+    k = (cf.astype(np.float64) * (1.0 / cf.astype(np.float64).sum())).astype(np.float32)
+    imp = torch.zeros(1, 1, n, n)
+    imp[0, 0, n // 2, n // 2] = 1
+    padded = F.pad(imp, (n // 2,) * 4, mode="reflect")                   # torch's "reflect" = OpenCV's BORDER_REFLECT_101 (edge sample not repeated)
+    kt = torch.from_numpy(k)
+    rows = F.conv2d(padded, kt.reshape(1, 1, 1, n))
+    blur = F.conv2d(rows, kt.reshape(1, 1, n, 1))[0, 0].numpy()
+    assert blur.shape == (n, n)
+    ref = blur / blur.max()
+    got = OS._gaussian_patch(n)
+    assert np.abs(got - ref).max() < 1e-6, np.abs(got - ref).max()
+    # the reflection really is what doubles the outer ring (without it the corner would be a quarter of this)
+    assert abs(ref[0, 0] / (4 * (k[0] / k[n // 2]) ** 2) - 1) < 1e-5
