@@ -7,8 +7,13 @@
 // The kernels accumulate the six cross terms x_i w_j, i + j <= 2, in fp32 (bf16 x bf16 is exact in fp32); the dropped ones are
 //     x1 w2 + x2 w1 + x2 w2,   |x1| <= 2^-8 |x|_binade,  |x2|, |w2| <= 2^-17  ->  <= 2^-25 |x w| each, of EITHER sign.
 // Rounds 1-3 split by truncation (x0 = the leading 16 bits): also exact, but every residual then has the sign of x, the dropped terms
-// the sign of x w and four times the size -- on all-positive activations against one-signed weights a systematic pull toward zero of about
-// 1.4 * 2^-24 * sum |x||w| that the fp32 pipe does not have (tests/test_gpu_cnn.py: test_bf16x3_forward_error_per_element measures both).
+// the sign of x w and four times the size -- on all-positive activations against one-signed weights a systematic pull toward zero.
+// Measured per output element in units of 2^-24 * sum |x||w| (profiles/r04_bias_ab_split.txt, tools/bias_ab.sh; the fp32-pipe kernels:
+// mean 0.00, standard deviation 2.9-4.1): truncating split mean -0.78 ... -0.81 (fused Residual tail -1.50), this split -0.11 ... -0.18
+// (-0.30).  What is left is not the split's: v_mfma_f32_32x32x16_bf16 aligns its 16 products and the accumulator and drops the
+// shifted-out bits (toward -inf, ~12 guard bits) instead of rounding, 6 K / 16 times per output; the same -0.02 shows on sign-mixed
+// data.  It is 1/20 of the rounding noise either pipe has, and the standard deviation and the worst element of the bf16x3 kernels are
+// BELOW the fp32 pipe's in every case measured (fewer roundings: 6 K / 16 against K).
 // v_cvt_pk_bf16_f32 (gfx950) converts two values per instruction with round-to-nearest-even; per pair of values the split is
 // 3 conversions + 4 expansions + 2 packed subtractions, no more instructions than the truncating form took.
 #pragma once
