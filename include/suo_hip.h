@@ -176,6 +176,24 @@ int suo_conv3x3_wino_conv1x1_skip(const float* in_dev, int L, int H, int W, cons
 /* ... and with the Hourglass's "up1 + up2(low3)" (hg.py:56-58) folded in: out += nearest-neighbour 2x up-sampling of up_dev [L,H/2,W/2,256] */
 int suo_conv3x3_wino_conv1x1_skip_up(const float* in_dev, int L, int H, int W, const float* wq2_dev, const float* bias2_dev, const float* wp3_dev,
                                      const float* bias3_dev, const float* skip_dev, const float* up_dev, float* out_dev, void* stream);
+/* csrc/res_small.hip (what suo_net_forward launches for the Hourglass blocks at 32x32 and below when a call holds few crops -- the reference's
+ * call shape, one frame per call, lib/object_slam.py:1099): a WHOLE 256 -> 256 Residual block (layers/Residual.py:20-35) in one launch,
+ *   out = W3 relu(conv3x3(relu(W1 relu(x * pro_scale + pro_shift) + b1)) + b2) + b3 + x [+ 2x up-sampling of up_dev]
+ * x_dev [L,H,W,256] NHWC -- or, pool_in = 1, [L,2H,2W,256] whose 2x2 max-pool is the block's input (hg.py:41).  Weights with their
+ * BatchNorms folded by the caller: w1 [128][256], w2 [128][128][3][3] (times scale2[n] if given), w3 [256][128], packed by
+ * suo_pack_res_block into w1p [128*256], w2p [128*128*9], w3p [256*128] floats.  Bit-identical to suo_conv1x1 (prologue, ReLU) ->
+ * suo_conv_kxk(3) (ReLU) -> suo_conv1x1 (+ skip) -> suo_upsample2_add on the same tensors. */
+int suo_pack_res_block(const float* w1, const float* w2, const float* scale2, const float* w3, float* w1p, float* w2p, float* w3p);
+int suo_res_block(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev, const float* w1p_dev,
+                  const float* b1_dev, const float* w2p_dev, const float* b2_dev, const float* w3p_dev, const float* b3_dev, const float* up_dev,
+                  float* out_dev, void* stream);
+/* csrc/res_small_x3.hip: the same block with every product on the bf16 matrix pipe at fp32 accuracy (3-way operand split, csrc/bf16x3.h), 4 x 8 pixel
+ * tiles -- the network's default for the 32x32 and 16x16 levels of a one-frame call.  Weights as uint16 planes: w1x [3*128*256], w2x [3*128*128*9],
+ * w3x [3*256*128] from suo_pack_res_block_bf16x3 (same inputs as suo_pack_res_block). */
+int suo_pack_res_block_bf16x3(const float* w1, const float* w2, const float* scale2, const float* w3, uint16_t* w1x, uint16_t* w2x, uint16_t* w3x);
+int suo_res_block_bf16x3(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev,
+                         const uint16_t* w1x_dev, const float* b1_dev, const uint16_t* w2x_dev, const float* b2_dev, const uint16_t* w3x_dev,
+                         const float* b3_dev, const float* up_dev, float* out_dev, void* stream);
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 

@@ -62,6 +62,10 @@ SIGNATURES = {
     "suo_conv3x3_wino_conv1x1_skip": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_conv3x3_wino_conv1x1_skip_up": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_conv3x3_conv1x1_skip": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_pack_res_block": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
+    "suo_res_block": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_pack_res_block_bf16x3": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
+    "suo_res_block_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_maxpool2": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_upsample2_add": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_pnp_batch": (C.c_int, [C.c_int, VP, VP, VP, C.c_double, C.c_uint64, C.c_int, VP, VP, VP, VP]),

@@ -250,6 +250,38 @@ int suo_conv3x3_conv1x1_skip(const float* in, int L, int H, int W, const float* 
     return suo::launch_conv3x3_fused(c, (hipStream_t)stream);
 }
 
+int suo_pack_res_block(const float* w1, const float* w2, const float* scale2, const float* w3, float* w1p, float* w2p, float* w3p) {
+    if (!w1 || !w2 || !w3 || !w1p || !w2p || !w3p) { suo_set_error("suo_pack_res_block: null argument"); return SUO_ERR_ARG; }
+    suo::pack_res16_gemm(w1, 128, 256, w1p);
+    suo::pack_res16_conv3x3(w2, 128, 128, scale2, w2p);
+    suo::pack_res16_gemm(w3, 256, 128, w3p);
+    return SUO_OK;
+}
+
+int suo_res_block(const float* x, int L, int H, int W, int pool_in, const float* pro_scale, const float* pro_shift, const float* w1p, const float* b1,
+                  const float* w2p, const float* b2, const float* w3p, const float* b3, const float* up, float* out, void* stream) {
+    suo::ResBlockArgs a = {};
+    a.x = x; a.L = L; a.H = H; a.W = W; a.pool_in = pool_in; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.W1 = w1p; a.b1 = b1; a.W2 = w2p; a.b2 = b2;
+    a.W3 = w3p; a.b3 = b3; a.up = up; a.out = out;
+    return suo::launch_res_block(a, (hipStream_t)stream);
+}
+
+int suo_pack_res_block_bf16x3(const float* w1, const float* w2, const float* scale2, const float* w3, uint16_t* w1x, uint16_t* w2x, uint16_t* w3x) {
+    if (!w1 || !w2 || !w3 || !w1x || !w2x || !w3x) { suo_set_error("suo_pack_res_block_bf16x3: null argument"); return SUO_ERR_ARG; }
+    suo::pack_gemm_weight_bf16x3(w1, 128, 256, w1x);
+    suo::pack_res_conv3x3_bf16x3(w2, scale2, w2x);
+    suo::pack_gemm_weight_bf16x3(w3, 256, 128, w3x);
+    return SUO_OK;
+}
+
+int suo_res_block_bf16x3(const float* x, int L, int H, int W, int pool_in, const float* pro_scale, const float* pro_shift, const uint16_t* w1x, const float* b1,
+                         const uint16_t* w2x, const float* b2, const uint16_t* w3x, const float* b3, const float* up, float* out, void* stream) {
+    suo::ResBlockArgs a = {};
+    a.x = x; a.L = L; a.H = H; a.W = W; a.pool_in = pool_in; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.W1 = (const float*)w1x; a.b1 = b1;
+    a.W2 = (const float*)w2x; a.b2 = b2; a.W3 = (const float*)w3x; a.b3 = b3; a.up = up; a.out = out;
+    return suo::launch_res_block_x3(a, (hipStream_t)stream);
+}
+
 int suo_maxpool2(const float* in, float* out, int L, int H, int W, int C, void* stream) {
     return suo::launch_maxpool2(in, out, L, H, W, C, (hipStream_t)stream);
 }

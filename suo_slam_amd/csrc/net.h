@@ -23,6 +23,9 @@ struct ResidualW {
     GemmW c1; ConvW c2; GemmW c3;
     int cin = 0, cout = 0; bool has_skip_conv = false;
     float* c3x = nullptr;                                // conv3 as bf16x3 planes for the fused Winograd tail on the bf16 pipe (256 <- 128 only)
+    // 256 -> 256 blocks: the whole block in one launch on small maps (csrc/res_small.hip fp32 pipe; csrc/res_small_x3.hip bf16 pipe)
+    float* rb_w[3] = {nullptr, nullptr, nullptr};        // pack_res16_gemm(W1 bn1-folded) | pack_res16_conv3x3(W2, bn2 scale) | pack_res16_gemm(W3)
+    float* rbx_w[3] = {nullptr, nullptr, nullptr};       // the same as bf16x3 planes (uint16)
 };
 struct HourglassW {
     int n = 0;
@@ -59,6 +62,8 @@ private:
     int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr, float* pool_out = nullptr);
     int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const float* Wx3 = nullptr);
     bool residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const;
+    int residual_in_one_launch(const ResidualW& r, int L, int H, int W) const;      // 0: no; 1: csrc/res_small.hip; 2: csrc/res_small_x3.hip
+    int residual_one_launch(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, bool pool_in);
     int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx, const float* x_pooled = nullptr);
     int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s);
     int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s);

@@ -231,6 +231,31 @@ void Net::make_residual(const std::string& p, ResidualW& r) {
     // conv3 (+ conv4 on the raw input as a second K segment: out = W3*mid + W4*x + b3 + b4)
     make_gemm(p + ".conv3", "", r.has_skip_conv ? p + ".conv4" : "", r.c3);
     r.cout = r.c3.n_valid;
+    if (r.cin == 256 && r.cout == 256 && !r.has_skip_conv) {
+        // the block in one launch (small maps): bn1 folded into W1's rows and bn2 into W2's exactly as make_gemm / make_conv fold them
+        // (float products w * s), so the fp32 form is bit-identical to the per-layer launches
+        const HostTensor& w1 = T(p + ".conv1.weight");
+        const HostTensor& w2 = T(p + ".conv2.weight");
+        const HostTensor& w3 = T(p + ".conv3.weight");
+        std::vector<float> s1, t1, s2, t2;
+        bn_affine(*this, p + ".bn1", s1, t1);
+        bn_affine(*this, p + ".bn2", s2, t2);
+        std::vector<float> w1f((size_t)128 * 256);
+        for (int n = 0; n < 128; ++n)
+            for (int k = 0; k < 256; ++k) w1f[(size_t)n * 256 + k] = w1.data[(size_t)n * 256 + k] * s1[n];
+        std::vector<float> p1((size_t)128 * 256), p2((size_t)128 * 128 * 9), p3((size_t)256 * 128);
+        pack_res16_gemm(w1f.data(), 128, 256, p1.data());
+        pack_res16_conv3x3(w2.data, 128, 128, s2.data(), p2.data());
+        pack_res16_gemm(w3.data, 256, 128, p3.data());
+        r.rb_w[0] = upload(p1); r.rb_w[1] = upload(p2); r.rb_w[2] = upload(p3);
+        if (wino_bf16x3()) {
+            std::vector<float> x1((size_t)3 * 128 * 256 / 2), x2((size_t)3 * 128 * 128 * 9 / 2), x3((size_t)3 * 256 * 128 / 2);      // uint16 planes
+            pack_gemm_weight_bf16x3(w1f.data(), 128, 256, reinterpret_cast<uint16_t*>(x1.data()));
+            pack_res_conv3x3_bf16x3(w2.data, s2.data(), reinterpret_cast<uint16_t*>(x2.data()));
+            pack_gemm_weight_bf16x3(w3.data, 256, 128, reinterpret_cast<uint16_t*>(x3.data()));
+            r.rbx_w[0] = upload(x1); r.rbx_w[1] = upload(x2); r.rbx_w[2] = upload(x3);
+        }
+    }
     if (r.c2.Wq3 && !r.has_skip_conv) {
         const HostTensor& w3 = T(p + ".conv3.weight");
         if (w3.shape[0] == 256 && w3.shape[1] == 128) {
@@ -400,6 +425,37 @@ bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const 
            r.c3.K1 == 128 && r.cin == 256;
 }
 
+// A 256 -> 256 block on a small map in ONE launch (csrc/res_small_x3.hip / csrc/res_small.hip) instead of three: the call shape of the
+// reference (one frame = 8 crops per call, lib/object_slam.py:1099).  Measured per block at 8 crops (tools/bench_res_block.py, us; per-layer
+// launches -> one launch on the bf16 pipe): 32x32 47 -> 29.6, 16x16 26.6 -> 25.0; at 8x8 and 4x4 the three per-layer launches (13.5) stay
+// faster -- a workgroup streams all 0.85 / 1.28 MB of the block's weights through ONE CU whatever its tile, 20-24 us at 35 bytes per clock.
+//   SUO_RES_FUSED = 0: never; 1: the fp32-pipe kernel (bit-identical to the per-layer launches); 2 (default with SUO_WINO_BF16X3): the bf16x3 kernel
+//   SUO_RES_FUSED_MAX_TILES: largest launch (4 x 8 pixel tiles) that takes it; beyond that the Winograd kernels' larger tiles win
+int Net::residual_in_one_launch(const ResidualW& r, int L, int H, int W) const {
+    static const int mode = getenv("SUO_RES_FUSED") ? atoi(getenv("SUO_RES_FUSED")) : 2;
+    static const long max_tiles = getenv("SUO_RES_FUSED_MAX_TILES") ? atol(getenv("SUO_RES_FUSED_MAX_TILES")) : 768;
+    static const int min_side = getenv("SUO_RES_FUSED_MIN_SIDE") ? atoi(getenv("SUO_RES_FUSED_MIN_SIDE")) : 16;
+    if (mode <= 0 || !r.rb_w[0] || H > 32 || W > 32 || H < min_side || W < min_side) return 0;
+    const long t32 = (long)L * ((H + 3) / 4) * ((W + 7) / 8);
+    if (t32 > max_tiles) return 0;
+    return (mode >= 2 && r.rbx_w[0]) ? 2 : 1;
+}
+
+int Net::residual_one_launch(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, bool pool_in) {
+    const int kind = residual_in_one_launch(r, L, H, W);
+    ResBlockArgs a = {};
+    a.x = x; a.L = L; a.H = H; a.W = W; a.pool_in = pool_in ? 1 : 0; a.pro_scale = r.pro_scale; a.pro_shift = r.pro_shift;
+    a.b1 = r.c1.bias; a.b2 = r.c2.bias; a.b3 = r.c3.bias; a.up = up; a.out = out;
+    if (kind == 2) {
+        a.W1 = r.rbx_w[0]; a.W2 = r.rbx_w[1]; a.W3 = r.rbx_w[2];
+        SUO_LAUNCH(launch_res_block_x3(a, s));
+    } else {
+        a.W1 = r.rb_w[0]; a.W2 = r.rb_w[1]; a.W3 = r.rb_w[2];
+        SUO_LAUNCH(launch_res_block(a, s));
+    }
+    return SUO_OK;
+}
+
 // A 1x1 convolution whose result is also wanted max-pooled (nn.MaxPool2d(2, 2)): pooled in the GEMM's epilogue when the launch
 // would use the persistent 128x128 kernel anyway (csrc/gemm_persist.hip: POOL), else GEMM + max-pool kernel.  g.out may be nullptr
 // when only the pooled tensor is wanted.
@@ -431,6 +487,12 @@ int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hi
 
 int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, float* pool_out) {
     const int M = L * H * W;
+    if (residual_in_one_launch(r, L, H, W)) {
+        if (!out) out = alloc((size_t)M * 256);
+        SUO_TRY(residual_one_launch(r, x, out, L, H, W, s, up, false));
+        if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
+        return SUO_OK;
+    }
     float* mid1 = alloc((size_t)M * r.c1.N);
     float* mid2 = alloc((size_t)M * r.c2.N);
     GemmArgs g1 = {};
@@ -503,20 +565,24 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     // branch itself and writes `out` -- no up-sample kernel, no extra pass over the high-resolution tensor.  The block then has to
     // wait for the low branch; its predecessor still runs beside it on the side stream.
     static const int fuse_up = getenv("SUO_FUSE_UPSAMPLE") ? atoi(getenv("SUO_FUSE_UPSAMPLE")) : 1;              // 0: A/B
-    const bool up_in_tail = fuse_up && residual_tail_is_fused(h.up1[1], L, H, W);
+    const bool up_in_tail = fuse_up && (residual_tail_is_fused(h.up1[1], L, H, W) || residual_in_one_launch(h.up1[1], L, H, W));
     SUO_TRY(residual(h.up1[0], x, up_a, L, H, W, side));
     if (!up_in_tail) SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
     SUO_HIP_LIVE(hipEventRecord(ev_join, side));
 
     const float* pooled = x_pooled;                           // (the caller's producer kernel may have pooled x already)
-    if (!pooled) {
+    // max_pool2d(x) (hg.py:41) has ONE reader, the first low block: when that block runs in one launch it takes the pool while staging x
+    static const int pool_in_block = getenv("SUO_RES_POOL_IN") ? atoi(getenv("SUO_RES_POOL_IN")) : 1;           // 0: A/B
+    const bool pool_by_block = !pooled && pool_in_block && residual_in_one_launch(h.low1[0], L, H / 2, W / 2) && (H % 2 == 0) && (W % 2 == 0);
+    if (!pooled && !pool_by_block) {
         float* p = alloc(n_lo);
         SUO_LAUNCH(launch_maxpool2(x, p, L, H, W, C, s));
         pooled = p;
     }
     float* lo_a = alloc(n_lo);
     float* lo_b = alloc(n_lo);
-    SUO_TRY(residual(h.low1[0], pooled, lo_a, L, H / 2, W / 2, s));
+    if (pool_by_block) SUO_TRY(residual_one_launch(h.low1[0], x, lo_a, L, H / 2, W / 2, s, nullptr, true));
+    else SUO_TRY(residual(h.low1[0], pooled, lo_a, L, H / 2, W / 2, s));
     SUO_TRY(residual(h.low1[1], lo_a, lo_b, L, H / 2, W / 2, s));
     float* low2 = alloc(n_lo);
     if (h.n > 1) {

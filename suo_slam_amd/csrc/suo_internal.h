@@ -82,6 +82,26 @@ int launch_gemm_small(const GemmArgs& a, hipStream_t s);
 int launch_gemm_persist(const GemmArgs& a, int cfg, hipStream_t s);    // cfg 1: 128x128, 2: 128x64, 3: 64x64 tiles
 int launch_conv7x7s2(const ConvArgs& a, hipStream_t s);
 
+// A whole 256 -> 256 Residual block in one launch on small maps (csrc/res_small.hip): out = W3 relu(conv3x3(relu(W1 relu(x * scale + shift) + b1)) + b2) + b3 + x [+ up]
+struct ResBlockArgs {
+    const float* x; int L, H, W;                         // [L,H,W,256] -- or, pool_in: [L,2H,2W,256] whose 2x2 max-pool is the block's input
+    int pool_in;
+    const float* pro_scale; const float* pro_shift;      // the block's leading BatchNorm, [256]
+    const float* W1; const float* b1;                    // pack_res16_gemm(W1 * bn1 scale [128][256]), [128]
+    const float* W2; const float* b2;                    // pack_res16_conv3x3(W2 [128][128][3][3], bn2 scale), [128]
+    const float* W3; const float* b3;                    // pack_res16_gemm(W3 [256][128]), [256]
+    const float* up;                                     // optional [L,H/2,W/2,256]: out += its nearest-neighbour 2x up-sampling (hg.py:56-58)
+    float* out;                                          // [L,H,W,256]
+};
+void pack_res16_gemm(const float* W, int N, int K, float* out);
+void pack_res16_conv3x3(const float* W, int N, int C, const float* out_scale, float* out);
+bool res_block_takes(const ResBlockArgs& a);
+int launch_res_block(const ResBlockArgs& a, hipStream_t s);
+// the same block with its products on the bf16 matrix pipe (csrc/res_small_x3.hip; 4 x 8 pixel tiles): W1 / W3 = pack_gemm_weight_bf16x3 planes,
+// W2 = pack_res_conv3x3_bf16x3 planes (uint16, passed through the float pointers of ResBlockArgs)
+void pack_res_conv3x3_bf16x3(const float* W, const float* out_scale, uint16_t* out);
+int launch_res_block_x3(const ResBlockArgs& a, hipStream_t s);
+
 int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);
 int launch_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, hipStream_t s);
 int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, int out_c,

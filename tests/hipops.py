@@ -209,3 +209,40 @@ def conv3x3_wino_x3_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc=N
                "suo_conv3x3_wino_x3_conv1x1_skip_up")
     torch.cuda.synchronize()
     return out
+
+
+def res_block(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=False):
+    """csrc/res_small.hip: a whole 256 -> 256 Residual block in one launch.  x [L,H,W,256] (pool_in: [L,2H,2W,256]); pro = (scale, shift) [256];
+    w1 [128,256], w2 [128,128,3,3], w3 [256,128] with their BatchNorms already folded; up [L,H/2,W/2,256] or None."""
+    lib = _lib.lib()
+    L, H, W, Cc = x_nhwc.shape
+    if pool_in:
+        H, W = H // 2, W // 2
+    assert Cc == 256 and w1.shape == (128, 256) and w2.shape == (128, 128, 3, 3) and w3.shape == (256, 128)
+    w1, w2, w3 = (np.ascontiguousarray(t, np.float32) for t in (w1, w2, w3))
+    p1, p2, p3 = np.empty(128 * 256, np.float32), np.empty(128 * 128 * 9, np.float32), np.empty(256 * 128, np.float32)
+    _lib.check(lib.suo_pack_res_block(w1.ctypes.data, w2.ctypes.data, None, w3.ctypes.data, p1.ctypes.data, p2.ctypes.data, p3.ctypes.data), "suo_pack_res_block")
+    d = [dev(t) for t in (pro[0], pro[1], p1, b1, p2, b2, p3, b3)]
+    out = torch.empty((L, H, W, 256), device="cuda")
+    _lib.check(lib.suo_res_block(P(x_nhwc), L, H, W, int(pool_in), P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(d[5]), P(d[6]), P(d[7]), P(up_nhwc), P(out), S()),
+               "suo_res_block")
+    torch.cuda.synchronize()
+    return out
+
+
+def res_block_x3(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=False):
+    """csrc/res_small_x3.hip: the one-launch Residual block on the bf16 matrix pipe (3-way split operands); arguments as res_block."""
+    lib = _lib.lib()
+    L, H, W, Cc = x_nhwc.shape
+    if pool_in:
+        H, W = H // 2, W // 2
+    w1, w2, w3 = (np.ascontiguousarray(t, np.float32) for t in (w1, w2, w3))
+    p1, p2, p3 = np.empty(3 * 128 * 256, np.uint16), np.empty(3 * 128 * 128 * 9, np.uint16), np.empty(3 * 256 * 128, np.uint16)
+    _lib.check(lib.suo_pack_res_block_bf16x3(w1.ctypes.data, w2.ctypes.data, None, w3.ctypes.data, p1.ctypes.data, p2.ctypes.data, p3.ctypes.data), "suo_pack_res_block_bf16x3")
+    dw = [torch.from_numpy(t.view(np.int16)).cuda() for t in (p1, p2, p3)]
+    d = [dev(t) for t in (pro[0], pro[1], b1, b2, b3)]
+    out = torch.empty((L, H, W, 256), device="cuda")
+    _lib.check(lib.suo_res_block_bf16x3(P(x_nhwc), L, H, W, int(pool_in), P(d[0]), P(d[1]), P(dw[0]), P(d[2]), P(dw[1]), P(d[3]), P(dw[2]), P(d[4]), P(up_nhwc), P(out), S()),
+               "suo_res_block_bf16x3")
+    torch.cuda.synchronize()
+    return out
