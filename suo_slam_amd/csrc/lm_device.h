@@ -30,12 +30,23 @@ DEV void q_to_R(const double* q, double* R) {
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
+// 1 / sqrt(s) to the last bit or two: v_rsq_f64 (~27 bits) + two Newton steps + one residual correction, ~14 instructions where
+// sqrt() followed by a division is ~60 -- these kernels are single dependent chains of fp64 instructions, so the count IS the time
+DEV double rsqrt_nr(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    const double h = 0.5 * s;
+    y = y * fma(-(h * y), y, 1.5);
+    y = y * fma(-(h * y), y, 1.5);
+    const double e = fma(-(s * y), y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
 DEV void R_to_q(const double* R, double* q) {
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
-        t = sqrt(t + 1.0);
-        q[0] = 0.5 * t;
-        t = 0.5 / t;
+        const double r = rsqrt_nr(t + 1.0);                  // t = sqrt(t + 1); q0 = t / 2; the others times 1 / (2 t)
+        q[0] = 0.5 * ((t + 1.0) * r);
+        t = 0.5 * r;
         q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
     } else {
         int i = 0;
@@ -52,8 +63,8 @@ DEV void R_to_q(const double* R, double* q) {
         q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
     }
     if (q[0] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    const double inv = rsqrt_nr(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);      // (one reciprocal root instead of a root and four divisions)
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 
 DEV void q_mul(const double* a, const double* b, double* o) {
@@ -74,25 +85,42 @@ DEV void pose_to_T(const Pose& p, double* T) {
     for (int r = 0; r < 3; ++r) { T[4 * r] = R[3 * r]; T[4 * r + 1] = R[3 * r + 1]; T[4 * r + 2] = R[3 * r + 2]; T[4 * r + 3] = p.t[r]; }
 }
 
-// T <- exp([omega, upsilon]) * T
+// T <- exp([omega, upsilon]) * T   (SE3Quat::exp + operator*, thirdparty/g2opy/g2o/types/slam3d/se3quat.h:220-254, :101-114)
+// Rodrigues coefficients a = sin(th) / th, b = (1 - cos(th)) / th^2, c = (th - sin(th)) / th^3 of R = I + a Om + b Om^2, V = I + b Om + c Om^2:
+//   th < 1e-5          g2o's own shortcut R = V = I + Om + Om^2 (se3quat.h:236-240), kept as it is;
+//   th^2 < 0.09        their Taylor series in th^2 (eight terms: < 1e-17 relative) -- no square root, no sin / cos, no divisions; these
+//                      are the values the closed forms approximate (the closed forms lose digits of b, c to cancellation at small th);
+//   else               the closed forms.
+// Om^2 is written out (w w^T - th^2 I with the diagonal as sums of two squares): the same values as the 3x3 product, whose 18 products by
+// a literal zero the compiler may not drop.
 DEV void pose_oplus(Pose& p, const double* u) {
     const double* w = u;
     const double* ups = u + 3;
-    const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double w00 = w[0] * w[0], w11 = w[1] * w[1], w22 = w[2] * w[2];
+    const double th2 = (w00 + w11) + w22;
     const double Om[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-    double Om2[9];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) Om2[3 * r + c] = Om[3 * r] * Om[c] + Om[3 * r + 1] * Om[3 + c] + Om[3 * r + 2] * Om[6 + c];
-    double R[9], V[9];
-    if (theta < 0.00001) {
-        for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
+    const double w01 = w[0] * w[1], w02 = w[0] * w[2], w12 = w[1] * w[2];
+    const double Om2[9] = {-(w22 + w11), w01, w02, w01, -(w22 + w00), w12, w02, w12, -(w11 + w00)};
+    double a, b, b2, c;                                       // R = I + a Om + b Om2,  V = I + b2 Om + c Om2
+    if (th2 < 1e-10) {
+        a = 1; b = 1; b2 = 1; c = 1;
+    } else if (th2 < 0.09) {
+        const double t = th2;
+        a = fma(t, fma(t, fma(t, fma(t, fma(t, fma(t, fma(t, -1.0 / 1307674368000.0, 1.0 / 6227020800.0), -1.0 / 39916800.0), 1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        b = fma(t, fma(t, fma(t, fma(t, fma(t, fma(t, fma(t, -1.0 / 20922789888000.0, 1.0 / 87178291200.0), -1.0 / 479001600.0), 1.0 / 3628800.0), -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
+        c = fma(t, fma(t, fma(t, fma(t, fma(t, fma(t, fma(t, -1.0 / 355687428096000.0, 1.0 / 1307674368000.0), -1.0 / 6227020800.0), 1.0 / 39916800.0), -1.0 / 362880.0), 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
+        b2 = b;
     } else {
         // (theta^3 as two multiplications: the libm pow() of se3quat.h:247 costs ~200 instructions per trial and differs from this by <= 1 ulp)
-        const double st = sin(theta), a = st / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - st) / (theta * theta * theta);
-        for (int i = 0; i < 9; ++i) {
-            R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
-            V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
-        }
+        const double theta = sqrt(th2), st = sin(theta);
+        a = st / theta; b = (1 - cos(theta)) / (theta * theta); c = (theta - st) / (theta * theta * theta);
+        b2 = b;
+    }
+    double R[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+        V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b2 * Om[i] + c * Om2[i];
     }
     double eq[4], et[3];
     R_to_q(R, eq);
@@ -102,8 +130,8 @@ DEV void pose_oplus(Pose& p, const double* u) {
     for (int r = 0; r < 3; ++r) nt[r] = et[r] + Re[3 * r] * p.t[0] + Re[3 * r + 1] * p.t[1] + Re[3 * r + 2] * p.t[2];
     q_mul(eq, p.q, nq);
     if (nq[0] < 0) { nq[0] = -nq[0]; nq[1] = -nq[1]; nq[2] = -nq[2]; nq[3] = -nq[3]; }
-    const double n = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
-    for (int k = 0; k < 4; ++k) p.q[k] = nq[k] / n;
+    const double inv = rsqrt_nr(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    for (int k = 0; k < 4; ++k) p.q[k] = nq[k] * inv;
     for (int k = 0; k < 3; ++k) p.t[k] = nt[k];
 }
 
@@ -468,7 +496,7 @@ DEV void accumulate_pairs(const LmProblem& P) { accumulate_pairs_range(P, 0, P.n
 // solve the symmetric positive definite 6x6 system A x = b by Cholesky; false if not PD (x is then unspecified).
 // Fully unrolled with compile-time indices and inlined: as a plain function with runtime loop indices the factor lived in SCRATCH
 // memory (368 bytes per lane in lm_frame_kernel) and every one of its ~100 accesses per call was a memory round trip -- the single
-// largest cost of a frame's LM trial.  One reciprocal per pivot instead of a division per element (1 ulp from the divided form).
+// largest cost of a frame's LM trial.  One reciprocal ROOT per pivot (rsqrt_nr) instead of a root and a division per element (an ulp or two from the divided form).
 DEV bool spd_solve6(const double* A, const double* b, double* x) {
     double L[6][6], dinv[6];
     bool ok = true;
@@ -481,8 +509,9 @@ DEV bool spd_solve6(const double* A, const double* b, double* x) {
             for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
             if (i == j) {
                 if (!(s > 0) || !isfinite(s)) ok = false;
-                L[i][i] = sqrt(ok ? s : 1.0);
-                dinv[i] = 1.0 / L[i][i];
+                const double sp = ok ? s : 1.0;
+                dinv[i] = rsqrt_nr(sp);                          // 1 / L_ii and L_ii = s / sqrt(s) from one reciprocal root
+                L[i][i] = sp * dinv[i];
             } else {
                 L[i][j] = s * dinv[j];
             }

@@ -208,17 +208,24 @@ DEV void lm_frame2_body(const LmProblem& P, double* Es) {
         }
         const int iterations = osum(gsum<G>(nact)) > 0 ? P.its[round] : 0;
         double lambda = -1, ni = 2;
+        // The linearisation of iteration it + 1 is taken at the pose iteration it accepted -- the very pose whose chi2 the accepting trial
+        // has just evaluated edge by edge.  So every trial pass also accumulates J^T W J / J^T W r at ITS pose (h2): accepted, they ARE the
+        // next iteration's system (same inputs, same instructions: bit-identical to linearising again) and the separate pass per
+        // iteration is gone; rejected (rare: 104 trials for 100 iterations on the bench frame), they are dropped.
+        double h[27], chi_o = 0;
         for (int it = 0; it < iterations; ++it) {
             // ---- errors, chi2, every object's 6x6 system --------------------------------------------------------
-            double Ro[9], h[27];
-            q_to_R(pose.q, Ro);
+            if (it == 0) {
+                double Ro[9];
+                q_to_R(pose.q, Ro);
 #pragma unroll
-            for (int k = 0; k < 27; ++k) h[k] = 0;
-            LF2_T(0);
-            const double chi_o = edge_pass(Ro, pose.t, robust_on, std::true_type{}, h);
-            LF2_T(1);
+                for (int k = 0; k < 27; ++k) h[k] = 0;
+                LF2_T(0);
+                chi_o = edge_pass(Ro, pose.t, robust_on, std::true_type{}, h);
+                LF2_T(1);
 #pragma unroll
-            for (int k = 0; k < 27; ++k) h[k] = gsum<G>(h[k]);
+                for (int k = 0; k < 27; ++k) h[k] = gsum<G>(h[k]);
+            }
             double currentChi = osum(chi_o);
             LF2_T(2);
             if (it == 0) {                                       // computeLambdaInit: tau * max |diag H| over all free vertices
@@ -259,10 +266,12 @@ DEV void lm_frame2_body(const LmProblem& P, double* Es) {
                     }
                     LF2_T(4);
                 }
-                double Rt[9];
+                double Rt[9], h2[27];
                 q_to_R(trial.q, Rt);
+#pragma unroll
+                for (int k = 0; k < 27; ++k) h2[k] = 0;
                 // (a failed block anywhere rejects the whole trial: the chi2 evaluated here is then discarded)
-                const double temp_o = edge_pass(Rt, trial.t, robust_on, std::false_type{}, h);
+                const double temp_o = edge_pass(Rt, trial.t, robust_on, std::true_type{}, h2);
                 LF2_T(5);
                 const double s_bad = osum(ok_o ? 0.0 : 1.0), s_chi = osum(temp_o), s_sc = osum(sc_o);      // (independent: they overlap)
                 const bool ok2 = s_bad == 0.0;
@@ -278,6 +287,9 @@ DEV void lm_frame2_body(const LmProblem& P, double* Es) {
                     ni = 2;
                     currentChi = tempChi;
                     pose = trial;                                 // update(x) is kept
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) h[k] = gsum<G>(h2[k]);      // ... and with it the system at the new pose
+                    chi_o = temp_o;
                 } else {
                     lambda *= ni;
                     ni *= 2;                                      // pop(): the trial pose is simply dropped
@@ -314,7 +326,7 @@ DEV void lm_frame2_body(const LmProblem& P, double* Es) {
 
 // frames of <= 8 objects: 8 lanes per object; 9-16: 4.  Chosen per FRAME, so that a frame's result does not depend on what else is in
 // the launch.
-__global__ __launch_bounds__(64) void lm_frame2_kernel(const LmProblem* __restrict__ problems) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_frame2_kernel(const LmProblem* __restrict__ problems) {
     extern __shared__ __attribute__((aligned(16))) double Es[];          // [edge][12]
     const LmProblem& P = problems[blockIdx.x];
     if (P.n_obj <= 8) lm_frame2_body<8>(P, Es);
