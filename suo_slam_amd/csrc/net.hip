@@ -438,7 +438,9 @@ int Net::residual_in_one_launch(const ResidualW& r, int L, int H, int W) const {
     if (mode <= 0 || !r.rb_w[0] || H > 32 || W > 32 || H < min_side || W < min_side) return 0;
     const long t32 = (long)L * ((H + 3) / 4) * ((W + 7) / 8);
     if (t32 > max_tiles) return 0;
-    return (mode >= 2 && r.rbx_w[0]) ? 2 : 1;
+    // the bf16x3 kernel has one tile shape (4 x 8 pixels); below a workgroup per CU the fp32 kernel's 4 x 4 tiles finish sooner
+    // (16x16 at 8 crops: 64 workgroups x 28 us against 128 x 23.4)
+    return (mode >= 2 && r.rbx_w[0] && t32 >= 256) ? 2 : 1;
 }
 
 int Net::residual_one_launch(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, bool pool_in) {

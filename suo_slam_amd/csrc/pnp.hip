@@ -323,10 +323,26 @@ DEV unsigned count_inliers(const double* xs, const double* ys, int n, double thr
     return inl;
 }
 
+// Wave-wide sum, the same value in every lane: DPP register moves inside a row of 16 lanes (quad permutes, half-row and row mirrors), the four
+// row sums by v_readlane, added in row order (as csrc/lm_device.h: wsum).  The __shfl_xor butterfly this replaces is two ds_bpermute_b32
+// per step on a double, ~120 cycles of dependent latency each: 27 sums x 6 steps per refinement iteration were most of PNP::refine's time.
+template <int CTRL>
+DEV double pnp_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 DEV double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += pnp_dpp<0xB1>(v);            // lane ^ 1
+    v += pnp_dpp<0x4E>(v);            // lane ^ 2
+    v += pnp_dpp<0x141>(v);           // row_half_mirror
+    v += pnp_dpp<0x140>(v);           // row_mirror -> every lane of a row holds the row sum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return ((r0 + r1) + r2) + r3;
 }
 DEV double bcast_d(double v, int src) { return __shfl(v, src, 64); }
 
@@ -345,20 +361,43 @@ DEV void quat_plus(const double* q, const double* d, double* o) {
     } else { o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3]; }
 }
 
-__device__ bool chol6(const double* A, const double* b, double* x) {
-    double Lm[36];
-    for (int i = 0; i < 36; ++i) Lm[i] = 0;
-    for (int i = 0; i < 6; ++i)
+// 6x6 Cholesky solve, fully unrolled with compile-time indices (as a function with runtime loops the factor lived in scratch memory),
+// one reciprocal per pivot
+DEV bool chol6(const double* A, const double* b, double* x) {
+    double L[6][6], dinv[6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
         for (int j = 0; j <= i; ++j) {
             double s = A[i * 6 + j];
-            for (int k = 0; k < j; ++k) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
-            if (i == j) { if (!(s > 0)) return false; Lm[i * 6 + i] = sqrt(s); }
-            else Lm[i * 6 + j] = s / Lm[j * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 0)) ok = false;
+                L[i][i] = sqrt(ok ? s : 1.0);
+                dinv[i] = 1.0 / L[i][i];
+            } else {
+                L[i][j] = s * dinv[j];
+            }
         }
+    }
     double y[6];
-    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= Lm[i * 6 + k] * y[k]; y[i] = s / Lm[i * 6 + i]; }
-    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= Lm[k * 6 + i] * x[k]; x[i] = s / Lm[i * 6 + i]; }
-    return true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s * dinv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * x[k];
+        x[i] = s * dinv[i];
+    }
+    return ok;
 }
 
 constexpr int PNP_MAX_PER_LANE = 16;   // n <= 1024 points per object
@@ -504,7 +543,10 @@ DEV unsigned select_inliers(const double* xs, const double* ys, int n, double th
 // sequential accept rule over them in index order -- hypotheses beyond the (shrinking) iteration count are discarded exactly as the
 // sequential loop would never have drawn them.  1000 iterations (the cap: bad keypoints) are 4 rounds instead of 16, the usual 100-500
 // are 1-2.  The refinement runs on wave 0.
-constexpr int PNP_WAVES = 4;
+// PNP_WAVES = 4 for launches of many objects (batched frames: more workgroups per CU), 16 for a frame or two (the one-frame call: 1000
+// iterations -- the cap, what random-weight keypoints run to -- in ONE round instead of four: 152 -> ~70 us for 8 objects).  The result
+// does not depend on it: the accept rule is replayed in index order whatever the round size.
+template <int PNP_WAVES>
 __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __restrict__ offsets, const int* __restrict__ counts,
                                                                    const int* __restrict__ group_first, const double* __restrict__ xs_all,
                                                                    const double* __restrict__ ys_all, double threshold, uint64_t seed,
@@ -555,13 +597,65 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
             }
             s_cnt[wv * 64 + lane] = cnt;
             __syncthreads();
-            // replay the sequential accept rule of PNP::compute over these hypotheses, every wave identically
+            // Replay the sequential accept rule of PNP::compute over these hypotheses, every wave identically:
+            //     for j: if (base + j >= iters) break;  if (cnt[j] > best) { best = cnt[j]; win = j; iters = tab[best]; }
+            // as a scan instead of a loop of 64 PNP_WAVES dependent LDS reads.  With P(j) = max(best, cnt[0 .. j-1]) the bound in force when the
+            // loop reaches j is tab[P(j)]; tab is non-increasing, so "processed(j) = base + j < tab[P(j)]" holds for a prefix j < J.  The new
+            // best is P(J), the winner the FIRST j < J that reaches it (if it exceeds the old best), the loop counter at exit base + J.
             int win = -1;
-            for (int j = 0; j < 64 * PNP_WAVES; ++j) {
-                if (base + j >= iters) break;
-                const unsigned cj = s_cnt[j];
-                if (cj > best) { best = cj; win = j; iters = (unsigned)tab[best]; }
-                i_done = base + j + 1;           // total_iters of PNP::compute = loop counter at exit
+            {
+                constexpr int E = PNP_WAVES;                    // entries per lane: j = lane * E + e
+                unsigned c[E], run = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { c[e] = s_cnt[lane * E + e]; run = c[e] > run ? c[e] : run; }
+                unsigned incl = run;                            // inclusive scan of the lane maxima
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned o = (unsigned)__shfl_up((int)incl, d, 64);
+                    if (lane >= d) incl = o > incl ? o : incl;
+                }
+                unsigned P = (unsigned)__shfl_up((int)incl, 1, 64);
+                P = lane == 0 ? best : (P > best ? P : best);   // P(j) of the lane's first entry
+                int first_stop = 64 * E;                        // first entry the loop does not reach
+                unsigned seen = 0;                              // maximum over the lane's processed entries
+                int first_of[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int j = lane * E + e;
+                    const bool processed = base + (unsigned)j < (unsigned)tab[P];
+                    if (!processed && first_stop == 64 * E) first_stop = j;
+                    if (processed && first_stop == 64 * E) seen = c[e] > seen ? c[e] : seen;
+                    first_of[e] = j;
+                    P = c[e] > P ? c[e] : P;
+                }
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) {
+                    const int o = __shfl_xor(first_stop, m, 64);
+                    first_stop = o < first_stop ? o : first_stop;
+                }
+                const int J = first_stop;
+                // entries of lanes wholly beyond J do not count
+                unsigned nb = lane * E < J ? seen : 0u;
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) {
+                    const unsigned o = (unsigned)__shfl_xor((int)nb, m, 64);
+                    nb = o > nb ? o : nb;
+                }
+                if (nb > best) {
+                    int w0 = 64 * E;
+#pragma unroll
+                    for (int e = E - 1; e >= 0; --e)
+                        if (first_of[e] < J && c[e] == nb) w0 = first_of[e];
+#pragma unroll
+                    for (int m = 32; m > 0; m >>= 1) {
+                        const int o = __shfl_xor(w0, m, 64);
+                        w0 = o < w0 ? o : w0;
+                    }
+                    win = w0;
+                    best = nb;
+                    iters = (unsigned)tab[best];
+                }
+                if (J > 0) i_done = base + (unsigned)J;          // total_iters of PNP::compute = loop counter at exit
             }
             if (win >= 0) {
                 if (wv == (win >> 6) && lane == (win & 63)) {
@@ -604,8 +698,13 @@ int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, co
                             const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                             int* iters_out, hipStream_t s) {
     if (n_obj <= 0) return SUO_OK;
-    hipLaunchKernelGGL(pnp_batch_kernel, dim3(n_obj), dim3(64 * PNP_WAVES), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
-                       do_refine, T_out, status, best_out, iters_out);
+    static const int wide_upto = getenv("SUO_PNP_WIDE_UPTO") ? atoi(getenv("SUO_PNP_WIDE_UPTO")) : 32;      // objects per launch that still take 16 waves each (0: never)
+    if (n_obj <= wide_upto)
+        hipLaunchKernelGGL(pnp_batch_kernel<16>, dim3(n_obj), dim3(1024), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
+                           do_refine, T_out, status, best_out, iters_out);
+    else
+        hipLaunchKernelGGL(pnp_batch_kernel<4>, dim3(n_obj), dim3(256), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
+                           do_refine, T_out, status, best_out, iters_out);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
