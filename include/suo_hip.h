@@ -315,6 +315,24 @@ int suo_ba_schur_dev(suo_ba_ctx* ctx, double lambda, double* sch_dev, void* stre
 int suo_ba_solve_update_dev(suo_ba_ctx* ctx, double lambda, int robust_on, int world, const double* lin_dev, const double* sch_dev,
                             double* red_dev, void* stream);
 int suo_ba_restore_dev(suo_ba_ctx* ctx, void* stream);
+/* The same phases under a DEVICE-RESIDENT LM schedule: g2o's accept / reject arithmetic (optimization_algorithm_levenberg.cpp:88-148) runs in
+ * one-thread kernels on the reduced scalars and keeps its state in ctl_dev [16 doubles]:
+ *   [0] lambda [1] ni [2] current chi2 [3] state (0: the next unit linearises, 1: the next unit is a trial on the standing linearisation,
+ *   2: the round is over) [4] iterations done this round [5] iteration budget [6] qmax [7] LM iterations [8] LM trials (all rounds; zero them
+ *   once) [9] rho [10] restore flag [11] ranks.
+ * One UNIT = suo_ba_lm_linearize_dev (live in state 0; always leaves this rank's totals in lin_dev) -> all-reduce(lin_dev) ->
+ * suo_ba_lm_schur_dev (chi2 / lambda init of a fresh linearisation, then the Schur phase for ctl's lambda) -> all-reduce(sch_dev) ->
+ * suo_ba_lm_solve_update_dev -> all-reduce(red_dev[0:3]) -> suo_ba_lm_decide_dev (gain ratio, lambda / ni, restore of a rejected step,
+ * next state).  Phases that are not live return at once, so units may be enqueued blindly -- the host reads ctl_dev once per batch of
+ * units instead of four doubles per trial (suo_slam_amd/ba_dist.py: optimize_distributed).  suo_ba_lm_begin_dev starts a round of `its`
+ * iterations (optimizer.optimize(its), lib/object_slam.py:873-875). */
+int suo_ba_lm_begin_dev(suo_ba_ctx* ctx, double* ctl_dev, int its, int world, void* stream);
+int suo_ba_lm_linearize_dev(suo_ba_ctx* ctx, int robust_on, int rank, int world, const double* ctl_dev, double* lin_local_dev, double* lin_dev,
+                            void* stream);
+int suo_ba_lm_schur_dev(suo_ba_ctx* ctx, double* ctl_dev, const double* lin_dev, double* sch_dev, void* stream);
+int suo_ba_lm_solve_update_dev(suo_ba_ctx* ctx, int robust_on, int world, const double* ctl_dev, const double* lin_dev, const double* sch_dev,
+                               double* red_dev, void* stream);
+int suo_ba_lm_decide_dev(suo_ba_ctx* ctx, double* ctl_dev, const double* red_dev, void* stream);
 /* Test entry (finite-difference checks of what the KERNELS linearise, not of the oracle): after suo_ba_linearize, per edge in
  * the caller's order jac_out[e][29] = [J_cam 2x6 | J_obj 2x6 | w*info (xx,xy,yy) | -w*info*err (2)] (EdgeSE3ProjectFromObject::
  * linearizeOplus, types_object_slam.cpp:70-123, columns = [omega, upsilon]) and err_out[e][2] (computeError, :45-60). */

@@ -54,7 +54,12 @@ class HipPhases:
         self.sch = torch.zeros(self.ns * self.ns + self.ns + 1, dtype=torch.float64, device=dev)
         self.red = torch.zeros(4, dtype=torch.float64, device=dev)
         self.good = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._pin = torch.empty(self.lin.numel(), dtype=torch.float64).pin_memory()
+        self._pin = torch.empty(max(self.lin.numel(), 16), dtype=torch.float64).pin_memory()
+        # device-resident LM schedule (csrc/lm_dist.hip: ctl): this rank's own linearisation totals (the in-place reduce starts from them every
+        # unit) and the control block g2o's accept / reject arithmetic lives in
+        self.lin_loc = torch.zeros_like(self.lin)
+        self.ctl = torch.zeros(16, dtype=torch.float64, device=dev)
+        self._graphs, self._graph_failed = {}, False
 
     @staticmethod
     def _p(t):
@@ -79,6 +84,47 @@ class HipPhases:
 
     def restore(self):
         _lib.check(self.lib.suo_ba_restore_dev(self._h, self._stream()), "suo_ba_restore_dev")
+
+    def begin_round(self, its, world):
+        _lib.check(self.lib.suo_ba_lm_begin_dev(self._h, self._p(self.ctl), int(its), int(world), self._stream()), "suo_ba_lm_begin_dev")
+
+    def unit(self, robust_on, rank, world, reduce_):
+        """One unit of the device-resident schedule: [linearise] -> reduce -> [lambda init] Schur -> reduce -> solve + update + chi2 -> reduce ->
+        decide [+ restore]; the phases that the control block does not call for return at once.  No host synchronisation."""
+        s = self._stream()
+        _lib.check(self.lib.suo_ba_lm_linearize_dev(self._h, int(robust_on), rank, world, self._p(self.ctl), self._p(self.lin_loc), self._p(self.lin), s),
+                   "suo_ba_lm_linearize_dev")
+        reduce_(self.lin)
+        _lib.check(self.lib.suo_ba_lm_schur_dev(self._h, self._p(self.ctl), self._p(self.lin), self._p(self.sch), s), "suo_ba_lm_schur_dev")
+        reduce_(self.sch)                                  # the pose-graph reduce: [S | r | ok-count], in place
+        _lib.check(self.lib.suo_ba_lm_solve_update_dev(self._h, int(robust_on), world, self._p(self.ctl), self._p(self.lin), self._p(self.sch),
+                                                       self._p(self.red), s), "suo_ba_lm_solve_update_dev")
+        reduce_(self.red[:3])
+        _lib.check(self.lib.suo_ba_lm_decide_dev(self._h, self._p(self.ctl), self._p(self.red), s), "suo_ba_lm_decide_dev")
+
+    def unit_replay(self, robust_on, rank, world, reduce_):
+        """The same unit as a captured hipGraph (one per robust_on): its launches are identical from trial to trial -- lambda and the
+        live / dead decision of every phase come from the control block -- so 17 launches become one graph launch (host 10-16 us instead
+        of ~80, kernel boundaries ~1.5 us).  SUO_BA_GRAPH=0: eager; 1 (default): captured when the unit holds no collective (one rank);
+        2: captured with its collectives (RCCL inside hipGraph capture)."""
+        mode = int(os.environ.get("SUO_BA_GRAPH", "1"))
+        has_collectives = world > 1 or _collectives_forced()
+        if mode <= 0 or (has_collectives and mode < 2) or self._graph_failed:
+            return self.unit(robust_on, rank, world, reduce_)
+        key = (int(robust_on), rank, world, has_collectives)
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):                   # (capture only: nothing of the unit runs here)
+                    self.unit(robust_on, rank, world, reduce_)
+                self._graphs[key] = g
+            except Exception:                               # capture is an optimisation: fall back to eager launches for good
+                self._graph_failed = True
+                torch.cuda.synchronize()
+                return self.unit(robust_on, rank, world, reduce_)
+        g.replay()
 
     def read(self, t):
         """The host's look at a few reduced scalars (what the LM schedule decides on): one small D2H into pinned memory."""
@@ -152,13 +198,22 @@ def split_problem(full: _ba.Problem, rank: int, world: int):
     return local, cams, sel
 
 
+def host_schedule_forced():
+    """SUO_BA_HOST_SCHEDULE=1: the round-2/3 schedule (the host reads four doubles per trial and decides) also for the HIP phases -- A/B and
+    the equivalence test of the device-resident schedule."""
+    return os.environ.get("SUO_BA_HOST_SCHEDULE", "0") not in ("", "0")
+
+
 def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
     """Run the robust LM rounds of `full` across the ranks of the default process group.  Every rank passes the
     same `full` problem and gets the complete result back (cam_T, obj_T, inlier, chi2, stats) in `full`.
 
     Per LM iteration: one collective (linearisation totals; the lambda-init maximum travels in per-rank slots of the same SUM).
     Per LM trial: COLLECTIVES_PER_TRIAL = 2 collectives -- the pose-graph reduce [S | r | ok] and the 3-scalar step result --
-    both in place on device buffers, and ONE read of 4 doubles on which g2o's accept / reject decision is taken."""
+    both in place on device buffers.  With the HIP phases g2o's accept / reject decision is taken ON THE DEVICE (control block, csrc/lm_dist.hip)
+    and the host reads 16 doubles once per batch of units (a round of n iterations whose trials are all accepted: once); the numpy phases of
+    the CPU tests -- and SUO_BA_HOST_SCHEDULE=1 -- keep the schedule on the host, one read of 4 doubles per trial.  A trial on a standing
+    linearisation (after a rejected one) repeats the iteration's collective: the units are uniform, a repeat costs 3.5 KB."""
     rank, world = _world()
     local, cams, sel = split_problem(full, rank, world)
     ph = phases_factory(local, world)
@@ -177,10 +232,29 @@ def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
         num_good = classify(False)
     robust_on = True
     drop = max(1, len(full.its) // 2)
+    device_schedule = hasattr(ph, "unit") and not host_schedule_forced()
     for rnd, its in enumerate(full.its):
         if n_edge_total < 4 or num_good < 4:
             break
         rounds += 1
+        if device_schedule:
+            # g2o's lambda / nu / gain-ratio logic runs on the device (csrc/lm_dist.hip: ba_ctl_*_kernel); the host enqueues units blindly --
+            # `its` of them cover a round whose every trial is accepted, a rejected trial costs one more -- and looks at the control block
+            # once per batch.  Every rank enqueues the same units: the decisions are taken on all-reduced quantities.
+            ph.begin_round(int(its), world)
+            batch = int(os.environ.get("SUO_BA_UNITS_PER_LOOK", "12"))      # units between two looks at the control block (a dead unit costs ~50 us of empty launches)
+            budget, done = min(int(its), batch), int(its) <= 0
+            while not done:
+                for _ in range(budget):
+                    (ph.unit_replay if hasattr(ph, "unit_replay") else ph.unit)(robust_on, rank, world, _reduce_)
+                ctl = ph.read(ph.ctl)
+                done = int(ctl[3]) == 2
+                budget = min(max(1, int(its) - int(ctl[4])) + 1, batch)
+            lm_its, lm_trials = int(ctl[7]), int(ctl[8])
+            num_good = classify(False)
+            if rnd == drop:
+                robust_on = False
+            continue
         lam, ni = -1.0, 2.0
         for it in range(int(its)):
             ph.linearize(robust_on, rank, world)
@@ -203,7 +277,8 @@ def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
                     temp_chi, scale = float(red[0]), float(red[1]) + float(red[3])
                 rho = (current_chi - temp_chi) / (scale + 1e-3)
                 if rho > 0 and math.isfinite(temp_chi):
-                    alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                    r21 = 2 * rho - 1
+                    alpha = min(1.0 - r21 * r21 * r21, 2.0 / 3.0)        # (the products as the kernels form them: the two schedules agree bit for bit)
                     lam *= max(1.0 / 3.0, alpha)
                     ni = 2.0
                     current_chi = temp_chi

@@ -27,6 +27,20 @@ constexpr int BA_SCRATCH_DOUBLES = BA_WGS + 8;
 #define GT (blockIdx.x * LM_THREADS + threadIdx.x)
 #define GS (gridDim.x * LM_THREADS)
 
+// ---- device-resident LM schedule (round 4) ------------------------------------------------------------------------------------------
+// g2o's accept / reject logic (optimization_algorithm_levenberg.cpp:88-148) is branch-free arithmetic on a handful of all-reduced scalars.
+// Instead of reading them back per trial, the host enqueues UNITS -- [linearise] -> reduce -> [lambda init] -> Schur -> reduce -> solve +
+// update + chi2 -> reduce -> decide [+ restore] -- and a control block on the device says which of them are live:
+//   ctl[0] lambda   [1] ni   [2] current chi2   [3] state (0: the next unit linearises; 1: the next unit is a trial on the standing
+//   linearisation; 2: the round is over)   [4] iterations done in this round   [5] its iteration budget   [6] qmax   [7] LM iterations (all
+//   rounds)   [8] LM trials (all rounds)   [9] rho   [10] restore flag of the unit   [11] ranks
+// Every phase kernel takes (ctl, want): with ctl it returns at once unless ctl[3] == want and reads lambda from ctl[0].  A unit enqueued
+// after the round ended is a handful of empty launches; the host looks at ctl once per batch of units, not once per trial.
+constexpr int CTL_LAMBDA = 0, CTL_NI = 1, CTL_CHI = 2, CTL_STATE = 3, CTL_IT = 4, CTL_ITS = 5, CTL_QMAX = 6, CTL_LM_ITS = 7, CTL_TRIALS = 8, CTL_RHO = 9,
+              CTL_RESTORE = 10, CTL_WORLD = 11;
+constexpr int ST_LINEARIZE = 0, ST_TRIAL = 1, ST_DONE = 2;
+#define BA_GUARD(ctl, want) do { if ((ctl) && (int)(ctl)[CTL_STATE] != (want)) return; } while (0)
+
 // ---- phase 0: poses from the 3x4 matrices, reset levels ---------------------------------------------------
 __global__ __launch_bounds__(LM_THREADS) void ba_init_kernel(const LmProblem* __restrict__ Pp) {
     const LmProblem& P = *Pp;
@@ -69,17 +83,20 @@ __global__ __launch_bounds__(LM_THREADS) void ba_classify_kernel(const LmProblem
 
 // ---- linearise: edge pass | pair blocks | diagonal blocks | tail --------------------------------------------
 __global__ __launch_bounds__(LM_THREADS) void ba_edge_pass_kernel(const LmProblem* __restrict__ Pp, int robust_on, int with_jac,
-                                                                   double* __restrict__ partial) {
+                                                                   double* __restrict__ partial, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
     const double c = block_sum(edge_pass_partial(P, 0, P.n_edge, robust_on != 0, with_jac != 0, GT, GS), red);
     if (threadIdx.x == 0) partial[blockIdx.x] = c;
 }
-__global__ __launch_bounds__(LM_THREADS) void ba_accumulate_kernel(const LmProblem* __restrict__ Pp) {
+__global__ __launch_bounds__(LM_THREADS) void ba_accumulate_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     accumulate_pairs_range(*Pp, 0, Pp->n_pair, GT, GS);
 }
 // own cameras: Hcc / bc; objects: this rank's share of (Hoo 21 + bo 6) -> out[1 + 27 o + k]
-__global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ out) {
+__global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ out, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     for (int idx = GT; idx < P.n_cam * 27; idx += GS) {
         const int c = idx / 27, k = idx - c * 27;
@@ -101,7 +118,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* 
 // out[0] = chi2_local, out[1 + 27 n_obj + rank] = max |diag Hcc| over the local free cameras (the other ranks' slots are
 // zeroed: a SUM all-reduce then carries every rank's maximum, so the max needs no collective of its own)
 __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ partial, int n,
-                                                                        double* __restrict__ out, int rank, int world) {
+                                                                        double* __restrict__ out, int rank, int world, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
     double md = 0;
@@ -119,7 +137,10 @@ __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmP
 }
 
 // ---- local Schur complement for this lambda: push() + camera inverses | Y | S_g, r_g ---------------------------
-__global__ __launch_bounds__(LM_THREADS) void ba_schur_cams_kernel(const LmProblem* __restrict__ Pp, double lambda, int* __restrict__ bad) {
+__global__ __launch_bounds__(LM_THREADS) void ba_schur_cams_kernel(const LmProblem* __restrict__ Pp, double lambda, int* __restrict__ bad,
+                                                                    const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
+    if (ctl) lambda = ctl[CTL_LAMBDA];
     const LmProblem& P = *Pp;
     for (int c = GT; c < P.n_cam; c += GS) P.cam_bak[c] = P.cam[c];
     for (int o = GT; o < P.n_obj; o += GS) P.obj_bak[o] = P.obj[o];
@@ -137,7 +158,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_cams_kernel(const LmProbl
         }
     }
 }
-__global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem* __restrict__ Pp) {
+__global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     for (int idx = GT; idx < P.n_pair * 36; idx += GS) {
         const int p = idx / 36, rc = idx - p * 36, r = rc / 6, cc = rc - r * 6;
@@ -155,7 +177,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem*
 // threads, slices summed in slice order through LDS (deterministic).  (One thread per element walking the whole list: 45 us -- its
 // three dependent index loads per camera are pure latency.)  The right-hand side rows follow, one thread per row.
 __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem* __restrict__ Pp, int ns, const int* __restrict__ bad,
-                                                                 double* __restrict__ out) {
+                                                                 double* __restrict__ out, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     constexpr int NSL = LM_THREADS / 36;                      // camera slices (7 with 256 threads)
     __shared__ double part[NSL * 36];
@@ -212,7 +235,9 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
 // HB = [Hoo_total(21)+bo_total(6) per object], St = [S_total (ns x ns) | r_total (ns) | number of ranks whose Schur phase was ok]
 __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
                                                                const double* __restrict__ HB, const double* __restrict__ St, int expect_ok,
-                                                               int* __restrict__ bad) {
+                                                               int* __restrict__ bad, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
+    if (ctl) lambda = ctl[CTL_LAMBDA];
     const LmProblem& P = *Pp;
     __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch (+ slack)
     __shared__ double rhs[LM_NS];
@@ -252,7 +277,10 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
 // summation order differs from the LDS path.
 __global__ __launch_bounds__(LM_THREADS) void ba_solve_big_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
                                                                    const double* __restrict__ HB, const double* __restrict__ St, int expect_ok,
-                                                                   int* __restrict__ bad, double* __restrict__ S, double* __restrict__ rhs) {
+                                                                   int* __restrict__ bad, double* __restrict__ S, double* __restrict__ rhs,
+                                                                   const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
+    if (ctl) lambda = ctl[CTL_LAMBDA];
     const LmProblem& P = *Pp;
     __shared__ int sh_ok;
     __shared__ double sh_d;
@@ -316,7 +344,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_big_kernel(const LmProble
 // x_c = y_c - sum_o Y(c,o) x_o for the own cameras, then T <- exp(x) T for cameras and objects (one thread per pose)
 // x_c = y_c - sum_o Y(c,o) x_o and the pose updates.  Six threads per camera (one per row of x_c): the dependent index chain of a
 // camera's pair list runs once per row in parallel instead of six times in a row (one thread per camera: 47 us for 32 cameras).
-__global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* __restrict__ Pp, const int* __restrict__ bad) {
+__global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* __restrict__ Pp, const int* __restrict__ bad, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     const bool ok = *bad == 0;
     constexpr int CPW = LM_THREADS / 6;                       // cameras per workgroup and sweep
@@ -348,7 +377,9 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* 
 // (the first three are summed over ranks; the object part is identical on every rank)
 __global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProblem* __restrict__ Pp, double lambda, const double* __restrict__ partial,
                                                                      int n, const double* __restrict__ HB, const int* __restrict__ bad,
-                                                                     double* __restrict__ out) {
+                                                                     double* __restrict__ out, const double* __restrict__ ctl, int want) {
+    BA_GUARD(ctl, want);
+    if (ctl) lambda = ctl[CTL_LAMBDA];
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
     const int tid = threadIdx.x;
@@ -370,7 +401,8 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProb
 }
 
 // ---- pop(): restore the poses saved by the Schur phase -------------------------------------------------------
-__global__ __launch_bounds__(LM_THREADS) void ba_restore_kernel(const LmProblem* __restrict__ Pp) {
+__global__ __launch_bounds__(LM_THREADS) void ba_restore_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ ctl) {
+    if (ctl && ctl[CTL_RESTORE] == 0.0) return;
     const LmProblem& P = *Pp;
     for (int c = GT; c < P.n_cam; c += GS) P.cam[c] = P.cam_bak[c];
     for (int o = GT; o < P.n_obj; o += GS) P.obj[o] = P.obj_bak[o];
@@ -380,6 +412,72 @@ __global__ __launch_bounds__(LM_THREADS) void ba_finalize_kernel(const LmProblem
     const LmProblem& P = *Pp;
     for (int c = GT; c < P.n_cam; c += GS) pose_to_T(P.cam[c], P.cam_T + 12 * c);
     for (int o = GT; o < P.n_obj; o += GS) pose_to_T(P.obj[o], P.obj_T + 12 * o);
+}
+
+// ---- the schedule's own steps (one thread each: a dozen scalar operations) ---------------------------------------------------------
+// start of a round (ObjectSLAM.optimize's optimizer.optimize(n), object_slam.py:873-875): n iterations to go, the next unit linearises
+__global__ void ba_ctl_begin_kernel(double* __restrict__ ctl, int its, int world) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl[CTL_STATE] = its > 0 ? ST_LINEARIZE : ST_DONE;
+        ctl[CTL_IT] = 0; ctl[CTL_ITS] = its; ctl[CTL_QMAX] = 0; ctl[CTL_RHO] = 0; ctl[CTL_RESTORE] = 0; ctl[CTL_WORLD] = world;
+        ctl[CTL_LAMBDA] = -1; ctl[CTL_NI] = 2;
+    }
+}
+// after the linearisation totals are reduced: chi2 of the iteration; in the first iteration computeLambdaInit (tau * max |diag H| over ALL
+// free vertices: the cameras' maxima travel in per-rank slots of the same SUM, the objects' diagonals are in the totals)
+__global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ ctl, const double* __restrict__ lin) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || (int)ctl[CTL_STATE] != ST_LINEARIZE) return;
+    const LmProblem& P = *Pp;
+    ctl[CTL_CHI] = lin[0];
+    if ((int)ctl[CTL_IT] == 0) {
+        double maxd = 0;
+        const int world = (int)ctl[CTL_WORLD];
+        for (int r = 0; r < world; ++r) maxd = fmax(maxd, lin[1 + 27 * P.n_obj + r]);
+        for (int o = 0; o < P.n_obj; ++o)
+            if (!P.obj_fixed[o])
+                for (int d = 0; d < 6; ++d) maxd = fmax(maxd, fabs(lin[1 + 27 * o + DIAG21[d]]));
+        ctl[CTL_LAMBDA] = 1e-5 * maxd;
+        ctl[CTL_NI] = 2;
+    }
+    ctl[CTL_QMAX] = 0; ctl[CTL_RHO] = 0;
+    ctl[CTL_STATE] = ST_TRIAL;
+}
+// after the step's [chi2 | scale over cameras | ok-count] are reduced (red[3] = scale over objects, identical on every rank): the gain ratio,
+// accept / reject, lambda / ni, the trial and iteration counters, what the next unit is
+__global__ void ba_ctl_decide_kernel(double* __restrict__ ctl, const double* __restrict__ red) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctl[CTL_RESTORE] = 0;
+    if ((int)ctl[CTL_STATE] != ST_TRIAL) return;
+    const int world = (int)ctl[CTL_WORLD];
+    double lambda = ctl[CTL_LAMBDA], ni = ctl[CTL_NI], current = ctl[CTL_CHI];
+    double temp = 1.7976931348623157e308, scale = 0;
+    if ((int)(red[2] + 0.5) == world) { temp = red[0]; scale = red[1] + red[3]; }
+    const double rho = (current - temp) / (scale + 1e-3);
+    bool lam_finite = true;
+    int qmax = (int)ctl[CTL_QMAX];
+    if (rho > 0 && isfinite(temp)) {
+        const double r21 = 2 * rho - 1;
+        double alpha = 1. - r21 * r21 * r21;
+        alpha = fmin(alpha, 2. / 3.);
+        lambda *= fmax(1. / 3., alpha);
+        ni = 2;
+        current = temp;
+    } else {
+        lambda *= ni;
+        ni *= 2;
+        ctl[CTL_RESTORE] = 1;                                  // pop()
+        if (!isfinite(lambda)) lam_finite = false;
+    }
+    if (lam_finite) { ++qmax; ctl[CTL_TRIALS] += 1; }
+    ctl[CTL_LAMBDA] = lambda; ctl[CTL_NI] = ni; ctl[CTL_CHI] = current; ctl[CTL_RHO] = rho; ctl[CTL_QMAX] = qmax;
+    if (lam_finite && rho < 0 && qmax < 10) return;            // another trial on the same linearisation
+    ctl[CTL_LM_ITS] += 1;
+    const int it = (int)ctl[CTL_IT] + 1;
+    ctl[CTL_IT] = it;
+    ctl[CTL_STATE] = (qmax == 10 || rho == 0 || !lam_finite || it >= (int)ctl[CTL_ITS]) ? ST_DONE : ST_LINEARIZE;
+}
+__global__ void ba_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 #define BA_GRID(k, ...) hipLaunchKernelGGL(k, dim3(BA_WGS), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ##__VA_ARGS__)
@@ -394,36 +492,56 @@ int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch
     hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)scratch, BA_WGS, out, 0);
     BA_DONE
 }
-int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s) {
-    BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch);
-    BA_GRID(ba_accumulate_kernel);
-    BA_GRID(ba_gather_kernel, out);
-    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world);
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl) {
+    BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch, ctl, ST_LINEARIZE);
+    BA_GRID(ba_accumulate_kernel, ctl, ST_LINEARIZE);
+    BA_GRID(ba_gather_kernel, out, ctl, ST_LINEARIZE);
+    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world, ctl, ST_LINEARIZE);
     BA_DONE
 }
-int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s) {
+int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s, const double* ctl) {
     int* bad = (int*)(scratch + BA_WGS);
     SUO_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
-    BA_GRID(ba_schur_cams_kernel, lambda, bad);
-    BA_GRID(ba_schur_y_kernel);
+    BA_GRID(ba_schur_cams_kernel, lambda, bad, ctl, ST_TRIAL);
+    BA_GRID(ba_schur_y_kernel, ctl, ST_TRIAL);
     {   // one workgroup per 6 x 6 block of S
         const int nb = ns / 6, g = nb * nb < BA_WGS ? BA_WGS : (nb * nb > 1024 ? 1024 : nb * nb);
-        hipLaunchKernelGGL(ba_schur_s_kernel, dim3(g), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ns, (const int*)bad, out);
+        hipLaunchKernelGGL(ba_schur_s_kernel, dim3(g), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ns, (const int*)bad, out, ctl, ST_TRIAL);
     }
     BA_DONE
 }
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
-                           double* scratch, double* big, hipStream_t s) {
+                           double* scratch, double* big, hipStream_t s, const double* ctl) {
     int* bad = (int*)(scratch + BA_WGS);          // carries over from the Schur phase of the same trial
-    if (ns <= LM_NS) BA_ONE(ba_solve_kernel, lambda, ns, HB, St, expect_ok, bad);
+    if (ns <= LM_NS) BA_ONE(ba_solve_kernel, lambda, ns, HB, St, expect_ok, bad, ctl, ST_TRIAL);
     else if (!big) { suo_set_error("bundle adjustment: reduced system of %d rows needs the big-system scratch", ns); return SUO_ERR_ARG; }
-    else BA_ONE(ba_solve_big_kernel, lambda, ns, HB, St, expect_ok, bad, big, big + (size_t)ns * ns);
-    BA_GRID(ba_update_kernel, (const int*)bad);
-    BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch);
-    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out);
+    else BA_ONE(ba_solve_big_kernel, lambda, ns, HB, St, expect_ok, bad, big, big + (size_t)ns * ns, ctl, ST_TRIAL);
+    BA_GRID(ba_update_kernel, (const int*)bad, ctl, ST_TRIAL);
+    BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch, ctl, ST_TRIAL);
+    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out, ctl, ST_TRIAL);
     BA_DONE
 }
-int launch_ba_restore(const void* P, hipStream_t s) { BA_GRID(ba_restore_kernel); BA_DONE }
+int launch_ba_ctl_begin(double* ctl, int its, int world, hipStream_t s) {
+    hipLaunchKernelGGL(ba_ctl_begin_kernel, dim3(1), dim3(64), 0, s, ctl, its, world);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+int launch_ba_ctl_lin(const void* P, double* ctl, const double* lin, hipStream_t s) {
+    hipLaunchKernelGGL(ba_ctl_lin_kernel, dim3(1), dim3(64), 0, s, (const LmProblem*)P, ctl, lin);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+int launch_ba_ctl_decide(const void* P, double* ctl, const double* red, hipStream_t s) {
+    hipLaunchKernelGGL(ba_ctl_decide_kernel, dim3(1), dim3(64), 0, s, ctl, red);
+    BA_GRID(ba_restore_kernel, (const double*)ctl);            // pop() when the trial was rejected
+    BA_DONE
+}
+int launch_ba_copy(const double* src, double* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(ba_copy_kernel, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, s, src, dst, n);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+int launch_ba_restore(const void* P, hipStream_t s) { BA_GRID(ba_restore_kernel, (const double*)nullptr); BA_DONE }
 int launch_ba_finalize(const void* P, hipStream_t s) { BA_GRID(ba_finalize_kernel); BA_DONE }
 
 }  // namespace suo

@@ -328,3 +328,29 @@ def test_phase_wise_global_ba_matches_oracle_and_single_kernel(ba, n_cam, n_obj)
         for a, b in zip(got, want):
             assert _pose_close(a, b, 1e-6, 1e-6), np.abs(a - b).max()
     np.testing.assert_allclose(full.chi2, ref[3], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_cam,n_obj,big", [(12, 6, False), (32, 16, False), (10, 20, True)])
+def test_device_resident_lm_schedule_equals_the_host_schedule(ba, monkeypatch, n_cam, n_obj, big):
+    """suo_slam_amd/ba_dist.py: with the HIP phases g2o's accept / reject arithmetic (optimization_algorithm_levenberg.cpp:88-148) runs in
+    one-thread kernels on a device control block and the host looks at it once per batch of units; SUO_BA_HOST_SCHEDULE=1 keeps the
+    round-2/3 schedule (the host reads four doubles per trial and decides).  Same kernels, same arithmetic, same order: poses, inlier
+    flags, chi2 and the round / iteration / trial counters are bit-identical -- incl. a graph whose reduced system is factorised in global
+    memory (> 16 free objects)."""
+    from suo_slam_amd import ba_dist
+    rng = np.random.default_rng(n_cam * 31 + n_obj)
+    if big:
+        P = S.make_pose_graph(rng, n_cam, n_obj, kp_per_obj=8)
+        P.pop("obj_gt"); P.pop("cam_gt")
+    else:
+        P, _ = _multi_view_scene(rng, n_cam, n_obj)
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SUO_BA_HOST_SCHEDULE", mode)
+        out[mode] = ba_dist.optimize_distributed(ba.Problem(*[P[k].copy() for k in keys]))
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a.stats, b.stats), (a.stats, b.stats)
+    assert a.stats[2] >= a.stats[1] > 4
+    assert np.array_equal(a.cam_T, b.cam_T) and np.array_equal(a.obj_T, b.obj_T)
+    assert np.array_equal(a.inlier, b.inlier) and np.array_equal(a.chi2, b.chi2)
