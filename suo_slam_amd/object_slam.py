@@ -354,6 +354,7 @@ class ObjectSLAM:
         """object_slam.py:327-451."""
         assert view_id not in self.cam_poses, f"Repeat view_id {view_id}"
         import torch
+        self._frame_key = self._frame_dev = None            # (the frame is uploaded once per view: _frame_on_device)
         if self.model is not None:
             torch.cuda.synchronize()
         tt0 = time()
@@ -545,6 +546,17 @@ class ObjectSLAM:
                 self.obj_poses[obj_id] = invert_SE3(to4x4(self.cam_poses[view_id])) @ detection[obj_id]["pose"]
 
     # ---------------------------------------------------------------------------------------------
+    def _frame_on_device(self, img):
+        """The frame of the current view on the device: uploaded once (pinned staging + copy kernel, pkpnet.PkpNet._to_device) and handed to
+        BOTH network passes of a SLAM view (the reference uploads the full frame per pass, lib/object_slam.py:1092-1098)."""
+        import torch
+        key = (id(img), getattr(img, "shape", None))
+        if getattr(self, "_frame_key", None) != key or self._frame_dev is None:
+            host = np.ascontiguousarray(img)
+            self._frame_dev = self.model._to_device(torch.from_numpy(host)) if isinstance(host, np.ndarray) and host.dtype == np.uint8 else host
+            self._frame_key = key
+        return self._frame_dev
+
     def _run_kp_model(self, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks_gt=None, uv_gt=None, prior_dets=None):
         """object_slam.py:1077-1167.  Network + masks on the GPU, then ONE batched PnP launch for all
         objects of the frame (the reference loops lambdatwist.pnp per object)."""
@@ -565,7 +577,7 @@ class ObjectSLAM:
                 for k, obj_id in enumerate(obj_ids):
                     if obj_id in prior_dets:
                         prior_uv[k], prior_mask[k] = prior_dets[obj_id]
-            pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None,
+            pred = self.model(self._frame_on_device(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None,
                               prior_uv=prior_uv, prior_mask=prior_mask)
             if self.no_network_cov:
                 bt, vt = self.bbox_thresh, 1e30

@@ -52,7 +52,9 @@ def make_texture(rng, H=480, W=640):
     for ax in (0, 1):
         img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, img)
     img += rng.normal(0, 0.02, img.shape)
-    return (np.clip(img, 0, 1) * 255).astype(np.uint8)
+    # C-contiguous like a frame from cv2.imread (bop.py:438): apply_along_axis leaves a permuted layout behind, and a strided 0.9 MB copy
+    # per network call (0.7-2.5 ms on the host) is not something the reference's frames ever cost
+    return np.ascontiguousarray((np.clip(img, 0, 1) * 255).astype(np.uint8))
 
 
 def make_frame(rng, n_obj=8, K=K_YCBV, H=480, W=640, noise=0.01, outlier_frac=0.0, with_image=True):
