@@ -3,13 +3,13 @@
 # installed file starts with the command that produced it, taken from the cmd_*.txt the profiling script wrote (not retyped here).
 #   bash tools/install_profiles.sh <tag> [round-prefix, default r03]
 set -eu
-TAG=$1; P=${2:-r03}
+TAG=$1; P=${2:-r04}
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/round_$TAG
 for extra in "" _driver_flags _objects16; do
   if [ -s $SRC/bench_line$extra.json ]; then tail -1 $SRC/bench_line$extra.json > profiles/${P}_bench_line$extra.json; fi
 done
-for name in bench cnn_serial dominant dominant_latency latency slam; do
+for name in bench cnn_serial dominant dominant_latency latency slam global_ba; do
   if [ -s $SRC/${name}_kernel_stats.txt ]; then
     { echo "# $(cat $SRC/cmd_$name.txt)   (1x MI355X; tools/profile_round.sh $TAG; per kernel x grid, tools/rocpd_stats.py)"; cat $SRC/${name}_kernel_stats.txt; } > profiles/${P}_${name}_kernel_stats.txt
   fi
@@ -19,6 +19,7 @@ done
   cat $SRC/pmc.txt; } > profiles/${P}_pmc_dominant_conv.txt
 { echo "# SUO_PMC_GEMM_M=1048576 bash tools/profile_gemm_pmc.sh conv1_x3 conv1   (rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_gemm.py run <shape> 10, one pass per group; conv1_x3 = gemm_bf16x3_kernel, what the network launches; conv1 = the fp32-pipe kernel)"
   cat $SRC/pmc_gemm.txt; } > profiles/${P}_pmc_gemm.txt
+if [ -s $SRC/res_block.txt ]; then { echo "# python3 tools/bench_res_block.py 8; python3 tools/bench_res_block.py 32   (1x MI355X; tools/profile_round.sh $TAG; HIP events, 50 launches each)"; cat $SRC/res_block.txt; } > profiles/${P}_res_block.txt; fi
 cp $SRC/pmc_dominant_conv.json profiles/pmc_dominant_conv.json
 [ -s $SRC/pmc_gemm.json ] && cp $SRC/pmc_gemm.json profiles/pmc_gemm.json
 for f in latency.log slam.log; do [ -s $SRC/$f ] && grep -v "amdgpu.ids\|rocprofv3\|simple_timer\|^W2026" $SRC/$f > profiles/${P}_${f%.log}_run.txt || true; done

@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (one gpurun call): bench lines, kernel traces, dominant-kernel stats, PMC passes.
 #   bash tools/profile_round.sh <round-tag>      -> gpurun_out/round_<tag>/...   (then: bash tools/install_profiles.sh <tag> <prefix>)
 # Every rocprofv3 command is written next to its output (cmd_*.txt) so that the installed files carry the command that made them.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -29,6 +29,15 @@ run_traced dominant_latency $R/tools/bench_dominant.py 100 8
 run_traced latency $R/tools/time_frame_chain.py
 # 6. one SLAM sequence through ObjectSLAM.process_view (BASELINE configs[2])
 run_traced slam $R/tools/profile_slam_view.py
+# 6b. the one-launch Residual blocks of the one-frame call shape against the three per-layer launches (HIP events), and the in-kernel phase times
+python3 $R/tools/bench_res_block.py 8 2>&1 | grep -v amdgpu.ids > $OUT/res_block.txt
+python3 $R/tools/bench_res_block.py 32 2>&1 | grep -v amdgpu.ids >> $OUT/res_block.txt
+# 6c. the multi-GPU bundle adjustment schedule at one rank (bench.py's global_ba leg): kernels of the phase units
+echo "rocprofv3 --kernel-trace -- python3 -c 'import bench; bench.global_ba_leg(1, 16)'" > $OUT/cmd_global_ba.txt
+printf 'import sys\nsys.path.insert(0, "%s")\nimport bench\nprint(bench.global_ba_leg(1, 16))\n' $R > /tmp/gba.py
+rocprofv3 --kernel-trace -d $OUT/global_ba_trace -o trace -- python3 /tmp/gba.py > $OUT/global_ba.log 2>&1
+python3 $R/tools/rocpd_stats.py $(find $OUT/global_ba_trace -name "*.db" | head -1) grid > $OUT/global_ba_kernel_stats.txt
+rm -rf $OUT/global_ba_trace
 # 7. PMC passes (separate runs per counter group, nothing but --kernel-trace beside --pmc)
 mkdir -p $R/gpurun_out/pmc && rm -f $R/gpurun_out/pmc/*
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" \
