@@ -21,6 +21,8 @@ int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream
 int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);
 int launch_lm_cam(const void* problems_dev, int n_problems, hipStream_t s);
+int launch_lm_cam2(const void* problems_dev, int n_problems, int max_edges, hipStream_t s);
+int lm_cam2_max_edges();
 int launch_lm_frame(const void* problems_dev, int n_problems, int max_obj, hipStream_t s);
 int launch_lm_frame2(const void* problems_dev, int n_problems, int max_obj, int max_edges, hipStream_t s);
 int lm_frame2_max_edges();
@@ -423,7 +425,12 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         frame_max_obj = std::max(frame_max_obj, probs[i].n_obj);
     }
     if (cam_only) {
-        rc = launch_lm_cam(g_arena.dev + st.o_structs, n_prob, g_arena.stream);
+        // the camera alone in its graph (what ObjectSLAM.optimize(curr_only=True) builds): registers / LDS only (csrc/lm_cam2.hip)
+        static const int cam2 = getenv("SUO_LM_CAM2") ? atoi(getenv("SUO_LM_CAM2")) : 1;                  // 0: csrc/lm_cam.hip (A/B)
+        bool alone = cam2 != 0;
+        for (int i = 0; i < n_prob && alone; ++i) alone = probs[i].n_cam == 1 && probs[i].n_edge <= lm_cam2_max_edges();
+        if (alone) rc = launch_lm_cam2(g_arena.dev + st.o_structs, n_prob, max_edges, g_arena.stream);
+        else rc = launch_lm_cam(g_arena.dev + st.o_structs, n_prob, g_arena.stream);
     } else if (frame_only) {
         // one fixed camera (the single-view frame of evaluate.py): one WAVE per frame, the objects side by side (csrc/lm_frame2.hip)
         static const int frame2 = getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1;              // 0: one wave per object (A/B)
