@@ -170,6 +170,18 @@ def test_limits_fail_loudly():
         _launch(fg2, [_frame_inputs(rng, 17)], seed=0)                                # > 16 objects in one frame with LM
 
 
+def test_frames_of_more_than_64_crops_are_refused_even_without_lm():
+    """fg_build_kernel is one wave per frame, a lane per crop: beyond 64 crops of one frame nothing would be written and
+    fetch() would return stale bytes -- the launch is refused whatever do_lm says; 17 ... 64 crops without LM are fine."""
+    from suo_slam_amd._lib import SuoError
+    rng = np.random.default_rng(8)
+    fg = FrameGeometry(80, 1)
+    r = _launch(fg, [_frame_inputs(rng, 40)], seed=1, do_lm=False)
+    assert r["T_pnp"].shape[0] == 40 and np.isfinite(r["T_pnp"]).all() and set(np.unique(r["accepted"])) <= {0, 1}
+    with pytest.raises(SuoError):
+        _launch(fg, [_frame_inputs(rng, 65)], seed=1, do_lm=False)
+
+
 def _mesh_db(fr, diam=None):
     return {o: {"diameter": float((fr["diameter"] if diam is None else diam)[i]), "is_symmetric": False} for i, o in enumerate(fr["obj_ids"])}
 

@@ -354,3 +354,29 @@ def test_device_resident_lm_schedule_equals_the_host_schedule(ba, monkeypatch, n
     assert a.stats[2] >= a.stats[1] > 4
     assert np.array_equal(a.cam_T, b.cam_T) and np.array_equal(a.obj_T, b.obj_T)
     assert np.array_equal(a.inlier, b.inlier) and np.array_equal(a.chi2, b.chi2)
+
+
+def test_single_view_frame_with_many_edges_per_object_leaves_the_one_wave_kernel(ba):
+    """csrc/lm_frame2.hip keeps a lane's outlier flags in a 32-bit mask: at most 32 edges per lane = 256 per object with 8 lanes.
+    A two-object frame with 300 keypoints each fits its edge budget (656) but not that cap -- the dispatcher must hand it to the general
+    kernel; the result still matches the oracle."""
+    rng = np.random.default_rng(77)
+    n_obj, n_kp = 2, 300
+    k = np.array([600.0, 600.0, 320.0, 240.0])
+    obj_gt = np.zeros((n_obj, 3, 4))
+    e_obj, e_p, e_uv = [], [], []
+    for o in range(n_obj):
+        obj_gt[o, :, :3] = S.random_rotation(rng)
+        obj_gt[o, :, 3] = [rng.uniform(-150, 150), rng.uniform(-100, 100), rng.uniform(800, 1000)]
+        pts = rng.uniform(-60, 60, (n_kp, 3))
+        pc = pts @ obj_gt[o, :, :3].T + obj_gt[o, :, 3]
+        uv = np.c_[k[0] * pc[:, 0] / pc[:, 2] + k[2], k[1] * pc[:, 1] / pc[:, 2] + k[3]] + rng.normal(0, 0.5, (n_kp, 2))
+        uv[rng.random(n_kp) < 0.05] = rng.uniform(0, 480, 2)
+        e_obj += [o] * n_kp; e_p += list(pts); e_uv += list(uv)
+    E = len(e_obj)
+    P = {"cam_T": np.eye(4)[None, :3], "cam_fixed": np.array([1], np.uint8),
+         "obj_T": np.stack([_perturb(np.vstack([T, [0, 0, 0, 1]]), rng, 3e-4, 0.2) for T in obj_gt]), "obj_fixed": np.zeros(n_obj, np.uint8),
+         "edge_cam": np.zeros(E, np.int32), "edge_obj": np.array(e_obj, np.int32), "edge_camk": np.tile(k, (E, 1)), "edge_p": np.array(e_p),
+         "edge_uv": np.array(e_uv), "edge_info": np.tile([4.0, 0, 4.0], (E, 1)), "edge_inlier": np.ones(E, np.uint8)}
+    got, ref = _compare_ba(ba, P)
+    assert got[4][0] == 4

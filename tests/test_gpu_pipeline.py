@@ -191,3 +191,29 @@ def test_symmetric_objects_get_prior_heatmaps_through_the_network(state_dict):
     b = net(fr["image"], bx, None)["prob_logits"]
     c = net(fr["image"], bx, [torch.zeros(2, 41, 256, 256)])["prob_logits"]
     assert torch.equal(b, c) and float((a - b).abs().max()) > 1e-3
+
+
+def test_debug_gt_kp_with_the_network_running_still_uses_the_ground_truth_keypoints():
+    """debug_gt_kp + run_network_in_debug in single-view mode has a model, but the keypoints must still be the projected ground
+    truth (lib/object_slam.py:1129-1131), not the (random-weight) network's -- the device chain, which consumes the network's own output,
+    must not take that frame.  Same seed with and without the network pass => identical poses; and they recover the ground truth."""
+    from suo_slam_amd import _lib, weights
+    from suo_slam_amd.object_slam import ObjectSLAM
+    _lib.require_gpu()
+    rng = np.random.default_rng(4)
+    fr = S.make_frame(rng, 8, noise=0.0)
+    uv_gt = _gt_uv(fr)
+    sd = weights.make_random_state_dict(0, 8.0)
+    poses = []
+    for net in (False, True):
+        slam = ObjectSLAM(None, _mesh_db(fr), debug_gt_kp=True, sfm_mode=True, single_view_mode=True, seed=9,
+                          state_dict=sd if net else None, max_crops=8, run_network_in_debug=net)
+        slam.process_view(0, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
+                          fr["model_kps_masks"], uv_gt=uv_gt)
+        res = slam.collect_results(last_only=False, no_viz=True)[0]["poses"]
+        poses.append({o: r["T_OtoC"] for o, r in res.items() if r["T_OtoC"] is not None})
+    assert len(poses[0]) >= 7 and poses[0].keys() == poses[1].keys()
+    for o in poses[0]:
+        assert np.array_equal(poses[0][o], poses[1][o])
+        k = list(fr["obj_ids"]).index(o)
+        assert np.linalg.norm(poses[0][o][:3, 3] - fr["T_OtoC"][k][:3, 3]) < 0.03 * fr["T_OtoC"][k][2, 3]
