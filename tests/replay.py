@@ -41,7 +41,8 @@ def record():
 
     def forward(self, images, boxes, prior_kp=None, **kw):
         out = orig_fwd(self, images, boxes, prior_kp, **kw)
-        rec.forward.append({"image": np.array(images), "boxes": np.asarray(boxes[0].cpu() if hasattr(boxes[0], "cpu") else boxes[0], dtype=np.float32), "prior_uv": kw.get("prior_uv"),
+        # (since round 4 ObjectSLAM uploads the frame once per view and hands the DEVICE tensor to both network passes)
+        rec.forward.append({"image": images.cpu().numpy() if hasattr(images, "cpu") else np.array(images), "boxes": np.asarray(boxes[0].cpu() if hasattr(boxes[0], "cpu") else boxes[0], dtype=np.float32), "prior_uv": kw.get("prior_uv"),
                             "prior_mask": kw.get("prior_mask"),
                             "out": {k: out[k].cpu().numpy() for k in ("uv", "cov", "kp_mask", "prob_logits")}})
         return out
