@@ -158,7 +158,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned q0 = s3_pack_rn(v[0], v[1]), q1 = s3_pack_rn(v[2], v[3]);       // round-to-nearest terms (csrc/bf16x3.h); p == 2: exact
+#ifdef SUO_WX3_EXP_NOCONFLICT                                 // timing experiment (wrong results): the V stores of a wave at consecutive 8-byte addresses -- no bank conflict
+            *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + (tid & 63) * 4 + (tid >> 6) * 256] = x_u32x2{q0, q1};
+#else
             *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + vbase] = x_u32x2{q0, q1};
+#endif
 #ifndef SUO_WX3_EXP_NOSPLIT                                   // (timing experiment, wrong results: the three planes hold the same term)
             if (p < 2) {
                 v = x_sub4(v, x_f32x4{s3_lo(q0), s3_hi(q0), s3_lo(q1), s3_hi(q1)});        // exact residual

@@ -437,12 +437,15 @@ int Net::residual_in_one_launch(const ResidualW& r, int L, int H, int W) const {
     static const int min_side = getenv("SUO_RES_FUSED_MIN_SIDE") ? atoi(getenv("SUO_RES_FUSED_MIN_SIDE")) : 16;
     if (mode <= 0 || !r.rb_w[0] || H > 32 || W > 32) return 0;
     const long t32 = (long)L * ((H + 3) / 4) * ((W + 7) / 8);
-    // One to three workgroups per CU of 4 x 8 pixel tiles: the bf16x3 kernel, whatever the map (one frame at 32x32; batched frames at 8x8
+    // Half a round to three rounds of 4 x 8 pixel tiles (one workgroup per CU): the bf16x3 kernel, whatever the map (one frame at 32x32; batched frames at 8x8
     // and 4x4, where it replaces three launches of 17-47 us by one or two rounds of 30).  Fewer tiles than CUs on a map of >= 16 pixels a
     // side: the fp32 kernel's 4 x 4 tiles (16x16 at 8 crops: 128 workgroups x 23.4 us against 64 x 28).  Everything else -- few tiles on
     // 8x8 / 4x4 maps (the three per-layer launches spread over all CUs, 13.5 us), many tiles (the Winograd kernels) -- stays per-layer.
-    if (mode >= 2 && r.rbx_w[0] && t32 >= 256 && t32 <= max_tiles) return 2;
-    if (H >= min_side && W >= min_side && (t32 < 256 || (mode == 1 && t32 <= max_tiles))) return 1;
+    // (129 ... 255 tiles, e.g. the 5 crops of a SLAM pass at 32x32: one partial round of the bf16x3 kernel, 30 us, against 4 x 4 tiles
+    //  that no longer fit one per CU, ~40)
+    static const long x3_from = getenv("SUO_RES_FUSED_X3_FROM") ? atol(getenv("SUO_RES_FUSED_X3_FROM")) : 129;
+    if (mode >= 2 && r.rbx_w[0] && t32 >= x3_from && t32 <= max_tiles) return 2;
+    if (H >= min_side && W >= min_side && (t32 < x3_from || (mode == 1 && t32 <= max_tiles))) return 1;
     return 0;
 }
 
