@@ -194,6 +194,13 @@ int suo_pack_res_block_bf16x3(const float* w1, const float* w2, const float* sca
 int suo_res_block_bf16x3(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev,
                          const uint16_t* w1x_dev, const float* b1_dev, const uint16_t* w2x_dev, const float* b2_dev, const uint16_t* w3x_dev,
                          const float* b3_dev, const float* up_dev, float* out_dev, void* stream);
+/* csrc/stem_x3.hip (what suo_net_forward launches for the prior-less pass unless SUO_STEM_X3=0): RoIAlign of the frame (pkpnet.py:93) + the stem
+ * conv1_ 7x7 / stride 2 over the 3 image channels + bn1 + ReLU (hg.py:67-69,96-98) in one launch, products on the bf16 matrix pipe (3-way split);
+ * the staged [L,256,256,*] crop tensor is never written.  wx = suo_pack_stem_weight_bf16x3(W[64][Cw][7][7], Cw, bn scale[64] or NULL) ->
+ * 14 * 2 * 3 * 64 * 8 uint16; bias [64] (folded); frame / boxes / box_img as suo_roi_align_concat; out_dev [L,128,128,64] NHWC. */
+int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint16_t* out);
+int suo_stem_x3(const void* img_dev, int fmt, int H, int W, const float* boxes_dev, const int* box_img_dev, int L, const uint16_t* wx_dev,
+                const float* bias_dev, float* out_dev, void* stream);
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 

@@ -282,6 +282,17 @@ int suo_res_block_bf16x3(const float* x, int L, int H, int W, int pool_in, const
     return suo::launch_res_block_x3(a, (hipStream_t)stream);
 }
 
+int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint16_t* out) {
+    if (!w || !out || Cw < 3) { suo_set_error("suo_pack_stem_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_stem_weight_bf16x3(w, Cw, scale, out);
+    return SUO_OK;
+}
+
+int suo_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* wx, const float* bias, float* out,
+                void* stream) {
+    return suo::launch_stem_x3(img, fmt, H, W, boxes, box_img, L, wx, bias, out, (hipStream_t)stream);
+}
+
 int suo_maxpool2(const float* in, float* out, int L, int H, int W, int C, void* stream) {
     return suo::launch_maxpool2(in, out, L, H, W, C, (hipStream_t)stream);
 }

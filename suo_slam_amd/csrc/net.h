@@ -65,13 +65,16 @@ private:
     int residual_in_one_launch(const ResidualW& r, int L, int H, int W) const;      // 0: no; 1: csrc/res_small.hip; 2: csrc/res_small_x3.hip
     int residual_one_launch(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, bool pool_in);
     int hourglass(const HourglassW& h, const float* x, float* out, int L, int H, int W, hipStream_t s, int depth_idx, const float* x_pooled = nullptr);
-    int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s);
-    int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s);
-    int ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec);
+    int backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s, bool stem_done = false);
+    int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s, bool stem_done = false);
+    int ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec, bool stem_done = false);
+    bool fused_stem() const;
 
     std::map<std::string, HostTensor> tensors_;
     std::vector<float*> owned_;
     ConvW stem_, stem_img_;      // all 44 input channels | the 3 image channels only (no priors: SLAM_C = 16)
+    float* stem_x3_w_ = nullptr; float* stem_x3_bias_ = nullptr;      // the image-only stem as bf16x3 planes for the fused RoIAlign + stem launch (csrc/stem_x3.hip)
+    float* stem_slab_ = nullptr;                                      // [max_crops,128,128,64] persistent slab of the stem's output
     ResidualW r1_, r4_, r5_, post_[2][2];
     HourglassW hg_[2];
     GemmW lin_[2], head_[2], reinject_;

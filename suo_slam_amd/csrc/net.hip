@@ -320,6 +320,17 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
     // channels are zeros: multiply only the 3 image channels.  Same taps, same order, so the result is bit-identical
     // to feeding zero priors through the full filter; 13 % of the network's MACs (41/44 of the stem) are never issued.
     make_conv(b + ".conv1_", b + ".bn1", IMG_C, stem_img_, 3);
+    if (wino_bf16x3()) {                                      // ... and for the fused RoIAlign + stem launch on the bf16 pipe (csrc/stem_x3.hip)
+        const HostTensor& w = T(b + ".conv1_.weight");
+        const HostTensor& bb = T(b + ".conv1_.bias");
+        std::vector<float> sc, sh;
+        bn_affine(*this, b + ".bn1", sc, sh);
+        std::vector<float> wx((size_t)14 * 2 * 3 * 64 * 8 / 2), bias(64);        // uint16 planes
+        pack_stem_weight_bf16x3(w.data, (int)w.shape[1], sc.data(), reinterpret_cast<uint16_t*>(wx.data()));
+        for (int n = 0; n < 64; ++n) bias[n] = bb.data[n] * sc[n] + sh[n];
+        stem_x3_w_ = upload(wx);
+        stem_x3_bias_ = upload(bias);
+    }
     make_residual(b + ".r1", r1_);
     make_residual(b + ".r4", r4_);
     make_residual(b + ".r5", r5_);
@@ -377,6 +388,7 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
     ws_used_ = 0;
     (void)alloc((size_t)max_crops_ * CROP * CROP * IN_C);
     (void)alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+    stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);
     ws_mark_ = ws_used_;
     if (backbone(nullptr, IN_C, nullptr, max_crops_, nullptr) != SUO_OK) throw std::runtime_error("dry run failed");
     ws_floats_ = ws_used_;
@@ -611,15 +623,17 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
 }
 
 // HourglassNet.forward (hg.py:95-119) from the staged NHWC input to NCHW logits
-int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s) {
+int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s, bool stem_done) {
     ws_used_ = ws_mark_;
     ev_next_ = 0;
-    float* stem = alloc((size_t)L * 128 * 128 * 64);
-    ConvArgs c = {};
-    const ConvW& sw = in_c == IMG_C ? stem_img_ : stem_;
-    c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = in_c; c.Wp = sw.Wp; c.bias = sw.bias;
-    c.out = stem; c.OH = 128; c.OW = 128; c.N = 64; c.relu = 1;
-    SUO_LAUNCH(launch_conv7x7s2(c, s));
+    float* stem = stem_slab_;
+    if (!stem_done) {                                          // (the fused stem of the prior-less pass has filled the slab already: csrc/stem_x3.hip)
+        ConvArgs c = {};
+        const ConvW& sw = in_c == IMG_C ? stem_img_ : stem_;
+        c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = in_c; c.Wp = sw.Wp; c.bias = sw.bias;
+        c.out = stem; c.OH = 128; c.OW = 128; c.N = 64; c.relu = 1;
+        SUO_LAUNCH(launch_conv7x7s2(c, s));
+    }
     // pool(r1(x)): the full-resolution r1 output has no other reader, so only its pooled form is written (csrc/gemm_persist.hip: POOL)
     float* p1 = alloc((size_t)L * 64 * 64 * 128);
     SUO_TRY(residual(r1_, stem, nullptr, L, 128, 128, s, nullptr, p1));
@@ -661,13 +675,13 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
     return SUO_OK;
 }
 
-int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec) {
-    const int key = L * 2 + (in_c == IMG_C ? 1 : 0);          // one captured graph per (crop count, staging layout)
+int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec, bool stem_done) {
+    const int key = L * 4 + (in_c == IMG_C ? 1 : 0) + (stem_done ? 2 : 0);      // one captured graph per (crop count, staging layout, with / without the stem)
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
         GraphEntry ge;
         SUO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        int r = backbone(in0, in_c, logits, L, s);
+        int r = backbone(in0, in_c, logits, L, s, stem_done);
         hipError_t e = hipStreamEndCapture(s, &ge.graph);
         if (r != SUO_OK) return r;
         SUO_HIP_CHECK(e);
@@ -678,14 +692,20 @@ int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s,
     return SUO_OK;
 }
 
-int Net::run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s) {
+int Net::run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s, bool stem_done) {
     if (use_graph_) {
         hipGraphExec_t exec = nullptr;
-        SUO_TRY(ensure_graph(in0, in_c, logits, L, s, &exec));
+        SUO_TRY(ensure_graph(in0, in_c, logits, L, s, &exec, stem_done));
         SUO_HIP_CHECK(hipGraphLaunch(exec, s));
         return SUO_OK;
     }
-    return backbone(in0, in_c, logits, L, s);
+    return backbone(in0, in_c, logits, L, s, stem_done);
+}
+
+// SUO_STEM_X3=0: the prior-less pass stages the crop (roi_align_concat_kernel) and runs the stem on the fp32 pipe inside the backbone, as rounds 1-3 did
+bool Net::fused_stem() const {
+    static const int on = getenv("SUO_STEM_X3") ? atoi(getenv("SUO_STEM_X3")) : 1;
+    return on != 0 && stem_x3_w_ != nullptr;
 }
 
 // Capture the backbone graph for L crops ahead of time (nothing runs): a stream of frames with a varying number of
@@ -699,9 +719,10 @@ int Net::prepare(int L, int with_priors, hipStream_t s) {
         ws_used_ = 0;                                             // the same persistent slabs as forward()
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+        stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);          // the stem's output: persistent, the fused stem writes it OUTSIDE the captured graph
         ws_mark_ = ws_used_;
         hipGraphExec_t exec = nullptr;
-        SUO_TRY(ensure_graph(in0, with_priors ? IN_C : IMG_C, logits, L, s, &exec));
+        SUO_TRY(ensure_graph(in0, with_priors ? IN_C : IMG_C, logits, L, s, &exec, !with_priors && fused_stem()));
     } catch (const std::exception& e) {
         suo_set_error("suo_net_prepare: %s", e.what());
         return SUO_ERR_ARG;
@@ -718,6 +739,7 @@ int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStre
         ws_used_ = 0;
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+        stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);          // the stem's output: persistent, the fused stem writes it OUTSIDE the captured graph
         ws_mark_ = ws_used_;
         if (in0_user)
             SUO_HIP_CHECK(hipMemcpyAsync(in0, in0_user, (size_t)L * CROP * CROP * IN_C * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -743,10 +765,18 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         ws_used_ = 0;
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
+        stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);          // the stem's output: persistent, the fused stem writes it OUTSIDE the captured graph
         ws_mark_ = ws_used_;
         const int in_c = (priors || prior_uv) ? IN_C : IMG_C;     // the slab is sized for IN_C; the prior-less layout uses a sixth of it
-        SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, in_c, priors, prior_uv, prior_mask, in0, s));
-        SUO_TRY(run_backbone(in0, in_c, logits, L, s));
+        if (in_c == IMG_C && fused_stem()) {
+            // prior-less pass: RoIAlign + stem in one launch on the bf16 pipe (csrc/stem_x3.hip), ahead of the captured backbone (the frame and
+            // the boxes are the caller's buffers: their addresses change from call to call, a captured launch could not take them)
+            SUO_LAUNCH(launch_stem_x3(img, fmt, H, W, boxes, box_img, L, reinterpret_cast<const uint16_t*>(stem_x3_w_), stem_x3_bias_, stem_slab_, s));
+            SUO_TRY(run_backbone(in0, in_c, logits, L, s, true));
+        } else {
+            SUO_LAUNCH(launch_roi_align_concat(img, fmt, H, W, boxes, box_img, L, in_c, priors, prior_uv, prior_mask, in0, s));
+            SUO_TRY(run_backbone(in0, in_c, logits, L, s, false));
+        }
         SUO_LAUNCH(launch_decode(logits, L, uv, cov, d_mean_logit_, nullptr, nullptr, s));
         SUO_LAUNCH(launch_classifier(d_mean_logit_, cls_w_, cls_b_, L, kp_logit, kp_prob, s));
         if (logits_out)

@@ -1,0 +1,181 @@
+// The stem of the prior-less pass -- RoIAlign of the frame + conv 7x7 / stride 2 over the 3 image channels + BN + ReLU (lib/models/pkpnet.py:93,
+// lib/models/hg.py:67-69,96-98; priors are zeros in every single-view pass, lib/object_slam.py:1094-1097) -- in ONE launch on the bf16 matrix
+// pipe at fp32 accuracy (3-way operand split, csrc/bf16x3.h).  It replaces roi_align_concat_kernel<*, 4> + convk_kernel<7,2,4,...>: the staged
+// [L,256,256,4] tensor (268 MB at 256 crops) is never written, and the 147-term dot products leave the fp32 pipe (864 us at 256 crops).
+//
+// Workgroup = 8 x 16 output pixels of one crop x all 64 channels.  The 21 x 37 input pixels it needs are SAMPLED from the frame while staging
+// (csrc/roi_sample.h: the crop kernel's own arithmetic, so the values are the ones roi_align_concat_kernel would have written; outside the crop:
+// the convolution's zero padding), split into three bf16 terms and stored de-interleaved by column parity, 4 channels (3 + a zero) per entry:
+// with stride 2 the seven taps of an output column are entries [ox, ox + 3] of the EVEN buffer (kx = 0, 2, 4, 6) and [ox, ox + 2] of the ODD
+// one (kx = 1, 3, 5) -- contiguous, 8-byte aligned runs.  K is therefore walked as 7 rows x {even, odd} = 14 steps of 16 (21 of every 32
+// products real); A fragments are two ds_read_b64 per plane, B fragments host-split planes straight from L2.  Four waves as 2 x 2: wave
+// (wm, wn) owns 64 pixels x 32 channels.  Epilogue through an LDS patch, 16-byte stores.
+#include <string.h>
+
+#include "bf16x3.h"
+#include "buffer_ops.h"
+#include "roi_sample.h"
+#include "suo_internal.h"
+
+namespace suo {
+
+typedef float sx_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sx_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned sx_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SX_STEPS = 14, SX_N = 64;
+// timing experiments only (tools/build_variant.sh -DSUO_SX_EXP=n; results are wrong): 1 no sampling (constants staged), 2 no products, 3 no output stores
+#ifndef SUO_SX_EXP
+#define SUO_SX_EXP 0
+#endif
+
+// host: W[64][Cw][7][7] (the first 3 input channels; times out_scale[n]: bn1 folded) -> [step = ky * 2 + h][n-tile][plane][lane][8 bf16],
+//   k = 8 (lane >> 5) + e  ->  entry j = k / 4, channel c = k % 4, tap kx = 2 j + h   (zero for c == 3 and for the odd buffer's 4th entry)
+void pack_stem_weight_bf16x3(const float* W, int Cw, const float* out_scale, uint16_t* out) {
+    memset(out, 0, (size_t)SX_STEPS * 2 * 3 * 64 * 8 * sizeof(uint16_t));
+    for (int ky = 0; ky < 7; ++ky)
+        for (int h = 0; h < 2; ++h)
+            for (int n = 0; n < SX_N; ++n)
+                for (int k = 0; k < 16; ++k) {
+                    const int j = k / 4, c = k % 4, kx = 2 * j + h;
+                    if (c == 3 || kx > 6) continue;
+                    const int s = ky * 2 + h, nb = n / 32, lane = (k / 8) * 32 + (n % 32), e = k % 8;
+                    const float sc = out_scale ? out_scale[n] : 1.f;
+                    uint16_t t[3];
+                    s3_split_host(W[(((size_t)n * Cw + c) * 7 + ky) * 7 + kx] * sc, t);
+                    for (int p = 0; p < 3; ++p) out[((((size_t)(s * 2 + nb) * 3 + p) * 64) + lane) * 8 + e] = t[p];
+                }
+}
+
+__device__ __forceinline__ int sx_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+struct StemArgs {
+    const void* img; int fmt, H, W;                     // frame(s): FMT 0 uint8 HWC, FMT 1 float32 CHW
+    const float* boxes; const int* box_img; int L;      // [L,4] xyxy; optional frame index per crop
+    const uint16_t* Wx; const float* bias;              // pack_stem_weight_bf16x3 planes, folded bias [64]
+    float* out;                                         // [L,128,128,64]
+};
+
+template <int FMT>
+__global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
+    constexpr int TH = 8, TW = 16, IR = 2 * TH + 5, IC = 2 * TW + 5;          // 21 x 37 input pixels
+    constexpr int HALF_B = 160, ROW_B = 2 * HALF_B, PLANE_B = IR * ROW_B;    // bytes: 20 entries of 8 per half row
+    constexpr int PP = SX_N + 4;                                             // epilogue patch pitch (floats)
+    constexpr int LDS_B = TH * TW * PP * 4 > 3 * PLANE_B ? TH * TW * PP * 4 : 3 * PLANE_B;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_B];       // the staged planes, then (dead by then) the epilogue patch: 34 KB, 4 workgroups per CU
+    unsigned char* A3 = lds;
+    float* P = (float*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
+    const int l = bid >> 7, t = bid & 127;                                   // 16 x 8 tiles per crop
+    const int oy0 = (t >> 3) * TH, ox0 = (t & 7) * TW;
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wx, (size_t)SX_STEPS * 2 * 3 * 1024);
+    const int wv = lane * 16;
+    constexpr int R = 4;
+    sx_u32x4 ring[R][3];
+    auto loadw = [&](int s, sx_u32x4 (&b)[3]) {
+        const int k = s < SX_STEPS ? s : SX_STEPS - 1;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(sx_u32x4, buf_load(w_srd, wv + p * 1024, (k * 2 + wn) * 3072));
+    };
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) loadw(s, ring[s]);
+
+    // ---- stage: 21 rows x 2 halves x 20 entries; slot -> input pixel (r, xl = 2 j + h) ---------------------------------------------------
+    {
+        const size_t img_elems = (size_t)a.H * a.W * 3;
+        const void* img = a.box_img ? (FMT == 0 ? (const void*)((const uint8_t*)a.img + a.box_img[l] * img_elems)
+                                                : (const void*)((const float*)a.img + a.box_img[l] * img_elems)) : a.img;
+        const float x1 = a.boxes[l * 4 + 0], y1 = a.boxes[l * 4 + 1], x2 = a.boxes[l * 4 + 2], y2 = a.boxes[l * 4 + 3];
+        for (int slot = tid; slot < IR * 40; slot += 256) {
+            const int r = slot / 40, q = slot - r * 40, h = q / 20, j = q - h * 20;
+            const int xl = 2 * j + h;
+            const int py = 2 * oy0 - 3 + r, px = 2 * ox0 - 3 + xl;
+            float v[3] = {0.f, 0.f, 0.f};
+            if (SUO_SX_EXP == 1) v[0] = v[1] = v[2] = (float)slot * x1;
+            else if (xl < IC && py >= 0 && py < CROP && px >= 0 && px < CROP) roi_sample<FMT>(img, a.H, a.W, x1, y1, x2, y2, py, px, v);
+            float c0 = v[0], c1 = v[1], c2 = v[2];
+            unsigned char* d = A3 + r * ROW_B + h * HALF_B + j * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned q0 = s3_pack_rn(c0, c1), q1 = s3_pack_rn(c2, 0.f);
+                *(sx_u32x2*)(d + p * PLANE_B) = sx_u32x2{q0, q1};
+                if (p < 2) { c0 -= s3_lo(q0); c1 -= s3_hi(q0); c2 -= s3_lo(q1); }
+            }
+        }
+    }
+    __syncthreads();
+
+    sx_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // the six cross terms, smallest first
+    // this lane's pixels: m-tile i of the wave = tile pixels 64 wm + 32 i + (lane & 31)
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = 64 * wm + 32 * i + (lane & 31), oyl = p >> 4, oxl = p & 15;
+        abase[i] = (2 * oyl) * ROW_B + oxl * 8 + (lane >> 5) * 16;
+    }
+#pragma unroll
+    for (int s = 0; s < (SUO_SX_EXP == 2 ? 1 : SX_STEPS); ++s) {                        // s = ky * 2 + h
+        loadw(s + R - 1, ring[(s + R - 1) % R]);
+        sx_bf16x8 af[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned char* src = A3 + p * PLANE_B + abase[i] + (s >> 1) * ROW_B + (s & 1) * HALF_B;
+                const sx_u32x2 lo = *(const sx_u32x2*)src, hi = *(const sx_u32x2*)(src + 8);      // (8-byte aligned runs: two ds_read_b64)
+                af[i][p] = __builtin_bit_cast(sx_bf16x8, sx_u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TI[tt]], __builtin_bit_cast(sx_bf16x8, ring[s % R][TJ[tt]]), acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // relu(acc + bias) -> patch [pixel][64], then 16-byte stores
+    __syncthreads();                                            // (every wave has read its last A fragment: the patch overwrites the planes)
+    {
+        const int col = 32 * wn + (lane & 31);
+        const float b = a.bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[(64 * wm + 32 * i + sx_acc_row(r, lane)) * PP + col] = fmaxf(acc[i][r] + b, 0.f);
+    }
+    __syncthreads();
+    {
+        float* o = a.out + (size_t)l * 128 * 128 * SX_N;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + 256 * k, p = idx >> 4, q = idx & 15;
+            const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+            if (SUO_SX_EXP != 3 || P[p * PP + 4 * q] == 12345.f) *(sx_f32x4*)(o + ((size_t)oy * 128 + ox) * SX_N + 4 * q) = *(const sx_f32x4*)&P[p * PP + 4 * q];
+        }
+    }
+}
+
+// frame(s) + boxes -> stem output [L,128,128,64] (prior-less pass); Wx = pack_stem_weight_bf16x3, bias = bn1-folded conv bias
+int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* Wx, const float* bias,
+                   float* out, hipStream_t s) {
+    if (L <= 0 || H <= 1 || W <= 1 || !img || !boxes || !Wx || !bias || !out) { suo_set_error("stem_x3: bad arguments"); return SUO_ERR_ARG; }
+    StemArgs a = {img, fmt, H, W, boxes, box_img, L, Wx, bias, out};
+    if (fmt == 0) hipLaunchKernelGGL(stem_x3_kernel<0>, dim3(L * 128), dim3(256), 0, s, a);
+    else if (fmt == 1) hipLaunchKernelGGL(stem_x3_kernel<1>, dim3(L * 128), dim3(256), 0, s, a);
+    else { suo_set_error("stem_x3: unknown image format %d", fmt); return SUO_ERR_ARG; }
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
+}  // namespace suo

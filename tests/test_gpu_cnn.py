@@ -678,9 +678,13 @@ def test_forward_matches_oracle_end_to_end(ops, state_dict):
     # float CHW entry (the tensor PkpNet.forward receives in the reference) gives the same result
     out2 = net(torch.from_numpy(O.image_to_chw(img))[None], [torch.from_numpy(boxes)], None)
     assert torch.equal(out2["prob_logits"], out["prob_logits"])
-    # priors given as zeros == priors omitted (pkpnet.py:95-97)
+    # priors given as zeros == priors omitted (pkpnet.py:95-97).  Two different first launches here -- the 44-channel stem on the fp32 pipe
+    # with priors, the fused RoIAlign + 3-channel stem on the bf16 pipe without (csrc/stem_x3.hip) -- so: held to the oracle like `out`, and to
+    # each other far inside that tolerance (bit-identical with SUO_STEM_X3=0: tests/test_gpu_stem.py runs that mode)
     out3 = net(img, [torch.from_numpy(boxes)], [torch.zeros(3, 41, 256, 256)])
-    assert torch.equal(out3["prob_logits"], out["prob_logits"])
+    lg3 = out3["prob_logits"].cpu().numpy()
+    assert np.abs(lg3 - lr).max() / np.abs(lr).max() < 1e-5
+    assert np.abs(lg3 - lg).max() / np.abs(lr).max() < 3e-6
 
 
 def test_render_priors_matches_host_restatement_and_reference_windows(ops):

@@ -190,7 +190,8 @@ def test_symmetric_objects_get_prior_heatmaps_through_the_network(state_dict):
     a = net(fr["image"], bx, [torch.from_numpy(pri)])["prob_logits"]
     b = net(fr["image"], bx, None)["prob_logits"]
     c = net(fr["image"], bx, [torch.zeros(2, 41, 256, 256)])["prob_logits"]
-    assert torch.equal(b, c) and float((a - b).abs().max()) > 1e-3
+    # (zero prior vs omitted: the 44-channel fp32-pipe stem vs the fused 3-channel stem on the bf16 pipe -- equal to rounding, tests/test_gpu_stem.py)
+    assert float((b - c).abs().max()) < 3e-6 * float(b.abs().max()) and float((a - b).abs().max()) > 1e-3
 
 
 def test_debug_gt_kp_with_the_network_running_still_uses_the_ground_truth_keypoints():

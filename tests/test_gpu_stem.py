@@ -1,0 +1,96 @@
+"""csrc/stem_x3.hip: RoIAlign of the frame + stem conv 7x7 / stride 2 (3 image channels) + BN + ReLU in one launch on the bf16 matrix pipe --
+against the two launches it replaces (roi_align_concat -> convk<7,2,4> on the fp32 pipe) and against fp64 on the crop kernel's own samples."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from suo_slam_amd import _lib
+    _lib.require_gpu()
+    from tests import hipops
+    return hipops
+
+
+def _stem_inputs(rng, fmt):
+    img = rng.integers(0, 256, (2, 480, 640, 3), dtype=np.uint8)
+    boxes = np.array([[100.3, 50.7, 300.9, 260.2], [0, 0, 640, 480], [-20.5, -10, 90, 120], [600, 400, 700, 520], [320, 240, 320.5, 240.2],
+                      [10, 20, 522, 472], [200, 100, 330, 420]], np.float32)          # incl. > 256 px (4 samples per bin), out of image, degenerate
+    idx = np.array([0, 1, 0, 1, 1, 0, 1], np.int32)
+    if fmt == 1:
+        imgd = torch.from_numpy((img.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2).copy()).cuda()
+    else:
+        imgd = torch.from_numpy(img).cuda()
+    return imgd, boxes, idx
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_fused_stem_equals_roi_align_then_stem(ops, fmt):
+    """The staged values are the crop kernel's (same device function, csrc/roi_sample.h); the convolution on the bf16 pipe is within 5e-6 of
+    fp64 on those values and never worse than 2x the fp32-pipe stem (+1e-7); every crop is checked (frame index per crop, boxes larger than
+    256 px, boxes leaving the image)."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(31 + fmt)
+    imgd, boxes, idx = _stem_inputs(rng, fmt)
+    L = len(boxes)
+    w = (rng.standard_normal((64, 44, 7, 7)) / np.sqrt(49 * 3)).astype(np.float32)       # the checkpoint's conv1_ (44 input channels): only 3 are used
+    scale = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    bias = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    wx = np.empty(14 * 2 * 3 * 64 * 8, np.uint16)
+    _lib.check(lib.suo_pack_stem_weight_bf16x3(w.ctypes.data, 44, scale.ctypes.data, wx.ctypes.data), "suo_pack_stem_weight_bf16x3")
+    wxd, bd, boxd, idxd = torch.from_numpy(wx.view(np.int16)).cuda(), ops.dev(bias), ops.dev(boxes), torch.from_numpy(idx).cuda()
+    out = torch.full((L, 128, 128, 64), -7.0, device="cuda")
+    _lib.check(lib.suo_stem_x3(ops.P(imgd), fmt, 480, 640, ops.P(boxd), ops.P(idxd), L, ops.P(wxd), ops.P(bd), ops.P(out), ops.S()), "suo_stem_x3")
+    torch.cuda.synchronize()
+    # the two launches it replaces: staged crop (4 channels) -> fp32-pipe stem with the same folded weights
+    crops = []
+    for i in range(L):                                           # (suo_roi_align_concat takes one frame: crop by crop)
+        st = torch.zeros((1, 256, 256, 48), device="cuda")
+        one = imgd[idx[i]].contiguous()
+        _lib.check(lib.suo_roi_align_concat(ops.P(one), fmt, 480, 640, ops.P(boxd[i:i + 1].contiguous()), 1, None, ops.P(st), ops.S()), "suo_roi_align_concat")
+        crops.append(st[..., :4])
+    torch.cuda.synchronize()
+    staged = torch.cat(crops).contiguous()
+    wf = (w[:, :3] * scale[:, None, None, None]).astype(np.float32)
+    f32 = ops.conv_kxk(staged, wf, bias, relu=True)                         # convk_kernel<7,2,4,...>
+    x = staged[..., :3].permute(0, 3, 1, 2).double().cpu()
+    ref = F.relu(F.conv2d(x, torch.from_numpy(wf).double(), torch.from_numpy(bias).double(), stride=2, padding=3)).permute(0, 2, 3, 1).numpy()
+    got, f = out.cpu().numpy(), f32.cpu().numpy()
+    rng_ = np.abs(ref).max()
+    for i in range(L):
+        e3, e32 = np.abs(got[i] - ref[i]).max() / rng_, np.abs(f[i] - ref[i]).max() / rng_
+        assert e3 < 5e-6, (i, e3)
+        assert e3 <= 2.0 * e32 + 1e-7, (i, e3, e32)
+
+
+def test_network_with_and_without_the_fused_stem(monkeypatch):
+    """SUO_STEM_X3 (read once per process: child processes) switches the prior-less pass between the fused stem and roi_align + fp32 stem; the
+    network's outputs agree to the 1e-5 the path is held to (tests/test_gpu_cnn.py holds either against the reference's golden logits)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from suo_slam_amd import weights; from suo_slam_amd.pkpnet import PkpNet\n"
+            "sd = weights.make_random_state_dict(seed=0, logit_gain=8.0); rng = np.random.default_rng(3)\n"
+            "img = (rng.uniform(0, 1, (480, 640, 3)) * 255).astype(np.uint8)\n"
+            "boxes = np.array([[100, 80, 300, 290], [350.5, 100.25, 600, 400], [10, 200, 130, 330]], np.float32)\n"
+            "out = PkpNet(state_dict=sd, max_crops=4)(img, [torch.from_numpy(boxes)], None); torch.cuda.synchronize()\n"
+            "z = PkpNet(state_dict=sd, max_crops=4)(img, [torch.from_numpy(boxes)], [torch.zeros(3, 41, 256, 256)])['prob_logits'].cpu().numpy()\n"
+            "np.savez(sys.argv[1], zeros_prior=z, **{k: out[k].cpu().numpy() for k in ('prob_logits', 'uv', 'cov', 'kp_mask')})\n") % root
+    outs = {}
+    for mode in ("1", "0"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"suo_stem_{os.getpid()}_{mode}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, SUO_STEM_X3=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = dict(np.load(path))
+        os.remove(path)
+    lg = outs["0"]["prob_logits"]
+    assert np.array_equal(outs["0"]["zeros_prior"], lg)                           # same stem kernel either way: priors of zeros == no priors, bit for bit
+    assert not np.array_equal(outs["1"]["prob_logits"], lg)                        # (different kernels really ran)
+    assert np.abs(outs["1"]["prob_logits"] - lg).max() < 1e-5 * np.abs(lg).max()
+    for k in ("uv", "cov", "kp_mask"):
+        assert np.abs(outs["1"][k] - outs["0"][k]).max() < 1e-5, k

@@ -7,7 +7,7 @@ C=$ROOT/suo_slam_amd/csrc
 V=$ROOT/suo_slam_amd/variants
 mkdir -p $V
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
-VAR="conv conv_wino conv_wino_x3 gemm_persist gemm_bf16x3 conv_small res_small res_small_x3 lm_grid lm_frame lm_frame2 net misc"
+VAR="conv conv_wino conv_wino_x3 gemm_persist gemm_bf16x3 conv_small res_small res_small_x3 stem_x3 lm_grid lm_frame lm_frame2 net misc"
 for f in $VAR; do /opt/rocm/bin/hipcc $FL "$@" -c $C/$f.hip -o $V/${f}_$NAME.o & done
 wait
 OBJS=""
