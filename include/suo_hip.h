@@ -356,6 +356,22 @@ int suo_mesh_db_create(int n_models, const int* n_pts, const float* pts, void** 
 void suo_mesh_db_destroy(void* mesh_db);
 int suo_pose_errors(void* mesh_db, int n, const int* model_index, const float* T_pred, const float* T_gt, float* add, float* adds);
 
+/* ---- SLAM-mode hypothesis scoring ------------------------------------------
+ * Replaces the per-pair numpy of ObjectSLAM.__estimate_camera_pose's hypothesis loop (lib/object_slam.py:1000-1066) and of
+ * __maybe_reinit_objects' inlier counts (:619-690): count_k [ z_k > 0 and chi2_k <= chi2_max ] for n_pairs (pose, detection) pairs in one launch.
+ * A detection is written once into a device-resident store (suo_slam_store_put; host rows [n][SUO_SLAM_ROW] doubles:
+ *   model keypoints [41][3] | predicted uv [41][2] | covariances [41][2][2] | K_bbox [3][3] row-major | n | has_cov (0 / 1), unused keypoints zero);
+ * a pair is SUO_SLAM_PAIR doubles: T [3][4] row-major (detection's object -> camera), the keypoint selection as the 64 bits of a uint64
+ * (bit k = keypoint k counts: k < n, and its inlier flag where the reference scores inliers only, :1040), the store slot as the 64 bits of an int64.
+ * chi2 = r^T Sigma^-1 r with Sigma's diagonal clamped at 1e-4 (:669,:1054), or |r|^2 / kp_std2 for a detection without covariances.
+ * counts_host [n_pairs + 1]: the counts, then a flag: some selected keypoint's chi2 was NaN (the reference asserts on it).  Blocking; host buffers. */
+#define SUO_SLAM_ROW 380
+#define SUO_SLAM_PAIR 14
+void* suo_slam_store_create(int capacity);
+void suo_slam_store_destroy(void* store);
+int suo_slam_store_put(void* store, int first_slot, int n, const double* rows_host);
+int suo_slam_score(void* store, int n_pairs, const double* pairs_host, double chi2_max, double kp_std2, int32_t* counts_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,6 +102,10 @@ SIGNATURES = {
     "suo_mesh_db_create": (C.c_int, [C.c_int, VP, VP, C.POINTER(VP)]),
     "suo_mesh_db_destroy": (None, [VP]),
     "suo_pose_errors": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),
+    "suo_slam_store_create": (VP, [C.c_int]),
+    "suo_slam_store_destroy": (None, [VP]),
+    "suo_slam_store_put": (C.c_int, [VP, C.c_int, C.c_int, VP]),
+    "suo_slam_score": (C.c_int, [VP, C.c_int, VP, C.c_double, C.c_double, VP]),
 }
 
 

@@ -22,6 +22,7 @@ import numpy as np
 
 from . import ba as _ba
 from . import lambdatwist as _lt
+from . import slam_score as _sc
 from .geometry import fix_K_for_bbox_ndc, invert_SE3, normalize_uv, to4x4
 from .weights import NUM_KP
 
@@ -109,36 +110,6 @@ def make_prior_kp_input(kp_uv, kp_uv_mask, img_shape, ndc=True):
     return x
 
 
-def _chi2_inliers(T_OtoC, det, use_inlier_subset, manual_kp_std):
-    """Shared scoring of __estimate_camera_pose (:1032-1066) and __maybe_reinit_objects (:648-681):
-    number of keypoints whose re-projection has chi2 <= 5.991 under the detection's covariance."""
-    sel = det["inliers"] if use_inlier_subset else np.ones(len(det["model_kp"]), bool)
-    pts = det["model_kp"][sel]
-    if pts.shape[0] == 0:
-        return 0
-    p = pts @ T_OtoC[:3, :3].T + T_OtoC[:3, 3]
-    uvw = p @ det["K"].T
-    pos = uvw[:, 2] > 0
-    if not np.any(pos):
-        return 0
-    uv_proj = (uvw[:, :2] / uvw[:, 2:3])[pos]
-    res = det["uv_pred"][sel][pos] - uv_proj
-    rx, ry = res[:, 0], res[:, 1]
-    cov = det["cov_pred"]
-    if cov is not None:
-        cov = np.asarray(cov[sel][pos], dtype=np.float64)
-        a = np.maximum(cov[:, 0, 0], 1e-4)                                     # ensure invertible (:669,:1054)
-        d = np.maximum(cov[:, 1, 1], 1e-4)
-        b, c = cov[:, 0, 1], cov[:, 1, 0]
-        det2 = a * d - b * c
-        # r^T inv([[a,b],[c,d]]) r in closed form (this runs O(objects^2 + 15 objects) times per SLAM view)
-        chi2 = (d * rx * rx - (b + c) * rx * ry + a * ry * ry) / det2
-        assert not np.any(np.isnan(chi2)), "NaN in information matrix"
-    else:
-        chi2 = (rx * rx + ry * ry) / manual_kp_std ** 2
-    return int(np.count_nonzero(chi2 <= CHI2_2DOF_95))
-
-
 def _det_cache(d):
     """Padded copies of a detection's immutable arrays (keypoints, predictions, covariances, intrinsics), built once
     per detection: the scoring rules below run O(objects^2 + 15 objects) times per SLAM view and the graph assembly
@@ -181,46 +152,6 @@ def _det_edges(d):
         c["info"] = info
         c["camk"] = np.array([Kd[0, 0], Kd[1, 1], Kd[0, 2], Kd[1, 2]])
     return c
-
-
-def _chi2_inliers_many(Ts, dets, use_inlier_subset, manual_kp_std):
-    """``_chi2_inliers`` for B (pose, detection) pairs at once: the same arithmetic on arrays padded to NUM_KP
-    keypoints.  Returns B counts."""
-    B = len(dets)
-    if B == 0:
-        return np.zeros(0, dtype=np.int64)
-    cs = [_det_cache(d) for d in dets]
-    has_cov = cs[0]["cov"] is not None
-    if any(((c["cov"] is not None) != has_cov) or c["n"] > NUM_KP for c in cs):
-        return np.array([_chi2_inliers(T, d, use_inlier_subset, manual_kp_std) for T, d in zip(Ts, dets)], dtype=np.int64)
-    n = np.array([c["n"] for c in cs])
-    sel = np.arange(NUM_KP)[None, :] < n[:, None]
-    if use_inlier_subset:
-        inl = np.zeros((B, NUM_KP), dtype=bool)
-        for i, d in enumerate(dets):
-            inl[i, :n[i]] = d["inliers"]
-        sel &= inl
-    pts = np.stack([c["pts"] for c in cs])
-    uv = np.stack([c["uv"] for c in cs])
-    Ks = np.stack([c["K"] for c in cs])
-    Ts = np.asarray(Ts, dtype=np.float64)
-    p = pts @ Ts[:, :3, :3].transpose(0, 2, 1) + Ts[:, None, :3, 3]
-    uvw = p @ Ks.transpose(0, 2, 1)
-    pos = uvw[..., 2] > 0
-    z = np.where(pos, uvw[..., 2], 1.0)
-    rx = uv[..., 0] - uvw[..., 0] / z
-    ry = uv[..., 1] - uvw[..., 1] / z
-    if has_cov:
-        cov = np.stack([c["cov"] for c in cs])
-        a = np.maximum(cov[..., 0, 0], 1e-4)                                   # ensure invertible (:669,:1054)
-        dd = np.maximum(cov[..., 1, 1], 1e-4)
-        b, cc = cov[..., 0, 1], cov[..., 1, 0]
-        chi2 = (dd * rx * rx - (b + cc) * rx * ry + a * ry * ry) / (a * dd - b * cc)
-    else:
-        chi2 = (rx * rx + ry * ry) / manual_kp_std ** 2
-    ok = sel & pos
-    assert not np.any(np.isnan(chi2[ok])), "NaN in information matrix"
-    return np.count_nonzero(ok & (chi2 <= CHI2_2DOF_95), axis=1)
 
 
 class _EdgeRefs:
@@ -636,10 +567,14 @@ class ObjectSLAM:
             return None
         hyps = [curr[i]["pose"] @ invert_SE3(to4x4(self.obj_poses[i])) for i in obj_ids]
         scored = [j for j in obj_ids if np.count_nonzero(curr[j]["inliers"]) > 0]
-        T_obj = [to4x4(self.obj_poses[j]).astype(np.float32).astype(np.float64) for j in scored]   # float32 container (:1004)
-        # all |hypotheses| x |objects| scorings in one vectorised pass
-        counts = _chi2_inliers_many([Th @ To for Th in hyps for To in T_obj], [curr[j] for _ in hyps for j in scored],
-                                    True, self.manual_kp_std).reshape(len(hyps), len(scored)).sum(axis=1)
+        counts = np.zeros(len(hyps), dtype=np.int64)
+        if scored:
+            T_obj = np.stack([to4x4(self.obj_poses[j]) for j in scored]).astype(np.float32).astype(np.float64)   # float32 container (:1004)
+            # all |hypotheses| x |objects| scorings in one launch (csrc/slam_score.hip); the products as one stacked matmul (numpy runs the
+            # same 4x4 kernel per pair as the reference's per-pair `@`)
+            Ts = (np.stack(hyps)[:, None] @ T_obj[None]).reshape(-1, 4, 4)
+            counts = _sc.chi2_counts(self, Ts, [curr[j] for _ in hyps for j in scored], True, self.manual_kp_std,
+                                     CHI2_2DOF_95).reshape(len(hyps), len(scored)).sum(axis=1)
         best, best_n = None, -1
         for T_GtoC, n in zip(hyps, counts):
             if n >= min_num_inliers and n > best_n:
@@ -659,18 +594,20 @@ class ObjectSLAM:
             return {}
         T_CtoG = invert_SE3(to4x4(self.cam_poses[view_id]))
         views = [self.view_ids[-(i + 1)] for i in range(check_n_views)]
-        T_cam32 = {v: to4x4(self.cam_poses[v]).astype(np.float32) for v in views}                     # float32 containers (:619,:631)
-        T_cam = {v: T.astype(np.float64) for v, T in T_cam32.items()}
+        T_cam32 = np.stack([to4x4(self.cam_poses[v]) for v in views]).astype(np.float32)              # float32 containers (:619,:631)
+        T_cam = T_cam32.astype(np.float64)
         T_pnp = {o: T_CtoG @ curr[o]["pose"] for o in obj_ids}
-        T_est32 = {o: to4x4(self.obj_poses[o]).astype(np.float32) for o in obj_ids}
-        # every (object, recent view) pair under both poses in one vectorised pass; objects are independent of each other.
+        T_pnp_all = np.stack([T_pnp[o] for o in obj_ids])
+        T_est32 = np.stack([to4x4(self.obj_poses[o]) for o in obj_ids]).astype(np.float32)
+        # every (object, recent view) pair under both poses in one launch (csrc/slam_score.hip); objects are independent of each other.
         # The reference's products keep numpy's promotion: float32 camera @ float64 PnP pose -> float64, but
-        # float32 camera @ float32 map pose -> a float32 product (:634-637)
-        pairs = [(k, v) for k, o in enumerate(obj_ids) for v in views if o in self.detections[v]]
-        dets = [self.detections[v][obj_ids[k]] for k, v in pairs]
-        Ts = [T_cam[v] @ T_pnp[obj_ids[k]] for k, v in pairs] + [(T_cam32[v] @ T_est32[obj_ids[k]]).astype(np.float64) for k, v in pairs]
-        counts = _chi2_inliers_many(Ts, dets + dets, False, self.manual_kp_std)
+        # float32 camera @ float32 map pose -> a float32 product (:634-637); as stacked matmuls (the same 4x4 kernel per pair)
+        pairs = [(k, i) for k, o in enumerate(obj_ids) for i, v in enumerate(views) if o in self.detections[v]]
+        dets = [self.detections[views[i]][obj_ids[k]] for k, i in pairs]
         owner = np.array([k for k, _ in pairs], dtype=np.int64)
+        vi = np.array([i for _, i in pairs], dtype=np.int64)
+        Ts = np.concatenate([T_cam[vi] @ T_pnp_all[owner], (T_cam32[vi] @ T_est32[owner]).astype(np.float64)])
+        counts = _sc.chi2_counts(self, Ts, dets + dets, False, self.manual_kp_std, CHI2_2DOF_95)
         n_pnp = np.bincount(owner, weights=counts[:len(pairs)], minlength=len(obj_ids)).astype(np.int64)
         n_est = np.bincount(owner, weights=counts[len(pairs):], minlength=len(obj_ids)).astype(np.int64)
         report = {}

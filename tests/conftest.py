@@ -32,3 +32,18 @@ def cnn_golden():
 def state_dict():
     from suo_slam_amd import weights
     return weights.make_random_state_dict(seed=0, logit_gain=8.0)
+
+
+@pytest.fixture(autouse=True)
+def host_scoring_without_a_gpu(request, monkeypatch):
+    """The SLAM rules' inlier counts run on the device in the product (suo_slam_amd/slam_score.py; it raises without a GPU).  The CPU suite
+    checks the host logic AROUND them (hypotheses, float32 containers, the 3x rule, whole sequences with the oracle's PnP / LM injected): there
+    the counts come from the host restatement in tests/host_scoring.py -- test-side injection, like the PnP / LM backends of
+    tests/test_slam_golden.py.  With a GPU nothing is replaced (tests/test_gpu_slam_score.py re-runs these rule tests on the kernel)."""
+    if request.node.get_closest_marker("gpu") is None:
+        import torch
+        if not torch.cuda.is_available():
+            from suo_slam_amd import slam_score
+            from tests import host_scoring
+            monkeypatch.setattr(slam_score, "chi2_counts", host_scoring.chi2_counts)
+    yield

@@ -6,6 +6,7 @@ import pytest
 from suo_slam_amd import geometry as geo
 from suo_slam_amd import object_slam as OS
 from suo_slam_amd import synthetic as S
+from tests import host_scoring as HS
 
 
 def test_prior_patch_properties():
@@ -64,12 +65,12 @@ def test_chi2_scoring_counts_all_keypoints_at_the_true_pose():
     for k, o in enumerate(fr["obj_ids"]):
         d = slam.detections[0][o]
         n = len(d["model_kp"])
-        assert OS._chi2_inliers(fr["T_OtoC"][k], d, True, 0.005) == n
+        assert HS._chi2_inliers(fr["T_OtoC"][k], d, True, 0.005) == n
         T_bad = fr["T_OtoC"][k].copy()
         T_bad[:3, 3] += [80.0, 0, 0]
-        assert OS._chi2_inliers(T_bad, d, True, 0.005) < n // 2
+        assert HS._chi2_inliers(T_bad, d, True, 0.005) < n // 2
         d2 = dict(d, cov_pred=None)                                   # manual sigma path (object_slam.py:1059-1061)
-        assert OS._chi2_inliers(fr["T_OtoC"][k], d2, False, 0.005) == n
+        assert HS._chi2_inliers(fr["T_OtoC"][k], d2, False, 0.005) == n
 
 
 @pytest.mark.parametrize("with_cov", [True, False])
@@ -102,11 +103,11 @@ def test_vectorised_chi2_scoring_equals_the_per_detection_rule(with_cov):
             Ts.append(T)
             dets.append(d)
     for subset in (True, False):
-        many = OS._chi2_inliers_many(Ts, dets, subset, 0.005)
-        one = [OS._chi2_inliers(T, d, subset, 0.005) for T, d in zip(Ts, dets)]
+        many = HS._chi2_inliers_many(Ts, dets, subset, 0.005)
+        one = [HS._chi2_inliers(T, d, subset, 0.005) for T, d in zip(Ts, dets)]
         assert list(many) == one
     assert max(one) > 0 and min(one) == 0
-    assert len(OS._chi2_inliers_many([], [], True, 0.005)) == 0
+    assert len(HS._chi2_inliers_many([], [], True, 0.005)) == 0
 
 
 def test_build_problem_flattens_the_reference_graph():
