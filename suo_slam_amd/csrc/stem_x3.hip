@@ -10,6 +10,8 @@
 // one (kx = 1, 3, 5) -- contiguous, 8-byte aligned runs.  K is therefore walked as 7 rows x {even, odd} = 14 steps of 16 (21 of every 32
 // products real); A fragments are two ds_read_b64 per plane, B fragments host-split planes straight from L2.  Four waves as 2 x 2: wave
 // (wm, wn) owns 64 pixels x 32 channels.  Epilogue through an LDS patch, 16-byte stores.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "bf16x3.h"
@@ -49,6 +51,13 @@ void pack_stem_weight_bf16x3(const float* W, int Cw, const float* out_scale, uin
                 }
 }
 
+#ifdef SUO_SX_PROF      // tools/build_variant.sh sxprof -DSUO_SX_PROF: per-workgroup phase stamps (s_memtime) + hardware ids, dumped by the launcher (tools/stem_phases.py)
+__device__ long long sx_prof[65536 * 6];
+#define SX_T(i) do { if (tid == 0 && blockIdx.x < 65536) sx_prof[blockIdx.x * 6 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SX_T(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int sx_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 struct StemArgs {
@@ -67,6 +76,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_B];       // the staged planes, then (dead by then) the epilogue patch: 34 KB, 4 workgroups per CU
     unsigned char* A3 = lds;
     float* P = (float*)lds;
+    __shared__ float lut[256];                                              // u / 255.0f for the uint8 frame (csrc/roi_sample.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -74,6 +84,10 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
     const int l = bid >> 7, t = bid & 127;                                   // 16 x 8 tiles per crop
     const int oy0 = (t >> 3) * TH, ox0 = (t & 7) * TW;
+    SX_T(0);
+#ifdef SUO_SX_PROF
+    if (tid == 0 && blockIdx.x < 65536) sx_prof[blockIdx.x * 6 + 5] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+#endif
     const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wx, (size_t)SX_STEPS * 2 * 3 * 1024);
     const int wv = lane * 16;
     constexpr int R = 4;
@@ -83,23 +97,27 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(sx_u32x4, buf_load(w_srd, wv + p * 1024, (k * 2 + wn) * 3072));
     };
-#pragma unroll
-    for (int s = 0; s < R - 1; ++s) loadw(s, ring[s]);
-
     // ---- stage: 21 rows x 2 halves x 20 entries; slot -> input pixel (r, xl = 2 j + h) ---------------------------------------------------
+    if (FMT == 0) {
+        roi_fill_lut(lut, tid);
+        __syncthreads();
+    }
     {
         const size_t img_elems = (size_t)a.H * a.W * 3;
         const void* img = a.box_img ? (FMT == 0 ? (const void*)((const uint8_t*)a.img + a.box_img[l] * img_elems)
                                                 : (const void*)((const float*)a.img + a.box_img[l] * img_elems)) : a.img;
         const float x1 = a.boxes[l * 4 + 0], y1 = a.boxes[l * 4 + 1], x2 = a.boxes[l * 4 + 2], y2 = a.boxes[l * 4 + 3];
-        for (int slot = tid; slot < IR * 40; slot += 256) {
-            const int r = slot / 40, q = slot - r * 40, h = q / 20, j = q - h * 20;
+        // slot -> (row r, half h, entry j): input pixel (r, xl = 2 j + h) of the tile, crop pixel (py, px); entries beyond the 37th column and
+        // pixels outside the crop (the convolution's zero padding) are written as zeros
+        auto slot_geom = [&](int slot, int& r, int& h, int& j, int& py, int& px) {
+            r = slot / 40;
+            const int q = slot - r * 40;
+            h = q / 20; j = q - h * 20;
             const int xl = 2 * j + h;
-            const int py = 2 * oy0 - 3 + r, px = 2 * ox0 - 3 + xl;
-            float v[3] = {0.f, 0.f, 0.f};
-            if (SUO_SX_EXP == 1) v[0] = v[1] = v[2] = (float)slot * x1;
-            else if (xl < IC && py >= 0 && py < CROP && px >= 0 && px < CROP) roi_sample<FMT>(img, a.H, a.W, x1, y1, x2, y2, py, px, v);
-            float c0 = v[0], c1 = v[1], c2 = v[2];
+            py = 2 * oy0 - 3 + r; px = 2 * ox0 - 3 + xl;
+            return xl < IC && py >= 0 && py < CROP && px >= 0 && px < CROP;
+        };
+        auto store3 = [&](int r, int h, int j, float c0, float c1, float c2) {
             unsigned char* d = A3 + r * ROW_B + h * HALF_B + j * 8;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
@@ -107,9 +125,50 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
                 *(sx_u32x2*)(d + p * PLANE_B) = sx_u32x2{q0, q1};
                 if (p < 2) { c0 -= s3_lo(q0); c1 -= s3_hi(q0); c2 -= s3_lo(q1); }
             }
+        };
+        constexpr int NSLOT = IR * 40, NIT = (NSLOT + 255) / 256;
+        const RoiBins bins = roi_bins(x1, y1, x2, y2);
+        if (SUO_SX_EXP != 1 && bins.gh == 1 && bins.gw == 1) {
+            // boxes of <= 256 px (one sample per bin): the taps of ALL of this thread's slots are requested before the first is consumed --
+            // one memory latency per tile instead of one per slot
+            RoiTaps<FMT> tp[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                int r, h, j, py, px;
+                const int slot = tid + 256 * i;
+                tp[i].in = false;
+                if (slot < NSLOT && slot_geom(slot, r, h, j, py, px)) {
+                    float y, x;
+                    roi_single_sample_pos(bins, py, px, y, x);
+                    roi_taps_issue<FMT>(img, a.H, a.W, y, x, tp[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                int r, h, j, py, px;
+                const int slot = tid + 256 * i;
+                if (slot < NSLOT) {
+                    slot_geom(slot, r, h, j, py, px);
+                    float v[3] = {0.f, 0.f, 0.f};
+                    roi_taps_value<FMT, FMT == 0>(tp[i], lut, v);
+                    store3(r, h, j, v[0], v[1], v[2]);
+                }
+            }
+        } else {
+            for (int slot = tid; slot < NSLOT; slot += 256) {
+                int r, h, j, py, px;
+                const bool inside = slot_geom(slot, r, h, j, py, px);
+                float v[3] = {0.f, 0.f, 0.f};
+                if (SUO_SX_EXP == 1) v[0] = v[1] = v[2] = (float)slot * x1;
+                else if (inside) roi_sample<FMT, FMT == 0>(img, a.H, a.W, x1, y1, x2, y2, py, px, v, lut);
+                store3(r, h, j, v[0], v[1], v[2]);
+            }
         }
     }
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) loadw(s, ring[s]);          // (after the staging: its tap registers are free again; the barrier hides the L2 latency)
     __syncthreads();
+    SX_T(1);
 
     sx_f32x16 acc[2];
 #pragma unroll
@@ -145,6 +204,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     // relu(acc + bias) -> patch [pixel][64], then 16-byte stores
+    SX_T(2);
     __syncthreads();                                            // (every wave has read its last A fragment: the patch overwrites the planes)
     {
         const int col = 32 * wn + (lane & 31);
@@ -155,6 +215,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
             for (int r = 0; r < 16; ++r) P[(64 * wm + 32 * i + sx_acc_row(r, lane)) * PP + col] = fmaxf(acc[i][r] + b, 0.f);
     }
     __syncthreads();
+    SX_T(3);
     {
         float* o = a.out + (size_t)l * 128 * 128 * SX_N;
 #pragma unroll
@@ -164,6 +225,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
             if (SUO_SX_EXP != 3 || P[p * PP + 4 * q] == 12345.f) *(sx_f32x4*)(o + ((size_t)oy * 128 + ox) * SX_N + 4 * q) = *(const sx_f32x4*)&P[p * PP + 4 * q];
         }
     }
+    SX_T(4);
 }
 
 // frame(s) + boxes -> stem output [L,128,128,64] (prior-less pass); Wx = pack_stem_weight_bf16x3, bias = bn1-folded conv bias
@@ -175,6 +237,30 @@ int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, c
     else if (fmt == 1) hipLaunchKernelGGL(stem_x3_kernel<1>, dim3(L * 128), dim3(256), 0, s, a);
     else { suo_set_error("stem_x3: unknown image format %d", fmt); return SUO_ERR_ARG; }
     SUO_HIP_CHECK(hipGetLastError());
+#if defined(SUO_SX_PROF) || defined(SUO_SX_OCC)
+    {
+        static int n_occ = 0;
+        if (n_occ++ == 0) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_x3_kernel<0>, 256, 0);
+            fprintf(stderr, "stem_x3_kernel<0>: %d workgroups per CU by the runtime's occupancy calculation\n", nb);
+        }
+    }
+#endif
+#ifdef SUO_SX_PROF
+    {
+        static int n_dump = 0;
+        if (getenv("SUO_SX_PROF_OUT") && ++n_dump == 8) {
+            SUO_HIP_CHECK(hipStreamSynchronize(s));
+            const int n = L * 128 < 65536 ? L * 128 : 65536;
+            long long* h = (long long*)malloc((size_t)n * 6 * 8);
+            SUO_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(sx_prof), (size_t)n * 6 * 8));
+            FILE* f = fopen(getenv("SUO_SX_PROF_OUT"), "wb");
+            if (f) { fwrite(h, 8, (size_t)n * 6, f); fclose(f); }
+            free(h);
+        }
+    }
+#endif
     return SUO_OK;
 }
 
