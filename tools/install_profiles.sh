@@ -20,6 +20,8 @@ done
 { echo "# SUO_PMC_GEMM_M=1048576 bash tools/profile_gemm_pmc.sh conv1_x3 conv1   (rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_gemm.py run <shape> 10, one pass per group; conv1_x3 = gemm_bf16x3_kernel, what the network launches; conv1 = the fp32-pipe kernel)"
   cat $SRC/pmc_gemm.txt; } > profiles/${P}_pmc_gemm.txt
 if [ -s $SRC/res_block.txt ]; then { echo "# python3 tools/bench_res_block.py 8; python3 tools/bench_res_block.py 32   (1x MI355X; tools/profile_round.sh $TAG; HIP events, 50 launches each)"; cat $SRC/res_block.txt; } > profiles/${P}_res_block.txt; fi
+if [ -s $SRC/stem.txt ]; then { echo "# python3 tools/bench_stem.py 256; python3 tools/bench_stem.py 8   (1x MI355X; tools/profile_round.sh $TAG; HIP events, 30 launches each; it replaces roi_align_concat_kernel<0,4> + convk_kernel<7,2,4,...>: 171 + 864 us at 256 crops, 8 + 29 at 8)"; cat $SRC/stem.txt; } > profiles/${P}_stem.txt; fi
+if [ -s $SRC/slam_stages.txt ]; then { echo "# python3 tools/time_slam_stages.py 1   (1x MI355X; tools/profile_round.sh $TAG; bench.py's slam leg configuration, perf_counter around the host methods)"; cat $SRC/slam_stages.txt; } > profiles/${P}_slam_stages.txt; fi
 cp $SRC/pmc_dominant_conv.json profiles/pmc_dominant_conv.json
 [ -s $SRC/pmc_gemm.json ] && cp $SRC/pmc_gemm.json profiles/pmc_gemm.json
 for f in latency.log slam.log; do [ -s $SRC/$f ] && grep -v "amdgpu.ids\|rocprofv3\|simple_timer\|^W2026" $SRC/$f > profiles/${P}_${f%.log}_run.txt || true; done

@@ -32,6 +32,10 @@ run_traced slam $R/tools/profile_slam_view.py
 # 6b. the one-launch Residual blocks of the one-frame call shape against the three per-layer launches (HIP events), and the in-kernel phase times
 python3 $R/tools/bench_res_block.py 8 2>&1 | grep -v amdgpu.ids > $OUT/res_block.txt
 python3 $R/tools/bench_res_block.py 32 2>&1 | grep -v amdgpu.ids >> $OUT/res_block.txt
+# 6b'. the fused RoIAlign + stem launch (HIP events), and the stages of a SLAM view (perf_counter around the host methods, no profiler)
+python3 $R/tools/bench_stem.py 256 2>&1 | grep -v amdgpu.ids > $OUT/stem.txt
+python3 $R/tools/bench_stem.py 8 2>&1 | grep -v amdgpu.ids >> $OUT/stem.txt
+python3 $R/tools/time_slam_stages.py 1 2>&1 | grep -v amdgpu.ids > $OUT/slam_stages.txt
 # 6c. the multi-GPU bundle adjustment schedule at one rank (bench.py's global_ba leg): kernels of the phase units
 echo "rocprofv3 --kernel-trace -- python3 -c 'import bench; bench.global_ba_leg(1, 16)'" > $OUT/cmd_global_ba.txt
 printf 'import sys\nsys.path.insert(0, "%s")\nimport bench\nprint(bench.global_ba_leg(1, 16))\n' $R > /tmp/gba.py
