@@ -23,14 +23,17 @@ typedef float x3_f32x16 __attribute__((ext_vector_type(16)));
 typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 16, X3_PITCH = 24;      // LDS row pitch in bf16 (48 bytes: conflict-free 16-byte fragment reads)
-#ifndef SUO_X3_SGB
-#define SUO_X3_SGB 0
+#ifndef SUO_X3_BK
+#define SUO_X3_BK 16
 #endif
-#ifndef SUO_X3_LEAD
-#define SUO_X3_LEAD 3
-#endif
-constexpr int X3_LEAD = SUO_X3_LEAD;                                                // k-steps between a request and its use, for BOTH global streams
+// k-step per barrier: 16 (one MFMA k-group, 24 MFMAs between barriers) or 32 (tools/build_variant.sh bk32 -DSUO_X3_BK=32: 48 MFMAs between barriers,
+// 128-byte row segments per request, 61 KB of LDS).  Measured equal within 3 % on every shape of the network (tools/bench_gemm_x3_shapes.py), as is
+// the depth of the request ring (1 or 3 steps ahead): the kernel's time follows its MFMA count -- the call runs at the package power cap, see DESIGN 4.2
+constexpr int X3_BM = 128, X3_BN = 128, X3_BK = SUO_X3_BK, X3_GH = X3_BK / 16, X3_PITCH = X3_BK + 8;      // LDS row pitch in bf16 (48 / 80 bytes: conflict-free 16-byte fragment reads)
+constexpr int X3_LPR = X3_BK / 4, X3_RPP = 256 / X3_LPR, X3_NR = X3_BM / X3_RPP;   // staging: lanes per row (a float4 each), rows per pass, passes
+constexpr int X3_ASLOTS = 64 / X3_BK;                                              // activation steps in flight (K a multiple of 64: slots and stages are compile-time indices)
+constexpr int X3_BSLOTS = 4;                                                       // weight k-groups in flight (a ring over 16-wide groups)
+static_assert(X3_BK == 16 || X3_BK == 32, "k-step");
 
 // host: W[N][K] fp32 -> B-operand order of v_mfma_f32_32x32x16_bf16, split like the device does (csrc/bf16x3.h: round-to-nearest terms):
 //   out[((ks * NB + nb) * 3 + plane) * 64 + lane][e] = term `plane` of W[nb*32 + (lane&31)][ks*16 + 8*(lane>>5) + e]
@@ -52,7 +55,7 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 //     round-to-nearest split (csrc/bf16x3.h) -> three bf16 planes in LDS (two stages) -> A fragments by ds_read_b128;
 //   * weights: host-split, B-operand order, straight from L2 into registers (the two waves of a column half read the same lines: L1);
 //   * vmcnt retires in order, so a request can only be waited for once everything issued before it has landed: both streams are requested
-//     the same X3_LEAD k-steps ahead (an activation load from HBM issued just before a "nearer" weight load would stall that one);
+//     a fixed number of k-steps ahead (an activation load from HBM issued just before a "nearer" weight load would stall that one);
 //   * epilogue: accumulators transposed through a wave-private LDS patch, bias (+ ReLU) and stores on 16-byte vectors.
 // POOL: the result's 2x2 max-pool (nn.MaxPool2d(2, 2)) written as well (or only: g.out may be null).  The tile is then two image rows x 64 columns
 // (row r of the tile = pixel (y0 + (r >> 6), x0 + (r & 63))): the horizontal maximum is a lane exchange (rows j, j + 1 sit 8 lanes apart), the vertical
@@ -86,64 +89,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const __amdgpu_buffer_rsrc_t a1_srd = make_srd(g.A1, (size_t)M * g.lda1 * sizeof(float));
     const __amdgpu_buffer_rsrc_t a2_srd = make_srd(DUAL ? g.A2 : g.A1, DUAL ? (size_t)M * g.lda2 * sizeof(float) : 0);
     const __amdgpu_buffer_rsrc_t w_srd = make_srd(Wp, (size_t)g.N * K * 3 * sizeof(uint16_t));
-    // staging roles per k-step: rows tid / 4 and 64 + tid / 4, the 4 floats at k = 4 (tid & 3)
-    const int ar = tid >> 2, aq = tid & 3;
-    int avoff1[2], avoff2[2];
+    // staging roles per k-step: rows tid / LPR + RPP i, the 4 floats at k = 4 (tid % LPR): the LPR lanes of a row fetch its 64 / 128 contiguous bytes
+    const int ar = tid / X3_LPR, aq = tid % X3_LPR;
+    int avoff1[X3_NR], avoff2[X3_NR];
+    bool rok[X3_NR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = pixel_of(64 * i + ar);
+    for (int i = 0; i < X3_NR; ++i) {
+        const int row = pixel_of(X3_RPP * i + ar);
+        rok[i] = row < M;
         avoff1[i] = row < M ? (row * g.lda1 + 4 * aq) * 4 : BUF_OOB;          // rows past M read zeros (and the prologue's result is zeroed below)
         avoff2[i] = DUAL && row < M ? (row * g.lda2 + 4 * aq) * 4 : BUF_OOB;
     }
-    const bool rok[2] = {pixel_of(ar) < M, pixel_of(64 + ar) < M};
     const int wvoff = lane * 16;
-    x3_f32x4 araw[X3_LEAD + 1][2];
-    x3_u32x4 braw[X3_LEAD + 1][2][3];
+    x3_f32x4 araw[X3_ASLOTS][X3_NR];
+    x3_u32x4 braw[X3_BSLOTS][2][3];
     auto requestA = [&](int ks, int slot) {
 #ifdef SUO_X3_EXP_NOLOADA
-        for (int i = 0; i < 2; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
+        for (int i = 0; i < X3_NR; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
 #else
         if (!DUAL || ks < ns1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) araw[slot][i] = buf_load(a1_srd, avoff1[i], ks * X3_BK * 4);
+            for (int i = 0; i < X3_NR; ++i) araw[slot][i] = buf_load(a1_srd, avoff1[i], ks * X3_BK * 4);
         } else {                                                              // second K segment (conv4 on the block's input)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) araw[slot][i] = buf_load(a2_srd, avoff2[i], (ks - ns1) * X3_BK * 4);
+            for (int i = 0; i < X3_NR; ++i) araw[slot][i] = buf_load(a2_srd, avoff2[i], (ks - ns1) * X3_BK * 4);
         }
 #endif
     };
-    auto requestB = [&](int ks, int slot) {
+    auto requestB = [&](int kg, int slot) {                                   // kg: 16-wide k-group
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((ks * NBT + 4 * tn + 2 * wn + cb) * 3) * 1024));
+                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((kg * NBT + 4 * tn + 2 * wn + cb) * 3) * 1024));
     };
     auto split_store = [&](int ks, int slot, int stage) {
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[4 * i + t] = araw[slot][i][t];
-        if (PRO) {                                                            // (single K segment only: checked by the launcher)
-            const x3_f32x4 sc = *(const x3_f32x4*)&P[0][ks * X3_BK + 4 * aq], sh = *(const x3_f32x4*)&P[1][ks * X3_BK + 4 * aq];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) x[4 * i + t] = rok[i] ? fmaxf(fmaf(x[4 * i + t], sc[t], sh[t]), 0.f) : 0.f;
-        }
         uint16_t* As = &S[stage][0];
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        x3_f32x4 sc, sh;
+        if (PRO) { sc = *(const x3_f32x4*)&P[0][ks * X3_BK + 4 * aq]; sh = *(const x3_f32x4*)&P[1][ks * X3_BK + 4 * aq]; }      // (single K segment only: checked by the launcher)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            unsigned q[4];
+        for (int i = 0; i < X3_NR; ++i) {
+            float x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] = s3_pack_rn(x[2 * j], x[2 * j + 1]);      // (p == 2: the conversion is exact)
+            for (int t = 0; t < 4; ++t) x[t] = araw[slot][i][t];
+            if (PRO) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *(u32x2*)&As[p * PLANE + (64 * i + ar) * X3_PITCH + 4 * aq] = u32x2{q[2 * i], q[2 * i + 1]};
-            if (p < 2) {
+                for (int t = 0; t < 4; ++t) x[t] = rok[i] ? fmaxf(fmaf(x[t], sc[t], sh[t]), 0.f) : 0.f;
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { x[2 * j] -= s3_lo(q[j]); x[2 * j + 1] -= s3_hi(q[j]); }      // exact residuals
+            for (int p = 0; p < 3; ++p) {
+                const unsigned q0 = s3_pack_rn(x[0], x[1]), q1 = s3_pack_rn(x[2], x[3]);      // (p == 2: the conversion is exact)
+                *(u32x2*)&As[p * PLANE + (X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{q0, q1};
+                if (p < 2) { x[0] -= s3_lo(q0); x[1] -= s3_hi(q0); x[2] -= s3_lo(q1); x[3] -= s3_hi(q1); }      // exact residuals
             }
         }
     };
@@ -154,59 +152,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // prologue: steps 0 .. LEAD in flight (slot = step % (LEAD + 1)), step 0 split into stage 0
+    const int ngroups = nsteps * X3_GH;
+    // prologue: the first ASLOTS activation steps and BSLOTS weight groups in flight, step 0 split into stage 0
 #pragma unroll
-    for (int u = 0; u <= X3_LEAD; ++u) { requestA(u < nsteps ? u : nsteps - 1, u); requestB(u < nsteps ? u : nsteps - 1, u); }
+    for (int u = 0; u < X3_ASLOTS; ++u) requestA(u < nsteps ? u : nsteps - 1, u);
+#pragma unroll
+    for (int u = 0; u < X3_BSLOTS; ++u) requestB(u < ngroups ? u : ngroups - 1, u);
     __syncthreads();                                                          // (scale / shift staged)
     split_store(0, 0, 0);
     constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // six cross terms, smallest first
     const int ko = 8 * (lane >> 5);
-    for (int ks0 = 0; ks0 < nsteps; ks0 += X3_LEAD + 1) {                      // (K1, K2 multiples of 64: slots and stages are compile-time indices)
+    for (int ks0 = 0; ks0 < nsteps; ks0 += X3_ASLOTS) {
 #pragma unroll
-        for (int u = 0; u <= X3_LEAD; ++u) {
+        for (int u = 0; u < X3_ASLOTS; ++u) {
             const int ks = ks0 + u;
             __syncthreads();                                                  // stage u & 1 complete; every wave is past its reads of the other stage
             // this step's A fragments are requested first: their LDS latency passes under the split of the next step's activations
             const uint16_t* As = &S[u & 1][0];
-            x3_bf16x8 af[2][3];
+            x3_bf16x8 af[X3_GH][2][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int h = 0; h < X3_GH; ++h)
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) af[rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (64 * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko];
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) af[h][rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (64 * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko + 16 * h];
             __builtin_amdgcn_sched_barrier(0);
-            // weights of this step out of their slot, then the slot's next requests; the next step's activations -> the other stage
-            x3_u32x4 bw[2][3];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bw[cb][p] = braw[u][cb][p];
 #ifndef SUO_X3_EXP_NOSPLIT
-            if (ks + 1 < nsteps) split_store(ks + 1, (u + 1) % (X3_LEAD + 1), (u + 1) & 1);
+            if (ks + 1 < nsteps) split_store(ks + 1, (u + 1) % X3_ASLOTS, (u + 1) & 1);
 #endif
-            {
-                const int kn = ks + X3_LEAD + 1 < nsteps ? ks + X3_LEAD + 1 : nsteps - 1;
-                requestB(kn, u);
-                requestA(kn, u);
+            requestA(ks + X3_ASLOTS < nsteps ? ks + X3_ASLOTS : nsteps - 1, u);
+#pragma unroll
+            for (int h = 0; h < X3_GH; ++h) {
+                // weights of this k-group out of their ring slot, then the slot's next request
+                const int slot = (u * X3_GH + h) % X3_BSLOTS, kg = ks * X3_GH + h;
+                x3_u32x4 bw[2][3];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bw[cb][p] = braw[slot][cb][p];
+                requestB(kg + X3_BSLOTS < ngroups ? kg + X3_BSLOTS : ngroups - 1, slot);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h][rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
-#if SUO_X3_SGB
-            // issue order: the split's VALU / LDS instructions and the requests in the gaps of the MFMA stream
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }

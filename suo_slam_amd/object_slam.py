@@ -236,6 +236,9 @@ class ObjectSLAM:
         self.obj_num_det_kps = defaultdict(int)
         self.remove_penalty = defaultdict(int)
         self.needs_opt = False
+        st = getattr(self, "_score_store", None)             # the scene's detections on the device (suo_slam_amd/slam_score.py)
+        if st is not None:
+            st.clear()
 
     def num_views_processed(self):
         return len(self.cam_poses)

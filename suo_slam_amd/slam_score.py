@@ -34,6 +34,12 @@ class DetectionStore:
             _lib.check(-1, "suo_slam_store_create")
         self.n_slots = 0
 
+    def clear(self):
+        """Forget every detection (ObjectSLAM.reset: a new scene); the device allocation is kept, stale ``_slot`` tags no longer match."""
+        DetectionStore._uids += 1
+        self.uid = DetectionStore._uids
+        self.n_slots = 0
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().suo_slam_store_destroy(self._h)

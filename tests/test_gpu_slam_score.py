@@ -90,6 +90,21 @@ def test_store_grows_and_keeps_old_rows():
     assert SC.chi2_counts(own, np.stack(Ts[:1]), [d], False, 0.005, CHI2_2DOF_95)[0] == HS._chi2_inliers(Ts[0], d, False, 0.005)
 
 
+def test_reset_starts_a_new_scene_in_the_same_store():
+    """ObjectSLAM.reset() (evaluate.py:338: once per scene) rewinds the store: slots are reused, detections of the previous scene are not found by tag."""
+    from suo_slam_amd.object_slam import ObjectSLAM
+    rng = np.random.default_rng(4)
+    Ts, dets = _cases(rng, True)
+    slam = ObjectSLAM(None, {1: {"diameter": 100.0, "is_symmetric": False}}, debug_gt_kp=True)
+    a = SC.chi2_counts(slam, np.stack(Ts[:8]), dets[:8], False, 0.005, CHI2_2DOF_95)
+    st = slam._score_store
+    assert st.n_slots == 8
+    slam.reset()
+    assert slam._score_store is st and st.n_slots == 0
+    b = SC.chi2_counts(slam, np.stack(Ts[4:12]), dets[4:12], False, 0.005, CHI2_2DOF_95)      # 4 of them carry tags of the old scene
+    assert st.n_slots == 8 and list(b) == [HS._chi2_inliers(T, d, False, 0.005) for T, d in zip(Ts[4:12], dets[4:12])] and list(a[4:]) == list(b[:4])
+
+
 def test_nan_in_the_information_matrix_is_reported():
     rng = np.random.default_rng(2)
     Ts, dets = _cases(rng, True)
