@@ -237,16 +237,6 @@ int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, c
     else if (fmt == 1) hipLaunchKernelGGL(stem_x3_kernel<1>, dim3(L * 128), dim3(256), 0, s, a);
     else { suo_set_error("stem_x3: unknown image format %d", fmt); return SUO_ERR_ARG; }
     SUO_HIP_CHECK(hipGetLastError());
-#if defined(SUO_SX_PROF) || defined(SUO_SX_OCC)
-    {
-        static int n_occ = 0;
-        if (n_occ++ == 0) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_x3_kernel<0>, 256, 0);
-            fprintf(stderr, "stem_x3_kernel<0>: %d workgroups per CU by the runtime's occupancy calculation\n", nb);
-        }
-    }
-#endif
 #ifdef SUO_SX_PROF
     {
         static int n_dump = 0;
