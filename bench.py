@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--no-global-ba-leg", action="store_true")
     ap.add_argument("--no-slam-leg", action="store_true")
     ap.add_argument("--legs-timeout", type=int, default=600, help="seconds the legs after the timed region may take before the line is printed without the rest")
+    ap.add_argument("--no-power-sample", action="store_true", help="do not run rocm-smi beside the timed region")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only: print the number of ranks seen and leave (no GPU work)")
     return ap.parse_args()
 
@@ -824,6 +825,43 @@ def print_line(text):
         os.write(_LINE_FD, data)
 
 
+def sample_power(out, stop=None, bdf=None):
+    """Package power / shader clock of GPU 0 while the caller's timed region runs, into `out`: amdgpu's hwmon files every 50 ms until `stop` is set
+    (mean / max over the samples), else ONE rocm-smi reading (a child process; it answers ~0.3 s in).  Silent when neither is there."""
+    import glob
+    import re
+    import subprocess
+    try:
+        hw = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if os.path.exists(os.path.join(h, "power1_average")) or os.path.exists(os.path.join(h, "power1_input"))]
+        if bdf:                                              # the card of THIS process's GPU (a box shows every card of the node in sysfs)
+            hw = [h for h in hw if os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).lower() == bdf.lower()]
+        if hw and stop is not None:
+            h = hw[0]
+            pf = os.path.join(h, "power1_average") if os.path.exists(os.path.join(h, "power1_average")) else os.path.join(h, "power1_input")
+            cap = os.path.join(h, "power1_cap")
+            w, f = [], []
+            while not stop.is_set():
+                w.append(int(open(pf).read()) / 1e6)
+                if os.path.exists(os.path.join(h, "freq1_input")):
+                    f.append(int(open(os.path.join(h, "freq1_input")).read()) / 1e6)
+                stop.wait(0.05)
+            if w:
+                out.update(package_w_mean=round(sum(w) / len(w), 1), package_w_max=round(max(w), 1), samples=len(w),
+                           cap_w=int(open(cap).read()) / 1e6 if os.path.exists(cap) else None, sclk_mhz_mean=round(sum(f) / len(f)) if f else None,
+                           source=f"{pf} ({bdf}) every 50 ms while the timed region ran")
+            return
+        t = time.perf_counter()
+        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"GPU\[0\][^\n]*Current Socket Graphics Package Power \(W\): ([0-9.]+)", r) or re.search(r"GPU\[0\][^\n]*Average Graphics Package Power \(W\): ([0-9.]+)", r)
+        c = re.search(r"GPU\[0\][^\n]*Max Graphics Package Power \(W\): ([0-9.]+)", r)
+        k = re.search(r"GPU\[0\][^\n]*sclk clock level: \S+ \((\d+)Mhz\)", r)
+        if m:
+            out.update(package_w=float(m.group(1)), cap_w=float(c.group(1)) if c else None, sclk_mhz=int(k.group(1)) if k else None, t_done=time.perf_counter(),
+                       source="rocm-smi, one reading of GPU 0 requested %.2f s into the timed region" % 0.0, t_req=t)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -903,12 +941,34 @@ def main():
     pipe.drain(args.warmup)
     pipe.reset_metrics()
     barrier()
+    power = {}
+    if rank == 0 and not args.no_power_sample:
+        # package power / shader clock WHILE the timed region runs (rocm-smi in a child process started now; it answers ~0.3 s in): the call runs
+        # at the package power cap (profiles/r04_power_trace.txt), which is what bounds its matrix-pipe utilisation
+        import threading as _th
+        power_stop = _th.Event()
+        bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        power_thread = _th.Thread(target=sample_power, args=(power, power_stop, bdf), daemon=True)
+        power_thread.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         pipe.step(args.warmup + i)
     pipe.drain(args.warmup + args.steps)        # every timed step's read-back is fetched inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    if rank == 0 and not args.no_power_sample:
+        power_stop.set()
+        power_thread.join(timeout=2.0)
+        if "t_done" in power:                                # (the rocm-smi route: keep the reading only if it came back inside the region)
+            inside = power.pop("t_done") <= t0 + dt
+            power.pop("t_req", None)
+            if not inside:
+                power.clear()
     assert pipe.n_frames == args.steps * F and pipe.n_crops == args.steps * F * L
     # max-over-ranks time + the only collective of the frame path: metric accumulators (RCCL all-reduce over xGMI)
     from suo_slam_amd import sharding
@@ -948,6 +1008,7 @@ def main():
             "cnn_executed_frac_of_fp32_mfma_peak": round(fps / world * L * exec_gflop / 1e3 / FP32_MFMA_PEAK_TF, 4),
             "cnn_tflops_algorithmic": round(fps * L * GFLOP_PER_CROP / 1e3, 2),           # reference-counted FLOPs per crop x crops/s
             "cnn_algorithmic_over_fp32_mfma_peak": round(fps / world * L * GFLOP_PER_CROP / 1e3 / FP32_MFMA_PEAK_TF, 4),
+            "power_in_timed_region": dict(power) if power else None,
             "geometry_in_timed_region": {"keypoints_passed_by_the_masks": int(n_kp), "poses_accepted": int(n_pose), "inlier_edges": int(n_inl),
                                          "lm_trials": int(n_trials), "crops": int(world * args.steps * F * L)},
         }
