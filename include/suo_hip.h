@@ -123,14 +123,14 @@ int suo_conv1x1_pool(const float* a1_dev, int lda1, int K1, const float* pro_sca
                      const float* a2_dev, int lda2, int K2, const float* wp_dev, const float* bias_dev,
                      const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N, int relu, int H, int W,
                      float* pool_out_dev, void* stream);
-/* The same 1x1 convolution (N = 128, K a multiple of 64 up to 512, optional BN + ReLU prologue, bias, optional ReLU) at fp32 accuracy on the
+/* The same 1x1 convolution (N = 128 or 64, K a multiple of 64 up to 512, optional BN + ReLU prologue, bias, optional ReLU) at fp32 accuracy on the
  * bf16 matrix pipe: both operands are split into three bf16 terms and 6 of the 9 cross products are accumulated in fp32
  * (csrc/gemm_bf16x3.hip; what suo_net_forward launches for conv1 of its Residual blocks at >= 32768 pixels unless SUO_WINO_BF16X3=0).
  * wp3 = suo_pack_gemm_weight_bf16x3(W[N][K]) -> 3*N*K uint16 (MFMA B-operand order). */
 int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out);
 int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* wp3_dev,
                        const float* bias_dev, float* out_dev, int ldo, int M, int N, int relu, void* stream);
-/* The general form: N a multiple of 128, an optional second K segment (a2, K2: the skip conv of a Residual block; then no prologue), an optional
+/* The general form: N a multiple of 128 (or 64), an optional second K segment (a2, K2: the skip conv of a Residual block; then no prologue), an optional
  * residual operand r_dev [M, ldr] added after the bias; K1, K2 multiples of 64; wp3 = suo_pack_gemm_weight_bf16x3 of the row-wise concatenation
  * [W1 | W2] (N rows, K1 + K2 columns).  What suo_net_forward launches for its N = 256 1x1 convolutions at 64x64 (lin, re-injection, conv3 + conv4). */
 int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev,

@@ -60,7 +60,8 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 // POOL: the result's 2x2 max-pool (nn.MaxPool2d(2, 2)) written as well (or only: g.out may be null).  The tile is then two image rows x 64 columns
 // (row r of the tile = pixel (y0 + (r >> 6), x0 + (r & 63))): the horizontal maximum is a lane exchange (rows j, j + 1 sit 8 lanes apart), the vertical
 // one meets through LDS (image row 0 belongs to the waves wm = 0, row 1 to wm = 1).
-template <bool PRO, bool DUAL, bool RES, bool POOL>
+// NCB: 32-column blocks per wave -- 2: the 128-column tile; 1: a 64-column tile (the 64-channel 1x1 convolutions of the first Residual blocks)
+template <bool PRO, bool DUAL, bool RES, bool POOL, int NCB = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
     constexpr int PLANE = X3_BM * X3_PITCH;                                   // bf16 elements of one plane
     __shared__ __attribute__((aligned(16))) uint16_t S[2][3 * PLANE];         // [stage][plane][row][pitch] = 36 864 bytes (the epilogue re-uses it)
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     // tile = (row tile, column tile of 128); the column tiles of a row tile are neighbours (the second one finds the activations in L2)
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order
-    const int ntn = g.N >> 7, NBT = g.N >> 5;
+    static_assert(NCB == 2 || !POOL, "the pooled epilogue is laid out for 128-column tiles");
+    constexpr int BN = 64 * NCB;                                              // columns of the tile
+    const int ntn = g.N / BN, NBT = g.N >> 5;
     const int tn = bid % ntn, mt = bid / ntn, m0 = mt * X3_BM;
     // pixel (row of the operands) of tile row r
     int pool_base = 0;                                                        // POOL: pixel of tile row 0; tile row r -> pool_base + (r >> 6) * W + (r & 63)
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     const int wvoff = lane * 16;
     x3_f32x4 araw[X3_ASLOTS][X3_NR];
-    x3_u32x4 braw[X3_BSLOTS][2][3];
+    x3_u32x4 braw[X3_BSLOTS][NCB][3];
     auto requestA = [&](int ks, int slot) {
 #ifdef SUO_X3_EXP_NOLOADA
         for (int i = 0; i < X3_NR; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     };
     auto requestB = [&](int kg, int slot) {                                   // kg: 16-wide k-group
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((kg * NBT + 4 * tn + 2 * wn + cb) * 3) * 1024));
+                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((kg * NBT + 2 * NCB * tn + NCB * wn + cb) * 3) * 1024));
     };
     auto split_store = [&](int ks, int slot, int stage) {
         uint16_t* As = &S[stage][0];
@@ -145,11 +148,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             }
         }
     };
-    x3_f32x16 acc[2][2];
+    x3_f32x16 acc[2][NCB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NCB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int ngroups = nsteps * X3_GH;
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int h = 0; h < X3_GH; ++h) {
                 // weights of this k-group out of their ring slot, then the slot's next request
                 const int slot = (u * X3_GH + h) % X3_BSLOTS, kg = ks * X3_GH + h;
-                x3_u32x4 bw[2][3];
+                x3_u32x4 bw[NCB][3];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bw[cb][p] = braw[slot][cb][p];
                 requestB(kg + X3_BSLOTS < ngroups ? kg + X3_BSLOTS : ngroups - 1, slot);
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
+                        for (int cb = 0; cb < NCB; ++cb)
                             acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h][rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int col = 128 * tn + 64 * wn + 32 * cb + (lane & 7) * 4;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int col = BN * tn + 32 * NCB * wn + 32 * cb + (lane & 7) * 4;
             x3_f32x4 bv = x3_f32x4{0.f, 0.f, 0.f, 0.f};
             if (g.bias) bv = *(const x3_f32x4*)(g.bias + col);
             x3_f32x4 rv[RES ? 4 : 1];
@@ -274,11 +277,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
 }
 
-// out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R ): N a multiple of 128, K1 and K2 multiples of 64 (K2 may be 0),
+// out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R ): N a multiple of 128 (or 64, un-pooled), K1 and K2 multiples of 64 (K2 may be 0),
 // the prologue only without a second segment; Wx3 = pack_gemm_weight_bf16x3 of the row-concatenated [W1 | W2] (N rows, K1 + K2 columns)
 bool gemm_bf16x3_takes(const GemmArgs& g) {
     const size_t lim = (size_t)1 << 31;
-    return g.N > 0 && g.N % 128 == 0 && g.n_valid == g.N && g.K1 > 0 && g.K1 % 64 == 0 && g.K2 % 64 == 0 && g.K1 <= 512 && !g.nchw_hw && (g.pool_out ? (g.pool_W % 64 == 0 && g.pool_H % 2 == 0 && g.M % (g.pool_H * g.pool_W) == 0) : g.out != nullptr) &&
+    return g.N > 0 && (g.N % 128 == 0 || (g.N == 64 && !g.pool_out)) && g.n_valid == g.N && g.K1 > 0 && g.K1 % 64 == 0 && g.K2 % 64 == 0 && g.K1 <= 512 && !g.nchw_hw && (g.pool_out ? (g.pool_W % 64 == 0 && g.pool_H % 2 == 0 && g.M % (g.pool_H * g.pool_W) == 0) : g.out != nullptr) &&
            (!g.K2 || (!g.pro_scale && g.A2 && g.lda2 % 4 == 0)) && g.lda1 % 4 == 0 && g.ldo % 4 == 0 && (!g.R || g.ldr % 4 == 0) &&
            ((g.pro_scale == nullptr) == (g.pro_shift == nullptr)) && (size_t)g.M * g.lda1 * 4 < lim && (!g.out || (size_t)g.M * g.ldo * 4 < lim) &&
            (!g.K2 || (size_t)g.M * g.lda2 * 4 < lim) && (!g.R || (size_t)g.M * g.ldr * 4 < lim);
@@ -289,8 +292,10 @@ int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t 
         suo_set_error("gemm_bf16x3: unsupported shape (N=%d K=%d+%d M=%d)", g.N, g.K1, g.K2, g.M);
         return SUO_ERR_ARG;
     }
-    const int tiles = ((g.M + X3_BM - 1) / X3_BM) * (g.N / 128);
+    const bool n64 = g.N % 128 != 0;                                          // 64 output channels: 64-column tiles
+    const int tiles = ((g.M + X3_BM - 1) / X3_BM) * (n64 ? 1 : g.N / 128);
 #define X3_LAUNCH(P_, D_, R_) do { if (g.pool_out) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, true>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
+                                   else if (n64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 1>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
                                    else hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false>), dim3(tiles), dim3(256), 0, s, g, Wx3); } while (0)
     const bool res = g.R != nullptr;
     if (g.pro_scale) { if (res) X3_LAUNCH(true, false, true); else X3_LAUNCH(true, false, false); }

@@ -165,6 +165,8 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
     g.Wp = upload(packed);
     g.bias = upload(bias);
     g.N = Np; g.n_valid = N; g.K1 = K1p; g.K2 = K2p;
+    // (N = 64 -- conv1 of r1 / r4 -- stays on the persistent fp32-pipe kernel: these launches are HBM-streaming, 430 / 180 us there against 563 / 194
+    //  in the bf16x3 kernel's 64-column tiles at 256 crops)
     if (N % 128 == 0 && Np == N && K1 == K1p && K2 == K2p && K1 % 64 == 0 && K2 % 64 == 0 && K1 <= 512 && wino_bf16x3()) {      // the same operator on the bf16 pipe at fp32 accuracy
         std::vector<float> x3((size_t)3 * N * Kp / 2);                         // uint16 planes
         pack_gemm_weight_bf16x3(full.data(), N, Kp, reinterpret_cast<uint16_t*>(x3.data()));

@@ -836,7 +836,7 @@ def test_fused_kernels_on_random_shapes(ops):
 
 
 @pytest.mark.parametrize("M,K1,K2,N,res,relu", [(4096, 256, 0, 256, False, 1), (128 * 9 + 77, 128, 128, 256, False, 0), (5000, 256, 0, 256, True, 0),
-                                                 (1000, 64, 64, 128, False, 0), (4096, 128, 128, 256, True, 1)])
+                                                 (1000, 64, 64, 128, False, 0), (4096, 128, 128, 256, True, 1), (3001, 64, 64, 64, True, 1), (700, 128, 0, 64, False, 0)])
 def test_bf16x3_gemm_general_form(ops, M, K1, K2, N, res, relu):
     """suo_conv1x1_bf16x3_ex (csrc/gemm_bf16x3.hip; what the network launches for lin, the re-injection and conv3 + conv4 at 64x64): N = 256 as two
     column tiles, a second K segment on a second operand, the residual operand; within 5e-6 of fp64 and of the fp32-pipe kernel on the same inputs."""
@@ -918,17 +918,17 @@ def test_bf16x3_gemm_with_the_pool_in_its_epilogue(ops, L, H, W, K1, K2, N, res,
         np.testing.assert_array_equal(gp[:M // 4], go[:M].reshape(L, H // 2, 2, W // 2, 2, N).max(axis=(2, 4)).reshape(M // 4, N))
 
 
-@pytest.mark.parametrize("K", [256, 128, 64])
-def test_bf16x3_gemm_is_fp32_accurate(ops, K):
+@pytest.mark.parametrize("K,N", [(256, 128), (128, 128), (64, 128), (64, 64), (128, 64)])
+def test_bf16x3_gemm_is_fp32_accurate(ops, K, N):
     """csrc/gemm_bf16x3.hip (what the network launches for conv1 of its Residual blocks at >= 32768 pixels): the 1x1 convolution on the bf16 matrix pipe with both operands
     split into three bf16 terms and 6 of 9 cross products accumulated in fp32 must be as accurate as the fp32 MFMA kernel: same
     bound against fp64 (rel 5e-6 of the output range, the bound every fp32 conv kernel is held to), with and without the BN + ReLU
-    prologue, ragged M (rows beyond the last full 128-row tile), never worse than 2x the fp32-pipe kernel's own error, and the split of the weights exact (w0 + w1 + w2 == w)."""
+    prologue, ragged M (rows beyond the last full 128-row tile), never worse than 2x the fp32-pipe kernel's own error, and the split of the weights exact (w0 + w1 + w2 == w).
+    N = 64: the 64-column tiles of the first Residual blocks' 64-channel 1x1 convolutions (r1 / r4 conv1)."""
     import ctypes as C
     from suo_slam_amd import _lib
     lib = _lib.lib()
     rng = np.random.default_rng(77)
-    N = 128
     w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
     w3 = np.empty(3 * N * K, np.uint16)
     _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
