@@ -176,12 +176,7 @@ class FramePipeline:
         P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         # ---- host side of the step (lib/object_slam.py:1082-1098): per-box intrinsics in the reference's float32 container
         boxes = np.concatenate([fr["boxes"] for fr in frames]).astype(np.float32)
-        K_bbox = np.empty((LF, 3, 3), np.float32)
-        k = 0
-        for fr in frames:
-            for b in fr["boxes"]:
-                K_bbox[k] = geo.fix_K_for_bbox_ndc(fr["K"], b.astype(np.float64))
-                k += 1
+        K_bbox = np.concatenate([geo.fix_K_for_bbox_ndc_many(fr["K"], fr["boxes"].astype(np.float64)) for fr in frames]).astype(np.float32)
         kinv, camk = kbbox_terms(K_bbox)
         min_depth = 0.5 * np.concatenate([fr["diameter"] for fr in frames])
         S["h_boxes"].numpy()[:] = boxes

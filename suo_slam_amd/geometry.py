@@ -26,6 +26,22 @@ def fix_K_for_bbox_ndc(K_, bbox):
     return S @ T @ K
 
 
+def fix_K_for_bbox_ndc_many(K_, bboxes):
+    """``fix_K_for_bbox_ndc`` for all boxes of a frame at once: the same products as stacked matmuls (numpy runs the same 3x3 kernel per box:
+    bit-identical, tests/test_host_logic.py)."""
+    b = np.asarray(bboxes, dtype=np.float64).reshape(-1, 4)
+    n = b.shape[0]
+    T = np.tile(np.eye(3), (n, 1, 1))
+    T[:, 0, 2] = -b[:, 0]
+    T[:, 1, 2] = -b[:, 1]
+    S = np.tile(np.eye(3), (n, 1, 1))
+    S[:, 0, :] *= (2.0 / (b[:, 2] - b[:, 0]))[:, None]
+    S[:, 1, :] *= (-2.0 / (b[:, 3] - b[:, 1]))[:, None]
+    S[:, 0, 2] -= 1
+    S[:, 1, 2] += 1
+    return S @ T @ np.array(K_, dtype=np.float64)
+
+
 def invert_SE3(T):
     Tinv = np.eye(4)
     Tinv[:3, :3] = T[:3, :3].T

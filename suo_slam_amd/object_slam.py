@@ -23,7 +23,7 @@ import numpy as np
 from . import ba as _ba
 from . import lambdatwist as _lt
 from . import slam_score as _sc
-from .geometry import fix_K_for_bbox_ndc, invert_SE3, normalize_uv, to4x4
+from .geometry import fix_K_for_bbox_ndc, fix_K_for_bbox_ndc_many, invert_SE3, normalize_uv, to4x4
 from .weights import NUM_KP
 
 CHI2_2DOF_95 = 5.991
@@ -366,7 +366,7 @@ class ObjectSLAM:
         from .frame_geom import FrameGeometry, kbbox_terms
         from .pkpnet import keypoint_masks
         L = len(obj_ids)
-        K_bbox = np.stack([fix_K_for_bbox_ndc(K, bboxes[k]) for k in range(L)]).astype(np.float32)     # float32 container (:1082)
+        K_bbox = fix_K_for_bbox_ndc_many(K, bboxes).astype(np.float32)                                   # float32 container (:1082)
         kinv, camk = kbbox_terms(K_bbox)
         min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for o in obj_ids], dtype=np.float64)
         pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None)
@@ -495,9 +495,7 @@ class ObjectSLAM:
         """object_slam.py:1077-1167.  Network + masks on the GPU, then ONE batched PnP launch for all
         objects of the frame (the reference loops lambdatwist.pnp per object)."""
         L = len(obj_ids)
-        K_bbox = np.zeros((L, 3, 3), dtype=np.float32)            # float32 container as in the reference (:1082)
-        for k in range(L):
-            K_bbox[k] = fix_K_for_bbox_ndc(K, bboxes[k])
+        K_bbox = fix_K_for_bbox_ndc_many(K, bboxes).astype(np.float32)            # float32 container as in the reference (:1082)
         cov_uv = None
         if not self.debug_gt_kp or self.run_network_in_debug:
             import torch
@@ -518,6 +516,8 @@ class ObjectSLAM:
             else:
                 bt, vt = self.bbox_thresh, self.kp_var_thresh
             masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, bt, vt)
+            # (three small read-backs, as the reference does, :1100-1111: packing them with torch.cat first costs more host time in
+            #  torch's dispatcher -- 4 extra ops, +0.2 ms per call on the GPU boxes -- than the two stream waits it saves)
             exp_uv = pred["uv"].cpu().numpy()
             kp_masks = masks_dev.cpu().numpy().astype(bool)
             if not self.no_network_cov or self.run_network_in_debug:
@@ -540,7 +540,9 @@ class ObjectSLAM:
         idx = [k for k in range(L) if per_obj[k][0].shape[0] >= 4]
         poses = {}
         if idx:
-            T, status = _lt.pnp_batch([per_obj[k][2] for k in idx], [normalize_uv(per_obj[k][0], per_obj[k][3]) for k in idx],
+            # normalize_uv per object (:34-36) with the L inverses taken in one stacked call (the same LAPACK routine per matrix)
+            KinvT = np.linalg.inv(K_bbox.astype(np.float64)).transpose(0, 2, 1)
+            T, status = _lt.pnp_batch([per_obj[k][2] for k in idx], [per_obj[k][0] @ KinvT[k][:2, :2] + KinvT[k][2:3, :2] for k in idx],
                                       0.001, seed=self._pnp_seed)
             self._pnp_seed += len(idx)
             for j, k in enumerate(idx):

@@ -60,6 +60,21 @@ def _slam_with_state(rng, noise=0.0):
     return slam, fr
 
 
+def test_k_bbox_of_all_boxes_at_once_is_bit_identical():
+    """geometry.fix_K_for_bbox_ndc_many (what process_view calls per frame) == fix_K_for_bbox_ndc per box (pinned to the reference's
+    utils.fix_K_for_bbox_ndc, tests/test_host_golden.py), bit for bit, also through the float32 container of object_slam.py:1082."""
+    rng = np.random.default_rng(0)
+    K = S.K_YCBV
+    for _ in range(100):
+        n = int(rng.integers(1, 17))
+        c, hw = rng.uniform([50, 50], [590, 430], (n, 2)), rng.uniform(3, 250, (n, 2))
+        b = np.concatenate([c - hw, c + hw], 1)
+        many = geo.fix_K_for_bbox_ndc_many(K, b)
+        one = np.stack([geo.fix_K_for_bbox_ndc(K, b[i]) for i in range(n)])
+        assert np.array_equal(many, one) and many.dtype == np.float64
+    assert geo.fix_K_for_bbox_ndc_many(K, np.zeros((0, 4))).shape == (0, 3, 3)
+
+
 def test_chi2_scoring_counts_all_keypoints_at_the_true_pose():
     slam, fr = _slam_with_state(np.random.default_rng(0))
     for k, o in enumerate(fr["obj_ids"]):
