@@ -727,9 +727,32 @@ def drop_in_leg(L, pool, n=40):
         n_pose += sum(r["T_OtoC"] is not None for r in res[it]["poses"].values())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"call": "ObjectSLAM.reset / process_view / collect_results per frame (evaluate.py:338-395), device chain", "frames": n,
-            "process_view_ms": round(1e3 * dt / n, 3), "evaluator_fps": round(n / dt, 2), "poses_returned": n_pose,
-            "tracking_meter_ms": round(1e3 * slam.track_time_meter.average(), 3)}
+    out = {"call": "ObjectSLAM.reset / process_view / collect_results per frame (evaluate.py:338-395), device chain", "frames": n,
+           "process_view_ms": round(1e3 * dt / n, 3), "evaluator_fps": round(n / dt, 2), "poses_returned": n_pose,
+           "tracking_meter_ms": round(1e3 * slam.track_time_meter.average(), 3)}
+    # the same loop with B views per device call (Evaluator(frames_per_call=B) -> ObjectSLAM.process_views_single): the views of a single-view
+    # evaluation are independent, so they can share a network call and a geometry launch; object ids made unique per frame (one mesh table)
+    B = 16
+    del slam
+    frames = [pool[i % len(pool)] for i in range(B)]
+    mesh_all = {100 * i + o: {"diameter": float(fr["diameter"][k]), "is_symmetric": False} for i, fr in enumerate(frames) for k, o in enumerate(fr["obj_ids"])}
+    slam = ObjectSLAM(None, mesh_all, sfm_mode=True, single_view_mode=True, state_dict=confident_state_dict(), max_crops=B * max(16, L),
+                      kp_var_thresh=KP_VAR_THRESH, bbox_thresh=BBOX_THRESH)
+    n_calls, n_pose_b = 4, 0
+    for it in range(n_calls + 2):
+        if it == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        views = [(it * B + i, fr["image"], fr["K"], 100 * i + np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
+                  fr["model_kps_masks"]) for i, fr in enumerate(frames)]
+        res = slam.process_views_single(views)
+        n_pose_b += sum(r["T_OtoC"] is not None for rv in res for v in rv.values() for r in v["poses"].values())
+    torch.cuda.synchronize()
+    dtb = time.perf_counter() - t0
+    out["views_per_call_%d" % B] = {"call": "ObjectSLAM.process_views_single (Evaluator(frames_per_call=%d))" % B, "frames": n_calls * B,
+                                    "ms_per_frame": round(1e3 * dtb / (n_calls * B), 3), "evaluator_fps": round(n_calls * B / dtb, 2),
+                                    "poses_returned_per_frame": round(n_pose_b / ((n_calls + 2) * B), 2)}
+    return out
 
 
 def slam_leg(n_views=60, n_obj=8):

@@ -61,11 +61,15 @@ def bop_eval_command(csv_path, outdir, targets_filename, repo_root="."):
 class Evaluator:
     def __init__(self, dataset, data_root, chkpt_path, nviews=1, no_network_cov=False, detection_type="saved", debug_gt_kp=False,
                  gt_cam_pose=False, no_prior_det=False, debug_saved_only=False, give_all_prior=False, out_dir=None, state_dict=None,
-                 do_add=None, seed=666, verbose=False, repo_root=".", run_bop_eval=False):
+                 do_add=None, seed=666, verbose=False, repo_root=".", run_bop_eval=False, frames_per_call=1):
         """``dataset``: "ycbv" | "tless"; ``data_root``: the dataset directory of the BOP tree.  ``out_dir`` defaults to
         the checkpoint's directory like the reference.  ``do_add`` overrides the per-dataset default (the reference
-        evaluates ADD only on YCB-V)."""
+        evaluates ADD only on YCB-V).  ``frames_per_call`` > 1 (single-view evaluation, nviews == 1, only): that many reference views go through
+        ONE network call and ONE geometry launch (ObjectSLAM.process_views_single) -- the views of evaluate.py's loop are independent there
+        (reset / process_view / collect_results per view, evaluate.py:338-395); results are the per-view loop's (geometry bit for bit on the same network
+        outputs; the shared network call agrees with per-view calls to the network's tolerance: ObjectSLAM.process_views_single)."""
         cfg = _SETTINGS[dataset]
+        self.frames_per_call = int(frames_per_call) if nviews == 1 else 1
         self.model_path = out_dir if out_dir is not None else os.path.dirname(chkpt_path or ".")
         self.do_add = cfg["do_add"] if do_add is None else do_add
         if debug_gt_kp:
@@ -82,7 +86,7 @@ class Evaluator:
                                           debug_gt_kp=debug_gt_kp, sfm_mode=nviews > 0, single_view_mode=nviews == 1,
                                           kp_var_thresh=cfg["kp_var_thresh"], bbox_thresh=cfg["bbox_thresh"], bbox_inflate=0.0,
                                           manual_kp_std=cfg["manual_kp_std"], opt_init_with_outliers=cfg["opt_init_with_outliers"],
-                                          give_all_prior=give_all_prior, state_dict=state_dict)
+                                          give_all_prior=give_all_prior, state_dict=state_dict, max_crops=16 * max(1, self.frames_per_call))
         self.saved_detections, self.saved_detections_map = None, {}
         if detection_type == "saved":
             load = detections.load_posecnn_results if dataset == "ycbv" else detections.load_pix2pose_results
@@ -103,34 +107,40 @@ class Evaluator:
             print(*a)
 
     # ---- one reference view (+ companions in SfM mode) through the hot path: evaluate.py:338-393 ----
+    def _view_args(self, scene_id, view_id, first_view):
+        """What evaluate.py:341-393 hands process_view for one view: (args tuple, keyword dict), or None when the view has no detections."""
+        gt_ids = self.dataset.obj_ids(scene_id, view_id)
+        if "gt" in self.detection_type:
+            obj_ids = gt_ids
+        else:
+            obj_ids = [o for o in self.saved_detections_map.get(scene_id, {}).get(view_id, {}).keys() if o in gt_ids]
+            assert len(obj_ids) == len(set(obj_ids)), "Duplicates in detections?"
+            if len(obj_ids) == 0:
+                self._log(f"WARNING no detections for scene {scene_id} view {view_id}")
+                return None
+        sample = self.dataset.get_raw(scene_id, view_id, obj_ids)
+        if "gt" in self.detection_type:
+            bboxes = sample["bboxes"].numpy()
+        else:
+            bboxes = [self.saved_detections["bboxes"][self.saved_detections_map[scene_id][view_id][o]] for o in obj_ids]
+        cam_pose = None
+        if self.gt_cam_pose:
+            first = -1 if self.nviews < 0 else first_view
+            cam_pose = self._to4(self.dataset.get_cam_pose(scene_id, view_id)) @ invert_SE3(self._to4(self.dataset.get_cam_pose(scene_id, first)))
+        img = (255 * sample["img"].numpy().transpose((1, 2, 0))).astype(np.uint8)
+        return ((view_id, img, sample["K"].numpy(), np.array(obj_ids, dtype=int), np.array(bboxes), sample["model_kps"].numpy(),
+                 sample["kp_model_masks"].numpy(), sample["kp_masks"].numpy()),
+                {"uv_gt": sample["kp_uvs"].numpy() if self.debug_gt_kp else None, "cam_pose": cam_pose})
+
     def _run_slam(self, scene_id, views_to_proc):
         if self.nviews > 0:
             self.object_slam.reset()
         else:
             assert len(views_to_proc) == 1
         for view_id in views_to_proc:
-            gt_ids = self.dataset.obj_ids(scene_id, view_id)
-            if "gt" in self.detection_type:
-                obj_ids = gt_ids
-            else:
-                obj_ids = [o for o in self.saved_detections_map.get(scene_id, {}).get(view_id, {}).keys() if o in gt_ids]
-                assert len(obj_ids) == len(set(obj_ids)), "Duplicates in detections?"
-                if len(obj_ids) == 0:
-                    self._log(f"WARNING no detections for scene {scene_id} view {view_id}")
-                    continue
-            sample = self.dataset.get_raw(scene_id, view_id, obj_ids)
-            if "gt" in self.detection_type:
-                bboxes = sample["bboxes"].numpy()
-            else:
-                bboxes = [self.saved_detections["bboxes"][self.saved_detections_map[scene_id][view_id][o]] for o in obj_ids]
-            cam_pose = None
-            if self.gt_cam_pose:
-                first = -1 if self.nviews < 0 else views_to_proc[0]
-                cam_pose = self._to4(self.dataset.get_cam_pose(scene_id, view_id)) @ invert_SE3(self._to4(self.dataset.get_cam_pose(scene_id, first)))
-            img = (255 * sample["img"].numpy().transpose((1, 2, 0))).astype(np.uint8)
-            self.object_slam.process_view(view_id, img, sample["K"].numpy(), np.array(obj_ids, dtype=int), np.array(bboxes),
-                                          sample["model_kps"].numpy(), sample["kp_model_masks"].numpy(), sample["kp_masks"].numpy(),
-                                          uv_gt=sample["kp_uvs"].numpy() if self.debug_gt_kp else None, cam_pose=cam_pose)
+            a = self._view_args(scene_id, view_id, views_to_proc[0])
+            if a is not None:
+                self.object_slam.process_view(*a[0], **a[1])
         return self.object_slam.collect_results(last_only=self.nviews < 0, no_viz=True)
 
     @staticmethod
@@ -162,9 +172,24 @@ class Evaluator:
             if not self.debug_saved_only and self.nviews < 0:
                 self.object_slam.reset()
             scene_results = []
+            batched = not self.debug_saved_only and self.frames_per_call > 1 and not self.debug_gt_kp and not self.gt_cam_pose
+            pending = []                                              # (view_id, gt_obj_ids, process_view arguments) waiting for their shared call
+
+            def flush():
+                if pending:
+                    for (vid, gt_ids, _), res in zip(pending, self.object_slam.process_views_single([p[2] for p in pending])):
+                        if len(res):
+                            scene_results.append((vid, res[vid]["poses"], gt_ids))
+                    pending.clear()
             for j, view_id in enumerate(view_ids):
                 gt_obj_ids = ds.obj_ids(scene_id, view_id)
-                if not self.debug_saved_only:
+                if batched:
+                    a = self._view_args(scene_id, view_id, view_id)
+                    if a is not None:
+                        pending.append((view_id, gt_obj_ids, a[0]))
+                        if len(pending) == self.frames_per_call:
+                            flush()
+                elif not self.debug_saved_only:
                     views = [view_id]
                     if self.nviews > 1:                               # SfM: nviews-1 random companions (evaluate.py:194-197)
                         views += self._rng.choice(view_ids[:j] + view_ids[j + 1:], size=self.nviews - 1, replace=False).tolist()
@@ -179,6 +204,7 @@ class Evaluator:
                             saved_meter.update([o], np.asarray(self.saved_detections["poses"][idx])[None, ...], ds.get_obj_pose(scene_id, view_id, o)[None, ...])
                         else:
                             saved_meter.update_no_det([o])
+            flush()
             if self.debug_saved_only:
                 continue
             final = self.object_slam.collect_results(no_viz=True, final=True) if self.nviews < 0 else None

@@ -380,12 +380,17 @@ class ObjectSLAM:
                         use_cov=not self.no_network_cov, do_lm=True, its=its)
         r = self._fg.fetch(copy=True)
         self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
+        self._ingest_single_view(view_id, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox, r, 0, 0)
+
+    def _ingest_single_view(self, view_id, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox, r, lo, frame):
+        """State of a single-view frame from the device chain's read-back (crops [lo, lo + L) of launch result r, frame index `frame`)."""
         detection = {}
         for k, obj_id in enumerate(obj_ids):
-            m = r["mask"][k]
-            n = int(r["n_kp"][k])
-            cov_pred = None if self.no_network_cov else r["cov"][k][m]
-            pose = r["T_pnp"][k].copy() if r["accepted"][k] else None
+            c = lo + k
+            m = r["mask"][c]
+            n = int(r["n_kp"][c])
+            cov_pred = None if self.no_network_cov else r["cov"][c][m]
+            pose = r["T_pnp"][c].copy() if r["accepted"][c] else None
             if cov_pred is not None and cov_pred.size > 0:
                 std = np.sqrt(cov_pred[..., [0, 1], [0, 1]])
                 self.avg_std_meter.update(std.mean(), std.size)
@@ -393,18 +398,86 @@ class ObjectSLAM:
             self.obj_num_det_kps[obj_id] += n
             assert obj_id not in self.obj_poses and obj_id not in detection, f"Object {obj_id} is in detections twice! obj_id must be an instance label."
             detection[obj_id] = {"bbox": bboxes[k], "model_kp_mask": model_kps_masks[k], "prior_uv": None, "pose": pose,
-                                 "inliers": r["inlier"][k, :n].copy(), "kp_mask": m, "model_kp": model_kps[k][m].astype(np.float64), "uv_gt": None,
-                                 "uv_pred": r["uv"][k][m].astype(np.float64), "cov_pred": cov_pred, "K": K_bbox[k].astype(np.float64),
+                                 "inliers": r["inlier"][c, :n].copy(), "kp_mask": m, "model_kp": model_kps[k][m].astype(np.float64), "uv_gt": None,
+                                 "uv_pred": r["uv"][c][m].astype(np.float64), "cov_pred": cov_pred, "K": K_bbox[k].astype(np.float64),
                                  "score": 0.0 if n == 0 else 1.0}
             if pose is not None:
-                self.obj_poses[obj_id] = r["T_opt"][k].copy()
+                self.obj_poses[obj_id] = r["T_opt"][c].copy()
         self.detections[view_id] = detection
         self.cam_poses[view_id] = np.eye(4)[:3, :]
         self.view_ids.append(view_id)
-        self.last_lm_stats = r["lm_stats"][0].copy()
+        self.last_lm_stats = r["lm_stats"][frame].copy()
         t0 = time()
-        self._cull_after_optimize([o for k, o in enumerate(obj_ids) if r["accepted"][k]], False, view_id)
+        self._cull_after_optimize([o for k, o in enumerate(obj_ids) if r["accepted"][lo + k]], False, view_id)
         self.opt_time_meter.update(time() - t0)
+
+    def single_views_take_the_device_chain(self, views):
+        """True when process_views_single can run `views` as ONE device call (else it processes them one by one)."""
+        if not (self.single_view_mode and self.device_chain and self.model is not None and not self.debug_gt_kp and len(views) > 1):
+            return False
+        shape = np.asarray(views[0][1]).shape
+        return all(0 < len(v[3]) <= 16 and np.asarray(v[1]).shape == shape and np.asarray(v[1]).dtype == np.uint8 for v in views)
+
+    def process_views_single(self, views):
+        """Single-view evaluation (evaluate.py --nviews 1: reset / process_view / collect_results per reference view, evaluate.py:338-395) of SEVERAL
+        independent views in one device call: `views` = [(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks), ...].
+        Returns [collect_results() of view 0, of view 1, ...] -- what the per-view loop returns: everything downstream of the network is bit for bit
+        the per-view loop's on the same network outputs (one geometry launch; the PnP sampler's keys continue from frame to frame as the per-view
+        loop advances its seed, csrc/pnp.hip); the shared network call picks its kernels by launch size, so its keypoints agree with the
+        per-view calls' to the network's tolerance (1e-5 of the reference either way).  tests/test_gpu_evaluator.py holds both."""
+        import torch
+        if not self.single_views_take_the_device_chain(views):
+            out = []
+            for v in views:
+                self.reset()
+                self.process_view(*v[:8])
+                out.append(self.collect_results(no_viz=True))
+            return out
+        from .frame_geom import FrameGeometry, kbbox_terms
+        from .pkpnet import keypoint_masks
+        torch.cuda.synchronize()
+        tt0 = time()
+        prep, ff = [], [0]
+        for view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, _ in views:
+            obj_ids = np.asarray(obj_ids)
+            bboxes = np.array(bboxes, dtype=np.float64)
+            bboxes[:, [0, 1]] *= 1.0 - self.bbox_inflate                                               # (process_view, :368-369)
+            bboxes[:, [2, 3]] *= 1.0 + self.bbox_inflate
+            K_bbox = fix_K_for_bbox_ndc_many(K, bboxes).astype(np.float32)
+            prep.append((view_id, img, K, obj_ids, bboxes, np.asarray(model_kps), np.asarray(model_kps_masks, dtype=bool), K_bbox))
+            ff.append(ff[-1] + len(obj_ids))
+        Ltot, B = ff[-1], len(views)
+        assert Ltot <= self.model.max_crops, f"{Ltot} crops in one call, the network was built for {self.model.max_crops} (ObjectSLAM(max_crops=...))"
+        K_all = np.concatenate([p[7] for p in prep])
+        kinv, camk = kbbox_terms(K_all)
+        min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for p in prep for o in p[3]], dtype=np.float64)
+        pred = self.model.forward_frames(np.stack([np.ascontiguousarray(p[1]) for p in prep]), [np.asarray(p[4], np.float32) for p in prep])
+        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+        mm_all = np.concatenate([p[6] for p in prep])
+        masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], mm_all, self.bbox_thresh, vt)
+        kps_dev = torch.as_tensor(np.ascontiguousarray(np.concatenate([p[5] for p in prep]), dtype=np.float32)).to(pred["uv"].device)
+        fg = getattr(self, "_fg_batch", None)
+        if fg is None or fg.max_crops < Ltot or fg.max_frames < B:
+            fg = self._fg_batch = FrameGeometry(max(256, Ltot), max(32, B))
+        its = (10, 10, 40, 40) if self.sfm_mode else (10, 10, 10, 10)
+        fg.launch(ff, pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
+                  use_cov=not self.no_network_cov, do_lm=True, its=its)
+        r = fg.fetch(copy=True)
+        self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
+        torch.cuda.synchronize()
+        per_view = (time() - tt0) / B
+        out = []
+        for f, (view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox) in enumerate(prep):
+            self.reset()
+            self.cam_K[view_id] = K
+            self.images[view_id] = img
+            self.all_time_num_views += 1
+            self._ingest_single_view(view_id, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox, r, ff[f], f)
+            if self.all_time_num_views > 5:
+                self.track_time_meter.update(per_view)
+            self.needs_opt = False
+            out.append(self.collect_results(no_viz=True))
+        return out
 
     def _cull_after_optimize(self, graph_objs, curr_only, view_curr):
         """object_slam.py:904-930: objects whose centre fell behind 0.5 diameter in the current view, then objects with too few inliers."""

@@ -107,3 +107,79 @@ def test_slam_mode_over_a_consistent_sequence(tmp_path):
             bad += 1
     assert bad <= 3, bad
     assert out["result"]["AUC of ADD-S"][0] > 0.7
+
+
+def _per_frame_forward_frames(self, images, boxes_per_frame):
+    """PkpNet.forward_frames as one PkpNet.forward per frame (the per-view loop's network calls), results concatenated."""
+    import torch
+    outs = [self.forward(np.ascontiguousarray(images[i]), [torch.as_tensor(np.asarray(b, np.float32))], None) for i, b in enumerate(boxes_per_frame)]
+    return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+
+def test_batched_single_view_evaluation_equals_the_per_view_loop(tmp_path, monkeypatch):
+    """Evaluator(frames_per_call=4) / ObjectSLAM.process_views_single: several reference views of evaluate.py's single-view loop (:338-395) through
+    one geometry launch.  (a) Given the SAME network outputs (forward_frames replaced by per-frame forwards) everything downstream -- masks,
+    compaction, PnP with the sampler's seed carried from view to view, acceptance, LM, culling, scores, CSV, meters -- equals the per-view loop
+    BIT FOR BIT, incl. a ragged last batch and views with different object counts.  (b) With the real batched network call the keypoints agree
+    with the per-view calls to the network's tolerance (the network picks its kernels by launch size: both forms are held to 1e-5 of the
+    reference, tests/test_gpu_cnn.py)."""
+    from suo_slam_amd import weights
+    from suo_slam_amd.pkpnet import PkpNet
+    desc = bop_tree.build(str(tmp_path), dset="ycbv", seed=41, n_scenes=2, n_views=5)
+    reader = bop.BopDataset(desc["data_root"], desc["split"], bop_dset="ycbv", ignore_symmetry=True)
+    bop_tree.write_saved_detections(str(tmp_path), desc, reader, seed=5, trans_noise_mm=4.0)
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    real_forward_frames = PkpNet.forward_frames
+    monkeypatch.setattr(PkpNet, "forward_frames", _per_frame_forward_frames)
+    outs = {}
+    for fpc in (1, 4):
+        ev = evaluator.Evaluator("ycbv", desc["data_root"], None, nviews=1, detection_type="saved", out_dir=str(tmp_path / f"out{fpc}"), state_dict=sd,
+                                 frames_per_call=fpc)
+        ev.object_slam.bbox_thresh, ev.object_slam.kp_var_thresh = 10.0, 1e6         # random weights: let the masks pass, so that PnP / LM run on what the network emitted
+        outs[fpc] = ev.run()
+        outs[fpc]["csv"] = open(outs[fpc]["csv_path"]).read()
+        ev.object_slam.model.close()
+    assert outs[1]["csv"] == outs[4]["csv"] and len(outs[1]["csv"].splitlines()) > 5
+    assert outs[1]["num_views"] == outs[4]["num_views"] == 10
+    for k, v in outs[1]["result"].items():
+        assert np.array_equal(np.asarray(v), np.asarray(outs[4]["result"][k])), k
+    # the entry point itself, against reset / process_view / collect_results per view
+    ev = evaluator.Evaluator("ycbv", desc["data_root"], None, nviews=1, detection_type="saved", out_dir=str(tmp_path / "o"), state_dict=sd, frames_per_call=8)
+    s = reader.scene_ids()[0]
+    views = [ev._view_args(s, v, v)[0] for v in reader.view_ids(s)]
+    slam = ev.object_slam
+    slam.bbox_thresh, slam.kp_var_thresh = 10.0, 1e6
+    assert slam.single_views_take_the_device_chain(views)
+    seed0 = slam._pnp_seed
+    got = slam.process_views_single(views)
+    seed1, slam._pnp_seed = slam._pnp_seed, seed0
+    want, want_uv = [], []
+    for v in views:
+        slam.reset()
+        slam.process_view(*v)
+        want.append(slam.collect_results(no_viz=True))
+        want_uv.append({o: d["uv_pred"].copy() for o, d in slam.detections[v[0]].items()})
+    assert slam._pnp_seed == seed1
+    n_pose = 0
+    for g, w in zip(got, want):
+        assert list(g.keys()) == list(w.keys())
+        for vid in g:
+            assert set(g[vid]["poses"]) == set(w[vid]["poses"])
+            for o, r in g[vid]["poses"].items():
+                assert r["score"] == w[vid]["poses"][o]["score"]
+                assert (r["T_OtoC"] is None) == (w[vid]["poses"][o]["T_OtoC"] is None)
+                if r["T_OtoC"] is not None:
+                    assert np.array_equal(r["T_OtoC"], w[vid]["poses"][o]["T_OtoC"])
+                    n_pose += 1
+    assert n_pose > 0
+    # (b) the real batched network call: same keypoints to the network's tolerance (NDC units), same keypoint selection
+    monkeypatch.setattr(PkpNet, "forward_frames", real_forward_frames)
+    slam._pnp_seed = seed0
+    slam.process_views_single(views[-2:])                     # (state left behind = the last view's)
+    last = views[-1][0]
+    for o, d in slam.detections[last].items():
+        assert d["uv_pred"].shape == want_uv[-1][o].shape and np.abs(d["uv_pred"] - want_uv[-1][o]).max() < 2e-5
+    # views that cannot share a call (here: one of them in another image size) are processed one by one, same results
+    odd = list(views[1])
+    odd[1] = np.ascontiguousarray(odd[1][:-2])
+    assert not slam.single_views_take_the_device_chain([views[0], tuple(odd)])
