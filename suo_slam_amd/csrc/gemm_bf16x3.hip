@@ -29,8 +29,8 @@ typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
 // k-step per barrier: 16 (one MFMA k-group, 24 MFMAs between barriers) or 32 (tools/build_variant.sh bk32 -DSUO_X3_BK=32: 48 MFMAs between barriers,
 // 128-byte row segments per request, 61 KB of LDS).  Measured equal within 3 % on every shape of the network (tools/bench_gemm_x3_shapes.py), as is
 // the depth of the request ring (1 or 3 steps ahead): the kernel's time follows its MFMA count -- the call runs at the package power cap, see DESIGN 4.2
-constexpr int X3_BM = 128, X3_BN = 128, X3_BK = SUO_X3_BK, X3_GH = X3_BK / 16, X3_PITCH = X3_BK + 8;      // LDS row pitch in bf16 (48 / 80 bytes: conflict-free 16-byte fragment reads)
-constexpr int X3_LPR = X3_BK / 4, X3_RPP = 256 / X3_LPR, X3_NR = X3_BM / X3_RPP;   // staging: lanes per row (a float4 each), rows per pass, passes
+constexpr int X3_BN = 128, X3_BK = SUO_X3_BK, X3_GH = X3_BK / 16, X3_PITCH = X3_BK + 8;      // LDS row pitch in bf16 (48 / 80 bytes: conflict-free 16-byte fragment reads)
+constexpr int X3_LPR = X3_BK / 4, X3_RPP = 256 / X3_LPR;                           // staging: lanes per row (a float4 each), rows per pass
 constexpr int X3_ASLOTS = 64 / X3_BK;                                              // activation steps in flight (K a multiple of 64: slots and stages are compile-time indices)
 constexpr int X3_BSLOTS = 4;                                                       // weight k-groups in flight (a ring over 16-wide groups)
 static_assert(X3_BK == 16 || X3_BK == 32, "k-step");
@@ -61,8 +61,12 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 // (row r of the tile = pixel (y0 + (r >> 6), x0 + (r & 63))): the horizontal maximum is a lane exchange (rows j, j + 1 sit 8 lanes apart), the vertical
 // one meets through LDS (image row 0 belongs to the waves wm = 0, row 1 to wm = 1).
 // NCB: 32-column blocks per wave -- 2: the 128-column tile; 1: a 64-column tile (the 64-channel 1x1 convolutions of the first Residual blocks)
-template <bool PRO, bool DUAL, bool RES, bool POOL, int NCB = 2>
+// RB: 32-row blocks per wave -- 2: 128-row tiles; 1: 64-row tiles, for launches that would otherwise be fewer tiles than two per CU (the one-frame call)
+template <bool PRO, bool DUAL, bool RES, bool POOL, int NCB = 2, int RB = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
+    static_assert(RB == 2 || !POOL, "the pooled epilogue is laid out for 128-row tiles");
+    constexpr int X3_BM = 64 * RB, X3_NR = X3_BM / X3_RPP;                    // rows of the tile; staging passes
+    static_assert(X3_NR >= 1, "64-row tiles need the 16-wide k-step");
     constexpr int PLANE = X3_BM * X3_PITCH;                                   // bf16 elements of one plane
     __shared__ __attribute__((aligned(16))) uint16_t S[2][3 * PLANE];         // [stage][plane][row][pitch] = 36 864 bytes (the epilogue re-uses it)
     __shared__ __attribute__((aligned(16))) float P[2][512];                  // prologue scale / shift (K1 <= 512)
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             }
         }
     };
-    x3_f32x16 acc[2][NCB];
+    x3_f32x16 acc[RB][NCB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < NCB; ++j)
 #pragma unroll
@@ -172,13 +176,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             __syncthreads();                                                  // stage u & 1 complete; every wave is past its reads of the other stage
             // this step's A fragments are requested first: their LDS latency passes under the split of the next step's activations
             const uint16_t* As = &S[u & 1][0];
-            x3_bf16x8 af[X3_GH][2][3];
+            x3_bf16x8 af[X3_GH][RB][3];
 #pragma unroll
             for (int h = 0; h < X3_GH; ++h)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) af[h][rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (64 * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko + 16 * h];
+                    for (int rb = 0; rb < RB; ++rb) af[h][rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (32 * RB * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko + 16 * h];
             __builtin_amdgcn_sched_barrier(0);
 #ifndef SUO_X3_EXP_NOSPLIT
             if (ks + 1 < nsteps) split_store(ks + 1, (u + 1) % X3_ASLOTS, (u + 1) & 1);
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb)
                             acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h][rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const __amdgpu_buffer_rsrc_t o_srd = make_srd((POOL && !g.out) ? (float*)g.pool_out : g.out, (POOL && !g.out) ? 0 : (size_t)M * ldo * sizeof(float));
     const __amdgpu_buffer_rsrc_t r_srd = make_srd(RES ? g.R : g.out, RES ? (size_t)M * g.ldr * sizeof(float) : 0);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int col = BN * tn + 32 * NCB * wn + 32 * cb + (lane & 7) * 4;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             if (RES) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int row = pixel_of(64 * wm + 32 * rb + (lane >> 3) + 8 * k);
+                    const int row = pixel_of(32 * RB * wm + 32 * rb + (lane >> 3) + 8 * k);
                     rv[k] = buf_load(r_srd, row < M ? (row * g.ldr + col) * 4 : BUF_OOB, 0);
                 }
             }
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int row = pixel_of(64 * wm + 32 * rb + (lane >> 3) + 8 * k);
+                const int row = pixel_of(32 * RB * wm + 32 * rb + (lane >> 3) + 8 * k);
                 x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv;
                 if (RES) o += rv[k];                                          // (bias, then the residual: the order of the fp32 kernels)
                 if (g.relu) {
@@ -293,9 +297,14 @@ int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t 
         return SUO_ERR_ARG;
     }
     const bool n64 = g.N % 128 != 0;                                          // 64 output channels: 64-column tiles
-    const int tiles = ((g.M + X3_BM - 1) / X3_BM) * (n64 ? 1 : g.N / 128);
+    // launches of fewer 128-row tiles than four per CU (the one-frame call: conv1 / lin at 64x64 for 8 crops = 256 / 512 tiles) take 64-row tiles: 2.206 -> 2.174 ms per network call, one frame in flight 2.857 -> 2.825 (tools/latency_ab.sh)
+    static const long rb1_max_tiles = getenv("SUO_X3_ROWS64_MAX_TILES") ? atol(getenv("SUO_X3_ROWS64_MAX_TILES")) : 1023;
+    const long tiles128 = (long)((g.M + 127) / 128) * (n64 ? 1 : g.N / 128);
+    const bool rows64 = !n64 && !g.pool_out && X3_BK == 16 && tiles128 <= rb1_max_tiles;
+    const int tiles = rows64 ? ((g.M + 63) / 64) * (g.N / 128) : (int)tiles128;
 #define X3_LAUNCH(P_, D_, R_) do { if (g.pool_out) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, true>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
                                    else if (n64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 1>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
+                                   else if (rows64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 2, 1>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
                                    else hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false>), dim3(tiles), dim3(256), 0, s, g, Wx3); } while (0)
     const bool res = g.R != nullptr;
     if (g.pro_scale) { if (res) X3_LAUNCH(true, false, true); else X3_LAUNCH(true, false, false); }
