@@ -48,6 +48,24 @@ int suo_net_set_graph(suo_net* net, int enable);          /* hipGraph replay of 
 int suo_net_prepare(suo_net* net, int L, int with_priors, void* stream);
 size_t suo_net_workspace_bytes(const suo_net* net);
 
+/* Matrix pipe of the network's large launches (the reference runs cuDNN's fp32 convolutions, lib/models/layers/Residual.py:20-35; all three forms are held
+ * to its outputs at 1e-5, tests/test_gpu_cnn.py).  Chosen when the network is created -- SUO_WINO_BF16X3=0: SUO_PIPE_F32; SUO_F16X2=0: SUO_PIPE_BF16X3;
+ * default SUO_PIPE_F16X2 -- and lowered at run time by suo_net_set_pipe (F16X2 -> BF16X3; the fp32 form only when created with it).
+ *   SUO_PIPE_F32     v_mfma_f32_32x32x2_f32, exact fp32 products
+ *   SUO_PIPE_BF16X3  operands as three bf16 terms, 6 of 9 cross products, fp32 accumulate (csrc/bf16x3.h): fp32's range
+ *   SUO_PIPE_F16X2   operands as two fp16 terms, 3 of 4 cross products, fp32 accumulate (csrc/f16x2.h): half the matrix-pipe work, fp16's RANGE --
+ *                    activations enter times 16, so a forward in which some |activation| >= 4094 is not computable in this form.  The kernels detect
+ *                    that (they never write inf silently) and raise a flag:
+ * suo_net_range_exceeded() returns 1 when a forward since its last call left the range -- the outputs of that forward are INVALID -- and clears the flag;
+ * the network has then already been moved to SUO_PIPE_BF16X3 and the caller re-issues the call.  Call it after synchronising the stream and before
+ * using the outputs.  Forwards on the NULL stream (blocking) check and re-issue by themselves. */
+#define SUO_PIPE_F32 0
+#define SUO_PIPE_BF16X3 1
+#define SUO_PIPE_F16X2 2
+int suo_net_get_pipe(const suo_net* net);
+int suo_net_set_pipe(suo_net* net, int pipe);
+int suo_net_range_exceeded(suo_net* net);
+
 /* One frame: image either SUO_IMG_U8_HWC = uint8 [H,W,3] as cv2.imread gives it (scaled by 1/255 on
  * device: object_slam.py:1092 fused) or SUO_IMG_F32_CHW = float32 [3,H,W] already scaled (the tensor
  * PkpNet.forward receives); boxes float32 [L,4] xyxy pixels, priors float32 [L,41,256,256] or NULL (= zeros, pkpnet.py:95-97).
@@ -141,6 +159,17 @@ int suo_conv1x1_bf16x3_ex(const float* a1_dev, int lda1, int K1, const float* pr
 int suo_conv1x1_bf16x3_pool(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev,
                             int lda2, int K2, const uint16_t* wp3_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo,
                             int M, int N, int relu, int H, int W, float* pool_out_dev, void* stream);
+/* The same kernel on TWO fp16 terms per operand, three MFMAs per product block (csrc/f16x2.h; what suo_net_forward launches by default).
+ * w16 = suo_pack_gemm_weight_f16x2(W[N][K]) -> 2*N*K uint16 (row n times 2^t_n, max |row| in [2^12, 2^13)) and oscale[N] = 2^-(t_n + 4), the factor the
+ * kernel's epilogue applies (activations enter times 2^4).  range_flag_dev: a device-visible word the kernel sets to 1 when a scaled activation reaches
+ * 65504 (the launch's results are then invalid: re-issue on the bf16x3 entry); never cleared by the library. */
+int suo_pack_gemm_weight_f16x2(const float* w, int N, int K, uint16_t* out, float* oscale_out);
+int suo_conv1x1_f16x2_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                         const uint16_t* w16_dev, const float* oscale_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N,
+                         int relu, unsigned* range_flag_dev, void* stream);
+int suo_conv1x1_f16x2_pool(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                           const uint16_t* w16_dev, const float* oscale_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N,
+                           int relu, int H, int W, float* pool_out_dev, unsigned* range_flag_dev, void* stream);
 /* KxK convolution, NHWC: KS=3 (stride 1, pad 1) or KS=7 (stride 2, pad 3) */
 int suo_conv_kxk(int KS, const float* in_dev, int L, int H, int W, int C, const float* wp_dev, const float* bias_dev,
                  float* out_dev, int N, int relu, void* stream);
@@ -170,6 +199,15 @@ int suo_pack_tail_weight_bf16x3(const float* w3, int N2, int K, uint16_t* out);
 int suo_conv3x3_wino_x3_conv1x1_skip_up(const float* in_dev, int L, int H, int W, const uint16_t* wq3_dev, const float* bias2_dev,
                                         const void* wp3_dev, int tail_bf16x3, const float* bias3_dev, const float* skip_dev,
                                         const float* up_dev, float* out_dev, void* stream);
+/* csrc/conv_wino_x3.hip on two fp16 terms per operand (csrc/f16x2.h; the network's default for the Residual blocks' 3x3 + tail): packers return the planes
+ * (2 * 16 * N * C / 2 * N2 * K uint16) and the per-output-channel factors; range_flag_dev as suo_conv1x1_f16x2_ex. */
+int suo_pack_wino_weight_f16x2(const float* w, int N, int C, uint16_t* out, float* oscale_out);
+int suo_conv3x3_wino_f16x2_n(const float* in_dev, int L, int H, int W, int channels, const uint16_t* wq16_dev, const float* oscale_dev, const float* bias_dev,
+                             float* out_dev, int relu, unsigned* range_flag_dev, void* stream);
+int suo_pack_tail_weight_f16x2(const float* w3, int N2, int K, uint16_t* out, float* oscale_out);
+int suo_conv3x3_wino_f16x2_conv1x1_skip_up(const float* in_dev, int L, int H, int W, const uint16_t* wq16_dev, const float* oscale2_dev, const float* bias2_dev,
+                                           const uint16_t* w3p16_dev, const float* oscale3_dev, const float* bias3_dev, const float* skip_dev, const float* up_dev,
+                                           float* out_dev, unsigned* range_flag_dev, void* stream);
 /* The same with the 3x3 convolution in Winograd form (wq2 from suo_pack_wino_weight): what the network launches for its 256 -> 256 blocks */
 int suo_conv3x3_wino_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wq2_dev, const float* bias2_dev, const float* wp3_dev,
                                   const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);

@@ -60,6 +60,10 @@ int suo_net_prepare(suo_net* net, int L, int with_priors, void* stream) {
 
 size_t suo_net_workspace_bytes(const suo_net* net) { return net ? net->impl->workspace_bytes() : 0; }
 
+int suo_net_get_pipe(const suo_net* net) { return net ? net->impl->pipe() : -1; }
+int suo_net_set_pipe(suo_net* net, int pipe) { return net ? net->impl->set_pipe(pipe) : SUO_ERR_ARG; }
+int suo_net_range_exceeded(suo_net* net) { return net ? net->impl->range_exceeded() : 0; }
+
 int suo_net_forward(suo_net* net, const void* img, int img_format, int H, int W, const float* boxes, int L, const float* priors,
                     float* uv, float* cov, float* kp_mask, float* kp_logits, float* logits, void* stream) {
     if (!net || !img || !boxes || !uv || !cov || !kp_mask) { suo_set_error("suo_net_forward: null argument"); return SUO_ERR_ARG; }
@@ -172,6 +176,60 @@ int suo_conv1x1_pool(const float* a1, int lda1, int K1, const float* pro_scale, 
     g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = N; g.relu = relu;
     g.pool_out = pool_out; g.pool_H = H; g.pool_W = W;
     return suo::launch_gemm1x1(g, (hipStream_t)stream);
+}
+
+int suo_pack_gemm_weight_f16x2(const float* w, int N, int K, uint16_t* out, float* oscale_out) {
+    if (!w || !out || !oscale_out || N <= 0 || (N % 32) || K <= 0 || (K % 16)) { suo_set_error("suo_pack_gemm_weight_f16x2: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_gemm_weight_f16x2(w, N, K, out, oscale_out);
+    return SUO_OK;
+}
+
+int suo_conv1x1_f16x2_pool(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                           const uint16_t* w16_dev, const float* oscale_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N,
+                           int relu, int H, int W, float* pool_out_dev, unsigned* range_flag_dev, void* stream) {
+    if (!a1_dev || !w16_dev || !oscale_dev || !range_flag_dev || (!out_dev && !pool_out_dev)) { suo_set_error("suo_conv1x1_f16x2: null argument"); return SUO_ERR_ARG; }
+    suo::GemmArgs g = {};
+    g.A1 = a1_dev; g.lda1 = lda1; g.K1 = K1; g.pro_scale = pro_scale_dev; g.pro_shift = pro_shift_dev; g.A2 = a2_dev; g.lda2 = lda2; g.K2 = a2_dev ? K2 : 0;
+    g.bias = bias_dev; g.R = r_dev; g.ldr = ldr; g.out = out_dev; g.ldo = ldo; g.M = M; g.N = N; g.n_valid = N; g.relu = relu;
+    g.pool_out = pool_out_dev; g.pool_H = H; g.pool_W = W; g.oscale = oscale_dev; g.range_flag = range_flag_dev;
+    return suo::launch_gemm_f16x2_args(g, w16_dev, (hipStream_t)stream);
+}
+
+int suo_conv1x1_f16x2_ex(const float* a1_dev, int lda1, int K1, const float* pro_scale_dev, const float* pro_shift_dev, const float* a2_dev, int lda2, int K2,
+                         const uint16_t* w16_dev, const float* oscale_dev, const float* bias_dev, const float* r_dev, int ldr, float* out_dev, int ldo, int M, int N,
+                         int relu, unsigned* range_flag_dev, void* stream) {
+    return suo_conv1x1_f16x2_pool(a1_dev, lda1, K1, pro_scale_dev, pro_shift_dev, a2_dev, lda2, K2, w16_dev, oscale_dev, bias_dev, r_dev, ldr, out_dev, ldo, M, N, relu, 0, 0,
+                                  nullptr, range_flag_dev, stream);
+}
+
+int suo_pack_wino_weight_f16x2(const float* w, int N, int C, uint16_t* out, float* oscale_out) {
+    if (!w || !out || !oscale_out || N % 32 || C % 16) { suo_set_error("suo_pack_wino_weight_f16x2: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_wino_weight_f16x2(w, N, C, N, C, nullptr, out, oscale_out);
+    return SUO_OK;
+}
+
+int suo_conv3x3_wino_f16x2_n(const float* in, int L, int H, int W, int channels, const uint16_t* wq16, const float* oscale, const float* bias, float* out, int relu,
+                             unsigned* range_flag_dev, void* stream) {
+    suo::ConvArgs c = {};
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = channels; c.Wp = (const float*)wq16; c.bias = bias; c.out = out; c.OH = H; c.OW = W; c.N = channels; c.relu = relu;
+    c.oscale = oscale; c.range_flag = range_flag_dev;
+    return suo::launch_conv3x3_wino_f16x2(c, (hipStream_t)stream);
+}
+
+int suo_pack_tail_weight_f16x2(const float* w3, int N2, int K, uint16_t* out, float* oscale_out) {
+    if (!w3 || !out || !oscale_out || N2 % 32 || K % 16) { suo_set_error("suo_pack_tail_weight_f16x2: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_tail_weight_f16x2(w3, N2, K, out, oscale_out);
+    return SUO_OK;
+}
+
+int suo_conv3x3_wino_f16x2_conv1x1_skip_up(const float* in, int L, int H, int W, const uint16_t* wq16, const float* oscale2, const float* bias2, const uint16_t* w3p16,
+                                           const float* oscale3, const float* bias3, const float* skip, const float* up, float* out, unsigned* range_flag_dev,
+                                           void* stream) {
+    suo::ConvArgs c = {};
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = 128; c.Wp = (const float*)wq16; c.bias = bias2; c.out = nullptr; c.OH = H; c.OW = W; c.N = 128; c.relu = 1;
+    c.W3p = (const float*)w3p16; c.bias3 = bias3; c.R = skip; c.out2 = out; c.N2 = 256; c.up = up; c.oscale = oscale2; c.oscale3 = oscale3; c.range_flag = range_flag_dev;
+    if (up && ((H | W) & 1)) { suo_set_error("suo_conv3x3_wino_f16x2_conv1x1_skip_up: odd map size"); return SUO_ERR_ARG; }
+    return suo::launch_conv3x3_wino_f16x2_fused(c, (hipStream_t)stream);
 }
 
 int suo_conv_kxk(int KS, const float* in, int L, int H, int W, int C, const float* wp, const float* bias, float* out, int N,

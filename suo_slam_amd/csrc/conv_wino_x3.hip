@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "bf16x3.h"
+#include "f16x2.h"
 #include "buffer_ops.h"
 #include "suo_internal.h"
 
@@ -25,6 +26,7 @@ typedef float x_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned x_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned x_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 x_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x_f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ x_f32x16 x_mfma32(float a, float b, x_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int x_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -76,18 +78,61 @@ void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out) {
         }
 }
 
+// host, two-term fp16 form (csrc/f16x2.h): the same U, every output channel n times 2^t_n (max over its C x 16 entries in [2^12, 2^13)), two planes;
+// oscale_out[n] = 2^-(t_n + S2_XSHIFT) for the kernel's epilogue
+void pack_wino_weight_f16x2(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out, float* oscale_out) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int NB = Np / 32;
+    memset(out, 0, (size_t)Np * Cp * 16 * 2 * sizeof(uint16_t));
+    for (int n = 0; n < Np; ++n) oscale_out[n] = ldexpf(1.f, -S2_XSHIFT);
+    float* Un = (float*)malloc((size_t)C * 16 * sizeof(float));
+    for (int n = 0; n < N; ++n) {
+        float mx = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* g = W + ((size_t)n * C + c) * 9;
+            const double sc = out_scale ? (double)out_scale[n] : 1.0;
+            double Gg[4][3];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 3; ++j) Gg[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const float u = (float)((Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2]) * sc);      // rounded once to fp32, as the bf16 form's
+                    Un[c * 16 + i * 4 + j] = i == 3 ? -u : u;                                                        // row xi = 3 stored negated
+                    mx = fmaxf(mx, fabsf(u));
+                }
+        }
+        const int t = s2_row_shift(mx);
+        oscale_out[n] = ldexpf(1.f, -(t + S2_XSHIFT));
+        for (int c = 0; c < C; ++c) {
+            const int chunk = c / X_CK, cc = c % X_CK, nb = n / 32, lane = (cc / 8) * 32 + (n % 32), e = cc % 8;
+            for (int comp = 0; comp < 16; ++comp) {
+                uint16_t h[2];
+                s2_split_host(ldexpf(Un[c * 16 + comp], t), h);
+                for (int p = 0; p < 2; ++p) out[((((size_t)(chunk * 16 + comp) * NB + nb) * 2 + p) * 64 + lane) * 8 + e] = h[p];
+            }
+        }
+    }
+    free(Un);
+}
+
+// host: conv3 weight of the fused tail, two fp16 planes: the layout of pack_gemm_weight_f16x2 (csrc/gemm_bf16x3.hip)
+void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float* oscale_out) { pack_gemm_weight_f16x2(W3, N2, K, out, oscale_out); }
+
 // NT = output channels / 32: 4 (128 channels: wave w owns n-tile w and all 16 components) or 2 (64 -> 64 channels: wave (wc, wn) owns n-tile wn and
 // the 8 components of rows xi = 2 wc, 2 wc + 1 -- one accumulator each, no fold; the two halves meet through LDS before the epilogue, as in
 // csrc/conv_wino.hip).
-template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4>
+// NP = operand planes: 3 = three bf16 terms, six MFMAs per product block (csrc/bf16x3.h); 2 = two fp16 terms, three MFMAs (csrc/f16x2.h: the staged input times
+// 2^S2_XSHIFT, U's rows times 2^t_n, accumulators back to scale by a.oscale / a.oscale3 in the epilogues, a.range_flag raised beyond fp16's range)
+template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
     static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
+    static_assert(NP == 3 || !FUSE || TX3, "the fp16 form's tail runs on the fp16 pipe");
     // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
     constexpr int HSZ = X_NPIX * X_PKH;                       // floats per halo buffer
     constexpr int VROW = 16;                                  // bf16 per (tile, chunk) row = 32 bytes; the two 16-byte halves swap where bits 2 and 3 of the tile differ (4-7, 8-11, 20-23, 24-27):
                                                               // conflict-free A-fragment ds_read_b128, 2-way instead of 4-way on the transform's ds_write_b64
     constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
-    constexpr int VFLOATS = 3 * VPL / 2;
+    constexpr int VFLOATS = NP * VPL / 2;
     __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
     float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
     uint16_t* V = reinterpret_cast<uint16_t*>(&S[2 * HSZ]);
@@ -104,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int nch = a.C / X_CK;
     const float* in_l = a.in + (size_t)l * a.H * a.W * a.C;
     const __amdgpu_buffer_rsrc_t in_srd = make_srd(in_l, (size_t)a.H * a.W * a.C * sizeof(float));
-    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * 16 * 3 * sizeof(uint16_t));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wp, (size_t)a.N * a.C * 16 * NP * sizeof(uint16_t));
     const __amdgpu_buffer_rsrc_t out_srd = make_srd(a.out + (size_t)l * a.OH * a.OW * a.N, (size_t)a.OH * a.OW * a.N * sizeof(float));
 
     // ---- halo staging (as csrc/conv_wino.hip): 180 pixels x 4 float4 per chunk over 256 threads -----------------------------
@@ -124,10 +169,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
         for (int i = 0; i < NLD; ++i) areg[i] = buf_load(in_srd, avoff[i], c * X_CK * 4);
     };
+    float dmax = 0.f;                                         // NP = 2: largest scaled input magnitude this lane staged (range guard)
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
+            if constexpr (NP == 2) {                              // the activation scale (exact) and the guard's running max ride on the staging copy
+                areg[i] *= S2_XSCALE;
+                dmax = s2_track(s2_track(dmax, areg[i][0], areg[i][1]), areg[i][2], areg[i][3]);
+            }
             if (idx < NF4) *(x_f32x4*)&Hin[buf][(idx >> 2) * X_PKH + (idx & 3) * 4] = areg[i];
         }
     };
@@ -138,15 +188,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int wvoff = lane * 16;
     const int wn = NT == 4 ? w : (w & 1), wc = NT == 4 ? 0 : (w >> 1);      // n-tile, component half
     constexpr int NPAIR = NT == 4 ? 8 : 4;                      // component pairs per chunk and wave
-    const int wsbase = wn * 3 * 1024;
-    auto bload = [&](int gc, x_u32x4 (&b)[3]) {               // gc = chunk * 16 + comp
+    const int wsbase = wn * NP * 1024;
+    auto bload = [&](int gc, x_u32x4 (&b)[NP]) {              // gc = chunk * 16 + comp
 #ifdef SUO_WX3_EXP_W0
         const int g = gc & 1;                                 // timing experiment (wrong results): weights from two cache-resident groups
 #else
         const int g = gc;
 #endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (NT * 3 * 1024) + wsbase));
+        for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (NT * NP * 1024) + wsbase));
     };
     // ---- transform: thread = (tile tt, channel quad tq, half th) as in csrc/conv_wino.hip; every result vector is split on its way to LDS ----
     const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;
@@ -155,6 +205,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     // V element offset of (component 0, tile tt, channels 4 tq ..): row tt, half (tq >> 1) swapped where bits 2, 3 of tt differ, 4 bf16 = 8 bytes
     const int vbase = tt * VROW + ((((tq >> 1) ^ (((tt >> 2) ^ (tt >> 3)) & 1)) * 8) + (tq & 1) * 4);
     auto vstore = [&](int comp, x_f32x4 v) {
+        if constexpr (NP == 2) {                                  // hi = rn16(v), lo = rn16(v - hi) (the residual is exact)
+            const unsigned h0 = s2_pack_rn(v[0], v[1]), h1 = s2_pack_rn(v[2], v[3]);
+            *(x_u32x2*)&V[comp * 32 * VROW + vbase] = x_u32x2{h0, h1};
+            const unsigned l0 = s2_pack_rn(v[0] - s2_lo(h0), v[1] - s2_hi(h0)), l1 = s2_pack_rn(v[2] - s2_lo(h1), v[3] - s2_hi(h1));
+            *(x_u32x2*)&V[VPL + comp * 32 * VROW + vbase] = x_u32x2{l0, l1};
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned q0 = s3_pack_rn(v[0], v[1]), q1 = s3_pack_rn(v[2], v[3]);       // round-to-nearest terms (csrc/bf16x3.h); p == 2: exact
@@ -190,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     *(x_u32x2*)&V[p * VPL + (xa * 4 + c) * 32 * VROW + vbase] = x_u32x2{__float_as_uint(L0[c][p]), __float_as_uint(L2[c][p])};
                     *(x_u32x2*)&V[p * VPL + (xb * 4 + c) * 32 * VROW + vbase] = x_u32x2{__float_as_uint(L1[c][p]), __float_as_uint(Lx[c][p])};
                 }
@@ -229,7 +286,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
         for (int r = 0; r < 16; ++r) Z[p][r] = 0.f;
     // the six cross terms of a component, smallest first
-    auto mac6 = [&](x_f32x16& acc, const x_bf16x8 (&f)[3], const x_u32x4 (&bw)[3], bool from_zero) {
+    auto mac6 = [&](x_f32x16& acc, const x_bf16x8 (&f)[NP], const x_u32x4 (&bw)[NP], bool from_zero) {
+        if constexpr (NP == 2) {                                  // hi lo, lo hi, hi hi
+            constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x_f16x8, f[UI[t]]), __builtin_bit_cast(x_f16x8, bw[UJ[t]]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
+            return;
+        }
         constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
 #ifdef SUO_WX3_EXP_MFMA3                                      // timing experiment (wrong results): half of the cross terms
@@ -237,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #else
         for (int t = 0; t < 6; ++t)
 #endif
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[TI[t]], __builtin_bit_cast(x_bf16x8, bw[TJ[t]]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[TI[t] % NP], __builtin_bit_cast(x_bf16x8, bw[TJ[t] % NP]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
     };
     // Consumption order of the components, in pairs: pairs 0-3 = (xi 0, xi 3) of nu = pair, accumulated straight into their Z; pairs 4-7 =
     // (xi 1, xi 2) of nu = pair - 4, through two scratch accumulators that are folded into Z[0][nu], Z[1][nu].  The weights of pair p + 1
@@ -250,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     };
     // A operand of component comp: tile = lane & 31, channels 8 (lane >> 5) .. + 7 (the half, swapped as the rows were written)
     const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ (((lane >> 2) ^ (lane >> 3)) & 1)) * 8);
-    x_u32x4 bring[2][2][3];                                   // [slot][which][plane]
+    x_u32x4 bring[2][2][NP];                                  // [slot][which][plane]
     gload(0);
     bload(comp_of(0, 0), bring[0][0]);
     bload(comp_of(0, 1), bring[0][1]);
@@ -274,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if (more) sstore(buf ^ 1);
         XPROF(2);
 #ifdef SUO_WX3_EXP_NOAREAD
-        x_u32x4 keepa[3];
+        x_u32x4 keepa[NP];
 #endif
 #pragma unroll
         for (int pair = 0; pair < NPAIR; ++pair) {
@@ -285,9 +349,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 bload(nc * 16 + comp_of(np, 1), bring[slot ^ 1][1]);
             }
             const int ca = comp_of(pair, 0), cb = comp_of(pair, 1);
-            x_bf16x8 afa[3], afb[3];
+            x_bf16x8 afa[NP], afb[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #ifdef SUO_WX3_EXP_NOAREAD                                    // timing experiment (wrong results): A fragments read once per chunk
                 if (pair > 0) { afa[p] = __builtin_bit_cast(x_bf16x8, keepa[p]); afb[p] = __builtin_bit_cast(x_bf16x8, keepa[p]); continue; }
 #endif
@@ -323,6 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #ifdef SUO_WX3_PROF
     if (blockIdx.x == 1000 && (tid & 63) == 0) printf("wave %d cycles: transform %lld  barrier1 %lld  sstore %lld  mfma+fold %lld  barrier2 %lld\n", w, pt[0], pt[1], pt[2], pt[3], pt[4]);
 #endif
+    if constexpr (NP == 2) s2_raise(a.range_flag, 4.f * dmax);    // |B^T d B| <= 4 max |d|: conservative by at most 4x, never late
     // second step of the output transform: R[h][j] = sum_nu A^T[j][nu] Z[4 h + nu].  128-channel form: h = i, R = Y; 64-channel form: h = the wave's local row
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -341,16 +406,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         // then its epilogue (transposition through a wave-private patch, + bias3 + skip [+ up], 16-byte stores).
         constexpr int KS_STRIDE = 64 * 32 + 32;                 // bytes per k-step image (+ 32: the two k-steps a wave stores to hit different banks)
         constexpr int PL_STRIDE = 8 * KS_STRIDE;
-        static_assert(3 * PL_STRIDE + 4 * 32 * 36 * 4 <= (2 * HSZ + VFLOATS) * 4, "tail staging must fit the workgroup's LDS");
+        static_assert(NP * PL_STRIDE + 4 * 32 * 36 * 4 <= (2 * HSZ + VFLOATS) * 4, "tail staging must fit the workgroup's LDS");
         unsigned char* AP = reinterpret_cast<unsigned char*>(&S[0]);
-        float* T = &S[3 * PL_STRIDE / 4] + w * (32 * 36);
-        const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * 3 * sizeof(uint16_t));
+        float* T = &S[NP * PL_STRIDE / 4] + w * (32 * 36);
+        const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * NP * sizeof(uint16_t));
         const size_t crop2 = (size_t)a.OH * a.OW * a.N2;
         const __amdgpu_buffer_rsrc_t r_srd = make_srd(a.R + (size_t)l * crop2, crop2 * sizeof(float));
         const __amdgpu_buffer_rsrc_t o2_srd = make_srd(a.out2 + (size_t)l * crop2, crop2 * sizeof(float));
         constexpr bool has_up = UP;
         const __amdgpu_buffer_rsrc_t up_srd = make_srd(has_up ? a.up + (size_t)l * (crop2 / 4) : a.R, has_up ? crop2 / 4 * sizeof(float) : 0);
-        const float b2v = a.bias[w * 32 + (lane & 31)];
+        // NP = 2: the conv2 accumulator carries 2^(t_n + S2_XSHIFT); conv3's operand is 2^S2_XSHIFT relu(conv2 + b2) = relu(acc 2^-t_n + 2^S2_XSHIFT b2): one fma
+        const float b2v = NP == 2 ? a.bias[w * 32 + (lane & 31)] * S2_XSCALE : a.bias[w * 32 + (lane & 31)];
+        const float c2v = NP == 2 ? a.oscale[w * 32 + (lane & 31)] * S2_XSCALE : 1.f;
+        float tmax = 0.f;
         // store address of the lane's channel n = 32 w + (lane & 31): k-step n >> 4, half (n >> 3) & 1 (swapped for pixels 8-15: = lane >> 5, see m below),
         // element n & 7; pixel m = 16 (r >> 2) + 2 (r & 3) + 8 (lane >> 5) + pj for accumulator row r (tile (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
         const int sbase = (2 * w + ((lane >> 4) & 1)) * KS_STRIDE + (lane >> 5) * (8 * 32) + ((((lane >> 3) & 1) ^ (lane >> 5)) * 16) + (lane & 7) * 2;
@@ -358,23 +426,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int aoff = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
         // weights: W3x[(ks * 8 + nb) * 3 + plane][lane][8 bf16], 1 KB each (pack_tail_weight_bf16x3); the wave's n-tiles are 2 w, 2 w + 1
         const int w3voff = lane * 16;
-        auto b3load = [&](int ks, x_u32x4 (&b)[2][3]) {
+        auto b3load = [&](int ks, x_u32x4 (&b)[2][NP]) {
             const int k = ks < 8 ? ks : 7;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + 2 * w + j) * 3) + p) * 1024));
+                for (int p = 0; p < NP; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + 2 * w + j) * NP) + p) * 1024));
         };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            x_u32x4 b3[2][2][3];
+            x_u32x4 b3[2][2][NP];
             b3load(0, b3[0]);
 #pragma unroll
             for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = fmaxf(out[2 * h + pj][r] + b2v, 0.f);
+                    float v = NP == 2 ? fmaxf(fmaf(out[2 * h + pj][r], c2v, b2v), 0.f) : fmaxf(out[2 * h + pj][r] + b2v, 0.f);
                     const int off = sbase + (16 * (r >> 2) + 2 * (r & 3) + pj) * 32;
+                    if constexpr (NP == 2) {
+                        tmax = fmaxf(tmax, v);                            // (v >= 0)
+                        const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                        *reinterpret_cast<_Float16*>(AP + off) = hi;
+                        *reinterpret_cast<_Float16*>(AP + PL_STRIDE + off) = lo;
+                        continue;
+                    }
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         const unsigned q = s3_pack_rn(v, v);              // both halves = rn(v): the store takes the upper one (ds_write_b16_d16_hi)
@@ -393,11 +468,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 b3load(ks + 1, b3[(ks + 1) & 1]);
-                x_bf16x8 af[2][3];
+                x_bf16x8 af[2][NP];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) af[i][p] = *(const x_bf16x8*)(AP + p * PL_STRIDE + ks * KS_STRIDE + i * 1024 + aoff);
+                    for (int p = 0; p < NP; ++p) af[i][p] = *(const x_bf16x8*)(AP + p * PL_STRIDE + ks * KS_STRIDE + i * 1024 + aoff);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -411,6 +486,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 for (int j = 0; j < 2; ++j) {
                     const int col = (2 * w + j) * 32 + (lane & 7) * 4;
                     const x_f32x4 bv = *(const x_f32x4*)(a.bias3 + col);
+                    x_f32x4 osc3 = x_f32x4{1.f, 1.f, 1.f, 1.f};
+                    if constexpr (NP == 2) osc3 = *(const x_f32x4*)(a.oscale3 + col);
                     int off[4];
                     x_f32x4 rv[4], uv[UP ? 4 : 1];
 #pragma unroll
@@ -427,7 +504,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        x_f32x4 o = (*(const x_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv) + rv[k];
+                        x_f32x4 o = *(const x_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4];
+                        if constexpr (NP == 2) o *= osc3;             // back to scale (an exact power of two per column)
+                        o = (o + bv) + rv[k];
                         if constexpr (UP) o += uv[k];
                         buf_store(o, o2_srd, off[k]);
                     }
@@ -435,6 +514,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 }
             if (h == 0) __syncthreads();                      // every wave is done with the A planes of pass 0
         }
+        if constexpr (NP == 2) s2_raise(a.range_flag, tmax);
         return;
     }
 
@@ -552,6 +632,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         float* T = &S[2 * HSZ] + w * (32 * 36);
         const int col = wn * 32 + (lane & 7) * 4;
         const x_f32x4 bv = *(const x_f32x4*)(a.bias + col);
+        x_f32x4 osc = x_f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (NP == 2) osc = *(const x_f32x4*)(a.oscale + col);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = 2 * wc + q, pi = p >> 1, pj = p & 1;
@@ -562,7 +644,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             for (int k = 0; k < 4; ++k) {
                 const int t = (lane >> 3) + 8 * k;
                 const int oy = oy0 + 2 * (t >> 3) + pi, ox = ox0 + 2 * (t & 7) + pj;
-                x_f32x4 o = *(const x_f32x4*)&T[t * 36 + (lane & 7) * 4] + bv;
+                x_f32x4 o = *(const x_f32x4*)&T[t * 36 + (lane & 7) * 4];
+                if constexpr (NP == 2) o *= osc;
+                o += bv;
                 if (a.relu) {
 #pragma unroll
                     for (int z = 0; z < 4; ++z) o[z] = fmaxf(o[z], 0.f);
@@ -578,6 +662,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     float* T = &S[2 * HSZ] + w * (32 * 36);
     const int col = w * 32 + (lane & 7) * 4;
     const x_f32x4 bv = *(const x_f32x4*)(a.bias + col);
+    x_f32x4 osc = x_f32x4{1.f, 1.f, 1.f, 1.f};
+    if constexpr (NP == 2) osc = *(const x_f32x4*)(a.oscale + col);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int pi = p >> 1, pj = p & 1;
@@ -588,7 +674,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         for (int k = 0; k < 4; ++k) {
             const int t = (lane >> 3) + 8 * k;
             const int oy = oy0 + 2 * (t >> 3) + pi, ox = ox0 + 2 * (t & 7) + pj;
-            x_f32x4 o = *(const x_f32x4*)&T[t * 36 + (lane & 7) * 4] + bv;
+            x_f32x4 o = *(const x_f32x4*)&T[t * 36 + (lane & 7) * 4];
+            if constexpr (NP == 2) o *= osc;
+            o += bv;
             if (a.relu) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
@@ -599,11 +687,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 }
 
-// a.Wp = weights packed by pack_wino_weight_bf16x3 (uint16 under a float pointer); 128 -> 128 channels only
-int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
+// a.Wp = weights packed by pack_wino_weight_bf16x3 / _f16x2 (uint16 under a float pointer); 128 -> 128 or 64 -> 64 channels
+template <int NP>
+static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
+    if (NP == 2 && (!a.oscale || !a.range_flag)) { suo_set_error("conv3x3_wino_f16x2: oscale / range_flag missing"); return SUO_ERR_ARG; }
     if (a.OH == a.H && a.OW == a.W && a.N == 64 && a.C == 64) {
         const int tiles64 = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-        hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2>), dim3(tiles64), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, NP>), dim3(tiles64), dim3(256), 0, s, a);
         SUO_HIP_CHECK(hipGetLastError());
         return SUO_OK;
     }
@@ -612,7 +702,22 @@ int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-    hipLaunchKernelGGL((wino3x3_x3_kernel<false>), dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s) { return launch_wino_split<3>(a, s); }
+int launch_conv3x3_wino_f16x2(const ConvArgs& a, hipStream_t s) { return launch_wino_split<2>(a, s); }
+
+// the fused Residual tail on two fp16 planes: a.Wp = pack_wino_weight_f16x2, a.W3p = pack_tail_weight_f16x2, a.oscale / a.oscale3 their factors
+int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s) {
+    if (a.OH != a.H || a.OW != a.W || a.N != 128 || a.C != 128 || a.N2 != 256 || !a.W3p || !a.bias3 || !a.R || !a.out2 || !a.oscale || !a.oscale3 || !a.range_flag) {
+        suo_set_error("conv3x3_wino_f16x2_fused: unsupported shape C=%d N=%d N2=%d", a.C, a.N, a.N2);
+        return SUO_ERR_ARG;
+    }
+    const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
+    if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

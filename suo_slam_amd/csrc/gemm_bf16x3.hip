@@ -13,12 +13,14 @@
 #include <string.h>
 
 #include "bf16x3.h"
+#include "f16x2.h"
 #include "buffer_ops.h"
 #include "suo_internal.h"
 
 namespace suo {
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
 typedef float x3_f32x16 __attribute__((ext_vector_type(16)));
 typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
@@ -48,6 +50,25 @@ void pack_gemm_weight_bf16x3(const float* W, int N, int K, uint16_t* out) {
         }
 }
 
+// host: the two-term fp16 form (csrc/f16x2.h).  Row n is scaled by 2^t_n (max_k |W[n][k]| 2^t_n in [2^12, 2^13)) before the split; the kernel's epilogue
+// multiplies by oscale[n] = 2^-(t_n + S2_XSHIFT) (the activations enter times 2^S2_XSHIFT).  Same B-operand order with two planes:
+//   out[((ks * NB + nb) * 2 + plane) * 64 + lane][e] = term `plane` of 2^t_n W[n = nb*32 + (lane&31)][ks*16 + 8*(lane>>5) + e]
+void pack_gemm_weight_f16x2(const float* W, int N, int K, uint16_t* out, float* oscale_out) {
+    const int NB = N / 32;
+    for (int n = 0; n < N; ++n) {
+        float mx = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(W[(size_t)n * K + k]));
+        const int t = s2_row_shift(mx);
+        oscale_out[n] = ldexpf(1.f, -(t + S2_XSHIFT));
+        for (int k = 0; k < K; ++k) {
+            const int ks = k / 16, kk = k % 16, lane = (kk / 8) * 32 + (n % 32), e = kk % 8, nb = n / 32;
+            uint16_t h[2];
+            s2_split_host(ldexpf(W[(size_t)n * K + k], t), h);
+            for (int p = 0; p < 2; ++p) out[((((size_t)(ks * NB + nb) * 2 + p) * 64 + lane) * 8) + e] = h[p];
+        }
+    }
+}
+
 __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // Workgroup = 128 rows x 128 columns, four waves as 2 x 2 (64 x 64 each = 2 x 2 accumulators), one 16-wide k-step per barrier.
@@ -62,20 +83,25 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 // one meets through LDS (image row 0 belongs to the waves wm = 0, row 1 to wm = 1).
 // NCB: 32-column blocks per wave -- 2: the 128-column tile; 1: a 64-column tile (the 64-channel 1x1 convolutions of the first Residual blocks)
 // RB: 32-row blocks per wave -- 2: 128-row tiles; 1: 64-row tiles, for launches that would otherwise be fewer tiles than two per CU (the one-frame call)
-template <bool PRO, bool DUAL, bool RES, bool POOL, int NCB = 2, int RB = 2>
+// NP: operand planes -- 3: three bf16 terms, six MFMAs per product block (csrc/bf16x3.h); 2: two fp16 terms, three MFMAs (csrc/f16x2.h: activations enter times
+//     2^S2_XSHIFT, the weights' rows times 2^t_n, the epilogue multiplies by g.oscale[n]; g.range_flag is raised when an activation leaves fp16's range)
+template <bool PRO, bool DUAL, bool RES, bool POOL, int NCB = 2, int RB = 2, int NP = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
     static_assert(RB == 2 || !POOL, "the pooled epilogue is laid out for 128-row tiles");
     constexpr int X3_BM = 64 * RB, X3_NR = X3_BM / X3_RPP;                    // rows of the tile; staging passes
     static_assert(X3_NR >= 1, "64-row tiles need the 16-wide k-step");
     constexpr int PLANE = X3_BM * X3_PITCH;                                   // bf16 elements of one plane
-    __shared__ __attribute__((aligned(16))) uint16_t S[2][3 * PLANE];         // [stage][plane][row][pitch] = 36 864 bytes (the epilogue re-uses it)
+    constexpr int EPI_BYTES = 4 * 32 * 36 * 4 + (POOL ? 16384 : 0);           // the epilogue's four transposition patches (+ the pooled rows' exchange)
+    constexpr int SFL = NP * PLANE >= EPI_BYTES / 4 ? NP * PLANE : EPI_BYTES / 4;      // uint16 per stage: two fp16 planes can be smaller than the patches
+    __shared__ __attribute__((aligned(16))) uint16_t S[2][SFL];               // [stage][plane][row][pitch] = 36 864 bytes at NP = 3 (the epilogue re-uses it)
     __shared__ __attribute__((aligned(16))) float P[2][512];                  // prologue scale / shift (K1 <= 512)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int M = g.M, K = g.K1 + (DUAL ? g.K2 : 0), ldo = g.ldo;
     if (PRO) {
-        for (int k = tid; k < g.K1; k += 256) { P[0][k] = g.pro_scale[k]; P[1][k] = g.pro_shift[k]; }
+        // (NP = 2: the activation scale rides in the prologue -- fmaf(x, 16 a, 16 b) = 16 fmaf(x, a, b) exactly, and relu commutes with it)
+        for (int k = tid; k < g.K1; k += 256) { P[0][k] = NP == 2 ? g.pro_scale[k] * S2_XSCALE : g.pro_scale[k]; P[1][k] = NP == 2 ? g.pro_shift[k] * S2_XSCALE : g.pro_shift[k]; }
     }
     // tile = (row tile, column tile of 128); the column tiles of a row tile are neighbours (the second one finds the activations in L2)
     int bid = blockIdx.x;
@@ -95,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     const int ns1 = g.K1 / X3_BK, nsteps = K / X3_BK;
     const __amdgpu_buffer_rsrc_t a1_srd = make_srd(g.A1, (size_t)M * g.lda1 * sizeof(float));
     const __amdgpu_buffer_rsrc_t a2_srd = make_srd(DUAL ? g.A2 : g.A1, DUAL ? (size_t)M * g.lda2 * sizeof(float) : 0);
-    const __amdgpu_buffer_rsrc_t w_srd = make_srd(Wp, (size_t)g.N * K * 3 * sizeof(uint16_t));
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(Wp, (size_t)g.N * K * NP * sizeof(uint16_t));
     // staging roles per k-step: rows tid / LPR + RPP i, the 4 floats at k = 4 (tid % LPR): the LPR lanes of a row fetch its 64 / 128 contiguous bytes
     const int ar = tid / X3_LPR, aq = tid % X3_LPR;
     int avoff1[X3_NR], avoff2[X3_NR];
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     const int wvoff = lane * 16;
     x3_f32x4 araw[X3_ASLOTS][X3_NR];
-    x3_u32x4 braw[X3_BSLOTS][NCB][3];
+    x3_u32x4 braw[X3_BSLOTS][NCB][NP];
     auto requestA = [&](int ks, int slot) {
 #ifdef SUO_X3_EXP_NOLOADA
         for (int i = 0; i < X3_NR; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
@@ -127,9 +153,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((kg * NBT + 2 * NCB * tn + NCB * wn + cb) * 3) * 1024));
+            for (int p = 0; p < NP; ++p)
+                braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w_srd, wvoff + p * 1024, ((kg * NBT + 2 * NCB * tn + NCB * wn + cb) * NP) * 1024));
     };
+    float xmax = 0.f;                                                         // NP = 2: largest scaled magnitude this lane split (range guard)
     auto split_store = [&](int ks, int slot, int stage) {
         uint16_t* As = &S[stage][0];
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -144,11 +171,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
                 for (int t = 0; t < 4; ++t) x[t] = rok[i] ? fmaxf(fmaf(x[t], sc[t], sh[t]), 0.f) : 0.f;
             }
+            if constexpr (NP == 3) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const unsigned q0 = s3_pack_rn(x[0], x[1]), q1 = s3_pack_rn(x[2], x[3]);      // (p == 2: the conversion is exact)
-                *(u32x2*)&As[p * PLANE + (X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{q0, q1};
-                if (p < 2) { x[0] -= s3_lo(q0); x[1] -= s3_hi(q0); x[2] -= s3_lo(q1); x[3] -= s3_hi(q1); }      // exact residuals
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned q0 = s3_pack_rn(x[0], x[1]), q1 = s3_pack_rn(x[2], x[3]);      // (p == 2: the conversion is exact)
+                    *(u32x2*)&As[p * PLANE + (X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{q0, q1};
+                    if (p < 2) { x[0] -= s3_lo(q0); x[1] -= s3_hi(q0); x[2] -= s3_lo(q1); x[3] -= s3_hi(q1); }      // exact residuals
+                }
+            } else {
+                if (!PRO) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x[t] *= S2_XSCALE;            // (exact; with a prologue the scale is in sc / sh)
+                }
+                xmax = s2_track(s2_track(xmax, x[0], x[1]), x[2], x[3]);
+                const unsigned h0 = s2_pack_rn(x[0], x[1]), h1 = s2_pack_rn(x[2], x[3]);
+                *(u32x2*)&As[(X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{h0, h1};
+                const unsigned l0 = s2_pack_rn(x[0] - s2_lo(h0), x[1] - s2_hi(h0)), l1 = s2_pack_rn(x[2] - s2_lo(h1), x[3] - s2_hi(h1));      // exact residuals, rounded once
+                *(u32x2*)&As[PLANE + (X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{l0, l1};
             }
         }
     };
@@ -168,6 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     __syncthreads();                                                          // (scale / shift staged)
     split_store(0, 0, 0);
     constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // six cross terms, smallest first
+    constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};                       // NP = 2: hi lo, lo hi, hi hi
     const int ko = 8 * (lane >> 5);
     for (int ks0 = 0; ks0 < nsteps; ks0 += X3_ASLOTS) {
 #pragma unroll
@@ -176,11 +216,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             __syncthreads();                                                  // stage u & 1 complete; every wave is past its reads of the other stage
             // this step's A fragments are requested first: their LDS latency passes under the split of the next step's activations
             const uint16_t* As = &S[u & 1][0];
-            x3_bf16x8 af[X3_GH][RB][3];
+            x3_bf16x8 af[X3_GH][RB][NP];
 #pragma unroll
             for (int h = 0; h < X3_GH; ++h)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) af[h][rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (32 * RB * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko + 16 * h];
             __builtin_amdgcn_sched_barrier(0);
@@ -192,24 +232,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int h = 0; h < X3_GH; ++h) {
                 // weights of this k-group out of their ring slot, then the slot's next request
                 const int slot = (u * X3_GH + h) % X3_BSLOTS, kg = ks * X3_GH + h;
-                x3_u32x4 bw[NCB][3];
+                x3_u32x4 bw[NCB][NP];
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bw[cb][p] = braw[slot][cb][p];
+                    for (int p = 0; p < NP; ++p) bw[cb][p] = braw[slot][cb][p];
                 requestB(kg + X3_BSLOTS < ngroups ? kg + X3_BSLOTS : ngroups - 1, slot);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < (NP == 3 ? 6 : 3); ++t)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cb = 0; cb < NCB; ++cb)
-                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h][rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
+                        for (int cb = 0; cb < NCB; ++cb) {
+                            if constexpr (NP == 3)
+                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[h][rb][TI[t]], __builtin_bit_cast(x3_bf16x8, bw[cb][TJ[t]]), acc[rb][cb], 0, 0, 0);
+                            else
+                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, af[h][rb][UI[t]]), __builtin_bit_cast(x3_f16x8, bw[cb][UJ[t]]), acc[rb][cb], 0, 0, 0);
+                        }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();                                                          // the stages are free: the epilogue's patches live there
+    if constexpr (NP == 2) s2_raise(g.range_flag, xmax);
     float* T = reinterpret_cast<float*>(&S[0][0]) + w * (32 * 36);
     x3_f32x4* PX = reinterpret_cast<x3_f32x4*>(reinterpret_cast<float*>(&S[0][0]) + 4 * 32 * 36);      // POOL: 16 KB behind the four patches
     x3_f32x4 hold[POOL ? 2 : 1][POOL ? 2 : 1][POOL ? 4 : 1];
@@ -222,6 +267,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             const int col = BN * tn + 32 * NCB * wn + 32 * cb + (lane & 7) * 4;
             x3_f32x4 bv = x3_f32x4{0.f, 0.f, 0.f, 0.f};
             if (g.bias) bv = *(const x3_f32x4*)(g.bias + col);
+            x3_f32x4 osc = x3_f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (NP == 2) osc = *(const x3_f32x4*)(g.oscale + col);
             x3_f32x4 rv[RES ? 4 : 1];
             if (RES) {
 #pragma unroll
@@ -236,7 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = pixel_of(32 * RB * wm + 32 * rb + (lane >> 3) + 8 * k);
-                x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4] + bv;
+                x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4];
+                if constexpr (NP == 2) o *= osc;                              // back to scale: an exact power of two per column
+                o += bv;
                 if (RES) o += rv[k];                                          // (bias, then the residual: the order of the fp32 kernels)
                 if (g.relu) {
 #pragma unroll
@@ -291,9 +340,10 @@ bool gemm_bf16x3_takes(const GemmArgs& g) {
            (!g.K2 || (size_t)g.M * g.lda2 * 4 < lim) && (!g.R || (size_t)g.M * g.ldr * 4 < lim);
 }
 
-int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t s) {
-    if (!gemm_bf16x3_takes(g) || !Wx3) {
-        suo_set_error("gemm_bf16x3: unsupported shape (N=%d K=%d+%d M=%d)", g.N, g.K1, g.K2, g.M);
+template <int NP>
+static int launch_gemm_split(const GemmArgs& g, const uint16_t* Wx3, hipStream_t s) {
+    if (!gemm_bf16x3_takes(g) || !Wx3 || (NP == 2 && (!g.oscale || !g.range_flag))) {
+        suo_set_error("gemm_%s: unsupported shape (N=%d K=%d+%d M=%d)", NP == 3 ? "bf16x3" : "f16x2", g.N, g.K1, g.K2, g.M);
         return SUO_ERR_ARG;
     }
     const bool n64 = g.N % 128 != 0;                                          // 64 output channels: 64-column tiles
@@ -302,10 +352,10 @@ int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t 
     const long tiles128 = (long)((g.M + 127) / 128) * (n64 ? 1 : g.N / 128);
     const bool rows64 = !n64 && !g.pool_out && X3_BK == 16 && tiles128 <= rb1_max_tiles;
     const int tiles = rows64 ? ((g.M + 63) / 64) * (g.N / 128) : (int)tiles128;
-#define X3_LAUNCH(P_, D_, R_) do { if (g.pool_out) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, true>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
-                                   else if (n64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 1>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
-                                   else if (rows64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 2, 1>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
-                                   else hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false>), dim3(tiles), dim3(256), 0, s, g, Wx3); } while (0)
+#define X3_LAUNCH(P_, D_, R_) do { if (g.pool_out) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, true, 2, 2, NP>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
+                                   else if (n64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 1, 2, NP>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
+                                   else if (rows64) hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 2, 1, NP>), dim3(tiles), dim3(256), 0, s, g, Wx3); \
+                                   else hipLaunchKernelGGL((gemm_bf16x3_kernel<P_, D_, R_, false, 2, 2, NP>), dim3(tiles), dim3(256), 0, s, g, Wx3); } while (0)
     const bool res = g.R != nullptr;
     if (g.pro_scale) { if (res) X3_LAUNCH(true, false, true); else X3_LAUNCH(true, false, false); }
     else if (g.K2) { if (res) X3_LAUNCH(false, true, true); else X3_LAUNCH(false, true, false); }
@@ -314,6 +364,10 @@ int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t 
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
+
+int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t s) { return launch_gemm_split<3>(g, Wx3, s); }
+// W16 = pack_gemm_weight_f16x2's planes; g.oscale its per-column factors, g.range_flag the guard flag (csrc/f16x2.h)
+int launch_gemm_f16x2_args(const GemmArgs& g, const uint16_t* W16, hipStream_t s) { return launch_gemm_split<2>(g, W16, s); }
 
 int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
                        float* out, int ldo, int M, int N, int relu, hipStream_t s) {

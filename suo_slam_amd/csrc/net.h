@@ -16,13 +16,16 @@ struct HostTensor {
     size_t numel = 0;
 };
 
-struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; float* Wx3 = nullptr; };   // Wx3: bf16x3 planes (N = 128, one K segment of a multiple of 64; csrc/gemm_bf16x3.hip)
-struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; float* Wq = nullptr; float* Wq3 = nullptr; };   // Wq: Winograd-packed (3x3, 128 -> 128 / 64 -> 64); Wq3: its bf16x3 planes (128 -> 128, csrc/conv_wino_x3.hip)
+// Wx3: bf16x3 planes (N a multiple of 128, K segments multiples of 64; csrc/gemm_bf16x3.hip); W16 / osc16: the two fp16 planes and the per-column factors (csrc/f16x2.h)
+struct GemmW { float* Wp = nullptr; float* bias = nullptr; int N = 0, n_valid = 0, K1 = 0, K2 = 0; float* Wx3 = nullptr; float* W16 = nullptr; float* osc16 = nullptr; };
+// Wq: Winograd-packed (3x3, 128 -> 128 / 64 -> 64); Wq3: its bf16x3 planes (csrc/conv_wino_x3.hip); Wq16 / osc16: its fp16 planes and per-channel factors
+struct ConvW { float* Wp = nullptr; float* bias = nullptr; int N = 0, C = 0, KS = 0; float* Wq = nullptr; float* Wq3 = nullptr; float* Wq16 = nullptr; float* osc16 = nullptr; };
 struct ResidualW {
     float* pro_scale = nullptr; float* pro_shift = nullptr;
     GemmW c1; ConvW c2; GemmW c3;
     int cin = 0, cout = 0; bool has_skip_conv = false;
     float* c3x = nullptr;                                // conv3 as bf16x3 planes for the fused Winograd tail on the bf16 pipe (256 <- 128 only)
+    float* c3x16 = nullptr; float* c3osc16 = nullptr;    // ... as two fp16 planes + per-column factors (csrc/f16x2.h)
     // 256 -> 256 blocks: the whole block in one launch on small maps (csrc/res_small.hip fp32 pipe; csrc/res_small_x3.hip bf16 pipe)
     float* rb_w[3] = {nullptr, nullptr, nullptr};        // pack_res16_gemm(W1 bn1-folded) | pack_res16_conv3x3(W2, bn2 scale) | pack_res16_gemm(W3)
     float* rbx_w[3] = {nullptr, nullptr, nullptr};       // the same as bf16x3 planes (uint16)
@@ -46,6 +49,11 @@ public:
     int forward_staged(const float* in0_user, int L, float* logits_out, hipStream_t s);
     int prepare(int L, int with_priors, hipStream_t s);
     void set_use_graph(bool v) { use_graph_ = v; }
+    // matrix pipe of the large launches: 0 = fp32 MFMA, 1 = three bf16 terms (6 MFMAs per product block), 2 = two fp16 terms (3 MFMAs; range-guarded)
+    int pipe() const { return pipe_; }
+    int set_pipe(int p);
+    // 1 when a forward since the last call of this function left the fp16 range (its outputs are invalid); clears the flag.  The caller has synchronised.
+    int range_exceeded();
     int max_crops() const { return max_crops_; }
     size_t workspace_bytes() const { return ws_floats_ * sizeof(float); }
     const HostTensor& T(const std::string& name) const;
@@ -60,7 +68,7 @@ private:
     float* alloc(size_t floats);
     // pool_out: also produce max_pool2d(out, 2, 2) (fused into the last GEMM where it can be, else a separate launch); `out` may then be nullptr
     int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr, float* pool_out = nullptr);
-    int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const float* Wx3 = nullptr);
+    int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const GemmW* gw = nullptr);
     bool residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const;
     int residual_in_one_launch(const ResidualW& r, int L, int H, int W) const;      // 0: no; 1: csrc/res_small.hip; 2: csrc/res_small_x3.hip
     int residual_one_launch(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, bool pool_in);
@@ -85,6 +93,8 @@ private:
     hipStream_t side_[kNumSide] = {}; hipStream_t own_stream_ = nullptr;
     hipEvent_t ev_[kNumEvents] = {}; int ev_next_ = 0;
     bool use_graph_ = true; bool dry_run_ = false;
+    int pipe_ = 1, pipe_built_ = 1;                      // the pipe in use / the best one the weights were packed for
+    unsigned* range_flag_ = nullptr;                     // mapped host memory: the f16x2 kernels raise it, the host reads it after any synchronisation
     struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
     std::map<int, GraphEntry> graphs_;
 };

@@ -4,8 +4,10 @@
 // Mirrors PkpNet.forward (/root/reference/lib/models/pkpnet.py:80-119) over a state_dict with the
 // reference's key names (backbone.* / classifier.2.*), see suo_slam_amd/weights.py.
 #include "net.h"
+#include "f16x2.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -134,6 +136,12 @@ static bool wino_bf16x3() {
     const char* e = getenv("SUO_WINO_BF16X3");
     return (e ? atoi(e) : SUO_WINO_BF16X3_DEFAULT) != 0;
 }
+// SUO_F16X2=0: stay on the three-term bf16 form; default: the large launches run the two-term fp16 form (csrc/f16x2.h: half the MFMAs per product, range-guarded --
+// a call that leaves fp16's range is reported by Net::range_exceeded and the network falls back to the bf16 form, whose planes are packed as well)
+static bool pipe_f16x2() {
+    const char* e = getenv("SUO_F16X2");
+    return wino_bf16x3() && (e ? atoi(e) : 1) != 0;
+}
 
 // 1x1 conv W[N][K] with optional per-output scale (BN folded) -> device packed weight + bias
 void Net::make_gemm(const std::string& conv, const std::string& bn_after, const std::string& conv2, GemmW& g) {
@@ -171,6 +179,12 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
         std::vector<float> x3((size_t)3 * N * Kp / 2);                         // uint16 planes
         pack_gemm_weight_bf16x3(full.data(), N, Kp, reinterpret_cast<uint16_t*>(x3.data()));
         g.Wx3 = upload(x3);
+        if (pipe_f16x2()) {
+            std::vector<float> h2((size_t)N * Kp), osc(N);                    // uint16 planes: 2 * N * Kp
+            pack_gemm_weight_f16x2(full.data(), N, Kp, reinterpret_cast<uint16_t*>(h2.data()), osc.data());
+            g.W16 = upload(h2);
+            g.osc16 = upload(osc);
+        }
     }
 }
 
@@ -205,6 +219,12 @@ void Net::make_conv(const std::string& conv, const std::string& bn_after, int CK
             std::vector<float> wq3((size_t)3 * 16 * N * C / 2);                  // uint16 planes
             pack_wino_weight_bf16x3(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), reinterpret_cast<uint16_t*>(wq3.data()));
             c.Wq3 = upload(wq3);
+            if (pipe_f16x2()) {
+                std::vector<float> wq16((size_t)16 * N * C), osc(N);             // uint16 planes: 2 * 16 * N * C
+                pack_wino_weight_f16x2(w.data, N, C, N, C, scale.empty() ? nullptr : scale.data(), reinterpret_cast<uint16_t*>(wq16.data()), osc.data());
+                c.Wq16 = upload(wq16);
+                c.osc16 = upload(osc);
+            }
         }
     }
 }
@@ -264,6 +284,12 @@ void Net::make_residual(const std::string& p, ResidualW& r) {
             std::vector<float> x3((size_t)3 * 256 * 128 / 2);
             pack_tail_weight_bf16x3(w3.data, 256, 128, reinterpret_cast<uint16_t*>(x3.data()));
             r.c3x = upload(x3);
+            if (r.c2.Wq16) {
+                std::vector<float> h2((size_t)256 * 128), osc(256);
+                pack_tail_weight_f16x2(w3.data, 256, 128, reinterpret_cast<uint16_t*>(h2.data()), osc.data());
+                r.c3x16 = upload(h2);
+                r.c3osc16 = upload(osc);
+            }
         }
     }
 }
@@ -373,6 +399,12 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
             std::vector<float> x3((size_t)3 * N * K / 2);                     // uint16 planes
             pack_gemm_weight_bf16x3(full.data(), N, K, reinterpret_cast<uint16_t*>(x3.data()));
             reinject_.Wx3 = upload(x3);
+            if (pipe_f16x2()) {
+                std::vector<float> h2((size_t)N * K), osc(N);
+                pack_gemm_weight_f16x2(full.data(), N, K, reinterpret_cast<uint16_t*>(h2.data()), osc.data());
+                reinject_.W16 = upload(h2);
+                reinject_.osc16 = upload(osc);
+            }
         }
     }
     {
@@ -382,6 +414,12 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
         cls_b_ = upload(std::vector<float>(bb.data, bb.data + bb.numel));
     }
     tensors_.clear();   // host pointers are not retained past construction
+    pipe_built_ = pipe_f16x2() ? 2 : (wino_bf16x3() ? 1 : 0);
+    pipe_ = pipe_built_;
+    // the range guard's flag: host memory mapped into the device's address space -- the kernels store to it (rarely: only beyond fp16's range), the host
+    // reads a plain word after whatever synchronisation its results needed anyway
+    if (hipHostMalloc(reinterpret_cast<void**>(&range_flag_), 64, hipHostMallocMapped) != hipSuccess) throw std::runtime_error("hipHostMalloc(range flag) failed");
+    *range_flag_ = 0;
 
     // ---- workspace: every intermediate gets its own slab (288 GB of HBM: no aliasing games).
     // Size it with a dry run of the launch schedule at max_crops.
@@ -411,6 +449,7 @@ Net::~Net() {
     for (float* p : owned_) (void)hipFree(p);
     if (ws_) (void)hipFree(ws_);
     if (d_mean_logit_) (void)hipFree(d_mean_logit_);
+    if (range_flag_) (void)hipHostFree(range_flag_);
     for (int i = 0; i < kNumSide; ++i) if (side_[i]) (void)hipStreamDestroy(side_[i]);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
     for (int i = 0; i < kNumEvents; ++i) if (ev_[i]) (void)hipEventDestroy(ev_[i]);
@@ -481,17 +520,21 @@ int Net::residual_one_launch(const ResidualW& r, const float* x, float* out, int
 // A 1x1 convolution whose result is also wanted max-pooled (nn.MaxPool2d(2, 2)): pooled in the GEMM's epilogue when the launch
 // would use the persistent 128x128 kernel anyway (csrc/gemm_persist.hip: POOL), else GEMM + max-pool kernel.  g.out may be nullptr
 // when only the pooled tensor is wanted.
-int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const float* Wx3) {
+int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const GemmW* gw) {
+    const float* Wx3 = gw ? gw->Wx3 : nullptr;
     static const int fuse_pool = getenv("SUO_FUSE_POOL") ? atoi(getenv("SUO_FUSE_POOL")) : 1;                    // 0: A/B
     // large launches with a bf16x3 form of the weights: on the bf16 pipe (csrc/gemm_bf16x3.hip)
     static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
     if (Wx3 && g.M >= x3_min_rows) {
         GemmArgs gx = g;
         gx.pool_out = pool_out; gx.pool_H = H; gx.pool_W = W;                  // the pool in the epilogue (maps of 64-column multiples), `out` optional
-        if (gemm_bf16x3_takes(gx)) { SUO_LAUNCH(launch_gemm_bf16x3_args(gx, reinterpret_cast<const uint16_t*>(Wx3), s)); return SUO_OK; }
+        const bool f16 = pipe_ == 2 && gw->W16;                              // the two-term fp16 form of the same kernel (csrc/f16x2.h)
+        if (f16) { gx.oscale = gw->osc16; gx.range_flag = range_flag_; }
+        auto launch = [&](const GemmArgs& a) { return f16 ? launch_gemm_f16x2_args(a, reinterpret_cast<const uint16_t*>(gw->W16), s) : launch_gemm_bf16x3_args(a, reinterpret_cast<const uint16_t*>(Wx3), s); };
+        if (gemm_bf16x3_takes(gx)) { SUO_LAUNCH(launch(gx)); return SUO_OK; }
         gx.pool_out = nullptr;                                                // else the pool as its own launch
         if (g.out && gemm_bf16x3_takes(gx)) {
-            SUO_LAUNCH(launch_gemm_bf16x3_args(gx, reinterpret_cast<const uint16_t*>(Wx3), s));
+            SUO_LAUNCH(launch(gx));
             if (pool_out) SUO_LAUNCH(launch_maxpool2(g.out, pool_out, L, H, W, g.N, s));
             return SUO_OK;
         }
@@ -521,7 +564,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     g1.A1 = x; g1.lda1 = r.cin; g1.K1 = r.c1.K1; g1.pro_scale = r.pro_scale; g1.pro_shift = r.pro_shift;
     g1.Wp = r.c1.Wp; g1.bias = r.c1.bias; g1.out = mid1; g1.ldo = r.c1.N; g1.M = M; g1.N = r.c1.N; g1.n_valid = r.c1.n_valid; g1.relu = 1;
     // large launches: on the bf16 pipe with 3-way split operands (464 vs 595 us at 256 crops / 64 x 64; below ~256 tiles the fp32 kernels' smaller tiles win)
-    SUO_TRY(gemm_maybe_pooled(g1, L, H, W, nullptr, s, r.c1.Wx3));
+    SUO_TRY(gemm_maybe_pooled(g1, L, H, W, nullptr, s, &r.c1));
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
     c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
@@ -542,7 +585,10 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
             // conv2 -> conv3 + skip in one launch (933 vs 713 + 346 us at 64x64 / 128 crops, 257 vs 195 + 91 at 32x32)
             if (!out) out = alloc((size_t)M * 256);
             c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256; c2.up = up;
-            if (r.c2.Wq3 && r.c3x) {                          // both products on the bf16 pipe, 3-way split operands
+            if (pipe_ == 2 && r.c2.Wq16 && r.c3x16) {        // both products as two fp16 terms (csrc/f16x2.h)
+                c2.Wp = r.c2.Wq16; c2.W3p = r.c3x16; c2.oscale = r.c2.osc16; c2.oscale3 = r.c3osc16; c2.range_flag = range_flag_;
+                SUO_LAUNCH(launch_conv3x3_wino_f16x2_fused(c2, s));
+            } else if (r.c2.Wq3 && r.c3x) {                   // both products on the bf16 pipe, 3-way split operands
                 c2.Wp = r.c2.Wq3; c2.W3p = r.c3x; c2.w3_bf16x3 = 1;
                 SUO_LAUNCH(launch_conv3x3_wino_x3_fused(c2, s));
             } else
@@ -550,7 +596,8 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
             if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
             return SUO_OK;
         }
-        if (r.c2.Wq3) { c2.Wp = r.c2.Wq3; SUO_LAUNCH(launch_conv3x3_wino_x3(c2, s)); }
+        if (pipe_ == 2 && r.c2.Wq16) { c2.Wp = r.c2.Wq16; c2.oscale = r.c2.osc16; c2.range_flag = range_flag_; SUO_LAUNCH(launch_conv3x3_wino_f16x2(c2, s)); }
+        else if (r.c2.Wq3) { c2.Wp = r.c2.Wq3; SUO_LAUNCH(launch_conv3x3_wino_x3(c2, s)); }
         else SUO_LAUNCH(launch_conv3x3_wino(c2, s));
     } else {
         SUO_LAUNCH(launch_conv3x3(c2, s));
@@ -561,7 +608,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     if (r.has_skip_conv) { g3.A2 = x; g3.lda2 = r.cin; g3.K2 = r.c3.K2; }
     else { g3.R = x; g3.ldr = r.cin; }
     g3.Wp = r.c3.Wp; g3.bias = r.c3.bias; g3.out = out; g3.ldo = r.cout; g3.M = M; g3.N = r.c3.N; g3.n_valid = r.c3.n_valid;
-    return gemm_maybe_pooled(g3, L, H, W, pool_out, s, r.c3.Wx3);
+    return gemm_maybe_pooled(g3, L, H, W, pool_out, s, &r.c3);
 }
 
 // Hourglass.forward (hg.py:37-58).  The up1 branch is independent of the low branch until the
@@ -656,7 +703,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         GemmArgs gl = {};
         gl.A1 = rb; gl.lda1 = 256; gl.K1 = 256; gl.Wp = lin_[i].Wp; gl.bias = lin_[i].bias; gl.out = ll; gl.ldo = 256;
         gl.M = M; gl.N = 256; gl.n_valid = 256; gl.relu = 1;
-        SUO_TRY(gemm_maybe_pooled(gl, L, 64, 64, nullptr, s, lin_[i].Wx3));
+        SUO_TRY(gemm_maybe_pooled(gl, L, 64, 64, nullptr, s, &lin_[i]));
         GemmArgs gh = {};
         gh.A1 = ll; gh.lda1 = 256; gh.K1 = 256; gh.Wp = head_[i].Wp; gh.bias = head_[i].bias; gh.M = M; gh.N = 64;
         if (i == 0) {
@@ -667,7 +714,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
             gr.Wp = reinject_.Wp; gr.bias = reinject_.bias; gr.R = x; gr.ldr = 256; gr.out = xn; gr.ldo = 256;
             gr.M = M; gr.N = 256; gr.n_valid = 256;
             xp = alloc((size_t)L * 32 * 32 * 256);
-            SUO_TRY(gemm_maybe_pooled(gr, L, 64, 64, xp, s, reinject_.Wx3));
+            SUO_TRY(gemm_maybe_pooled(gr, L, 64, 64, xp, s, &reinject_));
             x = xn;
         } else {
             gh.out = logits; gh.n_valid = NUM_KP; gh.nchw_hw = HEAT * HEAT;
@@ -678,7 +725,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
 }
 
 int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec, bool stem_done) {
-    const int key = L * 4 + (in_c == IMG_C ? 1 : 0) + (stem_done ? 2 : 0);      // one captured graph per (crop count, staging layout, with / without the stem)
+    const int key = (L * 4 + (in_c == IMG_C ? 1 : 0) + (stem_done ? 2 : 0)) * 4 + pipe_;      // one captured graph per (crop count, staging layout, with / without the stem, pipe)
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
         GraphEntry ge;
@@ -702,6 +749,28 @@ int Net::run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s,
         return SUO_OK;
     }
     return backbone(in0, in_c, logits, L, s, stem_done);
+}
+
+int Net::set_pipe(int p) {
+    if (p < 0 || p > pipe_built_ || (p == 0 && pipe_built_ != 0)) {
+        suo_set_error("suo_net_set_pipe: pipe %d not available (this network was built for pipe %d; the fp32 pipe needs SUO_WINO_BF16X3=0 at creation)", p, pipe_built_);
+        return SUO_ERR_ARG;
+    }
+    pipe_ = p;
+    return SUO_OK;
+}
+
+// The contract of the fp16 form (csrc/f16x2.h): a forward whose activations left fp16's range has INVALID outputs.  Whoever synchronised on them asks here
+// before using them; on 1 the network has already been moved to the bf16 form (which has fp32's range) and the caller re-issues the call.  The blocking
+// entries (stream == NULL) do this themselves.
+int Net::range_exceeded() {
+    const unsigned f = __atomic_exchange_n(range_flag_, 0u, __ATOMIC_RELAXED);
+    if (!f) return 0;
+    if (pipe_ == 2) {
+        pipe_ = 1;
+        fprintf(stderr, "libsuo_hip: an activation left the fp16 range (|x| >= %g); this network now runs the three-term bf16 form -- re-issue the call\n", (double)(S2_LIMIT / S2_XSCALE));
+    }
+    return 1;
 }
 
 // SUO_STEM_X3=0: the prior-less pass stages the crop (roi_align_concat_kernel) and runs the stem on the fp32 pipe inside the backbone, as rounds 1-3 did
@@ -752,7 +821,10 @@ int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStre
         suo_set_error("suo_net_backbone: %s", e.what());
         return SUO_ERR_ARG;
     }
-    if (own) SUO_HIP_CHECK(hipStreamSynchronize(s));
+    if (own) {
+        SUO_HIP_CHECK(hipStreamSynchronize(s));
+        if (range_exceeded()) return forward_staged(in0_user, L, logits_out, nullptr);      // (now on the bf16 form: cannot recurse twice)
+    }
     return SUO_OK;
 }
 
@@ -787,7 +859,10 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         suo_set_error("suo_net_forward: %s", e.what());
         return SUO_ERR_ARG;
     }
-    if (own) SUO_HIP_CHECK(hipStreamSynchronize(s));
+    if (own) {
+        SUO_HIP_CHECK(hipStreamSynchronize(s));
+        if (range_exceeded()) return forward(img, fmt, H, W, boxes, box_img, L, priors, prior_uv, prior_mask, uv, cov, kp_prob, kp_logit, logits_out, nullptr);
+    }
     return SUO_OK;
 }
 

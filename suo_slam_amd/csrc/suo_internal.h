@@ -54,6 +54,8 @@ struct GemmArgs {
     // optional fused 2x2 max-pool of the result (nn.MaxPool2d(2, 2) after a block, hg.py:41 / pkpnet.py stem): the M pixels are
     // images of pool_H x pool_W, pool_out is [M / 4, ldo]; `out` may then be nullptr (only the pooled tensor is wanted)
     float* pool_out; int pool_H; int pool_W;
+    // f16x2 form only (csrc/f16x2.h): per-column factor 2^-(t_n + S2_XSHIFT) that brings the accumulator back to scale, and the range-guard flag
+    const float* oscale; unsigned* range_flag;
 };
 int launch_gemm1x1(const GemmArgs& a, hipStream_t s);
 bool gemm1x1_can_pool(const GemmArgs& a);                // shapes the fused pool takes (128 x 128 tiles of 2 image rows x 64 columns)
@@ -68,6 +70,8 @@ struct ConvArgs {
     const float* W3p; const float* bias3; const float* R; float* out2; int N2;
     const float* up;                                     // optional [L,OH/2,OW/2,N2]: out2 += nearest-neighbour 2x up-sampling of it (hg.py:56-58)
     int w3_bf16x3;                                       // csrc/conv_wino_x3.hip only: W3p holds pack_tail_weight_bf16x3's uint16 planes
+    // f16x2 form only (csrc/f16x2.h): per-channel factors 2^-(t_n + S2_XSHIFT) of the 3x3 convolution [N] and of the tail's conv3 [N2], range-guard flag
+    const float* oscale; const float* oscale3; unsigned* range_flag;
 };
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 bool conv3x3_fusable(const ConvArgs& a);
@@ -113,11 +117,20 @@ bool gemm_bf16x3_takes(const GemmArgs& g);
 int launch_gemm_bf16x3_args(const GemmArgs& g, const uint16_t* Wx3, hipStream_t s);
 int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, const float* pro_shift, const uint16_t* Wp, const float* bias,
                        float* out, int ldo, int M, int N, int relu, hipStream_t s);
+// the same kernel on two fp16 terms per operand, three MFMAs per product block (csrc/f16x2.h): oscale_out[N] = 2^-(t_n + S2_XSHIFT) goes into GemmArgs.oscale,
+// GemmArgs.range_flag must name the guard flag; out = 2 * N * K uint16
+void pack_gemm_weight_f16x2(const float* W, int N, int K, uint16_t* out, float* oscale_out);
+int launch_gemm_f16x2_args(const GemmArgs& g, const uint16_t* W16, hipStream_t s);
 // experimental: Winograd 3x3 with its products on the bf16 matrix pipe at fp32 accuracy (csrc/conv_wino_x3.hip); ConvArgs.Wp = packed uint16
 void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out);
 void pack_wino_weight_bf16x3(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out);
 int launch_conv3x3_wino_x3(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_wino_x3_fused(const ConvArgs& a, hipStream_t s);
+// ... and on two fp16 terms per operand (csrc/f16x2.h; ConvArgs.oscale / oscale3 / range_flag set)
+void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float* oscale_out);
+void pack_wino_weight_f16x2(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out, float* oscale_out);
+int launch_conv3x3_wino_f16x2(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s);
 // RoIAlign + stem 7x7 / 2 (+ BN + ReLU) of the prior-less pass in one launch on the bf16 pipe (csrc/stem_x3.hip)
 void pack_stem_weight_bf16x3(const float* W, int Cw, const float* out_scale, uint16_t* out);
 int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* Wx, const float* bias,

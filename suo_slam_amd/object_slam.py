@@ -369,16 +369,19 @@ class ObjectSLAM:
         K_bbox = fix_K_for_bbox_ndc_many(K, bboxes).astype(np.float32)                                   # float32 container (:1082)
         kinv, camk = kbbox_terms(K_bbox)
         min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for o in obj_ids], dtype=np.float64)
-        pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None)
-        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
-        masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, self.bbox_thresh, vt)
-        kps_dev = torch.as_tensor(np.ascontiguousarray(model_kps, dtype=np.float32)).to(pred["uv"].device)
         if self._fg is None or self._fg.max_crops < L:
             self._fg = FrameGeometry(max(16, L), 1)
         its = (10, 10, 40, 40) if self.sfm_mode else (10, 10, 10, 10)                                    # (:843-846)
-        self._fg.launch([0, L], pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
-                        use_cov=not self.no_network_cov, do_lm=True, its=its)
-        r = self._fg.fetch(copy=True)
+        for _attempt in range(2):
+            pred = self.model(np.ascontiguousarray(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None, check=False)
+            vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+            masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, self.bbox_thresh, vt)
+            kps_dev = torch.as_tensor(np.ascontiguousarray(model_kps, dtype=np.float32)).to(pred["uv"].device)
+            self._fg.launch([0, L], pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
+                            use_cov=not self.no_network_cov, do_lm=True, its=its)
+            r = self._fg.fetch(copy=True)
+            if not self.model.range_exceeded():               # (fp16 form only: an activation left its range -> the network is on bf16x3 now, once more)
+                break
         self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
         self._ingest_single_view(view_id, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox, r, 0, 0)
 
@@ -451,18 +454,22 @@ class ObjectSLAM:
         K_all = np.concatenate([p[7] for p in prep])
         kinv, camk = kbbox_terms(K_all)
         min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for p in prep for o in p[3]], dtype=np.float64)
-        pred = self.model.forward_frames(np.stack([np.ascontiguousarray(p[1]) for p in prep]), [np.asarray(p[4], np.float32) for p in prep])
-        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
-        mm_all = np.concatenate([p[6] for p in prep])
-        masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], mm_all, self.bbox_thresh, vt)
-        kps_dev = torch.as_tensor(np.ascontiguousarray(np.concatenate([p[5] for p in prep]), dtype=np.float32)).to(pred["uv"].device)
         fg = getattr(self, "_fg_batch", None)
         if fg is None or fg.max_crops < Ltot or fg.max_frames < B:
             fg = self._fg_batch = FrameGeometry(max(256, Ltot), max(32, B))
         its = (10, 10, 40, 40) if self.sfm_mode else (10, 10, 10, 10)
-        fg.launch(ff, pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
-                  use_cov=not self.no_network_cov, do_lm=True, its=its)
-        r = fg.fetch(copy=True)
+        frames_host = np.stack([np.ascontiguousarray(p[1]) for p in prep])
+        for _attempt in range(2):
+            pred = self.model.forward_frames(frames_host, [np.asarray(p[4], np.float32) for p in prep], check=False)
+            vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+            mm_all = np.concatenate([p[6] for p in prep])
+            masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], mm_all, self.bbox_thresh, vt)
+            kps_dev = torch.as_tensor(np.ascontiguousarray(np.concatenate([p[5] for p in prep]), dtype=np.float32)).to(pred["uv"].device)
+            fg.launch(ff, pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
+                      use_cov=not self.no_network_cov, do_lm=True, its=its)
+            r = fg.fetch(copy=True)
+            if not self.model.range_exceeded():               # (fp16 form only: see _process_view_single_device)
+                break
         self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
         torch.cuda.synchronize()
         per_view = (time() - tt0) / B
@@ -582,19 +589,22 @@ class ObjectSLAM:
                 for k, obj_id in enumerate(obj_ids):
                     if obj_id in prior_dets:
                         prior_uv[k], prior_mask[k] = prior_dets[obj_id]
-            pred = self.model(self._frame_on_device(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None,
-                              prior_uv=prior_uv, prior_mask=prior_mask)
             if self.no_network_cov:
                 bt, vt = self.bbox_thresh, 1e30
             else:
                 bt, vt = self.bbox_thresh, self.kp_var_thresh
-            masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, bt, vt)
-            # (three small read-backs, as the reference does, :1100-1111: packing them with torch.cat first costs more host time in
-            #  torch's dispatcher -- 4 extra ops, +0.2 ms per call on the GPU boxes -- than the two stream waits it saves)
-            exp_uv = pred["uv"].cpu().numpy()
-            kp_masks = masks_dev.cpu().numpy().astype(bool)
-            if not self.no_network_cov or self.run_network_in_debug:
-                cov_uv = pred["cov"].cpu().numpy()
+            for _attempt in range(2):
+                pred = self.model(self._frame_on_device(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None,
+                                  prior_uv=prior_uv, prior_mask=prior_mask, check=False)
+                masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, bt, vt)
+                # (three small read-backs, as the reference does, :1100-1111: packing them with torch.cat first costs more host time in
+                #  torch's dispatcher -- 4 extra ops, +0.2 ms per call on the GPU boxes -- than the two stream waits it saves)
+                exp_uv = pred["uv"].cpu().numpy()
+                kp_masks = masks_dev.cpu().numpy().astype(bool)
+                if not self.no_network_cov or self.run_network_in_debug:
+                    cov_uv = pred["cov"].cpu().numpy()
+                if not self.model.range_exceeded():           # (fp16 form only: the read-backs above synchronised; on True the network is on bf16x3 now)
+                    break
         if self.debug_gt_kp:
             assert kp_masks_gt is not None and uv_gt is not None
             kp_masks = np.asarray(kp_masks_gt, dtype=bool)

@@ -94,10 +94,27 @@ class PkpNet:
     def workspace_bytes(self):
         return int(_lib.lib().suo_net_workspace_bytes(self._h))
 
-    def forward(self, images, boxes, prior_kp=None, want_prob=False, prior_uv=None, prior_mask=None):
+    # -- matrix pipe and the fp16 form's range guard (include/suo_hip.h: SUO_PIPE_*, suo_net_range_exceeded) -------------------------
+    def pipe(self):
+        """0 = fp32 MFMA, 1 = three bf16 terms, 2 = two fp16 terms (the default; range-guarded)."""
+        return int(_lib.lib().suo_net_get_pipe(self._h))
+
+    def set_pipe(self, pipe):
+        _lib.check(_lib.lib().suo_net_set_pipe(self._h, int(pipe)), "suo_net_set_pipe")
+
+    def range_exceeded(self):
+        """True when a forward since the last call of this method left the fp16 range: every forward of this network that was enqueued and not yet
+        checked is INVALID and must be re-issued (the network is on the bf16x3 form from now on).  The caller has synchronised on the outputs.
+        forward(..., check=True) -- the default -- does all of this itself."""
+        return bool(_lib.lib().suo_net_range_exceeded(self._h))
+
+    def forward(self, images, boxes, prior_kp=None, want_prob=False, prior_uv=None, prior_mask=None, check=True):
         """images: uint8 [H,W,3] (cv2 layout) or float32 [1,3,H,W] device/host tensor; boxes: list with
         one Tensor[L,4] (xyxy); prior_kp: list with one Tensor[L,41,256,256] or None.
-        Returns the reference's dict: uv, cov, prob_logits, kp_mask_logits, kp_mask (+ prob if asked)."""
+        Returns the reference's dict: uv, cov, prob_logits, kp_mask_logits, kp_mask (+ prob if asked).
+        check: on the fp16 form, wait for the call and re-issue it on bf16x3 if an activation left the range (the reference's callers read the
+        outputs back right away, lib/object_slam.py:1100-1111, so the wait costs them nothing); check=False returns at once -- the caller then
+        asks range_exceeded() after its own synchronisation and re-issues (what ObjectSLAM's device chains do)."""
         assert self._h is not None, "load_state_dict first"
         assert isinstance(boxes, (list, tuple)) and len(boxes) == 1, "one image per call (lib/object_slam.py:1092-1099)"
         dev = self.device
@@ -133,6 +150,10 @@ class PkpNet:
         else:
             _lib.check(_lib.lib().suo_net_forward(self._h, _ptr(img), fmt, H, W, _ptr(bx), L, _ptr(pr), _ptr(uv), _ptr(cov),
                                                   _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward")
+        if check and self.pipe() == 2:
+            torch.cuda.current_stream().synchronize()
+            if self.range_exceeded():
+                return self.forward(images, boxes, prior_kp, want_prob, prior_uv, prior_mask, check=False)     # (now on bf16x3: fp32's range)
         ret = {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
         if want_prob:
             ret.update(decode_extras(logits))
@@ -161,9 +182,9 @@ class PkpNet:
         ev.record()
         return dev_buf[:nbytes].view(images.dtype).view(images.shape)
 
-    def forward_frames(self, images, boxes_per_frame):
+    def forward_frames(self, images, boxes_per_frame, check=True):
         """Several independent frames in one call: images uint8 [B,H,W,3], boxes_per_frame list of B arrays [L_b,4].
-        Returns the same dict with the crops of all frames concatenated in frame order."""
+        Returns the same dict with the crops of all frames concatenated in frame order.  check: as forward()."""
         assert self._h is not None, "load_state_dict first"
         dev = self.device
         imgs = torch.as_tensor(images).to(dev).contiguous()
@@ -179,6 +200,10 @@ class PkpNet:
         _lib.check(_lib.lib().suo_net_forward_frames(self._h, _ptr(imgs), 0, int(imgs.shape[1]), int(imgs.shape[2]), _ptr(bx), _ptr(idx), L,
                                                      None, _ptr(uv), _ptr(cov), _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()),
                    "suo_net_forward_frames")
+        if check and self.pipe() == 2:
+            torch.cuda.current_stream().synchronize()
+            if self.range_exceeded():
+                return self.forward_frames(images, boxes_per_frame, check=False)
         return {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
 
 

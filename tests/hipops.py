@@ -211,6 +211,89 @@ def conv3x3_wino_x3_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc=N
     return out
 
 
+# ---- the two-term fp16 form (csrc/f16x2.h): every helper returns (out, range_flag) -- flag 1 = an activation left fp16's range, `out` is invalid -----------
+def _flag():
+    return torch.zeros(1, dtype=torch.int32, device="cuda")
+
+
+def pack_gemm_f16x2(w):
+    """-> (planes int16 cuda [2*N*K], oscale cuda [N], oscale numpy)"""
+    w = np.ascontiguousarray(w, np.float32)
+    N, K = w.shape
+    h = np.empty(2 * N * K, np.uint16)
+    osc = np.empty(N, np.float32)
+    _lib.check(_lib.lib().suo_pack_gemm_weight_f16x2(w.ctypes.data, N, K, h.ctypes.data, osc.ctypes.data), "pack_gemm_f16x2")
+    return torch.from_numpy(h.view(np.int16)).cuda(), dev(osc), osc
+
+
+def conv1x1_f16x2(a1, w1, bias, pro=None, a2=None, w2=None, res=None, relu=False, pool_hw=None):
+    """csrc/gemm_bf16x3.hip with NP = 2.  a1 [M,K1] cuda, w1 [N,K1]; optional pro=(scale,shift), a2 [M,K2] / w2 [N,K2], res [M,N], pool_hw=(H,W) -> also the pooled result."""
+    M, K1 = a1.shape
+    N = w1.shape[0]
+    K2 = a2.shape[1] if a2 is not None else 0
+    full = np.concatenate([w1, w2], 1) if a2 is not None else w1
+    w16, osc, _ = pack_gemm_f16x2(full)
+    b = dev(bias)
+    out = torch.empty((M, N), device="cuda")
+    flag = _flag()
+    ps, pt = (dev(pro[0]), dev(pro[1])) if pro is not None else (None, None)
+    lib = _lib.lib()
+    if pool_hw is None:
+        _lib.check(lib.suo_conv1x1_f16x2_ex(P(a1), a1.stride(0), K1, P(ps), P(pt), P(a2), a2.stride(0) if a2 is not None else 0, K2, P(w16), P(osc), P(b), P(res),
+                                            res.stride(0) if res is not None else 0, P(out), N, M, N, int(relu), P(flag), S()), "suo_conv1x1_f16x2_ex")
+        torch.cuda.synchronize()
+        return out, int(flag.item())
+    pooled = torch.empty((M // 4, N), device="cuda")
+    _lib.check(lib.suo_conv1x1_f16x2_pool(P(a1), a1.stride(0), K1, P(ps), P(pt), P(a2), a2.stride(0) if a2 is not None else 0, K2, P(w16), P(osc), P(b), P(res),
+                                          res.stride(0) if res is not None else 0, P(out), N, M, N, int(relu), pool_hw[0], pool_hw[1], P(pooled), P(flag), S()),
+               "suo_conv1x1_f16x2_pool")
+    torch.cuda.synchronize()
+    return (out, pooled), int(flag.item())
+
+
+def _pack_f16x2(w2, w3=None):
+    lib = _lib.lib()
+    w2 = np.ascontiguousarray(w2, np.float32)
+    n = w2.shape[0]
+    q = np.empty(2 * 16 * n * n, np.uint16)
+    o2 = np.empty(n, np.float32)
+    _lib.check(lib.suo_pack_wino_weight_f16x2(w2.ctypes.data, n, n, q.ctypes.data, o2.ctypes.data), "pack_wino_f16x2")
+    wq = torch.from_numpy(q.view(np.int16)).cuda()
+    if w3 is None:
+        return wq, dev(o2)
+    w3 = np.ascontiguousarray(w3, np.float32)
+    t = np.empty(2 * 256 * 128, np.uint16)
+    o3 = np.empty(256, np.float32)
+    _lib.check(lib.suo_pack_tail_weight_f16x2(w3.ctypes.data, 256, 128, t.ctypes.data, o3.ctypes.data), "pack_tail_f16x2")
+    return wq, dev(o2), torch.from_numpy(t.view(np.int16)).cuda(), dev(o3)
+
+
+def conv3x3_wino_f16x2(x_nhwc, w, bias, relu=False):
+    """csrc/conv_wino_x3.hip with NP = 2: the Winograd 3x3 convolution (128 -> 128 / 64 -> 64) on two fp16 terms per operand."""
+    L, H, W, C = x_nhwc.shape
+    assert C in (128, 64) and w.shape == (C, C, 3, 3)
+    wq, osc = _pack_f16x2(w)
+    b = dev(bias)
+    out = torch.empty((L, H, W, C), device="cuda")
+    flag = _flag()
+    _lib.check(_lib.lib().suo_conv3x3_wino_f16x2_n(P(x_nhwc), L, H, W, C, P(wq), P(osc), P(b), P(out), int(relu), P(flag), S()), "suo_conv3x3_wino_f16x2_n")
+    torch.cuda.synchronize()
+    return out, int(flag.item())
+
+
+def conv3x3_wino_f16x2_conv1x1_skip_up(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc=None):
+    """The fused Residual tail on two fp16 terms per operand (what the network launches by default)."""
+    L, H, W, C = x_nhwc.shape
+    wq, o2, w3p, o3 = _pack_f16x2(w2, w3)
+    out = torch.empty((L, H, W, 256), device="cuda")
+    b2d, b3d = dev(b2), dev(b3)
+    flag = _flag()
+    _lib.check(_lib.lib().suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(x_nhwc), L, H, W, P(wq), P(o2), P(b2d), P(w3p), P(o3), P(b3d), P(skip_nhwc), P(up_nhwc), P(out),
+                                                                 P(flag), S()), "suo_conv3x3_wino_f16x2_conv1x1_skip_up")
+    torch.cuda.synchronize()
+    return out, int(flag.item())
+
+
 def res_block(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=False):
     """csrc/res_small.hip: a whole 256 -> 256 Residual block in one launch.  x [L,H,W,256] (pool_in: [L,2H,2W,256]); pro = (scale, shift) [256];
     w1 [128,256], w2 [128,128,3,3], w3 [256,128] with their BatchNorms already folded; up [L,H/2,W/2,256] or None."""

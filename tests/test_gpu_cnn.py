@@ -510,16 +510,22 @@ def test_full_network_golden(ops, cnn_golden, state_dict):
 
 
 @pytest.mark.parametrize("L", [40, 16])
-@pytest.mark.parametrize("bf16x3", ["1", "0"])
-def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict, monkeypatch, bf16x3, L):
-    """Both forms of the Residual blocks' 3x3 + tail: on the bf16 matrix pipe with 3-way split operands (default) and on the fp32 pipe
-    (SUO_WINO_BF16X3=0, read when the network is built).  The same crop repeated 40 times: every 3x3 layer down to the 16x16 maps now has >= 256 tiles, so the Winograd kernels, the
+@pytest.mark.parametrize("pipe", ["f16x2", "bf16x3", "f32"])
+def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict, monkeypatch, pipe, L):
+    """All three forms of the Residual blocks' 3x3 + tail and of the large 1x1 convolutions: two fp16 terms per operand (the default, csrc/f16x2.h), three
+    bf16 terms (SUO_F16X2=0) and the fp32 pipe (SUO_WINO_BF16X3=0; both read when the network is built).  The same crop repeated 40 times: every 3x3 layer down to the 16x16 maps now has >= 256 tiles, so the Winograd kernels, the
     fused Residual tails, the fused up-sample adds and the pooled GEMMs run (test_full_network_golden at L = 1 takes the direct
     forms only).  Every copy against the REFERENCE's own logits; hard arg-max of the HIP logits = torch.argmax of the reference's
     wherever the runner-up is more than 1e-4 below the maximum."""
     from suo_slam_amd.pkpnet import PkpNet, decode_extras
-    monkeypatch.setenv("SUO_WINO_BF16X3", bf16x3)
+    monkeypatch.delenv("SUO_WINO_BF16X3", raising=False)
+    monkeypatch.delenv("SUO_F16X2", raising=False)
+    if pipe == "bf16x3":
+        monkeypatch.setenv("SUO_F16X2", "0")
+    if pipe == "f32":
+        monkeypatch.setenv("SUO_WINO_BF16X3", "0")
     net = PkpNet(state_dict=state_dict, max_crops=L)
+    assert net.pipe() == {"f32": 0, "bf16x3": 1, "f16x2": 2}[pipe]
     rng = np.random.Generator(np.random.PCG64(int(cnn_golden["backbone_in_seed"])))
     x = rng.uniform(0, 1, (1, 44, 256, 256)).astype(np.float32)
     xin = np.zeros((L, 256, 256, 48), np.float32)
@@ -528,6 +534,7 @@ def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict, m
     from tests.gpu_backbone import run_backbone_from_staged
     logits = run_backbone_from_staged(net, xin)
     assert logits.shape == (L, 41, 64, 64)
+    assert not net.range_exceeded() and net.pipe() == {"f32": 0, "bf16x3": 1, "f16x2": 2}[pipe]      # (the fp16 form stayed inside its range: these ARE its results)
     rel = np.abs(logits - ref).max() / np.abs(ref).max()
     assert rel < 1e-5, rel                                    # the reference's own logits, either pipe, every copy
     # ... and what the path hands on: uv / cov / mean logit decoded from the HIP logits vs the reference's decode of ITS logits
@@ -542,8 +549,8 @@ def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict, m
 
 
 def test_the_two_matrix_pipe_forms_are_both_reachable_and_agree(ops, state_dict, monkeypatch):
-    """SUO_WINO_BF16X3 selects the form when a network is built; the default is the bf16x3 one.  The two networks' logits on the same
-    input agree to fp32-rounding level but are not bit-identical (= different kernels really ran)."""
+    """SUO_WINO_BF16X3 / SUO_F16X2 select the form when a network is built; "1" below = the split forms with the default SUO_F16X2, i.e. the fp16 one.
+    The networks' logits on the same input agree to fp32-rounding level but are not bit-identical (= different kernels really ran)."""
     from suo_slam_amd.pkpnet import PkpNet
     from tests.gpu_backbone import run_backbone_from_staged
     L = 40

@@ -109,7 +109,7 @@ def test_slam_mode_over_a_consistent_sequence(tmp_path):
     assert out["result"]["AUC of ADD-S"][0] > 0.7
 
 
-def _per_frame_forward_frames(self, images, boxes_per_frame):
+def _per_frame_forward_frames(self, images, boxes_per_frame, check=True):
     """PkpNet.forward_frames as one PkpNet.forward per frame (the per-view loop's network calls), results concatenated."""
     import torch
     outs = [self.forward(np.ascontiguousarray(images[i]), [torch.as_tensor(np.asarray(b, np.float32))], None) for i, b in enumerate(boxes_per_frame)]

@@ -1,6 +1,7 @@
 """Pin the CNN oracle (oracle/cnn_oracle.py) against vectors produced by the reference's own
 modules (tests/golden/make_golden.py -> cnn_golden.npz).  CPU only."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -67,9 +68,12 @@ def test_roi_align_identity_box():
     # samples beyond [-1, H] contribute zero; the box far outside gives zeros
     out = O.roi_align(img, np.array([[-100, -100, -50, -50]], np.float32), (4, 4))
     assert np.all(out == 0)
-    # 2x downsample: grid 2x2 per bin
+    # 2x downsample: grid 2x2 per bin -- bin (ph, pw) covers pixels [2 ph, 2 ph + 2) and its four samples sit at 2 ph + {.5, 1.5}:
+    # each the mean of a 2x2 pixel neighbourhood, by hand
     out = O.roi_align(img, np.array([[0, 0, 32, 32]], np.float32), (16, 16))
-    assert out.shape == (1, 3, 16, 16) and np.isfinite(out).all()
+    m = 0.25 * (img[:, :-1, :-1] + img[:, 1:, :-1] + img[:, :-1, 1:] + img[:, 1:, 1:])      # m[y, x] = the sample at (y + .5, x + .5)
+    exp = 0.25 * (m[:, 0:32:2, 0:32:2] + m[:, 1:32:2, 0:32:2] + m[:, 0:32:2, 1:32:2] + m[:, 1:32:2, 1:32:2])
+    np.testing.assert_allclose(out[0], exp, atol=1e-6)
 
 
 # ---- independent cross-checks of the two "builder's reading only" pieces -----------------------------------------
@@ -121,6 +125,35 @@ def test_roi_align_equals_grid_sample_for_boxes_up_to_256_px():
     ref = resample(b[:, 0:1] + centres[None] * (b[:, 2:3] - b[:, 0:1]), b[:, 1:2] + centres[None] * (b[:, 3:4] - b[:, 1:2]))
     grad = max(np.abs(np.diff(chw, axis=1)).max(), np.abs(np.diff(chw, axis=2)).max())
     assert np.abs(got - ref).max() < 1e-6 + 2 * 8e-5 * grad, (np.abs(got - ref).max(), grad)
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (540, 720)])
+def test_roi_align_equals_grid_sample_for_boxes_beyond_256_px(H, W):
+    """Boxes of more than 256 px a side -- YCB-V 640x480 and T-LESS 720x540 detections reach the whole frame -- take ceil(roi / 256) = 2 or
+    3 samples per bin and axis (/root/reference/lib/models/pkpnet.py:93), and boxes leaving the image meet the `y < -1 or
+    y > H -> 0` and clamp-to-the-border rules.  200 random boxes, a third of them leaving the image; every sample interpolated by
+    F.grid_sample(align_corners=True) in float64 and averaged (tests/roi_ref.py), (A) at the positions RoIAlign's float32 arithmetic
+    gives, (B) at positions formed in float64 from the definition."""
+    from tests import roi_ref as R
+    from suo_slam_amd import synthetic as S
+    rng = np.random.default_rng(77 + H)
+    img = S.make_frame(rng, 1, noise=0.0)["image"]                       # uint8 [480,640,3], low-pass texture
+    if (H, W) != img.shape[:2]:                                          # T-LESS frame size: the same texture, tiled and cut
+        img = np.tile(img, (2, 2, 1))[:H, :W]
+    chw = O.image_to_chw(img)
+    boxes = R.large_boxes(rng, 200, H, W)
+    _, _, gw, gh = R.sample_positions(boxes)
+    assert set(gw) | set(gh) == {1, 2, 3}                                # every grid count the frame sizes can produce
+    got = O.roi_align(chw, boxes, (256, 256))
+    ref = R.roi_align_grid_sample(chw, boxes, 256, f32_positions=True)
+    assert np.abs(got - ref).max() < 1e-6, np.abs(got - ref).max()
+    ref64 = R.roi_align_grid_sample(chw, boxes, 256, f32_positions=False)
+    grad = max(np.abs(np.diff(chw, axis=1)).max(), np.abs(np.diff(chw, axis=2)).max())
+    # a float32 position is within ~1e-4 px of the float64 one (720 * 2^-23 per operation); a sample within that of the y = -1 / y = H
+    # rule may count on one side only: compare where the two agree on validity, and require that to be all but a handful of bins
+    d = np.abs(got - ref64)
+    close = d < 1e-6 + 4 * 1e-4 * grad
+    assert close.mean() > 1 - 1e-5 and d[close].max() < 1e-6 + 4 * 1e-4 * grad, (close.mean(), d.max())
 
 
 def test_prior_stamp_equals_conv2d_of_an_impulse_with_opencvs_kernel():

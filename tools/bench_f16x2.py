@@ -1,0 +1,88 @@
+"""A/B of the matrix-pipe forms at the network's launch shapes (256 crops): three bf16 terms / six MFMAs per product block (csrc/bf16x3.h) against two fp16 terms /
+three MFMAs (csrc/f16x2.h).  us per launch by HIP events, sustained.   python tools/bench_f16x2.py [crops]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from suo_slam_amd import _lib                           # noqa: E402
+from tests import hipops as ops                         # noqa: E402
+
+P, S = ops.P, ops.S
+
+
+def timed(f, iters=30):
+    for _ in range(8):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rows = []
+    # ---- 1x1 convolutions -------------------------------------------------------------------------------------------------------------
+    for name, HW, K, N, pro, res in (("conv1 256->128 @64x64 (BN+ReLU prologue)", 64, 256, 128, True, False), ("conv1 256->128 @32x32", 32, 256, 128, True, False),
+                                     ("lin 256->256 @64x64", 64, 256, 256, False, False), ("re-injection 256->256 + residual @64x64", 64, 256, 256, False, True),
+                                     ("conv3 128->256 + residual @64x64 (unfused)", 64, 128, 256, False, True)):
+        M = L * HW * HW
+        a = torch.rand((M, K), device="cuda") - 0.3
+        w = (rng.standard_normal((N, K)) / 16).astype(np.float32)
+        b = ops.dev(np.zeros(N, np.float32))
+        out = torch.empty((M, N), device="cuda")
+        r = torch.rand((M, N), device="cuda") if res else None
+        sc, sh = (ops.dev(rng.uniform(0.5, 1.5, K)), ops.dev(rng.standard_normal(K) * 0.1)) if pro else (None, None)
+        w3 = np.empty(3 * N * K, np.uint16)
+        _lib.check(lib.suo_pack_gemm_weight_bf16x3(np.ascontiguousarray(w).ctypes.data, N, K, w3.ctypes.data))
+        w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+        w16, osc, _ = ops.pack_gemm_f16x2(w)
+        f3 = lambda: _lib.check(lib.suo_conv1x1_bf16x3_ex(P(a), K, K, P(sc), P(sh), None, 0, 0, P(w3d), P(b), P(r), N, P(out), N, M, N, int(pro), S()))      # noqa: E731
+        f2 = lambda: _lib.check(lib.suo_conv1x1_f16x2_ex(P(a), K, K, P(sc), P(sh), None, 0, 0, P(w16), P(osc), P(b), P(r), N, P(out), N, M, N, int(pro), P(flag), S()))      # noqa: E731
+        t3, t2 = timed(f3), timed(f2)
+        gb = 4.0 * M * (K + N + (N if res else 0)) / 1e9
+        rows.append((name, t3, t2, "%.2f / %.2f TB/s" % (gb / t3 * 1e3, gb / t2 * 1e3)))
+    # ---- 3x3 Winograd, plain and fused tail --------------------------------------------------------------------------------------------
+    for name, HW, C, fused, up in (("fused tail 128->128->256 @64x64", 64, 128, True, False), ("fused tail + up-sampled addend @64x64", 64, 128, True, True),
+                                   ("fused tail @32x32", 32, 128, True, False), ("3x3 128->128 @64x64", 64, 128, False, False), ("3x3 64->64 @128x128", 128, 64, False, False)):
+        x = torch.rand((L, HW, HW, C), device="cuda") - 0.3
+        w2 = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+        b2 = ops.dev(np.zeros(C, np.float32))
+        if fused:
+            skip = torch.rand((L, HW, HW, 256), device="cuda")
+            upd = torch.rand((L, HW // 2, HW // 2, 256), device="cuda") if up else None
+            w3 = (rng.standard_normal((256, 128)) / 11).astype(np.float32)
+            b3 = ops.dev(np.zeros(256, np.float32))
+            wq3, w3x = ops._pack_x3(w2, w3)
+            wq, o2, w3p, o3 = ops._pack_f16x2(w2, w3)
+            out = torch.empty((L, HW, HW, 256), device="cuda")
+            f3 = lambda: _lib.check(lib.suo_conv3x3_wino_x3_conv1x1_skip_up(P(x), L, HW, HW, P(wq3), P(b2), P(w3x), 1, P(b3), P(skip), P(upd), P(out), S()))      # noqa: E731
+            f2 = lambda: _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(x), L, HW, HW, P(wq), P(o2), P(b2), P(w3p), P(o3), P(b3), P(skip), P(upd), P(out), P(flag), S()))      # noqa: E731
+            flop = 2.0 * L * HW * HW * (128 * 128 * 9 + 128 * 256)
+        else:
+            wq3 = ops._pack_x3(w2)
+            wq, o2 = ops._pack_f16x2(w2)
+            out = torch.empty((L, HW, HW, C), device="cuda")
+            f3 = lambda: _lib.check(lib.suo_conv3x3_wino_x3_n(P(x), L, HW, HW, C, P(wq3), P(b2), P(out), 1, S()))      # noqa: E731
+            f2 = lambda: _lib.check(lib.suo_conv3x3_wino_f16x2_n(P(x), L, HW, HW, C, P(wq), P(o2), P(b2), P(out), 1, P(flag), S()))      # noqa: E731
+            flop = 2.0 * L * HW * HW * C * C * 9
+        t3, t2 = timed(f3), timed(f2)
+        rows.append((name, t3, t2, "%.0f / %.0f algorithmic TFLOP/s" % (flop / t3 / 1e6, flop / t2 / 1e6)))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    print(f"{L} crops per launch; us per launch: bf16x3 (6 MFMA) | f16x2 (3 MFMA) | ratio")
+    for name, t3, t2, extra in rows:
+        print(f"  {name:48s} {t3:9.1f} {t2:9.1f}   {t3 / t2:5.2f}x   {extra}")
+
+
+if __name__ == "__main__":
+    main()
