@@ -46,7 +46,8 @@ GFLOP_PER_CROP = 31.495          # conv FLOPs, hook-counted on the reference mod
 # channels are structural zeros and their MACs are never issued (csrc/net.hip: stem_img_): 2*128*128*64*49*41 per crop.
 GFLOP_SKIPPED_PER_CROP = 2 * 128 * 128 * 64 * 49 * 41 / 1e9
 FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
-BF16_MFMA_PEAK_TF = 2500.0       # dense, same table (the fp32 pipe is 1/16 of it)
+BF16_MFMA_PEAK_TF = 2500.0       # dense, same table (the fp32 pipe is 1/16 of it); fp16 runs at the bf16 rate
+HBM_PEAK_GBPS = 8000.0           # HBM3E spec, same table (~6.3 TB/s achievable)
 BBOX_THRESH, KP_VAR_THRESH = 1.0, 0.5      # evaluate.py:66-74 (the T-LESS pair): with random weights the YCB-V pair masks everything
 
 
@@ -225,8 +226,10 @@ class FramePipeline:
         self.n_crops += self.L * self.F
         if self.only == "cnn":
             S["ev"].synchronize()
+            self.check_range(S)
             return None
         r = S["fg"].fetch(copy=False)
+        self.check_range(S)
         assert np.isfinite(r["uv"]).all() and np.isfinite(r["T_opt"][r["accepted"]]).all()
         self.n_kp += int(r["n_kp"].sum())
         self.n_pose += int(r["accepted"].sum())
@@ -240,6 +243,13 @@ class FramePipeline:
             self.pose_err += float(d[ok].sum())
             self.n_pose_gt += int(ok.sum())
         return r
+
+    @staticmethod
+    def check_range(S):
+        """The fp16 form's contract (include/suo_hip.h: suo_net_range_exceeded): a step whose activations left fp16's range has invalid outputs and would have
+        to be re-issued on bf16x3.  The synthetic weights sit 200x inside the range (profiles/r05_activation_range.txt): if this fires the measurement is void."""
+        if S["net"].range_exceeded():
+            raise RuntimeError("an activation left the fp16 range inside the timed region: the line would not be a measurement of the fp16 form")
 
     def drain(self, next_step):
         """Retire every step still in flight, oldest first."""
@@ -291,8 +301,29 @@ def wino_bf16x3_enabled():
     return os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
 
 
+def matrix_pipe():
+    """csrc/net.hip, read when a network is built: "f32" (SUO_WINO_BF16X3=0), "bf16x3" (SUO_F16X2=0: three bf16 terms per operand, six MFMAs per product block)
+    or "f16x2" (default: two fp16 terms, three MFMAs, range-guarded -- csrc/f16x2.h)."""
+    if not wino_bf16x3_enabled():
+        return "f32"
+    return "bf16x3" if os.environ.get("SUO_F16X2", "1") in ("0", "") else "f16x2"
+
+
+DTYPE_NOTE = {
+    "f16x2": ("fp32 tensors and fp32 accuracy end to end; the Residual blocks' 3x3 + tail and the large 1x1 convolutions form their products on the fp16 matrix "
+              "pipe from operands split into two fp16 terms (hi*lo + lo*hi + hi*hi, fp32 accumulate; operands scaled into fp16's range by exact powers of two, "
+              "a range guard re-issues a call that leaves it on the bf16x3 form): suo_slam_amd/csrc/f16x2.h, DESIGN.md section 4"),
+    "bf16x3": ("fp32 tensors and fp32 accuracy end to end; the Residual blocks' 3x3 + tail and the large 1x1 convolutions form their products on "
+               "the bf16 matrix pipe from operands split into three bf16 terms (6 cross terms, fp32 accumulate; SUO_F16X2=0): DESIGN.md section 4"),
+    "f32": "fp32 MFMA throughout (SUO_WINO_BF16X3=0)"}
+
+
+def dominant_kernel_name():
+    return {"f16x2": "wino3x3_x3_kernel<true,false,true,4,2>", "bf16x3": "wino3x3_x3_kernel<true,false,true,4,3>", "f32": "wino3x3_kernel<true"}[matrix_pipe()]
+
+
 def dominant_kernel_traffic(L):
-    return committed_traffic("pmc_dominant_conv.json", L, "wino3x3_x3_kernel<true" if wino_bf16x3_enabled() else "wino3x3_kernel<true")
+    return committed_traffic("pmc_dominant_conv.json", L, dominant_kernel_name())
 
 
 def _timed(f, st, iters):
@@ -341,6 +372,11 @@ def conv_roofline(L, iters=30):
     w3xh = np.empty(3 * 256 * 128, np.uint16)
     _lib.check(lib.suo_pack_tail_weight_bf16x3(np.ascontiguousarray(w3).ctypes.data, 256, 128, w3xh.ctypes.data), "pack_tail_x3")
     w3x = torch.from_numpy(w3xh.view(np.int16)).cuda()
+    wq16h, o2h, w3p16h, o3h = np.empty(2 * 16 * 128 * 128, np.uint16), np.empty(128, np.float32), np.empty(2 * 256 * 128, np.uint16), np.empty(256, np.float32)
+    _lib.check(lib.suo_pack_wino_weight_f16x2(np.ascontiguousarray(w2).ctypes.data, 128, 128, wq16h.ctypes.data, o2h.ctypes.data), "pack_wino_f16x2")
+    _lib.check(lib.suo_pack_tail_weight_f16x2(np.ascontiguousarray(w3).ctypes.data, 256, 128, w3p16h.ctypes.data, o3h.ctypes.data), "pack_tail_f16x2")
+    wq16, o2, w3p16, o3 = torch.from_numpy(wq16h.view(np.int16)).cuda(), torch.from_numpy(o2h).cuda(), torch.from_numpy(w3p16h.view(np.int16)).cuda(), torch.from_numpy(o3h).cuda()
+    rflag = torch.zeros(1, dtype=torch.int32, device="cuda")
     wp2 = torch.from_numpy(pack_conv(w2, 128, 128, 32)).cuda()
     wp3 = torch.from_numpy(pack_gemm(w3, 256, 128)).cuda()
     b2 = torch.zeros(128, device="cuda")
@@ -350,6 +386,13 @@ def conv_roofline(L, iters=30):
     st = torch.cuda.current_stream()
     s = C.c_void_p(st.cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def f16_fused():
+        _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(x), L, 64, 64, P(wq16), P(o2), P(b2), P(w3p16), P(o3), P(b3), P(skip), None, P(out), P(rflag), s),
+                   "suo_conv3x3_wino_f16x2_conv1x1_skip_up")
+
+    def f16_plain():
+        _lib.check(lib.suo_conv3x3_wino_f16x2_n(P(x), L, 64, 64, 128, P(wq16), P(o2), P(b2), P(mid), 1, P(rflag), s), "suo_conv3x3_wino_f16x2_n")
 
     def x3_fused():
         _lib.check(lib.suo_conv3x3_wino_x3_conv1x1_skip_up(P(x), L, 64, 64, P(wq3), P(b2), P(w3x), 1, P(b3), P(skip), None, P(out), s), "suo_conv3x3_wino_x3_conv1x1_skip_up")
@@ -368,12 +411,14 @@ def conv_roofline(L, iters=30):
 
     def direct_plain():
         _lib.check(lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp2), P(b2), P(mid), 128, 1, s), "suo_conv_kxk")
+    us_h, us_hp = (_timed(f, st, iters) for f in (f16_fused, f16_plain))
     us_x, us_xp, us_w, us_wp, us_df, us_dp = (_timed(f, st, iters) for f in (x3_fused, x3_plain, wino_fused, wino_plain, direct_fused, direct_plain))
     px = float(L) * 64 * 64
     flop3, flop1 = 2.0 * px * 128 * 128 * 9, 2.0 * px * 128 * 256
     flop = flop3 + flop1
     flop_exec = flop3 / 2.25 + flop1                               # 16 products per 2x2 tile and channel pair instead of 36
     flop_exec_bf16 = 6.0 * flop_exec                               # every product as 6 bf16 cross terms
+    flop_exec_f16 = 3.0 * flop_exec                                # ... as 3 fp16 cross terms
     tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
     fr = lambda f, t, pk=FP32_MFMA_PEAK_TF: round(f / (t * 1e-6) / 1e12 / pk, 4) if t == t else None  # noqa: E731
     f32_entry = {"avg_launch_us": round(us_w, 2), "frac": fr(flop_exec, us_w), "achieved_tflops": tf(flop_exec, us_w), "peak": FP32_MFMA_PEAK_TF,
@@ -381,7 +426,12 @@ def conv_roofline(L, iters=30):
     x3_entry = {"avg_launch_us": round(us_x, 2), "frac": fr(flop_exec_bf16, us_x, BF16_MFMA_PEAK_TF), "achieved_tflops": tf(flop_exec_bf16, us_x),
                 "peak": BF16_MFMA_PEAK_TF, "f32_equivalent_executed_tflops": tf(flop_exec, us_x), "f32_equivalent_over_f32_peak": fr(flop_exec, us_x),
                 "algorithmic_tflops": tf(flop, us_x)}
-    same = {"wino3x3_kernel<false> (fp32 pipe, 3x3 alone)": {"avg_launch_us": round(us_wp, 2), "frac": fr(flop3 / 2.25, us_wp), "algorithmic_tflops": tf(flop3, us_wp)},
+    f16_entry = {"avg_launch_us": round(us_h, 2), "frac": fr(flop_exec_f16, us_h, BF16_MFMA_PEAK_TF), "achieved_tflops": tf(flop_exec_f16, us_h),
+                 "peak": BF16_MFMA_PEAK_TF, "f32_equivalent_executed_tflops": tf(flop_exec, us_h), "f32_equivalent_over_f32_peak": fr(flop_exec, us_h),
+                 "algorithmic_tflops": tf(flop, us_h)}
+    same = {"wino3x3_x3_kernel<false,false,false,4,2> (f16x2, 3x3 alone)": {"avg_launch_us": round(us_hp, 2), "frac": fr(3.0 * flop3 / 2.25, us_hp, BF16_MFMA_PEAK_TF),
+                                                                            "f32_equivalent_over_f32_peak": fr(flop3 / 2.25, us_hp), "algorithmic_tflops": tf(flop3, us_hp)},
+            "wino3x3_kernel<false> (fp32 pipe, 3x3 alone)": {"avg_launch_us": round(us_wp, 2), "frac": fr(flop3 / 2.25, us_wp), "algorithmic_tflops": tf(flop3, us_wp)},
             "wino3x3_x3_kernel<false> (bf16x3, 3x3 alone)": {"avg_launch_us": round(us_xp, 2), "frac": fr(6.0 * flop3 / 2.25, us_xp, BF16_MFMA_PEAK_TF),
                                                              "f32_equivalent_over_f32_peak": fr(flop3 / 2.25, us_xp), "algorithmic_tflops": tf(flop3, us_xp)},
             "convk_kernel<3,1,32,8,16,2,2,2,2,true> (direct, fused tail)": {"avg_launch_us": round(us_df, 2) if us_df == us_df else None, "frac": fr(flop, us_df)},
@@ -392,7 +442,7 @@ def conv_roofline(L, iters=30):
     # products, the bf16x3 form six MFMAs per product block), the fp32-equivalent rate over the fp32 peak, and from the committed PMC pass of
     # this very launch shape the share of cycles the matrix pipe was busy and the shader clock under this kernel's load (the peaks are quoted
     # at 2.4 GHz; `*_at_measured_clock` rescale them to what the chip actually ran).
-    rec = committed_pmc("pmc_dominant_conv.json", L, "wino3x3_x3_kernel<true" if wino_bf16x3_enabled() else "wino3x3_kernel<true")
+    rec = committed_pmc("pmc_dominant_conv.json", L, dominant_kernel_name())
     clock = rec.get("shader_clock_ghz") if rec else None
     pmc = {"traffic": rec.get("hbm_bytes_per_launch") if rec else None, "traffic_source": "profiles/pmc_dominant_conv.json (rocprofv3 --pmc, tools/profile_round.sh)" if rec else None,
            "traffic_over_algorithmic_bytes": round(rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes"], 3) if rec else None,
@@ -402,6 +452,18 @@ def conv_roofline(L, iters=30):
                   algorithmic_bytes_per_launch=4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 16 + 128 * 256),
                   flop_basis="SURVEY.md 8(d): algorithmic FLOPs 2*px*(128*128*9 + 128*256) per launch / avg launch duration / dense peak of the pipe the kernel runs on")
     shape = "fused Residual tail: 3x3 128->128 (Winograd F(2x2,3x3)) + ReLU, 1x1 128->256 + skip @64x64, %d crops/launch" % L
+    if matrix_pipe() == "f16x2":
+        same["wino3x3_kernel<true> (fp32 pipe, SUO_WINO_BF16X3=0)"] = f32_entry
+        same["wino3x3_x3_kernel<true,false,true,4,3> (bf16x3, SUO_F16X2=0)"] = x3_entry
+        frac = fr(flop, us_h, BF16_MFMA_PEAK_TF)
+        return dict(common, kernel="wino3x3_x3_kernel<true,false,true,4,2> " + shape, dtype="f32 as 2 x fp16 (3 cross terms, fp32 accumulate)", pipe="fp16 MFMA",
+                    achieved=tf(flop, us_h), peak=BF16_MFMA_PEAK_TF, frac=frac, frac_at_measured_clock=at_clock(frac), avg_launch_us=f16_entry["avg_launch_us"],
+                    executed_flop_per_launch=flop_exec_f16, executed_tflops=f16_entry["achieved_tflops"], executed_frac=f16_entry["frac"],
+                    executed_frac_at_measured_clock=at_clock(f16_entry["frac"]),
+                    executed_flop_basis="fp16 FLOPs issued to the MFMA pipe: 3 * (2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1)); dense fp16 peak = the bf16 one",
+                    f32_equivalent_executed_tflops=f16_entry["f32_equivalent_executed_tflops"], f32_equivalent_over_f32_peak=f16_entry["f32_equivalent_over_f32_peak"],
+                    algorithmic_over_f32_peak=fr(flop, us_h), same_process=same)
+    same["wino3x3_x3_kernel<true,false,true,4,2> (f16x2, default)"] = f16_entry
     if wino_bf16x3_enabled():
         same["wino3x3_kernel<true> (fp32 pipe, SUO_WINO_BF16X3=0)"] = f32_entry
         frac = fr(flop, us_x, BF16_MFMA_PEAK_TF)
@@ -451,7 +513,14 @@ def gemm_roofline(L, iters=30):
 
     def gemm_x3():
         _lib.check(lib.suo_conv1x1_bf16x3(P(a), K, K, P(sc), P(sh), P(w3d), P(b), P(out), N, M, N, 1, s), "suo_conv1x1_bf16x3")
-    us, us3 = _timed(gemm, st, iters), _timed(gemm_x3, st, iters)
+    w16h, osch = np.empty(2 * N * K, np.uint16), np.empty(N, np.float32)
+    _lib.check(lib.suo_pack_gemm_weight_f16x2(w.ctypes.data, N, K, w16h.ctypes.data, osch.ctypes.data), "pack_f16x2")
+    w16d, oscd = torch.from_numpy(w16h.view(np.int16)).cuda(), torch.from_numpy(osch).cuda()
+    rflag = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def gemm_f16():
+        _lib.check(lib.suo_conv1x1_f16x2_ex(P(a), K, K, P(sc), P(sh), None, 0, 0, P(w16d), P(oscd), P(b), None, 0, P(out), N, M, N, 1, P(rflag), s), "suo_conv1x1_f16x2_ex")
+    us, us3, us16 = _timed(gemm, st, iters), _timed(gemm_x3, st, iters), _timed(gemm_f16, st, iters)
     flop = 2.0 * M * N * K
     tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
     shape = "1x1 conv K256->N128 with BN+ReLU prologue, + ReLU, M = %d pixels (%d crops @64x64)" % (M, L)
@@ -460,8 +529,28 @@ def gemm_roofline(L, iters=30):
     x3 = {"kernel": "gemm_bf16x3_kernel: " + shape, "avg_launch_us": round(us3, 2), "achieved_tflops": tf(6.0 * flop, us3), "peak": BF16_MFMA_PEAK_TF,
           "frac": round(6.0 * flop / (us3 * 1e-6) / 1e12 / BF16_MFMA_PEAK_TF, 4), "f32_equivalent_tflops": tf(flop, us3),
           "f32_equivalent_over_f32_peak": round(flop / (us3 * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
-    common = {"bound": "mfma", "unit": "TFLOP/s", "flop_per_launch": flop, "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N) + 4.0 * N * K}
+    abytes = 4.0 * (M * K + M * N) + 4.0 * N * K
+    # 42.7 FLOP per byte: below the ridge of either split form (six / three MFMAs per product block: 2500 / 6 / 6.3 TB/s = 66, 2500 / 3 / 6.3 = 132 FLOP/B) --
+    # the split-form launches are HBM-bound: `achieved` = algorithmic bytes / time against the HBM peak (8 TB/s spec; ~6.3 achievable), the matrix-pipe rates beside it
+    hbm = lambda t: {"bound": "hbm", "unit": "GB/s", "achieved": round(abytes / t / 1e3, 1), "peak": HBM_PEAK_GBPS, "frac": round(abytes / t / 1e3 / HBM_PEAK_GBPS, 4),  # noqa: E731
+                     "frac_of_achievable_6300": round(abytes / t / 1e3 / 6300.0, 4), "flop_per_launch": flop, "algorithmic_bytes_per_launch": abytes,
+                     "intensity_flop_per_byte": round(flop / abytes, 1)}
+    f16 = {"kernel": "gemm_bf16x3_kernel<...,NP=2>: " + shape, "avg_launch_us": round(us16, 2), "executed_tflops": tf(3.0 * flop, us16),
+           "executed_over_fp16_peak": round(3.0 * flop / (us16 * 1e-6) / 1e12 / BF16_MFMA_PEAK_TF, 4), "f32_equivalent_tflops": tf(flop, us16),
+           "f32_equivalent_over_f32_peak": round(flop / (us16 * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4), "hbm_gbps_algorithmic": round(abytes / us16 / 1e3, 1)}
+    common = {"bound": "mfma", "unit": "TFLOP/s", "flop_per_launch": flop, "algorithmic_bytes_per_launch": abytes}
+    if matrix_pipe() == "f16x2":
+        x3["hbm_gbps_algorithmic"] = round(abytes / us3 / 1e3, 1)
+        return dict(hbm(us16), kernel=f16["kernel"], dtype="f32 as 2 x fp16 (3 cross terms, fp32 accumulate)", avg_launch_us=f16["avg_launch_us"],
+                    executed_flop_per_launch=3.0 * flop, executed_tflops=f16["executed_tflops"], executed_over_fp16_peak=f16["executed_over_fp16_peak"],
+                    f32_equivalent_tflops=f16["f32_equivalent_tflops"], f32_equivalent_over_f32_peak=f16["f32_equivalent_over_f32_peak"],
+                    traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"), same_process={"bf16x3 (SUO_F16X2=0)": x3, "fp32 pipe (SUO_WINO_BF16X3=0)": f32})
     if wino_bf16x3_enabled():
+        return dict(hbm(us3), kernel=x3["kernel"], dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)", avg_launch_us=x3["avg_launch_us"],
+                    executed_flop_per_launch=6.0 * flop, executed_tflops=x3["achieved_tflops"], executed_over_bf16_peak=x3["frac"],
+                    f32_equivalent_tflops=x3["f32_equivalent_tflops"], f32_equivalent_over_f32_peak=x3["f32_equivalent_over_f32_peak"],
+                    traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"), same_process={"f16x2 (default)": f16, "fp32 pipe (SUO_WINO_BF16X3=0)": f32})
+    if False:
         return dict(common, kernel=x3["kernel"], dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)", achieved=x3["achieved_tflops"], peak=BF16_MFMA_PEAK_TF,
                     frac=x3["frac"], avg_launch_us=x3["avg_launch_us"], executed_flop_per_launch=6.0 * flop, f32_equivalent_tflops=x3["f32_equivalent_tflops"],
                     f32_equivalent_over_f32_peak=x3["f32_equivalent_over_f32_peak"], traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"),
@@ -1004,9 +1093,7 @@ def main():
             "metric": "frames/sec (obj-crops/sec) YCB-V 640x480 8-obj; ADD(-S) vs ref",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "dtype_note": ("fp32 tensors and fp32 accuracy end to end; the Residual blocks' 3x3 + tail and the large 1x1 convolutions form their products on "
-                                           "the bf16 matrix pipe from operands split into three bf16 terms (6 cross terms, fp32 accumulate): DESIGN.md section 4"
-                                           if wino_bf16x3_enabled() else "fp32 MFMA throughout (SUO_WINO_BF16X3=0)"),
+            "dtype": "f32", "dtype_note": DTYPE_NOTE[matrix_pipe()], "matrix_pipe": matrix_pipe(),
             "data": "synthetic", "n_ranks_seen": n_ranks_seen, "rccl_backend": rccl_backend,
             "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> H2D, RoI crop, hourglass keypoint "
                                    "CNN fp32, decode, masks, device-resident compaction -> batched PnP -> acceptance -> LM rounds [10,10,40,40], "

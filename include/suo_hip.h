@@ -251,6 +251,13 @@ int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev
  * seed keys the counter-based sampler (object o uses seed + o * 0x9E3779B97F4A7C15).  Never throws. */
 int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, uint64_t seed,
                   int do_refine, double* T_out, int* status, int* best_inliers, int* iterations);
+/* Index-work parity with the reference's sampler (legacy entry, not the batched fast path): the same RANSAC with hypothesis i of object o sampling the four
+ * points draws[(o * n_draws + i) * 4 .. + 3] (ascending indices into the object's points) instead of the counter-based generator.  Fed with the sequence the
+ * reference's process-global std::default_random_engine (seed 0) gives through get4RandomInRange0 (thirdparty/lambdatwist/pnp_ransac.cpp:161-183,
+ * utils/random.h:65-116; restated host-side in suo_slam_amd/lambdatwist.py: ReferenceSampler) the chosen sample and the consensus set are the reference's.
+ * n_draws >= 1000 (the iteration cap, parameters.h:76-102); winner[o] = index of the hypothesis that became the result, -1 if none; host buffers. */
+int suo_pnp_replay(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, const int* draws, int n_draws, int do_refine,
+                   double* T_out, int* status, int* best_inliers, int* iterations, int* winner);
 /* exact legacy signature: pnp(xs[N,3], ys[N,2], threshold) -> 4x4 */
 int suo_pnp(const double* xs, const double* ys, int n, double threshold, double* T_out);
 

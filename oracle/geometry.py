@@ -30,6 +30,14 @@ def lib():
         L.orc_sample4.argtypes = [C.c_uint64, C.c_uint32, C.c_int, _ip]
         L.orc_pnp_ransac.restype = C.c_int
         L.orc_pnp_ransac.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_uint64, C.c_int, _dp, C.POINTER(C.c_int)]
+        L.orc_pnp_ransac_draws.restype = C.c_int
+        L.orc_pnp_ransac_draws.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_uint64, _ip, C.c_int, C.c_int, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_ref_rng_seed.restype = None
+        L.orc_ref_rng_seed.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+        L.orc_ref_randui.restype = C.c_int
+        L.orc_ref_randui.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_int]
+        L.orc_ref_get4.restype = C.c_int
+        L.orc_ref_get4.argtypes = [C.POINTER(C.c_uint32), C.c_int, _ip]
         u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
         L.orc_optimize.restype = C.c_int
         L.orc_optimize.argtypes = [C.c_int, C.c_int, C.c_int, _dp, u8p, _dp, u8p, _ip, _ip, _dp, _dp, _dp, _dp, u8p, _dp, _ip,
@@ -96,6 +104,55 @@ def pnp(xs, ys, threshold=1e-3, seed=0, refine=True):
     best = C.c_int(0)
     its = lib().orc_pnp_ransac(xs, ys, len(xs), threshold, seed, int(refine), T, C.byref(best))
     return T.reshape(4, 4), best.value, its
+
+
+def pnp_with_draws(xs, ys, draws, threshold=1e-3, refine=True):
+    """The same RANSAC with hypothesis i's 4-point sample read from draws[i] (int32 [n,4]) -- e.g. the reference's own sequence (RefSampler).
+    Returns (T[4,4], best_inliers, iterations, winner) with winner = index of the hypothesis that became the result (-1: none)."""
+    xs = np.ascontiguousarray(xs, np.float64)
+    ys = np.ascontiguousarray(ys, np.float64)
+    d = np.ascontiguousarray(draws, np.int32).reshape(-1, 4)
+    T = np.zeros(16)
+    best, win = C.c_int(0), C.c_int(-1)
+    its = lib().orc_pnp_ransac_draws(xs, ys, len(xs), threshold, 0, d, len(d), int(refine), T, C.byref(best), C.byref(win))
+    return T.reshape(4, 4), best.value, its, win.value
+
+
+class RefSampler:
+    """The reference's RANSAC sampler restated (pnp_oracle.c: orc_ref_*): std::default_random_engine seeded with 0, consumed by
+    get4RandomInRange0 through std::uniform_int_distribution -- one process-global stream that continues from pnp call to pnp call."""
+
+    def __init__(self, seed=0):
+        self.state = C.c_uint32(0)
+        lib().orc_ref_rng_seed(C.byref(self.state), seed)
+
+    def randui(self, lo, hi):
+        return lib().orc_ref_randui(C.byref(self.state), lo, hi)
+
+    def get4(self, n_points, n_samples=1):
+        out = np.zeros((n_samples, 4), np.int32)
+        for i in range(n_samples):
+            lib().orc_ref_get4(C.byref(self.state), n_points, out[i])
+        return out
+
+    def fork(self):
+        c = RefSampler()
+        c.state = C.c_uint32(self.state.value)
+        return c
+
+
+def ref_random():
+    """The reference's random.h compiled here (oracle/_ref/librandom_ref.so), or None."""
+    path = os.path.join(HERE, "_ref", "librandom_ref.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_rng_reset.restype = None
+    L.ref_randui.restype = None
+    L.ref_randui.argtypes = [C.c_int, C.c_int, _ip]
+    L.ref_get4.restype = None
+    L.ref_get4.argtypes = [C.c_uint, C.c_int, _ip]
+    return L
 
 
 CHI2_THR = 5.991          # lib/object_slam.py:680,860

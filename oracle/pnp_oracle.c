@@ -366,6 +366,45 @@ ORC_API void orc_sample4(uint64_t seed, uint32_t iter, int n, int* idx) {
 }
 
 /* ---------------------------------------------------------------- refine (Ceres restatement) */
+/* ---- the REFERENCE's own sampler (index-work parity) --------------------------------------------------------------
+ * PNP::compute draws through get4RandomInRange0 (pnp_ransac.cpp:161-183): a std::set<uint> filled with mlib::randui<int>(0, max - 1)
+ * (utils/random.h:112-116) until it holds 4 values, read out in ascending order.  randui = std::uniform_int_distribution<int>(lo, hi) over the
+ * process-global std::default_random_engine seeded once with RANDOM_SEED_VALUE = 0 (random.h:40-42,65-86).  Both are libstdc++'s:
+ *   default_random_engine = minstd_rand0: x <- 16807 x mod (2^31 - 1); seed 0 -> state 1; min 1, max 2^31 - 2
+ *   uniform_int_distribution (range of the engine > range asked): scaling = urngrange / (hi - lo + 1), past = (hi - lo + 1) * scaling,
+ *   draw x - 1 until it is < past, return lo + (x - 1) / scaling                         (bits/uniform_int_dist.h, the "downscaling" branch)
+ * Pinned bit for bit against the reference's header compiled here (oracle/ref_random_shim.cpp -> tests/test_ref_sampler.py, tests/golden/sampler_golden.npz). */
+ORC_API void orc_ref_rng_seed(uint32_t* state, uint32_t seed) {
+    uint32_t x = (uint32_t)(seed % 2147483647u);
+    *state = x == 0 ? 1u : x;
+}
+static uint32_t ref_rng_next(uint32_t* state) {
+    *state = (uint32_t)(((uint64_t)*state * 16807u) % 2147483647u);
+    return *state;
+}
+ORC_API int orc_ref_randui(uint32_t* state, int lo, int hi) {
+    const uint64_t urngrange = 2147483646u - 1u, urange = (uint64_t)((unsigned)hi - (unsigned)lo);
+    const uint64_t uerange = urange + 1, scaling = urngrange / uerange, past = uerange * scaling;
+    uint64_t ret;
+    do ret = (uint64_t)ref_rng_next(state) - 1u; while (ret >= past);
+    return (int)(ret / scaling) + lo;
+}
+/* one get4RandomInRange0(max): 4 distinct values in [0, max), ascending; returns the number of randui calls it consumed */
+ORC_API int orc_ref_get4(uint32_t* state, int max, int* idx) {
+    int cnt = 0, calls = 0;
+    while (cnt < 4) {
+        const int v = orc_ref_randui(state, 0, max - 1);
+        ++calls;
+        int dup = 0;
+        for (int k = 0; k < cnt; ++k) dup |= (idx[k] == v);
+        if (dup) continue;
+        int pos = cnt++;
+        while (pos > 0 && idx[pos - 1] > v) { idx[pos] = idx[pos - 1]; --pos; }
+        idx[pos] = v;
+    }
+    return calls;
+}
+
 static void quat_mul(const double* a, const double* b, double* o) {
     o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
     o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
@@ -510,19 +549,33 @@ static int select_inliers(const double* xs, const double* ys, int n, double thr2
 
 /* PNP::compute + refine + py_pnp output convention.  T_out row-major 4x4; returns number of RANSAC
  * iterations executed; *best_inliers_out the consensus size.  n >= 4 (caller guarantees, object_slam.py:31). */
+/* draws != NULL: hypothesis i takes the sample draws[4 i .. 4 i + 3] (a table made by orc_ref_get4 -- the reference's sequence -- or anything else) instead of
+ * the counter-based sampler; n_draws must cover the loop (the iteration cap, orc_get_iterations(0)).  *winner_out = index of the hypothesis that became best_pose. */
+ORC_API int orc_pnp_ransac_draws(const double* xs, const double* ys, int n, double threshold, uint64_t seed, const int* draws, int n_draws, int do_refine,
+                                 double* T_out, int* best_inliers_out, int* winner_out);
 ORC_API int orc_pnp_ransac(const double* xs, const double* ys, int n, double threshold, uint64_t seed, int do_refine,
                            double* T_out, int* best_inliers_out) {
+    return orc_pnp_ransac_draws(xs, ys, n, threshold, seed, 0, 0, do_refine, T_out, best_inliers_out, 0);
+}
+ORC_API int orc_pnp_ransac_draws(const double* xs, const double* ys, int n, double threshold, uint64_t seed, const int* draws, int n_draws, int do_refine,
+                                 double* T_out, int* best_inliers_out, int* winner_out) {
     double bq[4] = {1, 0, 0, 0}, bt[3] = {0, 0, 0};
     unsigned best = 0;
     unsigned iters = (unsigned)orc_get_iterations(0.0);
     unsigned i;
+    int winner = -1;
     for (i = 0; i < iters; ++i) {
         int idx[4];
         double q[4], t[3];
+        if (draws) {
+            if ((int)i >= n_draws) break;
+            memcpy(idx, draws + 4 * i, sizeof(idx));
+        } else
         orc_sample4(seed, i, n, idx);
         orc_p4p(xs, ys, idx, q, t);
         unsigned inl = evaluate_inlier_set(xs, ys, n, threshold, q, t, best);
         if (inl > best) {
+            winner = (int)i;
             best = inl;
             memcpy(bq, q, sizeof(bq));
             memcpy(bt, t, sizeof(bt));
@@ -544,5 +597,6 @@ ORC_API int orc_pnp_ransac(const double* xs, const double* ys, int n, double thr
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T_out[4 * r + c] = R[3 * r + c]; T_out[4 * r + 3] = bt[r]; }
     T_out[12] = T_out[13] = T_out[14] = 0; T_out[15] = 1;
     if (best_inliers_out) *best_inliers_out = (int)best;
+    if (winner_out) *winner_out = winner;
     return (int)i;
 }

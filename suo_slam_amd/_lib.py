@@ -81,6 +81,7 @@ SIGNATURES = {
     "suo_maxpool2": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_upsample2_add": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_pnp_batch": (C.c_int, [C.c_int, VP, VP, VP, C.c_double, C.c_uint64, C.c_int, VP, VP, VP, VP]),
+    "suo_pnp_replay": (C.c_int, [C.c_int, VP, VP, VP, C.c_double, VP, C.c_int, C.c_int, VP, VP, VP, VP, VP]),
     "suo_pnp": (C.c_int, [VP, VP, C.c_int, C.c_double, VP]),
     "suo_optimize": (C.c_int, [VP]),
     "suo_optimize_batch": (C.c_int, [VP, C.c_int]),

@@ -14,6 +14,8 @@
 #include "suo_internal.h"
 
 namespace suo {
+int launch_pnp_replay(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, const int* iter_tab, const int* iter_tab_off,
+                      int do_refine, const int* draws, int n_draws, double* T_out, int* status, int* best_out, int* iters_out, int* win_out, hipStream_t s);
 int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, uint64_t seed,
                      const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                      int* iters_out, hipStream_t s);
@@ -128,10 +130,14 @@ using namespace suo;
 
 extern "C" {
 
-int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, uint64_t seed,
-                  int do_refine, double* T_out, int* status, int* best_inliers, int* iterations) {
+static int pnp_batch_impl(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, uint64_t seed, const int* draws, int n_draws,
+                          int do_refine, double* T_out, int* status, int* best_inliers, int* iterations, int* winner) {
     if (n_obj <= 0) return SUO_OK;
     if (!n_pts || !xs || !ys || !T_out) { suo_set_error("suo_pnp_batch: null argument"); return SUO_ERR_ARG; }
+    if (draws && n_draws < pnp_get_iterations(0.0)) {
+        suo_set_error("suo_pnp_replay: %d draws per object, the RANSAC loop may run %d iterations", n_draws, pnp_get_iterations(0.0));
+        return SUO_ERR_ARG;
+    }
     std::lock_guard<std::mutex> lock(g_arena.mu);
     std::vector<int> offsets(n_obj + 1, 0), tab_off(n_obj, 0);
     std::vector<int> tab;
@@ -145,9 +151,10 @@ int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* y
     Layout L;
     const size_t o_off = L.take(sizeof(int) * (n_obj + 1)), o_toff = L.take(sizeof(int) * n_obj), o_tab = L.take(sizeof(int) * tab.size());
     const size_t o_xs = L.take(sizeof(double) * 3 * (size_t)total), o_ys = L.take(sizeof(double) * 2 * (size_t)total);
+    const size_t o_dr = L.take(draws ? sizeof(int) * 4 * (size_t)n_draws * n_obj : 0);
     const size_t in_bytes = L.off;
     const size_t o_T = L.take(sizeof(double) * 16 * (size_t)n_obj), o_st = L.take(sizeof(int) * n_obj), o_best = L.take(sizeof(int) * n_obj),
-                 o_it = L.take(sizeof(int) * n_obj);
+                 o_it = L.take(sizeof(int) * n_obj), o_win = L.take(sizeof(int) * n_obj);
     int rc = g_arena.ensure(L.off);
     if (rc != SUO_OK) return rc;
     char* h = g_arena.host;
@@ -157,8 +164,14 @@ int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* y
     memcpy(h + o_tab, tab.data(), sizeof(int) * tab.size());
     memcpy(h + o_xs, xs, sizeof(double) * 3 * (size_t)total);
     memcpy(h + o_ys, ys, sizeof(double) * 2 * (size_t)total);
+    if (draws) memcpy(h + o_dr, draws, sizeof(int) * 4 * (size_t)n_draws * n_obj);
     hipStream_t s = g_arena.stream;
     SUO_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    if (draws)
+        rc = launch_pnp_replay(n_obj, (const int*)(d + o_off), (const double*)(d + o_xs), (const double*)(d + o_ys), threshold, (const int*)(d + o_tab),
+                               (const int*)(d + o_toff), do_refine, (const int*)(d + o_dr), n_draws, (double*)(d + o_T), (int*)(d + o_st), (int*)(d + o_best),
+                               (int*)(d + o_it), (int*)(d + o_win), s);
+    else
     rc = launch_pnp_batch(n_obj, (const int*)(d + o_off), (const double*)(d + o_xs), (const double*)(d + o_ys), threshold, seed,
                           (const int*)(d + o_tab), (const int*)(d + o_toff), do_refine, (double*)(d + o_T), (int*)(d + o_st),
                           (int*)(d + o_best), (int*)(d + o_it), s);
@@ -169,7 +182,19 @@ int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* y
     if (status) memcpy(status, h + o_st, sizeof(int) * n_obj);
     if (best_inliers) memcpy(best_inliers, h + o_best, sizeof(int) * n_obj);
     if (iterations) memcpy(iterations, h + o_it, sizeof(int) * n_obj);
+    if (winner && draws) memcpy(winner, h + o_win, sizeof(int) * n_obj);
     return SUO_OK;
+}
+
+int suo_pnp_batch(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, uint64_t seed,
+                  int do_refine, double* T_out, int* status, int* best_inliers, int* iterations) {
+    return pnp_batch_impl(n_obj, n_pts, xs, ys, threshold, seed, nullptr, 0, do_refine, T_out, status, best_inliers, iterations, nullptr);
+}
+
+int suo_pnp_replay(int n_obj, const int* n_pts, const double* xs, const double* ys, double threshold, const int* draws, int n_draws, int do_refine,
+                   double* T_out, int* status, int* best_inliers, int* iterations, int* winner) {
+    if (!draws) { suo_set_error("suo_pnp_replay: draws is NULL"); return SUO_ERR_ARG; }
+    return pnp_batch_impl(n_obj, n_pts, xs, ys, threshold, 0, draws, n_draws, do_refine, T_out, status, best_inliers, iterations, winner);
 }
 
 int suo_pnp(const double* xs, const double* ys, int n, double threshold, double* T_out) {

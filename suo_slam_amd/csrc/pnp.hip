@@ -546,13 +546,17 @@ DEV unsigned select_inliers(const double* xs, const double* ys, int n, double th
 // PNP_WAVES = 4 for launches of many objects (batched frames: more workgroups per CU), 16 for a frame or two (the one-frame call: 1000
 // iterations -- the cap, what random-weight keypoints run to -- in ONE round instead of four: 152 -> ~70 us for 8 objects).  The result
 // does not depend on it: the accept rule is replayed in index order whatever the round size.
-template <int PNP_WAVES>
+// REPLAY (suo_pnp_replay: index-work parity with the reference's own sampler): hypothesis i of object o takes the 4-point sample draws[(o * n_draws + i) * 4 ..]
+// -- a host-made table, e.g. the sequence std::default_random_engine + get4RandomInRange0 give (pnp_ransac.cpp:161-183) -- instead of sample4; win_out[o] = the
+// hypothesis that became best_pose (-1: none).  Everything else is the same code.
+template <int PNP_WAVES, bool REPLAY = false>
 __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __restrict__ offsets, const int* __restrict__ counts,
                                                                    const int* __restrict__ group_first, const double* __restrict__ xs_all,
                                                                    const double* __restrict__ ys_all, double threshold, uint64_t seed,
                                                                    const int* __restrict__ iter_tab, const int* __restrict__ iter_tab_off,
                                                                    int do_refine, double* __restrict__ T_out, int* __restrict__ status,
-                                                                   int* __restrict__ best_out, int* __restrict__ iters_out) {
+                                                                   int* __restrict__ best_out, int* __restrict__ iters_out,
+                                                                   const int* __restrict__ draws = nullptr, int n_draws = 0, int* __restrict__ win_out = nullptr) {
     const int o = blockIdx.x, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ unsigned s_cnt[64 * PNP_WAVES];
@@ -564,6 +568,7 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
     double bq[4] = {1, 0, 0, 0}, bt[3] = {0, 0, 0};
     unsigned best = 0;
     unsigned i_done = 0;
+    int win_abs = -1;
     const bool solvable = n >= 4 && n <= 64 * PNP_MAX_PER_LANE;
     const double thr2 = threshold * threshold;
     if (solvable) {
@@ -591,6 +596,10 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
             unsigned cnt = 0;
             if (base + wv * 64 < iters) {                  // (wave-uniform: a wave whose 64 hypotheses all lie beyond the loop skips them)
                 int idx[4];
+                if constexpr (REPLAY) {
+                    const int* d = draws + ((size_t)o * n_draws + (i < (unsigned)n_draws ? i : 0u)) * 4;      // (beyond the loop bound: never accepted, any sample)
+                    for (int k = 0; k < 4; ++k) idx[k] = d[k];
+                } else
                 sample4(oseed, i, n, idx);
                 p4p(xs, ys, idx, q, t);
                 cnt = count_inliers(xs, ys, n, thr2, q, t);
@@ -652,6 +661,7 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
                         w0 = o < w0 ? o : w0;
                     }
                     win = w0;
+                    win_abs = (int)base + w0;
                     best = nb;
                     iters = (unsigned)tab[best];
                 }
@@ -691,6 +701,7 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
         status[o] = ident ? 1 : 0;
         if (best_out) best_out[o] = (int)best;
         if (iters_out) iters_out[o] = (int)i_done;
+        if (REPLAY && win_out) win_out[o] = win_abs;
     }
 }
 
@@ -705,6 +716,15 @@ int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, co
     else
         hipLaunchKernelGGL(pnp_batch_kernel<4>, dim3(n_obj), dim3(256), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
                            do_refine, T_out, status, best_out, iters_out);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+// hypothesis samples from a table (draws [n_obj][n_draws][4], n_draws >= the iteration cap iter_tab[...][0]); win_out [n_obj]
+int launch_pnp_replay(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, const int* iter_tab, const int* iter_tab_off,
+                      int do_refine, const int* draws, int n_draws, double* T_out, int* status, int* best_out, int* iters_out, int* win_out, hipStream_t s) {
+    if (n_obj <= 0) return SUO_OK;
+    hipLaunchKernelGGL((pnp_batch_kernel<4, true>), dim3(n_obj), dim3(256), 0, s, offsets, (const int*)nullptr, (const int*)nullptr, xs, ys, threshold, (uint64_t)0, iter_tab,
+                       iter_tab_off, do_refine, T_out, status, best_out, iters_out, draws, n_draws, win_out);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }

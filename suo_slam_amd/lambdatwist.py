@@ -33,11 +33,85 @@ def pnp_batch(xs_list, ys_list, threshold=0.001, seed=0, refine=True, return_inf
     return T, status
 
 
+class ReferenceSampler:
+    """The reference's RANSAC sampler, host side: PNP::compute draws its 4-point samples through get4RandomInRange0
+    (/root/reference/thirdparty/lambdatwist/pnp_ransac.cpp:161-183) = a std::set<uint> filled with mlib::randui<int>(0, n - 1)
+    (utils/random.h:112-116) until it holds four values, read in ascending order; randui is std::uniform_int_distribution<int> over the PROCESS-GLOBAL
+    std::default_random_engine seeded once with RANDOM_SEED_VALUE = 0 (random.h:40-42,65-86) -- the stream continues from one pnp call to the next.
+    libstdc++: default_random_engine = minstd_rand0 (x <- 16807 x mod 2^31 - 1, seed 0 -> 1); the distribution scales down by rejection
+    (scaling = (2^31 - 3) / n; draw x - 1 until < n * scaling; divide).  Pinned against the reference's header compiled in the build container
+    (tests/test_ref_sampler.py, tests/golden/sampler_golden.npz)."""
+    M = 2147483647
+
+    def __init__(self, seed=0):
+        x = seed % self.M
+        self.state = 1 if x == 0 else x
+
+    def randui(self, lo, hi):
+        uerange = hi - lo + 1
+        scaling = (self.M - 3) // uerange                                       # urngrange = max - min = (M - 1) - 1 - ... = 2^31 - 3
+        past = uerange * scaling
+        while True:
+            self.state = (self.state * 16807) % self.M
+            r = self.state - 1
+            if r < past:
+                return lo + r // scaling
+
+    def get4(self, n_points):
+        picked = set()
+        while len(picked) < 4:
+            picked.add(self.randui(0, n_points - 1))
+        return sorted(picked)
+
+    def table(self, n_points, n_samples):
+        """The next n_samples samples as int32 [n_samples, 4] WITHOUT consuming the stream (a copy draws them)."""
+        c = ReferenceSampler()
+        c.state = self.state
+        return np.array([c.get4(n_points) for _ in range(n_samples)], np.int32)
+
+    def advance(self, n_points, n_samples):
+        for _ in range(n_samples):
+            self.get4(n_points)
+
+
+_reference_sampler = None          # set_reference_sampler(True): pnp() consumes the reference's own draw sequence (index-work parity mode)
+MAX_ITERATIONS = 1000              # PnpParams::get_iterations' cap (parameters.h:76-102)
+
+
+def set_reference_sampler(on=True, seed=0):
+    """pnp() -- the legacy one-object entry -- then samples exactly what the reference's process-global generator would hand PNP::compute, call after call
+    (the batched fast paths keep their counter-based sampler: hypothesis i of an object is a function of (seed, i) alone, which is what lets the device
+    evaluate a thousand of them at once)."""
+    global _reference_sampler
+    _reference_sampler = ReferenceSampler(seed) if on else None
+    return _reference_sampler
+
+
+def pnp_replay(xs_in, ys_in, draws, threshold=0.001, refine=True):
+    """One object with hypothesis i sampling draws[i] (int32 [>= 1000, 4]).  Returns (T[4,4], info) with info = best_inliers, iterations, winner."""
+    xs = np.ascontiguousarray(xs_in, np.float64)
+    ys = np.ascontiguousarray(ys_in, np.float64)
+    d = np.ascontiguousarray(draws, np.int32).reshape(-1, 4)
+    assert xs.ndim == 2 and xs.shape[1] == 3 and ys.shape == (xs.shape[0], 2)
+    lib = _lib.lib()
+    _lib.require_gpu()
+    T = np.zeros((4, 4))
+    n = np.array([xs.shape[0]], np.int32)
+    st, best, its, win = (np.zeros(1, np.int32) for _ in range(4))
+    _lib.check(lib.suo_pnp_replay(1, n.ctypes.data, xs.ctypes.data, ys.ctypes.data, float(threshold), d.ctypes.data, int(d.shape[0]), int(refine),
+                                  T.ctypes.data, st.ctypes.data, best.ctypes.data, its.ctypes.data, win.ctypes.data), "suo_pnp_replay")
+    return T, {"best_inliers": int(best[0]), "iterations": int(its[0]), "winner": int(win[0]), "status": int(st[0])}
+
+
 def pnp(xs_in, ys_in, threshold=0.001):
     """Legacy signature of lambdatwist.pnp: returns a fresh 4x4 float64 array (identity = failure)."""
     xs = np.ascontiguousarray(xs_in, np.float64)
     ys = np.ascontiguousarray(ys_in, np.float64)
     assert xs.ndim == 2 and xs.shape[1] == 3 and ys.shape == (xs.shape[0], 2)
+    if _reference_sampler is not None and xs.shape[0] >= 4:
+        T, info = pnp_replay(xs, ys, _reference_sampler.table(xs.shape[0], MAX_ITERATIONS), threshold)
+        _reference_sampler.advance(xs.shape[0], info["iterations"])           # PNP::compute drew exactly total_iters samples
+        return T
     lib = _lib.lib()
     _lib.require_gpu()
     T = np.zeros((4, 4))

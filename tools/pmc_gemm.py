@@ -6,7 +6,8 @@ Two roles:
 Shapes: residual  (K 128 -> N 256 + identity skip, M = 524288: Residual.conv3 at 64x64, 128 crops)
         conv1     (K 256 -> N 128, BN-ReLU prologue + ReLU, M = 524288: Residual.conv1)
         lin       (K 256 -> N 256 + ReLU, M = 524288: the lin_ head)
-        conv1_x3  (conv1 through gemm_bf16x3_kernel, the form the network launches by default: csrc/gemm_bf16x3.hip)
+        conv1_x3  (conv1 through gemm_bf16x3_kernel with three bf16 planes: csrc/gemm_bf16x3.hip, SUO_F16X2=0)
+        conv1_f16 (the same kernel on two fp16 planes, csrc/f16x2.h: the form the network launches by default)
 Driver: tools/profile_gemm_pmc.sh (one rocprofv3 process per counter group, no other tracing, as the micro-architecture
 guide prescribes)."""
 import json
@@ -21,6 +22,7 @@ SHAPES = {   # K1, N, kwargs, algorithmic bytes (activations + output (+ residua
     "conv1": (256, 128, dict(pro=True, relu=True), 4 * (M * 256 + M * 128 + 256 * 128)),
     "lin": (256, 256, dict(relu=True), 4 * (M * 256 + M * 256 + 256 * 256)),
     "conv1_x3": (256, 128, dict(pro=True, relu=True, x3=True), 4 * (M * 256 + M * 128) + 6 * 256 * 128),
+    "conv1_f16": (256, 128, dict(pro=True, relu=True, x3=True, f16=True), 4 * (M * 256 + M * 128) + 4 * 256 * 128),
 }
 
 
@@ -40,6 +42,9 @@ def run(shape, iters):
         w3 = np.empty(3 * N * K, np.uint16)
         _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data))
         w3d = torch.from_numpy(w3.view(np.int16)).cuda()
+        w16, osc = np.empty(2 * N * K, np.uint16), np.empty(N, np.float32)
+        _lib.check(lib.suo_pack_gemm_weight_f16x2(w.ctypes.data, N, K, w16.ctypes.data, osc.ctypes.data))
+        w16d, oscd, flag = torch.from_numpy(w16.view(np.int16)).cuda(), torch.from_numpy(osc).cuda(), torch.zeros(1, dtype=torch.int32, device="cuda")
         rot = 8                                                # distinct buffers: inputs are not L2-resident between launches
         a = [torch.randn((M, K), device="cuda") for _ in range(rot)]
         o = [torch.empty((M, N), device="cuda") for _ in range(rot)]
@@ -51,9 +56,12 @@ def run(shape, iters):
         def fn():
             k = i[0] % rot
             i[0] += 1
-            _lib.check(lib.suo_conv1x1_bf16x3(P(a[k]), K, K, P(sc), P(sh), P(w3d), P(b), P(o[k]), N, M, N, 1, s))
+            if kw.get("f16"):
+                _lib.check(lib.suo_conv1x1_f16x2_ex(P(a[k]), K, K, P(sc), P(sh), None, 0, 0, P(w16d), P(oscd), P(b), None, 0, P(o[k]), N, M, N, 1, P(flag), s))
+            else:
+                _lib.check(lib.suo_conv1x1_bf16x3(P(a[k]), K, K, P(sc), P(sh), P(w3d), P(b), P(o[k]), N, M, N, 1, s))
         us = bo.timeit(fn)
-        print(f"gemm_bf16x3 M={M} K={K} N={N}: {us:8.2f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF (fp32-equivalent)")
+        print(f"gemm_{'f16x2' if kw.get('f16') else 'bf16x3'} M={M} K={K} N={N}: {us:8.2f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF (fp32-equivalent)")
     else:
         bo.gemm(M, K, N, **{k: v for k, v in kw.items() if k != "x3"})
     torch.cuda.synchronize()
@@ -82,7 +90,7 @@ def report(shape):
     write = vals["WRITE_SIZE"] * 1024
     cycles = vals["GRBM_GUI_ACTIVE"] / 8           # summed over the 8 XCDs
     flop = 2.0 * M * K * N
-    rec = {"kernel": "gemm_bf16x3_kernel<true>" if kw.get("x3") else "gemm_persist_kernel<2,2,2,2,%s>" % ("true" if kw.get("res") else "false"),
+    rec = {"kernel": ("gemm_bf16x3_kernel<true,...,NP=2> (f16x2)" if kw.get("f16") else "gemm_bf16x3_kernel<true,...,NP=3>") if kw.get("x3") else "gemm_persist_kernel<2,2,2,2,%s>" % ("true" if kw.get("res") else "false"),
            "shape": f"M={M} K={K} N={N} {kw}",
            "avg_launch_us": round(dur[0] / 1e3, 2), "min_launch_us": round(dur[1] / 1e3, 2), "launches_timed": dur[2],
            "tflops": round(flop / dur[0] / 1e3, 1), "mfma_flop_per_busy_cycle": 1024 if kw.get("x3") else 64,
@@ -92,7 +100,7 @@ def report(shape):
            "mfma_util": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles), 3),
            "l2_hit_rate": round(vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), 3)}
     print(json.dumps(rec, indent=1))
-    want = "conv1_x3" if os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "") else "conv1"
+    want = "conv1" if os.environ.get("SUO_WINO_BF16X3", "1") in ("0", "") else ("conv1_x3" if os.environ.get("SUO_F16X2", "1") in ("0", "") else "conv1_f16")
     if shape == want and M == 1048576:                    # bench.py's roofline_all.largest_gemm reads `traffic` from here
         out = {"kernel": kname, "crops_per_launch": M // 4096, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "detail": rec}
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_gemm.json"), "w"), indent=1)

@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 # the fused Residual tail in Winograd form as the network launches it: bf16 pipe with 3-way split operands (default), or the fp32 pipe
 X3 = os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
-KERNEL = "wino3x3_x3_kernel<true,false,true,4>" if X3 else "wino3x3_kernel<true,4,false>"
+F16 = X3 and os.environ.get("SUO_F16X2", "1") not in ("0", "")          # two fp16 planes (csrc/f16x2.h), the default
+KERNEL = ("wino3x3_x3_kernel<true,false,true,4,2>" if F16 else "wino3x3_x3_kernel<true,false,true,4,3>") if X3 else "wino3x3_kernel<true,4,false>"
 vals = {}
 dur_ns = {}                                     # counter -> average duration of the kernel in the pass that collected it
 for f in os.listdir(os.path.join(ROOT, "gpurun_out", "pmc")):
@@ -33,7 +34,7 @@ write = vals["WRITE_SIZE"] * 1024
 cycles = vals["GRBM_GUI_ACTIVE"] / 8            # summed over the 8 XCDs
 rec = {"kernel": KERNEL, "crops_per_launch": L, "hbm_bytes_per_launch": round(fetch + write),
        "fetch_bytes_corrected": round(fetch), "write_bytes": round(write),
-       "algorithmic_bytes": L * 64 * 64 * (128 + 256 + 256) * 4 + (128 * 128 * 16 + 128 * 256) * (6 if X3 else 4),      # in 128 ch + skip 256 ch + out 256 ch + weights
+       "algorithmic_bytes": L * 64 * 64 * (128 + 256 + 256) * 4 + (128 * 128 * 16 + 128 * 256) * (4 if F16 or not X3 else 6),      # in 128 ch + skip 256 ch + out 256 ch + weights
        "mfma_busy_cycles": vals["SQ_VALU_MFMA_BUSY_CYCLES"], "kernel_cycles": cycles,
        "mfma_util": vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles),      # busy SIMD-cycles / (256 CUs x 4 SIMDs x kernel cycles)
        # shader clock under THIS kernel's load = GRBM_GUI_ACTIVE / 8 XCDs / the launch's duration in the same (profiled) pass

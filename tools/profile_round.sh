@@ -51,6 +51,6 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
 done
 python3 $R/tools/pmc_to_json.py 256 > $OUT/pmc.txt 2>&1
 cp $R/profiles/pmc_dominant_conv.json $OUT/ 2>/dev/null
-SUO_PMC_GEMM_M=1048576 bash $R/tools/profile_gemm_pmc.sh conv1_x3 conv1 > $OUT/pmc_gemm.txt 2>&1
+SUO_PMC_GEMM_M=1048576 bash $R/tools/profile_gemm_pmc.sh conv1_f16 conv1_x3 conv1 > $OUT/pmc_gemm.txt 2>&1
 cp $R/profiles/pmc_gemm.json $OUT/ 2>/dev/null
 ls $OUT
