@@ -288,6 +288,9 @@ typedef struct suo_frame_geom_params {
     int its[4]; int n_rounds;      /* {10,10,40,40}, 4 (:843-846) */
     double chi2_thr;               /* 5.991 */
     double huber_delta;            /* sqrt(5.991) */
+    uint64_t* seed_dev;            /* NULL, or a device-resident running key: the launch samples with seed + *seed_dev (read when its PnP kernel runs) and
+                                    * adds its number of solvable problems (crops with >= 4 keypoints) to *seed_dev when done -- what a host caller adds to
+                                    * `seed` between launches, without waiting for the previous launch's read-back (a second batch in flight) */
 } suo_frame_geom_params;
 typedef struct suo_frame_geom_result {
     int n_frames, n_crops;

@@ -133,7 +133,7 @@ class BaProblem(C.Structure):
 class FrameGeomParams(C.Structure):
     """ctypes mirror of suo_frame_geom_params."""
     _fields_ = [("pnp_threshold", C.c_double), ("seed", C.c_uint64), ("use_cov", C.c_int), ("do_lm", C.c_int), ("its", C.c_int * 4),
-                ("n_rounds", C.c_int), ("chi2_thr", C.c_double), ("huber_delta", C.c_double)]
+                ("n_rounds", C.c_int), ("chi2_thr", C.c_double), ("huber_delta", C.c_double), ("seed_dev", VP)]
 
 
 class FrameGeomResult(C.Structure):

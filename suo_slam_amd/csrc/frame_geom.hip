@@ -34,7 +34,7 @@ namespace suo {
 int pnp_get_iterations(double estimated_inliers);
 int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, const int* group_first, const double* xs, const double* ys, double threshold, uint64_t seed,
                             const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
-                            int* iters_out, hipStream_t s);
+                            int* iters_out, hipStream_t s, const uint64_t* seed_add = nullptr);
 int launch_lm_frame2(const void* problems_dev, int n_problems, int max_obj, int max_edges, hipStream_t s);
 
 constexpr int FG_MAX_OBJ = 16;          // objects per frame the one-wave-per-object LM kernel takes (csrc/lm_frame.hip: LF_MAX_OBJ)
@@ -99,14 +99,17 @@ __global__ __launch_bounds__(64) void fg_prep_kernel(FgArrays A, const float* __
 }
 
 // ---- acceptance (:1143-1165) + graph of the frame (:746-839) as an LmProblem -------------------------------------------------------
+// seed_run: the caller's device-resident running sampler key (suo_frame_geom_params.seed_dev) -- advanced here, AFTER the PnP launch of this chain read it, by the
+// frame's number of solvable problems: what a host caller adds to its seed between launches (suo_slam_amd/object_slam.py), without the read-back in between
 __global__ __launch_bounds__(64) void fg_build_kernel(FgArrays A, int n_rounds, int its0, int its1, int its2, int its3, double chi2_thr,
-                                                      double huber_delta) {
+                                                      double huber_delta, unsigned long long* seed_run) {
     const int f = blockIdx.x, lane = threadIdx.x;
     const int g0 = A.frame_first[f], nobj = A.frame_first[f + 1] - g0;
-    int ne = 0;
+    int ne = 0, nsolv = 0;
     if (lane < nobj) {
         const int g = g0 + lane;
         const int n = A.counts[g];
+        nsolv = n >= 4 ? 1 : 0;
         const double* T = A.T_pnp + 16 * g;
         const bool ok = A.status[g] == 0 && n >= 4 && T[11] > A.min_depth[g];      // T[2][3] > 0.5 * diameter
         A.accepted[g] = ok ? 1 : 0;
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(64) void fg_build_kernel(FgArrays A, int n_rounds, 
         ne = ok ? n : 0;
     }
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) ne += __shfl_xor(ne, m, 64);
+    for (int m = 32; m > 0; m >>= 1) { ne += __shfl_xor(ne, m, 64); nsolv += __shfl_xor(nsolv, m, 64); }
+    if (seed_run && lane == 0 && nsolv) atomicAdd(seed_run, (unsigned long long)nsolv);
     if (lane < 12) A.cam_T[12 * f + lane] = (lane % 5 == 0) ? 1.0 : 0.0;           // T_GtoC = eye(4)[:3] (:383-385), fixed (:774)
     if (lane == 0) {
         A.cam_fixed[f] = 1;
@@ -274,11 +278,11 @@ int suo_frame_geom_launch(suo_frame_geom* c, int n_frames, const int* frame_firs
     hipLaunchKernelGGL(fg_prep_kernel, dim3(L), dim3(64), 0, s, c->A, uv_dev, cov_dev, mask_dev, model_kps_dev, p->use_cov);
     SUO_HIP_CHECK(hipGetLastError());
     int rc = launch_pnp_batch_counts(L, c->A.offsets, c->A.counts, c->A.crop_frame_first, c->A.xs, c->A.ys, p->pnp_threshold, p->seed, c->A.iter_tab, c->A.tab_off, 1,
-                                     c->A.T_pnp, c->A.status, c->A.best, c->A.iters, s);
+                                     c->A.T_pnp, c->A.status, c->A.best, c->A.iters, s, p->seed_dev);
     if (rc != SUO_OK) return rc;
     const int nr = p->do_lm ? p->n_rounds : 0;
     hipLaunchKernelGGL(fg_build_kernel, dim3(n_frames), dim3(64), 0, s, c->A, nr, p->its[0], p->its[1], p->its[2], p->its[3], p->chi2_thr,
-                       p->huber_delta);
+                       p->huber_delta, (unsigned long long*)p->seed_dev);
     SUO_HIP_CHECK(hipGetLastError());
     if (p->do_lm) {
         rc = launch_lm_frame2(c->A.problems, n_frames, std::max(max_obj, 1), std::max(max_obj, 1) * NUM_KP, s);

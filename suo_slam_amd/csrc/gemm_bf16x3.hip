@@ -25,6 +25,9 @@ typedef float x3_f32x16 __attribute__((ext_vector_type(16)));
 typedef float x3_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SUO_X3_F16_WAVES
+#define SUO_X3_F16_WAVES 3      // waves per SIMD the fp16 form is compiled for: 3 = <= 168 registers, THREE workgroups per CU (with a 2-slot weight ring: 152-160
+#endif                          // registers, no spill).  Measured against 2 (184-192 registers, 4 slots) at 256 crops, us: conv1 394 -> 365, lin 703 -> 623, re-injection 796 -> 748
 #ifndef SUO_X3_BK
 #define SUO_X3_BK 16
 #endif
@@ -34,7 +37,13 @@ typedef unsigned x3_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int X3_BN = 128, X3_BK = SUO_X3_BK, X3_GH = X3_BK / 16, X3_PITCH = X3_BK + 8;      // LDS row pitch in bf16 (48 / 80 bytes: conflict-free 16-byte fragment reads)
 constexpr int X3_LPR = X3_BK / 4, X3_RPP = 256 / X3_LPR;                           // staging: lanes per row (a float4 each), rows per pass
 constexpr int X3_ASLOTS = 64 / X3_BK;                                              // activation steps in flight (K a multiple of 64: slots and stages are compile-time indices)
-constexpr int X3_BSLOTS = 4;                                                       // weight k-groups in flight (a ring over 16-wide groups)
+#ifndef SUO_X3_BSLOTS
+#define SUO_X3_BSLOTS 4
+#endif
+#ifndef SUO_X3_F16_BSLOTS
+#define SUO_X3_F16_BSLOTS 2
+#endif
+constexpr int X3_BSLOTS = SUO_X3_BSLOTS;                                                       // weight k-groups in flight (a ring over 16-wide groups)
 static_assert(X3_BK == 16 || X3_BK == 32, "k-step");
 
 // host: W[N][K] fp32 -> B-operand order of v_mfma_f32_32x32x16_bf16, split like the device does (csrc/bf16x3.h: round-to-nearest terms):
@@ -86,7 +95,7 @@ __device__ __forceinline__ int x3_acc_row(int r, int lane) { return (r & 3) + 8 
 // NP: operand planes -- 3: three bf16 terms, six MFMAs per product block (csrc/bf16x3.h); 2: two fp16 terms, three MFMAs (csrc/f16x2.h: activations enter times
 //     2^S2_XSHIFT, the weights' rows times 2^t_n, the epilogue multiplies by g.oscale[n]; g.range_flag is raised when an activation leaves fp16's range)
 template <bool PRO, bool DUAL, bool RES, bool POOL, int NCB = 2, int RB = 2, int NP = 3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? SUO_X3_F16_WAVES : 2))) void gemm_bf16x3_kernel(const GemmArgs g, const uint16_t* __restrict__ Wp) {
     static_assert(RB == 2 || !POOL, "the pooled epilogue is laid out for 128-row tiles");
     constexpr int X3_BM = 64 * RB, X3_NR = X3_BM / X3_RPP;                    // rows of the tile; staging passes
     static_assert(X3_NR >= 1, "64-row tiles need the 16-wide k-step");
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     }
     const int wvoff = lane * 16;
     x3_f32x4 araw[X3_ASLOTS][X3_NR];
-    x3_u32x4 braw[X3_BSLOTS][NCB][NP];
+    constexpr int BSL = NP == 2 ? SUO_X3_F16_BSLOTS : X3_BSLOTS;          // weight k-groups in flight
+    x3_u32x4 braw[BSL][NCB][NP];
     auto requestA = [&](int ks, int slot) {
 #ifdef SUO_X3_EXP_NOLOADA
         for (int i = 0; i < X3_NR; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
     for (int u = 0; u < X3_ASLOTS; ++u) requestA(u < nsteps ? u : nsteps - 1, u);
 #pragma unroll
-    for (int u = 0; u < X3_BSLOTS; ++u) requestB(u < ngroups ? u : ngroups - 1, u);
+    for (int u = 0; u < BSL; ++u) requestB(u < ngroups ? u : ngroups - 1, u);
     __syncthreads();                                                          // (scale / shift staged)
     split_store(0, 0, 0);
     constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // six cross terms, smallest first
@@ -231,13 +241,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
             for (int h = 0; h < X3_GH; ++h) {
                 // weights of this k-group out of their ring slot, then the slot's next request
-                const int slot = (u * X3_GH + h) % X3_BSLOTS, kg = ks * X3_GH + h;
+                const int slot = (u * X3_GH + h) % BSL, kg = ks * X3_GH + h;
                 x3_u32x4 bw[NCB][NP];
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                     for (int p = 0; p < NP; ++p) bw[cb][p] = braw[slot][cb][p];
-                requestB(kg + X3_BSLOTS < ngroups ? kg + X3_BSLOTS : ngroups - 1, slot);
+                requestB(kg + BSL < ngroups ? kg + BSL : ngroups - 1, slot);
 #pragma unroll
                 for (int t = 0; t < (NP == 3 ? 6 : 3); ++t)
 #pragma unroll

@@ -77,6 +77,7 @@ private:
     int run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s, bool stem_done = false);
     int ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s, hipGraphExec_t* exec, bool stem_done = false);
     bool fused_stem() const;
+    int follow_null_stream();
 
     std::map<std::string, HostTensor> tensors_;
     std::vector<float*> owned_;
@@ -95,7 +96,9 @@ private:
     bool use_graph_ = true; bool dry_run_ = false;
     int pipe_ = 1, pipe_built_ = 1;                      // the pipe in use / the best one the weights were packed for
     unsigned* range_flag_ = nullptr;                     // mapped host memory: the f16x2 kernels raise it, the host reads it after any synchronisation
-    struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    // two executables per captured graph, launched alternately: hipGraphLaunch of an executable whose previous launch is still running blocks the host until
+    // that one ends (measured: 14 ms per call with a second batch in flight behind ObjectSLAM.submit_views_single) -- with two, the host runs ahead by one call
+    struct GraphEntry { hipGraph_t graph = nullptr; hipGraphExec_t exec[2] = {nullptr, nullptr}; int next = 0; };
     std::map<int, GraphEntry> graphs_;
 };
 

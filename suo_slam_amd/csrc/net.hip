@@ -445,7 +445,7 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
 }
 
 Net::~Net() {
-    for (auto& kv : graphs_) { (void)hipGraphExecDestroy(kv.second.exec); (void)hipGraphDestroy(kv.second.graph); }
+    for (auto& kv : graphs_) { for (int i = 0; i < 2; ++i) if (kv.second.exec[i]) (void)hipGraphExecDestroy(kv.second.exec[i]); (void)hipGraphDestroy(kv.second.graph); }
     for (float* p : owned_) (void)hipFree(p);
     if (ws_) (void)hipFree(ws_);
     if (d_mean_logit_) (void)hipFree(d_mean_logit_);
@@ -625,7 +625,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     static const int n_side = getenv("SUO_NET_SIDE_STREAMS") ? std::max(0, std::min(kNumSide, atoi(getenv("SUO_NET_SIDE_STREAMS")))) : 0;
     static const bool serial = getenv("SUO_SERIAL") != nullptr || n_side == 0;     // one stream, kernels back to back
     hipStream_t side = serial ? s : side_[depth_idx % (n_side > 0 ? n_side : 1)];
-    hipEvent_t ev_fork = ev_[(ev_next_++) % kNumEvents], ev_join = ev_[(ev_next_++) % kNumEvents];
+    hipEvent_t ev_fork = ev_[(ev_next_++) % (kNumEvents - 1)], ev_join = ev_[(ev_next_++) % (kNumEvents - 1)];      // (the last event is follow_null_stream's)
     float* up_a = alloc(n_hi);
     float* up_b = alloc(n_hi);
     SUO_HIP_LIVE(hipEventRecord(ev_fork, s));
@@ -734,10 +734,11 @@ int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s,
         hipError_t e = hipStreamEndCapture(s, &ge.graph);
         if (r != SUO_OK) return r;
         SUO_HIP_CHECK(e);
-        SUO_HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+        for (int i = 0; i < 2; ++i) SUO_HIP_CHECK(hipGraphInstantiate(&ge.exec[i], ge.graph, nullptr, nullptr, 0));
         it = graphs_.emplace(key, ge).first;
     }
-    *exec = it->second.exec;
+    *exec = it->second.exec[it->second.next];
+    it->second.next ^= 1;
     return SUO_OK;
 }
 
@@ -749,6 +750,15 @@ int Net::run_backbone(float* in0, int in_c, float* logits, int L, hipStream_t s,
         return SUO_OK;
     }
     return backbone(in0, in_c, logits, L, s, stem_done);
+}
+
+// A NULL-stream call runs on an internal NON-BLOCKING stream, which the legacy NULL stream does not order: whatever the caller enqueued there before the call
+// (the frame's upload kernel, torch ops that produced the boxes) must have run before this call's first kernel reads it.
+int Net::follow_null_stream() {
+    hipEvent_t ev = ev_[kNumEvents - 1];
+    SUO_HIP_CHECK(hipEventRecord(ev, nullptr));
+    SUO_HIP_CHECK(hipStreamWaitEvent(own_stream_, ev, 0));
+    return SUO_OK;
 }
 
 int Net::set_pipe(int p) {
@@ -805,7 +815,7 @@ int Net::prepare(int L, int with_priors, hipStream_t s) {
 int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStream_t s) {
     if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_backbone: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
     const bool own = (s == nullptr);
-    if (own) s = own_stream_;
+    if (own) { s = own_stream_; SUO_TRY(follow_null_stream()); }
     try {
         ws_used_ = 0;
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
@@ -833,7 +843,7 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
                  float* kp_prob, float* kp_logit, float* logits_out, hipStream_t s) {
     if (L <= 0 || L > max_crops_) { suo_set_error("suo_net_forward: L=%d outside [1,%d]", L, max_crops_); return SUO_ERR_ARG; }
     const bool own = (s == nullptr);
-    if (own) s = own_stream_;   // the legacy NULL stream cannot be captured: run on an internal stream and block
+    if (own) { s = own_stream_; SUO_TRY(follow_null_stream()); }   // the legacy NULL stream cannot be captured: run on an internal stream and block
     try {
         // persistent slabs at the bottom of the workspace: staged input + logits
         ws_used_ = 0;

@@ -556,7 +556,8 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
                                                                    const int* __restrict__ iter_tab, const int* __restrict__ iter_tab_off,
                                                                    int do_refine, double* __restrict__ T_out, int* __restrict__ status,
                                                                    int* __restrict__ best_out, int* __restrict__ iters_out,
-                                                                   const int* __restrict__ draws = nullptr, int n_draws = 0, int* __restrict__ win_out = nullptr) {
+                                                                   const int* __restrict__ draws = nullptr, int n_draws = 0, int* __restrict__ win_out = nullptr,
+                                                                   const uint64_t* __restrict__ seed_add = nullptr) {
     const int o = blockIdx.x, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ unsigned s_cnt[64 * PNP_WAVES];
@@ -588,7 +589,8 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
             for (int m = 32; m > 0; m >>= 1) { r += __shfl_xor(r, m, 64); b += __shfl_xor(b, m, 64); }
             rank = r; before = b;
         }
-        const uint64_t oseed = seed + (uint64_t)before + (uint64_t)rank * 0x9E3779B97F4A7C15ULL;
+        // seed_add: the caller's running key lives on the device (suo_frame_geom_params.seed_dev): launch k + 1 is enqueued before launch k's counts are known
+        const uint64_t oseed = seed + (seed_add ? *seed_add : 0ULL) + (uint64_t)before + (uint64_t)rank * 0x9E3779B97F4A7C15ULL;
         int par = 0;
         for (unsigned base = 0; base < iters; base += 64 * PNP_WAVES) {
             const unsigned i = base + wv * 64 + lane;
@@ -707,15 +709,15 @@ __global__ __launch_bounds__(64 * PNP_WAVES) void pnp_batch_kernel(const int* __
 
 int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, const int* group_first, const double* xs, const double* ys, double threshold, uint64_t seed,
                             const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
-                            int* iters_out, hipStream_t s) {
+                            int* iters_out, hipStream_t s, const uint64_t* seed_add = nullptr) {
     if (n_obj <= 0) return SUO_OK;
     static const int wide_upto = getenv("SUO_PNP_WIDE_UPTO") ? atoi(getenv("SUO_PNP_WIDE_UPTO")) : 32;      // objects per launch that still take 16 waves each (0: never)
     if (n_obj <= wide_upto)
         hipLaunchKernelGGL(pnp_batch_kernel<16>, dim3(n_obj), dim3(1024), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
-                           do_refine, T_out, status, best_out, iters_out);
+                           do_refine, T_out, status, best_out, iters_out, (const int*)nullptr, 0, (int*)nullptr, seed_add);
     else
         hipLaunchKernelGGL(pnp_batch_kernel<4>, dim3(n_obj), dim3(256), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
-                           do_refine, T_out, status, best_out, iters_out);
+                           do_refine, T_out, status, best_out, iters_out, (const int*)nullptr, 0, (int*)nullptr, seed_add);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -732,7 +734,7 @@ int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const doub
                      const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                      int* iters_out, hipStream_t s) {
     return launch_pnp_batch_counts(n_obj, offsets, nullptr, nullptr, xs, ys, threshold, seed, iter_tab, iter_tab_off, do_refine, T_out, status, best_out,
-                                   iters_out, s);
+                                   iters_out, s, nullptr);
 }
 
 }  // namespace suo

@@ -175,12 +175,34 @@ class Evaluator:
             batched = not self.debug_saved_only and self.frames_per_call > 1 and not self.debug_gt_kp and not self.gt_cam_pose
             pending = []                                              # (view_id, gt_obj_ids, process_view arguments) waiting for their shared call
 
-            def flush():
+            inflight = []                                             # batches submitted and not yet collected (at most two), oldest first
+
+            def collect_one():
+                batch = inflight.pop(0)
+                for (vid, gt_ids, _), res in zip(batch, self.object_slam.collect_views_single()):
+                    if len(res):
+                        scene_results.append((vid, res[vid]["poses"], gt_ids))
+
+            def flush(last=False):
+                # a batch is SUBMITTED as soon as it is full and COLLECTED when the next one is on the device (ObjectSLAM.submit_views_single /
+                # collect_views_single): the host's bookkeeping of batch i and the preparation of batch i + 1 run under the device work of i + 1
                 if pending:
-                    for (vid, gt_ids, _), res in zip(pending, self.object_slam.process_views_single([p[2] for p in pending])):
-                        if len(res):
-                            scene_results.append((vid, res[vid]["poses"], gt_ids))
+                    batch = list(pending)
                     pending.clear()
+                    if self.object_slam.single_views_take_the_device_chain([p[2] for p in batch]):
+                        self.object_slam.submit_views_single([p[2] for p in batch])
+                        inflight.append(batch)
+                        if len(inflight) == 2:
+                            collect_one()
+                    else:
+                        while inflight:
+                            collect_one()
+                        for (vid, gt_ids, _), res in zip(batch, self.object_slam.process_views_single([p[2] for p in batch])):
+                            if len(res):
+                                scene_results.append((vid, res[vid]["poses"], gt_ids))
+                if last:
+                    while inflight:
+                        collect_one()
             for j, view_id in enumerate(view_ids):
                 gt_obj_ids = ds.obj_ids(scene_id, view_id)
                 if batched:
@@ -204,7 +226,7 @@ class Evaluator:
                             saved_meter.update([o], np.asarray(self.saved_detections["poses"][idx])[None, ...], ds.get_obj_pose(scene_id, view_id, o)[None, ...])
                         else:
                             saved_meter.update_no_det([o])
-            flush()
+            flush(last=True)
             if self.debug_saved_only:
                 continue
             final = self.object_slam.collect_results(no_viz=True, final=True) if self.nviews < 0 else None

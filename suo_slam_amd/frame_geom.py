@@ -45,9 +45,11 @@ class FrameGeometry:
             pass
 
     def launch(self, frame_first, uv_dev, cov_dev, mask_dev, model_kps_dev, kinv, camk, min_depth, seed=0, use_cov=True, do_lm=True,
-               its=(10, 10, 40, 40), pnp_threshold=1e-3, stream=None):
+               its=(10, 10, 40, 40), pnp_threshold=1e-3, stream=None, seed_dev=None):
         """Asynchronous.  uv_dev / cov_dev / mask_dev / model_kps_dev: torch CUDA tensors ([L,41,2] f32, [L,41,2,2] f32, [L,41] u8,
-        [L,41,3] f32) or raw device pointers; frame_first [F+1]; kinv [L,6], camk [L,4], min_depth [L] float64 (host)."""
+        [L,41,3] f32) or raw device pointers; frame_first [F+1]; kinv [L,6], camk [L,4], min_depth [L] float64 (host).
+        seed_dev: a device int64 tensor [1] holding a running sampler key -- the launch samples with seed + seed_dev[0] and adds its number of
+        solvable problems to it when done (suo_frame_geom_params.seed_dev): the next launch can be enqueued before this one's read-back."""
         ff = np.ascontiguousarray(frame_first, np.int32)
         L = int(ff[-1])
         kinv = np.ascontiguousarray(kinv, np.float64).reshape(L, 6)
@@ -59,6 +61,7 @@ class FrameGeometry:
         for i, v in enumerate(its):
             p.its[i] = int(v)
         p.n_rounds, p.chi2_thr, p.huber_delta = len(its), CHI2_THR, HUBER_DELTA
+        p.seed_dev = C.c_void_p(seed_dev.data_ptr()) if seed_dev is not None else None
 
         def ptr(t):
             return C.c_void_p(t.data_ptr()) if hasattr(t, "data_ptr") else C.c_void_p(int(t))

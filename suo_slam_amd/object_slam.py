@@ -169,6 +169,23 @@ class _EdgeRefs:
                 yield (v, o, k)
 
 
+def _on_stream(fn):
+    """Run a method's device work on the object's own (non-NULL) stream.  torch's default stream is the legacy NULL stream, on which libsuo_hip's network
+    entries BLOCK (include/suo_hip.h: "NULL = internal stream + blocking"): measured 13.3 ms of host time per 128-crop call that an asynchronous call returns
+    from in 0.3 ms.  Everything a method enqueues -- uploads, network, masks, geometry chain, read-backs -- goes to the one stream, so it stays ordered."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        st = getattr(self, "_gpu_stream", None)
+        if st is None:
+            return fn(self, *a, **kw)
+        import torch
+        with torch.cuda.stream(st):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class ObjectSLAM:
     def __init__(self, chkpt_path, mesh_db, no_network_cov=False, no_prior_det=False, pred_res=(256, 256),
                  debug_gt_kp=False, sfm_mode=False, single_view_mode=False, viz_cov=False, do_viz_extra=False,
@@ -214,6 +231,8 @@ class ObjectSLAM:
                 state_dict = ck["model"]
                 self.model_epoch = ck.get("epoch", -1)
             self.model = PkpNet(calc_cov=True, state_dict=state_dict, max_crops=max_crops)
+            import torch
+            self._gpu_stream = torch.cuda.Stream(device=self.model.device)
             # frames carry a varying number of detections: capture the graph of every crop count now, not inside a timed view
             self.model.prepare(with_priors=(False,) if (single_view_mode or no_prior_det) else (False, True))
         self.avg_std_meter = AverageMeter()
@@ -284,6 +303,7 @@ class ObjectSLAM:
         return results
 
     # ---------------------------------------------------------------------------------------------
+    @_on_stream
     def process_view(self, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt=None, cam_pose=None):
         """object_slam.py:327-451."""
         assert view_id not in self.cam_poses, f"Repeat view_id {view_id}"
@@ -421,25 +441,81 @@ class ObjectSLAM:
         shape = np.asarray(views[0][1]).shape
         return all(0 < len(v[3]) <= 16 and np.asarray(v[1]).shape == shape and np.asarray(v[1]).dtype == np.uint8 for v in views)
 
+    @_on_stream
     def process_views_single(self, views):
         """Single-view evaluation (evaluate.py --nviews 1: reset / process_view / collect_results per reference view, evaluate.py:338-395) of SEVERAL
         independent views in one device call: `views` = [(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks), ...].
         Returns [collect_results() of view 0, of view 1, ...] -- what the per-view loop returns: everything downstream of the network is bit for bit
         the per-view loop's on the same network outputs (one geometry launch; the PnP sampler's keys continue from frame to frame as the per-view
         loop advances its seed, csrc/pnp.hip); the shared network call picks its kernels by launch size, so its keypoints agree with the
-        per-view calls' to the network's tolerance (1e-5 of the reference either way).  tests/test_gpu_evaluator.py holds both."""
-        import torch
+        per-view calls' to the network's tolerance (1e-5 of the reference either way).  tests/test_gpu_evaluator.py holds both.
+        = submit_views_single + collect_views_single; a caller with more batches to come submits the next one BEFORE collecting this one
+        (Evaluator.run does), so that the host's share of a batch -- bookkeeping of the results, preparation of the next -- runs under the device's."""
         if not self.single_views_take_the_device_chain(views):
+            self.drain_views_single()
             out = []
             for v in views:
                 self.reset()
                 self.process_view(*v[:8])
                 out.append(self.collect_results(no_viz=True))
             return out
+        self.submit_views_single(views)
+        return self.collect_views_single()
+
+    def views_in_flight(self):
+        return len(getattr(self, "_tickets", ()))
+
+    @_on_stream
+    def drain_views_single(self):
+        """Collect (and drop) whatever submit_views_single left in flight."""
+        while self.views_in_flight():
+            self.collect_views_single()
+
+    def _enqueue_views(self, prep, ff):
+        """Network + masks + geometry chain of one prepared batch on the current stream; nothing here waits for the device."""
+        import torch
         from .frame_geom import FrameGeometry, kbbox_terms
         from .pkpnet import keypoint_masks
-        torch.cuda.synchronize()
-        tt0 = time()
+        Ltot, B = ff[-1], len(prep)
+        ring = getattr(self, "_fg_ring", None)
+        if ring is None:
+            ring = self._fg_ring = {"ctx": [None, None], "next": 0}
+        k = ring["next"]
+        ring["next"] = (k + 1) % 2
+        fg = ring["ctx"][k]
+        if fg is None or fg.max_crops < Ltot or fg.max_frames < B:
+            fg = ring["ctx"][k] = FrameGeometry(max(256, Ltot), max(32, B))
+        if getattr(self, "_seed_run", None) is None:
+            self._seed_run = torch.zeros(1, dtype=torch.int64, device=self.model.device)      # the sampler's running key, device-resident
+            self._seed_base = self._pnp_seed
+        K_all = np.concatenate([p[7] for p in prep])
+        kinv, camk = kbbox_terms(K_all)
+        min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for p in prep for o in p[3]], dtype=np.float64)
+        mm_all = np.concatenate([p[6] for p in prep]).astype(np.uint8)
+        kps_all = np.ascontiguousarray(np.concatenate([p[5] for p in prep]), dtype=np.float32)
+        pred = self.model.forward_frames([np.ascontiguousarray(p[1]) for p in prep], [np.asarray(p[4], np.float32) for p in prep], check=False,
+                                         extra=[mm_all, kps_all])
+        mm_dev, kps_dev = pred["extra"]
+        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+        masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], mm_dev, self.bbox_thresh, vt)
+        its = (10, 10, 40, 40) if self.sfm_mode else (10, 10, 10, 10)
+        fg.launch(ff, pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._seed_base, seed_dev=self._seed_run,
+                  use_cov=not self.no_network_cov, do_lm=True, its=its)
+        return fg, pred
+
+    @_on_stream
+    def submit_views_single(self, views):
+        """First half of process_views_single: prepare the batch and enqueue its device work.  Up to two batches may be in flight."""
+        import torch
+        assert self.single_views_take_the_device_chain(views), "submit_views_single: this batch does not take the device chain (process_views_single decides)"
+        assert self.views_in_flight() < 2, "two batches are already in flight: collect one first"
+        if not self.views_in_flight():
+            # nothing in flight: the host's seed is complete -- (re)base the device-resident key on it (another route may have advanced it meanwhile)
+            if getattr(self, "_seed_run", None) is not None and getattr(self, "_seed_expect", 0) + self._seed_base != self._pnp_seed:
+                self._seed_run.zero_()
+                self._seed_base, self._seed_expect = self._pnp_seed, 0
+            elif getattr(self, "_seed_run", None) is None:
+                self._seed_expect = 0
         prep, ff = [], [0]
         for view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, _ in views:
             obj_ids = np.asarray(obj_ids)
@@ -449,30 +525,40 @@ class ObjectSLAM:
             K_bbox = fix_K_for_bbox_ndc_many(K, bboxes).astype(np.float32)
             prep.append((view_id, img, K, obj_ids, bboxes, np.asarray(model_kps), np.asarray(model_kps_masks, dtype=bool), K_bbox))
             ff.append(ff[-1] + len(obj_ids))
-        Ltot, B = ff[-1], len(views)
-        assert Ltot <= self.model.max_crops, f"{Ltot} crops in one call, the network was built for {self.model.max_crops} (ObjectSLAM(max_crops=...))"
-        K_all = np.concatenate([p[7] for p in prep])
-        kinv, camk = kbbox_terms(K_all)
-        min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for p in prep for o in p[3]], dtype=np.float64)
-        fg = getattr(self, "_fg_batch", None)
-        if fg is None or fg.max_crops < Ltot or fg.max_frames < B:
-            fg = self._fg_batch = FrameGeometry(max(256, Ltot), max(32, B))
-        its = (10, 10, 40, 40) if self.sfm_mode else (10, 10, 10, 10)
-        frames_host = np.stack([np.ascontiguousarray(p[1]) for p in prep])
-        for _attempt in range(2):
-            pred = self.model.forward_frames(frames_host, [np.asarray(p[4], np.float32) for p in prep], check=False)
-            vt = 1e30 if self.no_network_cov else self.kp_var_thresh
-            mm_all = np.concatenate([p[6] for p in prep])
-            masks_dev = keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], mm_all, self.bbox_thresh, vt)
-            kps_dev = torch.as_tensor(np.ascontiguousarray(np.concatenate([p[5] for p in prep]), dtype=np.float32)).to(pred["uv"].device)
-            fg.launch(ff, pred["uv"], pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
-                      use_cov=not self.no_network_cov, do_lm=True, its=its)
-            r = fg.fetch(copy=True)
-            if not self.model.range_exceeded():               # (fp16 form only: see _process_view_single_device)
-                break
-        self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
-        torch.cuda.synchronize()
-        per_view = (time() - tt0) / B
+        assert ff[-1] <= self.model.max_crops, f"{ff[-1]} crops in one call, the network was built for {self.model.max_crops} (ObjectSLAM(max_crops=...))"
+        fg, pred = self._enqueue_views(prep, ff)
+        if not hasattr(self, "_tickets"):
+            self._tickets = []
+        self._tickets.append({"prep": prep, "ff": ff, "fg": fg, "pred": pred, "t0": time()})
+
+    @_on_stream
+    def collect_views_single(self):
+        """Second half: wait for the OLDEST batch in flight, install its state view by view and return [collect_results() per view]."""
+        tk = self._tickets[0]
+        r = tk["fg"].fetch(copy=True)
+        if self.model.range_exceeded():
+            # fp16 form only: an activation left its range -- every batch enqueued and not yet checked is invalid (and so is what they added to the running
+            # key).  The network is on bf16x3 now: re-issue all of them in order from the host's seed, which only ever counted valid batches.
+            redo = self._tickets
+            self._tickets = []
+            import torch
+            torch.cuda.synchronize()
+            self.model.range_exceeded()
+            self._seed_run.zero_()
+            self._seed_base, self._seed_expect = self._pnp_seed, 0
+            for t in redo:
+                fg, pred = self._enqueue_views(t["prep"], t["ff"])
+                self._tickets.append({"prep": t["prep"], "ff": t["ff"], "fg": fg, "pred": pred, "t0": t["t0"]})
+            tk = self._tickets[0]
+            r = tk["fg"].fetch(copy=True)
+        self._tickets.pop(0)
+        prep, ff = tk["prep"], tk["ff"]
+        n_solv = int(np.count_nonzero(r["n_kp"] >= 4))
+        self._pnp_seed += n_solv
+        self._seed_expect += n_solv
+        now = time()
+        per_view = (now - max(tk["t0"], getattr(self, "_last_collect", 0.0))) / len(prep)              # batches overlap: the time this batch added to the stream of results
+        self._last_collect = now
         out = []
         for f, (view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox) in enumerate(prep):
             self.reset()
@@ -803,6 +889,7 @@ class ObjectSLAM:
                 self.obj_poses[o] = obj_T[j].copy()
         self._cull_after_optimize(list(obj_index.keys()), curr_only, view_curr)
 
+    @_on_stream
     def optimize(self, curr_only=False):
         """object_slam.py:703-930 with the g2o graph replaced by one suo_optimize call."""
         built = self.build_problem(curr_only)

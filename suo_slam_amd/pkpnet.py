@@ -182,15 +182,56 @@ class PkpNet:
         ev.record()
         return dev_buf[:nbytes].view(images.dtype).view(images.shape)
 
-    def forward_frames(self, images, boxes_per_frame, check=True):
-        """Several independent frames in one call: images uint8 [B,H,W,3], boxes_per_frame list of B arrays [L_b,4].
-        Returns the same dict with the crops of all frames concatenated in frame order.  check: as forward()."""
+    def stage_block(self, arrays):
+        """Host arrays -> device tensors through ONE pinned block and ONE stream-ordered copy kernel (suo_upload), from a ring of two blocks: nothing here
+        waits for the device except for the upload that used the same block two calls ago.  (A pageable .to(device) is ordered behind everything already
+        enqueued on the stream AND blocks the host until it ran: with a second batch in flight that is a full device round trip per small array.)"""
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        offs, total = [], 0
+        for a in arrays:
+            offs.append(total)
+            total += (a.nbytes + 15) & ~15
+        ring = getattr(self, "_block_ring", None)
+        if ring is None:
+            ring = self._block_ring = {"slots": [None, None], "next": 0}
+        k = ring["next"]
+        ring["next"] = (k + 1) % 2
+        st = ring["slots"][k]
+        if st is None or st[0].numel() < total:
+            if st is not None:
+                st[2].synchronize()
+            cap = max(total, 1 << 20)
+            st = ring["slots"][k] = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device), torch.cuda.Event())
+        host, dev_buf, ev = st
+        ev.synchronize()                                    # the upload that last read this pinned block has run
+        base = host.data_ptr()
+        for a, o in zip(arrays, offs):
+            if a.nbytes:
+                C.memmove(base + o, a.ctypes.data, a.nbytes)
+        _lib.check(_lib.lib().suo_upload(_ptr(dev_buf), C.c_void_p(base), total, _stream()), "suo_upload")
+        ev.record()
+        tdt = {np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.bool_): torch.uint8,
+               np.dtype(np.float64): torch.float64, np.dtype(np.int64): torch.int64}
+        return [dev_buf[o:o + a.nbytes].view(tdt[a.dtype]).view(a.shape) for a, o in zip(arrays, offs)]
+
+    def forward_frames(self, images, boxes_per_frame, check=True, extra=None):
+        """Several independent frames in one call: images uint8 [B,H,W,3] (or a list of B frames), boxes_per_frame list of B arrays [L_b,4].
+        Returns the same dict with the crops of all frames concatenated in frame order.  check: as forward().
+        extra: host arrays to put on the device with the same upload (returned as ret["extra"], device tensors): what the caller's next kernels need."""
         assert self._h is not None, "load_state_dict first"
         dev = self.device
-        imgs = torch.as_tensor(images).to(dev).contiguous()
+        if isinstance(images, torch.Tensor) and images.is_cuda:
+            imgs = images.contiguous()
+            bx = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in boxes_per_frame]).to(dev).contiguous()
+            idx = torch.cat([torch.full((len(b),), i, dtype=torch.int32) for i, b in enumerate(boxes_per_frame)]).to(dev).contiguous()
+            extra_dev = [torch.as_tensor(np.ascontiguousarray(a)).to(dev) for a in (extra or [])]
+        else:
+            frames = np.stack([np.asarray(f) for f in images]) if isinstance(images, (list, tuple)) else np.asarray(images)
+            bxh = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4) for b in boxes_per_frame])
+            idxh = np.concatenate([np.full(len(b), i, np.int32) for i, b in enumerate(boxes_per_frame)])
+            staged = self.stage_block([frames, bxh, idxh] + list(extra or []))
+            imgs, bx, idx, extra_dev = staged[0], staged[1], staged[2], staged[3:]
         assert imgs.dtype == torch.uint8 and imgs.dim() == 4 and imgs.shape[3] == 3 and imgs.shape[0] == len(boxes_per_frame)
-        bx = torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in boxes_per_frame]).to(dev).contiguous()
-        idx = torch.cat([torch.full((len(b),), i, dtype=torch.int32) for i, b in enumerate(boxes_per_frame)]).to(dev).contiguous()
         L = int(bx.shape[0])
         uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
         cov = torch.empty((L, NUM_KP, 2, 2), dtype=torch.float32, device=dev)
@@ -203,8 +244,8 @@ class PkpNet:
         if check and self.pipe() == 2:
             torch.cuda.current_stream().synchronize()
             if self.range_exceeded():
-                return self.forward_frames(images, boxes_per_frame, check=False)
-        return {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
+                return self.forward_frames(images, boxes_per_frame, check=False, extra=extra)
+        return {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm, "extra": extra_dev}
 
 
 def decode_extras(logits):
@@ -240,7 +281,9 @@ def keypoint_masks(uv, cov, kp_mask, model_kps_masks, bbox_thresh=0.9, kp_var_th
     """Device version of the mask logic at lib/object_slam.py:1100-1115 -> uint8 [L,41]."""
     L = int(uv.shape[0])
     mm = None
-    if model_kps_masks is not None:
+    if isinstance(model_kps_masks, torch.Tensor) and model_kps_masks.is_cuda:
+        mm = model_kps_masks.contiguous()                  # already on the device (uint8 [L,41]: PkpNet.stage_block)
+    elif model_kps_masks is not None:
         mm = torch.as_tensor(np.asarray(model_kps_masks, dtype=np.uint8)).to(uv.device).contiguous()
     out = torch.empty((L, NUM_KP), dtype=torch.uint8, device=uv.device)
     _lib.check(_lib.lib().suo_keypoint_masks(_ptr(uv), _ptr(cov), _ptr(kp_mask), _ptr(mm), L, float(bbox_thresh),

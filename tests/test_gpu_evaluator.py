@@ -109,11 +109,13 @@ def test_slam_mode_over_a_consistent_sequence(tmp_path):
     assert out["result"]["AUC of ADD-S"][0] > 0.7
 
 
-def _per_frame_forward_frames(self, images, boxes_per_frame, check=True):
+def _per_frame_forward_frames(self, images, boxes_per_frame, check=True, extra=None):
     """PkpNet.forward_frames as one PkpNet.forward per frame (the per-view loop's network calls), results concatenated."""
     import torch
     outs = [self.forward(np.ascontiguousarray(images[i]), [torch.as_tensor(np.asarray(b, np.float32))], None) for i, b in enumerate(boxes_per_frame)]
-    return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+    ret = {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+    ret["extra"] = [torch.as_tensor(np.ascontiguousarray(a)).cuda() for a in (extra or [])]
+    return ret
 
 
 def test_batched_single_view_evaluation_equals_the_per_view_loop(tmp_path, monkeypatch):
