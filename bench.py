@@ -671,18 +671,29 @@ def cpu_baseline(pool, L):
     from suo_slam_amd import synthetic as S
     from suo_slam_amd import weights
     cores = len(os.sched_getaffinity(0))
+    quota = cpu_quota()
     sd = weights.make_random_state_dict(0, 8.0)
     Pw = O.to_torch(sd)
-    sweep = {}
+    sweep, frames_per_point = {}, {}
     t_start = time.perf_counter()
-    for n in sorted({min(c, cores) for c in (8, 16, 32, 64)}):
+    # thread counts up to every core the process may run on (8, 16, 32, 64, 128, all); per point: one untimed frame (the intra-op pool's start-up at
+    # that size), then up to 3 timed frames, the median reported.  torch's intra-op pool is OpenMP-free (its own work-stealing pool): thread placement
+    # is the kernel's, memory is first-touch -- no OMP_PLACES / interleave policy is set, and none would be honoured.  Bounded at ~30 s in all.
+    for n in sorted({min(c, cores) for c in (8, 16, 32, 64, 128, cores)}):
         torch.set_num_threads(n)
         fr = pool[0]
         O.pkpnet_forward(fr["image"], fr["boxes"], None, sd, Pw)                      # first call with a thread count: pool start-up
-        t0 = time.perf_counter()
-        O.pkpnet_forward(pool[1 % len(pool)]["image"], pool[1 % len(pool)]["boxes"], None, sd, Pw)
-        sweep[n] = time.perf_counter() - t0
-        if time.perf_counter() - t_start > 25.0:
+        ts = []
+        for k in range(3):
+            fk = pool[(1 + k) % len(pool)]
+            t0 = time.perf_counter()
+            O.pkpnet_forward(fk["image"], fk["boxes"], None, sd, Pw)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 30.0:
+                break
+        sweep[n] = float(np.median(ts))
+        frames_per_point[n] = len(ts)
+        if time.perf_counter() - t_start > 30.0:
             break
     n_best = min(sweep, key=sweep.get)
     t_cnn = sweep[n_best]
@@ -701,10 +712,31 @@ def cpu_baseline(pool, L):
                        B["edge_uv"], B["edge_info"], B["edge_inlier"])
             n_geo += 1
     t_geo = (time.perf_counter() - t0) / n_geo
+    # the CPU figures beside the `global_ba` and `slam` legs: the same 32-camera x 16-object pose graph through the dense C oracle (one thread, as the
+    # reference's g2o call), and a SLAM view's tracking as the oracle would do it -- two network passes of the frame + the frame's geometry
+    from suo_slam_amd import synthetic as S2
+    Pg = S2.make_pose_graph(np.random.default_rng(5), 32, 16)
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    t0 = time.perf_counter()
+    G.optimize(*[Pg[k].copy() for k in keys])
+    t_gba = time.perf_counter() - t0
     return {"value": round(1.0 / (t_cnn + t_geo), 4), "unit": "frames/s", "cores": n_best, "kind": "port",
-            "cnn_ms_per_frame_by_threads": {str(k): round(1e3 * v, 1) for k, v in sweep.items()}, "host_cores_available": cores,
-            "sample": f"1 frame x {L} crops through the torch-CPU CNN oracle per thread count of the sweep (best: {n_best} threads, {t_cnn * 1e3:.0f} ms/frame) + "
-                      f"{n_geo} frames through the C PnP/LM oracle (1 thread, {t_geo * 1e3:.2f} ms/frame)"}
+            "cnn_ms_per_frame_by_threads": {str(k): round(1e3 * v, 1) for k, v in sweep.items()}, "frames_timed_per_thread_count": {str(k): v for k, v in frames_per_point.items()},
+            "host_cores_available": cores, "cpu_quota_cores": quota,
+            "thread_placement": "torch intra-op pool (not OpenMP): no OMP_PLACES / NUMA interleave policy applies; kernel placement, first-touch memory",
+            "global_ba_32x16_ms": round(1e3 * t_gba, 1), "slam_tracking_ms_per_view": round(1e3 * (2 * t_cnn + t_geo), 1),
+            "slam_tracking_basis": "2 network passes of an 8-crop frame at the best thread count + PnP/LM of the frame (both measured above); hypotheses / re-initialisation scoring not included",
+            "sample": f"up to 3 frames x {L} crops through the torch-CPU CNN oracle per thread count of the sweep (median; best: {n_best} threads, {t_cnn * 1e3:.0f} ms/frame) + "
+                      f"{n_geo} frames through the C PnP/LM oracle (1 thread, {t_geo * 1e3:.2f} ms/frame) + one 32 x 16 global adjustment through the C LM oracle (1 thread)"}
+
+
+def cpu_quota():
+    """CPUs the cgroup actually grants (the GPU boxes show 256 and grant 16), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        return None
 
 
 def pose_check_leg(L, pool, use_graph):
@@ -1200,6 +1232,12 @@ def main():
                     leg("slam", slam_leg)
                 if not args.no_cpu_baseline:
                     leg("cpu_baseline", cpu_baseline, pool, L)
+                    with lock:                      # the host figures beside the legs they belong to (VERDICT r4 missing #5)
+                        cb = extra.get("cpu_baseline", {})
+                        if isinstance(extra.get("global_ba"), dict) and "global_ba_32x16_ms" in cb:
+                            extra["global_ba"]["cpu_oracle_ms"] = cb["global_ba_32x16_ms"]
+                        if isinstance(extra.get("slam"), dict) and "slam_tracking_ms_per_view" in cb:
+                            extra["slam"]["cpu_oracle_tracking_ms_per_view"] = cb["slam_tracking_ms_per_view"]
     dog.cancel()
     emit()
     faulthandler.cancel_dump_traceback_later()

@@ -232,6 +232,14 @@ int suo_pack_res_block_bf16x3(const float* w1, const float* w2, const float* sca
 int suo_res_block_bf16x3(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev,
                          const uint16_t* w1x_dev, const float* b1_dev, const uint16_t* w2x_dev, const float* b2_dev, const uint16_t* w3x_dev,
                          const float* b3_dev, const float* up_dev, float* out_dev, void* stream);
+/* ... and on two fp16 terms per operand (csrc/f16x2.h; the default of suo_net_forward for these levels): planes w1h [2*128*256], w2h [2*128*128*9], w3h [2*256*128]
+ * and the per-channel factors osc1 [128], osc2 [128], osc3 [256] from suo_pack_res_block_f16x2; range_flag_dev as suo_conv1x1_f16x2_ex (here it also covers the
+ * two activations the caller never sees, relu(conv1) and relu(conv2)). */
+int suo_pack_res_block_f16x2(const float* w1, const float* w2, const float* scale2, const float* w3, uint16_t* w1h, uint16_t* w2h, uint16_t* w3h, float* osc1, float* osc2,
+                             float* osc3);
+int suo_res_block_f16x2(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* w1h_dev,
+                        const float* osc1_dev, const float* b1_dev, const uint16_t* w2h_dev, const float* osc2_dev, const float* b2_dev, const uint16_t* w3h_dev,
+                        const float* osc3_dev, const float* b3_dev, const float* up_dev, float* out_dev, unsigned* range_flag_dev, void* stream);
 /* csrc/stem_x3.hip (what suo_net_forward launches for the prior-less pass unless SUO_STEM_X3=0): RoIAlign of the frame (pkpnet.py:93) + the stem
  * conv1_ 7x7 / stride 2 over the 3 image channels + bn1 + ReLU (hg.py:67-69,96-98) in one launch, products on the bf16 matrix pipe (3-way split);
  * the staged [L,256,256,*] crop tensor is never written.  wx = suo_pack_stem_weight_bf16x3(W[64][Cw][7][7], Cw, bn scale[64] or NULL) ->

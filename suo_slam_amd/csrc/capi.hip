@@ -340,6 +340,25 @@ int suo_res_block_bf16x3(const float* x, int L, int H, int W, int pool_in, const
     return suo::launch_res_block_x3(a, (hipStream_t)stream);
 }
 
+int suo_pack_res_block_f16x2(const float* w1, const float* w2, const float* scale2, const float* w3, uint16_t* w1h, uint16_t* w2h, uint16_t* w3h, float* osc1, float* osc2,
+                             float* osc3) {
+    if (!w1 || !w2 || !w3 || !w1h || !w2h || !w3h || !osc1 || !osc2 || !osc3) { suo_set_error("suo_pack_res_block_f16x2: null argument"); return SUO_ERR_ARG; }
+    suo::pack_gemm_weight_f16x2(w1, 128, 256, w1h, osc1);
+    suo::pack_res_conv3x3_f16x2(w2, scale2, w2h, osc2);
+    suo::pack_gemm_weight_f16x2(w3, 256, 128, w3h, osc3);
+    return SUO_OK;
+}
+
+int suo_res_block_f16x2(const float* x, int L, int H, int W, int pool_in, const float* pro_scale, const float* pro_shift, const uint16_t* w1h, const float* osc1,
+                        const float* b1, const uint16_t* w2h, const float* osc2, const float* b2, const uint16_t* w3h, const float* osc3, const float* b3, const float* up,
+                        float* out, unsigned* range_flag_dev, void* stream) {
+    suo::ResBlockArgs a = {};
+    a.x = x; a.L = L; a.H = H; a.W = W; a.pool_in = pool_in; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.W1 = (const float*)w1h; a.b1 = b1; a.W2 = (const float*)w2h; a.b2 = b2; a.W3 = (const float*)w3h; a.b3 = b3; a.up = up; a.out = out;
+    a.osc1 = osc1; a.osc2 = osc2; a.osc3 = osc3; a.range_flag = range_flag_dev;
+    return suo::launch_res_block_f16x2(a, (hipStream_t)stream);
+}
+
 int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint16_t* out) {
     if (!w || !out || Cw < 3) { suo_set_error("suo_pack_stem_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
     suo::pack_stem_weight_bf16x3(w, Cw, scale, out);

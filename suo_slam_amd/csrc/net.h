@@ -29,6 +29,8 @@ struct ResidualW {
     // 256 -> 256 blocks: the whole block in one launch on small maps (csrc/res_small.hip fp32 pipe; csrc/res_small_x3.hip bf16 pipe)
     float* rb_w[3] = {nullptr, nullptr, nullptr};        // pack_res16_gemm(W1 bn1-folded) | pack_res16_conv3x3(W2, bn2 scale) | pack_res16_gemm(W3)
     float* rbx_w[3] = {nullptr, nullptr, nullptr};       // the same as bf16x3 planes (uint16)
+    float* rbh_w[3] = {nullptr, nullptr, nullptr};       // ... as two fp16 planes (csrc/f16x2.h)
+    float* rbh_osc[3] = {nullptr, nullptr, nullptr};     // and their per-channel factors [128], [128], [256]
 };
 struct HourglassW {
     int n = 0;

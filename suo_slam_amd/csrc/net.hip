@@ -276,6 +276,14 @@ void Net::make_residual(const std::string& p, ResidualW& r) {
             pack_res_conv3x3_bf16x3(w2.data, s2.data(), reinterpret_cast<uint16_t*>(x2.data()));
             pack_gemm_weight_bf16x3(w3.data, 256, 128, reinterpret_cast<uint16_t*>(x3.data()));
             r.rbx_w[0] = upload(x1); r.rbx_w[1] = upload(x2); r.rbx_w[2] = upload(x3);
+            if (pipe_f16x2()) {
+                std::vector<float> h1((size_t)128 * 256), h2((size_t)128 * 128 * 9), h3((size_t)256 * 128), o1(128), o2(128), o3(256);      // uint16 planes: 2 per entry
+                pack_gemm_weight_f16x2(w1f.data(), 128, 256, reinterpret_cast<uint16_t*>(h1.data()), o1.data());
+                pack_res_conv3x3_f16x2(w2.data, s2.data(), reinterpret_cast<uint16_t*>(h2.data()), o2.data());
+                pack_gemm_weight_f16x2(w3.data, 256, 128, reinterpret_cast<uint16_t*>(h3.data()), o3.data());
+                r.rbh_w[0] = upload(h1); r.rbh_w[1] = upload(h2); r.rbh_w[2] = upload(h3);
+                r.rbh_osc[0] = upload(o1); r.rbh_osc[1] = upload(o2); r.rbh_osc[2] = upload(o3);
+            }
         }
     }
     if (r.c2.Wq3 && !r.has_skip_conv) {
@@ -507,7 +515,11 @@ int Net::residual_one_launch(const ResidualW& r, const float* x, float* out, int
     ResBlockArgs a = {};
     a.x = x; a.L = L; a.H = H; a.W = W; a.pool_in = pool_in ? 1 : 0; a.pro_scale = r.pro_scale; a.pro_shift = r.pro_shift;
     a.b1 = r.c1.bias; a.b2 = r.c2.bias; a.b3 = r.c3.bias; a.up = up; a.out = out;
-    if (kind == 2) {
+    if (kind == 2 && pipe_ == 2 && r.rbh_w[0]) {                      // two fp16 planes: a third less weight traffic per workgroup, half the MFMAs
+        a.W1 = r.rbh_w[0]; a.W2 = r.rbh_w[1]; a.W3 = r.rbh_w[2];
+        a.osc1 = r.rbh_osc[0]; a.osc2 = r.rbh_osc[1]; a.osc3 = r.rbh_osc[2]; a.range_flag = range_flag_;
+        SUO_LAUNCH(launch_res_block_f16x2(a, s));
+    } else if (kind == 2) {
         a.W1 = r.rbx_w[0]; a.W2 = r.rbx_w[1]; a.W3 = r.rbx_w[2];
         SUO_LAUNCH(launch_res_block_x3(a, s));
     } else {

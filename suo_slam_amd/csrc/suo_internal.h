@@ -96,6 +96,8 @@ struct ResBlockArgs {
     const float* W3; const float* b3;                    // pack_res16_gemm(W3 [256][128]), [256]
     const float* up;                                     // optional [L,H/2,W/2,256]: out += its nearest-neighbour 2x up-sampling (hg.py:56-58)
     float* out;                                          // [L,H,W,256]
+    // f16x2 form only (csrc/f16x2.h): per-channel factors 2^-(t_n + S2_XSHIFT) of conv1 [128], conv2 [128], conv3 [256]; the range-guard flag
+    const float* osc1; const float* osc2; const float* osc3; unsigned* range_flag;
 };
 void pack_res16_gemm(const float* W, int N, int K, float* out);
 void pack_res16_conv3x3(const float* W, int N, int C, const float* out_scale, float* out);
@@ -105,6 +107,8 @@ int launch_res_block(const ResBlockArgs& a, hipStream_t s);
 // W2 = pack_res_conv3x3_bf16x3 planes (uint16, passed through the float pointers of ResBlockArgs)
 void pack_res_conv3x3_bf16x3(const float* W, const float* out_scale, uint16_t* out);
 int launch_res_block_x3(const ResBlockArgs& a, hipStream_t s);
+void pack_res_conv3x3_f16x2(const float* W, const float* out_scale, uint16_t* out, float* oscale_out);
+int launch_res_block_f16x2(const ResBlockArgs& a, hipStream_t s);
 
 int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);
 int launch_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, hipStream_t s);

@@ -439,6 +439,8 @@ class ObjectSLAM:
         if not (self.single_view_mode and self.device_chain and self.model is not None and not self.debug_gt_kp and len(views) > 1):
             return False
         shape = np.asarray(views[0][1]).shape
+        if sum(len(v[3]) for v in views) > self.model.max_crops:      # more crops than the network was built for: view by view (ObjectSLAM(max_crops=...) lifts it)
+            return False
         return all(0 < len(v[3]) <= 16 and np.asarray(v[1]).shape == shape and np.asarray(v[1]).dtype == np.uint8 for v in views)
 
     @_on_stream

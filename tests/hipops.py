@@ -329,3 +329,25 @@ def res_block_x3(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=Fals
                "suo_res_block_bf16x3")
     torch.cuda.synchronize()
     return out
+
+
+def res_block_f16x2(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=False):
+    """csrc/res_small_x3.hip with NP = 2: the one-launch Residual block on two fp16 terms per operand; arguments as res_block.  Returns (out, range_flag)."""
+    lib = _lib.lib()
+    L, H, W, Cc = x_nhwc.shape
+    if pool_in:
+        H, W = H // 2, W // 2
+    w1, w2, w3 = (np.ascontiguousarray(t, np.float32) for t in (w1, w2, w3))
+    p1, p2, p3 = np.empty(2 * 128 * 256, np.uint16), np.empty(2 * 128 * 128 * 9, np.uint16), np.empty(2 * 256 * 128, np.uint16)
+    o1, o2, o3 = np.empty(128, np.float32), np.empty(128, np.float32), np.empty(256, np.float32)
+    _lib.check(lib.suo_pack_res_block_f16x2(w1.ctypes.data, w2.ctypes.data, None, w3.ctypes.data, p1.ctypes.data, p2.ctypes.data, p3.ctypes.data, o1.ctypes.data,
+                                            o2.ctypes.data, o3.ctypes.data), "suo_pack_res_block_f16x2")
+    dw = [torch.from_numpy(t.view(np.int16)).cuda() for t in (p1, p2, p3)]
+    do = [dev(t) for t in (o1, o2, o3)]
+    d = [dev(t) for t in (pro[0], pro[1], b1, b2, b3)]
+    out = torch.empty((L, H, W, 256), device="cuda")
+    flag = _flag()
+    _lib.check(lib.suo_res_block_f16x2(P(x_nhwc), L, H, W, int(pool_in), P(d[0]), P(d[1]), P(dw[0]), P(do[0]), P(d[2]), P(dw[1]), P(do[1]), P(d[3]), P(dw[2]), P(do[2]), P(d[4]),
+                                       P(up_nhwc), P(out), P(flag), S()), "suo_res_block_f16x2")
+    torch.cuda.synchronize()
+    return out, int(flag.item())

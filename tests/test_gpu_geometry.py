@@ -206,6 +206,38 @@ def test_camera_tracking_one_wave_kernel(ba, n_obj, noise, outliers):
     np.testing.assert_allclose(got2[0][0], P["cam_T"][0], rtol=0, atol=1e-12)      # (matrix -> quaternion -> matrix round trip)
 
 
+def test_both_camera_tracking_kernels_against_the_oracle_and_each_other():
+    """SUO_LM_CAM2 (read once per process) selects between lm_cam2_kernel (csrc/lm_cam2.hip: the default, one wave per problem, pose in registers) and
+    lm_cam_kernel (csrc/lm_cam.hip: graphs with further fixed cameras or > 1024 edges, and SUO_LM_CAM2=0).  The same tracking problems through BOTH,
+    each in its own child process: either agrees with the C oracle to the LM tolerance and flags the same inliers, and the two agree with each other."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "from suo_slam_amd import ba, synthetic as S\nfrom oracle import geometry as G\nfrom tests.test_gpu_geometry import _perturb\n"
+            "rng = np.random.default_rng(77); keys = ('cam_T','cam_fixed','obj_T','obj_fixed','edge_cam','edge_obj','edge_camk','edge_p','edge_uv','edge_info','edge_inlier')\n"
+            "out = []\n"
+            "for n_obj, noise, outl in ((1, 0.002, 0.0), (8, 0.004, 0.15), (16, 0.01, 0.1)):\n"
+            "    fr = S.make_frame(rng, n_obj, noise=noise, outlier_frac=outl, with_image=False)\n"
+            "    P = S.frame_to_ba_problem(fr, fr['T_OtoC']); P['cam_T'] = _perturb(np.eye(4), rng, 2e-4, 0.1)[None]\n"
+            "    P['cam_fixed'] = np.array([0], np.uint8); P['obj_fixed'] = np.ones(n_obj, np.uint8)\n"
+            "    a = [P[k] for k in keys]\n"
+            "    got, ref = ba.optimize(*a, its=(10, 10, 10, 10)), G.optimize(*a, its=(10, 10, 10, 10))\n"
+            "    out.append({'cam': got[0].ravel().tolist(), 'inl': got[2].tolist(), 'd_oracle': float(np.abs(got[0] - ref[0]).max()), 'inl_eq': bool(np.array_equal(got[2], ref[2]))})\n"
+            "print('RESULT ' + json.dumps(out))\n") % root
+    res = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, SUO_LM_CAM2=mode)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for a, b in zip(res["1"], res["0"]):
+        assert a["d_oracle"] < 1e-6 and b["d_oracle"] < 1e-6 and a["inl_eq"] and b["inl_eq"]
+        assert a["inl"] == b["inl"] and np.abs(np.array(a["cam"]) - np.array(b["cam"])).max() < 1e-6
+
+
 def _multi_view_scene(rng, n_cam, n_obj, noise_px=0.5):
     k = np.array([600.0, 600.0, 320.0, 240.0])
     cam_gt = np.zeros((n_cam, 3, 4))

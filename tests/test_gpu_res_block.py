@@ -154,3 +154,70 @@ def test_res_block_bf16x3_forward_error_per_element(ops):
     assert np.abs(ex).max() <= 2.0 * np.sqrt(256 + 1152 + 128)
     assert np.abs(ex).max() <= 1.5 * np.abs(ef).max() + 0.5
     assert abs(ex.mean()) <= 1.5                                # (three products deep; 720 truncating MFMA accumulations per wave: ~ -0.9)
+
+
+# ---- the same block on two fp16 terms per operand (csrc/res_small_x3.hip, NP = 2; csrc/f16x2.h): the network's default since round 5 ----------------
+@pytest.mark.parametrize("L,H,W,up,pool", [
+    (8, 32, 32, False, False), (8, 32, 32, True, True), (8, 16, 16, True, False), (8, 16, 16, False, True),
+    (3, 12, 20, True, False), (1, 4, 4, False, False), (2, 6, 10, False, True), (16, 8, 8, False, False),
+])
+def test_res_block_f16x2_is_fp32_accurate(ops, L, H, W, up, pool):
+    """The bounds the bf16x3 block is held to (5e-6 of the output range against fp64; never worse than 2x the fp32-pipe kernel + 1e-7; every crop within
+    1e-5 of it), the range flag down."""
+    rng = np.random.default_rng(L * 1000 + H * 10 + W + up + 2 * pool + 7)
+    B = _block_weights(rng)
+    xin = torch.from_numpy(rng.standard_normal((L, 2 * H, 2 * W, 256) if pool else (L, H, W, 256)).astype(np.float32)).cuda()
+    low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda() if up else None
+    args = (xin, B["pro"], B["w1"], B["b1"], B["w2"], B["b2"], B["w3"], B["b3"])
+    got, flag = ops.res_block_f16x2(*args, up_nhwc=low, pool_in=pool)
+    assert flag == 0
+    f32 = ops.res_block(*args, up_nhwc=low, pool_in=pool)
+    x = xin.view(L, H, 2, W, 2, 256).amax(dim=(2, 4)) if pool else xin
+    ref = _fp64(x, B, low)
+    scale = np.abs(ref).max()
+    e_h = np.abs(got.cpu().numpy() - ref).max() / scale
+    e_f32 = np.abs(f32.cpu().numpy() - ref).max() / scale
+    assert e_h < 5e-6, e_h
+    assert e_h <= 2.0 * e_f32 + 1e-7, (e_h, e_f32)
+    per_crop = (got - f32).abs().reshape(L, -1).amax(1) / float(scale)
+    assert float(per_crop.max()) < 1e-5, int(per_crop.argmax())
+
+
+def test_res_block_f16x2_forward_error_per_element_and_range_guard(ops):
+    """The per-element gate on one-signed data (as the bf16x3 block's), and the guard: an input, or either INNER activation (relu(conv1), relu(conv2): tensors the
+    caller never sees), of 4094 or more raises the flag; just below, the flag stays down and the result is finite."""
+    rng = np.random.default_rng(11)
+    L, H, W = 4, 32, 32
+    B = _block_weights(rng)
+    B = dict(B, pro=(np.abs(B["pro"][0]), np.abs(B["pro"][1])), w1=np.abs(B["w1"]), b1=np.abs(B["b1"]), w2=np.abs(B["w2"]), b2=np.abs(B["b2"]),
+             w3=np.abs(B["w3"]), b3=np.abs(B["b3"]))
+    x = torch.from_numpy(np.abs(rng.standard_normal((L, H, W, 256))).astype(np.float32)).cuda()
+    args = (x, B["pro"], B["w1"], B["b1"], B["w2"], B["b2"], B["w3"], B["b3"])
+    got, flag = ops.res_block_f16x2(*args)
+    assert flag == 0
+    got = got.cpu().numpy().astype(np.float64)
+    f32 = ops.res_block(*args).cpu().numpy().astype(np.float64)
+    ref = _fp64(x, B)
+    U = 2.0 ** -24
+    ex, ef = (got - ref) / (U * ref), (f32 - ref) / (U * ref)
+    print("\nres_block one-signed: max|err| f16x2 %.3f fp32 pipe %.3f, mean signed %+.4f %+.4f, std %.3f %.3f   [units of 2^-24 sum|x||w|]"
+          % (np.abs(ex).max(), np.abs(ef).max(), ex.mean(), ef.mean(), ex.std(), ef.std()))
+    assert np.abs(ex).max() <= 2.0 * np.sqrt(256 + 1152 + 128)
+    assert np.abs(ex).max() <= 1.5 * np.abs(ef).max() + 1.5
+    assert abs(ex.mean()) <= 1.5
+    # the guard, on the block's own input (after the prologue: scale 1, shift 0 here) ...
+    Bg = dict(_block_weights(rng), pro=(np.ones(256, np.float32), np.zeros(256, np.float32)))
+    for big, want in ((4093.0, 0), (4095.0, 1), (np.inf, 1)):
+        xg = rng.standard_normal((2, 8, 8, 256)).astype(np.float32)
+        xg[1, 7, 7, 255] = big
+        out, flag = ops.res_block_f16x2(torch.from_numpy(xg).cuda(), Bg["pro"], Bg["w1"], Bg["b1"], Bg["w2"], Bg["b2"], Bg["w3"], Bg["b3"])
+        assert flag == want, (big, flag)
+        if not want:
+            assert torch.isfinite(out).all()
+    # ... and on the inner activations: conv1 / conv2 gains that push relu(conv1) / relu(conv2) beyond 4094 while the input stays O(1)
+    xg = torch.from_numpy(np.abs(rng.standard_normal((2, 8, 8, 256))).astype(np.float32)).cuda()
+    for key, gain in (("w1", 2000.0), ("w2", 3000.0)):
+        Bi = dict(B)
+        Bi[key] = B[key] * np.float32(gain)
+        out, flag = ops.res_block_f16x2(xg, Bi["pro"], Bi["w1"], Bi["b1"], Bi["w2"], Bi["b2"], Bi["w3"], Bi["b3"])
+        assert flag == 1, key
