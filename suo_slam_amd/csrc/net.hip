@@ -504,7 +504,12 @@ int Net::residual_in_one_launch(const ResidualW& r, int L, int H, int W) const {
     // 8x8 / 4x4 maps (the three per-layer launches spread over all CUs, 13.5 us), many tiles (the Winograd kernels) -- stays per-layer.
     // (129 ... 255 tiles, e.g. the 5 crops of a SLAM pass at 32x32: one partial round of the bf16x3 kernel, 30 us, against 4 x 4 tiles
     //  that no longer fit one per CU, ~40)
-    static const long x3_from = getenv("SUO_RES_FUSED_X3_FROM") ? atol(getenv("SUO_RES_FUSED_X3_FROM")) : 129;
+    static const long x3_from_env = getenv("SUO_RES_FUSED_X3_FROM") ? atol(getenv("SUO_RES_FUSED_X3_FROM")) : 129;
+    // the fp16 form of the 4 x 8-tile kernel streams a third less weight per workgroup (csrc/res_small_x3.hip, NP = 2): 16.8 us at 64 tiles (16x16, 8 crops) where the
+    // fp32 kernel's 128 tiles of 4 x 4 take 23.4 and the bf16x3 form 23.1 -- it takes over from 33 tiles (tools/bench_res_block.py; 8x8 at 8 crops = 16 tiles: 16.6
+    // against 13.4 for the three per-layer launches, which stay)
+    static const long f16_from = getenv("SUO_RES_FUSED_F16_FROM") ? atol(getenv("SUO_RES_FUSED_F16_FROM")) : 33;
+    const long x3_from = (pipe_ == 2 && r.rbh_w[0] && mode >= 2) ? std::min(f16_from, x3_from_env) : x3_from_env;
     if (mode >= 2 && r.rbx_w[0] && t32 >= x3_from && t32 <= max_tiles) return 2;
     if (H >= min_side && W >= min_side && (t32 < x3_from || (mode == 1 && t32 <= max_tiles))) return 1;
     return 0;
@@ -635,8 +640,14 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     // and every extra stream competes for the 4 hardware queues with the other network and the geometry stream.  With a single
     // call in flight the fork is worth about 1 % (385 vs 381 frames/s at 8 crops).
     static const int n_side = getenv("SUO_NET_SIDE_STREAMS") ? std::max(0, std::min(kNumSide, atoi(getenv("SUO_NET_SIDE_STREAMS")))) : 0;
-    static const bool serial = getenv("SUO_SERIAL") != nullptr || n_side == 0;     // one stream, kernels back to back
-    hipStream_t side = serial ? s : side_[depth_idx % (n_side > 0 ? n_side : 1)];
+    // ... except on the SMALL maps of a call of few crops (the one-frame call: 16x16 and 8x8 at 8 crops): there every kernel is a handful of workgroups and a
+    // dependent launch costs its latency, not its work -- the up1 blocks (16.8 / 2 x 13.4 us) run beside the low branch instead of in front of it.
+    // SUO_NET_FORK_SMALL_PIXELS: largest L * H * W that forks (2048 = 16x16 at 8 crops); default 0 = never: MEASURED SLOWER -- one frame per call 2.010 ms with
+    // the fork against 1.897 without (same box, tools/time_frame_chain.py): the captured graph's extra branch costs more than the two or three launches it hides.
+    static const long fork_small = getenv("SUO_NET_FORK_SMALL_PIXELS") ? atol(getenv("SUO_NET_FORK_SMALL_PIXELS")) : 0;
+    const bool small_fork = getenv("SUO_SERIAL") == nullptr && fork_small > 0 && (long)L * H * W <= fork_small && H >= 8;
+    const bool serial = (getenv("SUO_SERIAL") != nullptr || n_side == 0) && !small_fork;     // one stream, kernels back to back
+    hipStream_t side = serial ? s : side_[depth_idx % (n_side > 0 ? n_side : kNumSide)];
     hipEvent_t ev_fork = ev_[(ev_next_++) % (kNumEvents - 1)], ev_join = ev_[(ev_next_++) % (kNumEvents - 1)];      // (the last event is follow_null_stream's)
     float* up_a = alloc(n_hi);
     float* up_b = alloc(n_hi);
