@@ -208,6 +208,14 @@ int suo_pack_tail_weight_f16x2(const float* w3, int N2, int K, uint16_t* out, fl
 int suo_conv3x3_wino_f16x2_conv1x1_skip_up(const float* in_dev, int L, int H, int W, const uint16_t* wq16_dev, const float* oscale2_dev, const float* bias2_dev,
                                            const uint16_t* w3p16_dev, const float* oscale3_dev, const float* bias3_dev, const float* skip_dev, const float* up_dev,
                                            float* out_dev, unsigned* range_flag_dev, void* stream);
+/* ... and with the NEXT Residual block's conv1 in the same launch (layers/Residual.py:22-24 of the block that consumes out_dev): next_out_dev [L,H,W,128] =
+ * relu(W1' relu(out * next_scale + next_shift) + next_b1) with W1' [128][256] (bn1 folded) as suo_pack_gemm_weight_f16x2 planes + factors.  out_dev is written as
+ * before; the 256-channel tensor is not re-read by a separate 1x1 launch.  Bit-identical to suo_conv3x3_wino_f16x2_conv1x1_skip_up followed by
+ * suo_conv1x1_f16x2_ex (same products, same order).  What suo_net_forward launches wherever a 256 -> 256 block on a large launch feeds another. */
+int suo_conv3x3_wino_f16x2_conv1x1_skip_up_next(const float* in_dev, int L, int H, int W, const uint16_t* wq16_dev, const float* oscale2_dev, const float* bias2_dev,
+                                                const uint16_t* w3p16_dev, const float* oscale3_dev, const float* bias3_dev, const float* skip_dev, const float* up_dev,
+                                                float* out_dev, const float* next_scale_dev, const float* next_shift_dev, const uint16_t* next_w1h_dev,
+                                                const float* next_osc1_dev, const float* next_b1_dev, float* next_out_dev, unsigned* range_flag_dev, void* stream);
 /* The same with the 3x3 convolution in Winograd form (wq2 from suo_pack_wino_weight): what the network launches for its 256 -> 256 blocks */
 int suo_conv3x3_wino_conv1x1_skip(const float* in_dev, int L, int H, int W, const float* wq2_dev, const float* bias2_dev, const float* wp3_dev,
                                   const float* bias3_dev, const float* skip_dev, float* out_dev, void* stream);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "suo_conv3x3_wino_f16x2_n": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP]),
     "suo_pack_tail_weight_f16x2": (C.c_int, [VP, C.c_int, C.c_int, VP, VP]),
     "suo_conv3x3_wino_f16x2_conv1x1_skip_up": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_conv3x3_wino_f16x2_conv1x1_skip_up_next": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_pack_wino_weight_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "suo_conv3x3_wino_x3": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP]),
     "suo_conv3x3_wino_x3_n": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP]),

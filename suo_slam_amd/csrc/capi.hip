@@ -232,6 +232,19 @@ int suo_conv3x3_wino_f16x2_conv1x1_skip_up(const float* in, int L, int H, int W,
     return suo::launch_conv3x3_wino_f16x2_fused(c, (hipStream_t)stream);
 }
 
+int suo_conv3x3_wino_f16x2_conv1x1_skip_up_next(const float* in, int L, int H, int W, const uint16_t* wq16, const float* oscale2, const float* bias2, const uint16_t* w3p16,
+                                                const float* oscale3, const float* bias3, const float* skip, const float* up, float* out, const float* next_scale,
+                                                const float* next_shift, const uint16_t* next_w1h, const float* next_osc1, const float* next_b1, float* next_out,
+                                                unsigned* range_flag_dev, void* stream) {
+    suo::ConvArgs c = {};
+    c.in = in; c.L = L; c.H = H; c.W = W; c.C = 128; c.Wp = (const float*)wq16; c.bias = bias2; c.out = nullptr; c.OH = H; c.OW = W; c.N = 128; c.relu = 1;
+    c.W3p = (const float*)w3p16; c.bias3 = bias3; c.R = skip; c.out2 = out; c.N2 = 256; c.up = up; c.oscale = oscale2; c.oscale3 = oscale3; c.range_flag = range_flag_dev;
+    c.n_scale = next_scale; c.n_shift = next_shift; c.n_W1 = (const float*)next_w1h; c.n_osc1 = next_osc1; c.n_b1 = next_b1; c.n_out = next_out;
+    if (!next_w1h) { suo_set_error("suo_conv3x3_wino_f16x2_conv1x1_skip_up_next: next_w1h is NULL"); return SUO_ERR_ARG; }
+    if (up && ((H | W) & 1)) { suo_set_error("suo_conv3x3_wino_f16x2_conv1x1_skip_up_next: odd map size"); return SUO_ERR_ARG; }
+    return suo::launch_conv3x3_wino_f16x2_fused(c, (hipStream_t)stream);
+}
+
 int suo_conv_kxk(int KS, const float* in, int L, int H, int W, int C, const float* wp, const float* bias, float* out, int N,
                  int relu, void* stream) {
     suo::ConvArgs c = {};

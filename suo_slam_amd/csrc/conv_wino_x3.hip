@@ -123,9 +123,13 @@ void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float
 // csrc/conv_wino.hip).
 // NP = operand planes: 3 = three bf16 terms, six MFMAs per product block (csrc/bf16x3.h); 2 = two fp16 terms, three MFMAs (csrc/f16x2.h: the staged input times
 // 2^S2_XSHIFT, U's rows times 2^t_n, accumulators back to scale by a.oscale / a.oscale3 in the epilogues, a.range_flag raised beyond fp16's range)
-template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3>
+// NEXT (fp16 form of the fused tail only): the block's output never comes back for the NEXT block's conv1 -- relu(bn_next(out2)) of the tile is split into LDS
+// right where out2 is stored and multiplied by the next block's W1 (256 -> 128) here: the 256-channel tensor is written once and not re-read by a GEMM launch
+// (csrc/net.hip: residual(..., next)).  Same products in the same order as gemm_bf16x3_kernel<NP = 2> forms them: bit-identical to the separate launch.
+template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
     static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
+    static_assert(!NEXT || (FUSE && TX3 && NP == 2), "the next block's conv1 rides on the fp16 tail");
     static_assert(NP == 3 || !FUSE || TX3, "the fp16 form's tail runs on the fp16 pipe");
     // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
     constexpr int HSZ = X_NPIX * X_PKH;                       // floats per halo buffer
@@ -424,14 +428,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         const int sbase = (2 * w + ((lane >> 4) & 1)) * KS_STRIDE + (lane >> 5) * (8 * 32) + ((((lane >> 3) & 1) ^ (lane >> 5)) * 16) + (lane & 7) * 2;
         // A operand: pixel m = 32 i + (lane & 31), channels 8 (lane >> 5) .. + 7 of the k-step
         const int aoff = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
-        // weights: W3x[(ks * 8 + nb) * 3 + plane][lane][8 bf16], 1 KB each (pack_tail_weight_bf16x3); the wave's n-tiles are 2 w, 2 w + 1
+        // weights: W3x[(ks * 8 + nb) * 3 + plane][lane][8 bf16], 1 KB each (pack_tail_weight_bf16x3); the wave's n-tiles are w and 4 + w (output channels
+        // [32 w, 32 w + 32) and [128 + 32 w, ...): the four waves' first tiles are channels 0-127 in order, which is the K order the NEXT conv1 consumes them in)
         const int w3voff = lane * 16;
         auto b3load = [&](int ks, x_u32x4 (&b)[2][NP]) {
             const int k = ks < 8 ? ks : 7;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + 2 * w + j) * NP) + p) * 1024));
+                for (int p = 0; p < NP; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + 4 * j + w) * NP) + p) * 1024));
         };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -480,14 +485,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                     for (int j = 0; j < 2; ++j) mac6(acc2[i][j], af[i], b3[ks & 1][j], false);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (NEXT) __syncthreads();              // every wave is past its conv3 reads of AP: the NEXT conv1's operand planes overwrite it
+            x_f32x16 acc1[2];                                 // NEXT: conv1 of the next block, 64 pixels x channels [32 w, 32 w + 32)
+            if constexpr (NEXT) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) acc1[i] = zero16;
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = (2 * w + j) * 32 + (lane & 7) * 4;
+            for (int j = 0; j < 2; ++j) {                     // j = the wave's n-tile: output channels [128 j + 32 w, + 32); NEXT: round j = conv1's K half j
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int col = (4 * j + w) * 32 + (lane & 7) * 4;
                     const x_f32x4 bv = *(const x_f32x4*)(a.bias3 + col);
                     x_f32x4 osc3 = x_f32x4{1.f, 1.f, 1.f, 1.f};
                     if constexpr (NP == 2) osc3 = *(const x_f32x4*)(a.oscale3 + col);
+                    x_f32x4 nsc, nsh;
+                    if constexpr (NEXT) { nsc = *(const x_f32x4*)(a.n_scale + col) * S2_XSCALE; nsh = *(const x_f32x4*)(a.n_shift + col) * S2_XSCALE; }
                     int off[4];
                     x_f32x4 rv[4], uv[UP ? 4 : 1];
 #pragma unroll
@@ -497,22 +510,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                         const bool in = oy < a.OH && ox < a.OW;
                         off[k] = in ? ((oy * a.OW + ox) * a.N2 + col) * 4 : BUF_OOB;
                         rv[k] = buf_load(r_srd, off[k], 0);
-                        if constexpr (UP) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
+                        if constexpr (UP && !NEXT) uv[k] = buf_load(up_srd, in ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) T[x_acc_row(r, lane) * 36 + (lane & 31)] = acc2[i][j][r];
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
+                        if constexpr (UP && NEXT) {           // (requested here, one at a time: with the next block's accumulators live there is no room for four)
+                            const int m = 32 * i + (lane >> 3) + 8 * k;
+                            const int oy = oy0 + 2 * (m >> 4) + h, ox = ox0 + (m & 15);
+                            uv[0] = buf_load(up_srd, (oy < a.OH && ox < a.OW) ? (((oy >> 1) * (a.OW >> 1) + (ox >> 1)) * a.N2 + col) * 4 : BUF_OOB, 0);
+                        }
                         x_f32x4 o = *(const x_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4];
                         if constexpr (NP == 2) o *= osc3;             // back to scale (an exact power of two per column)
                         o = (o + bv) + rv[k];
-                        if constexpr (UP) o += uv[k];
+                        if constexpr (UP) o += uv[NEXT ? 0 : k];
                         buf_store(o, o2_srd, off[k]);
+                        if constexpr (NEXT) {
+                            // the next block's operand: 2^S2_XSHIFT relu(bn_next(o)) of this pixel's 4 channels (local channel 32 w + 4 (lane & 7) of K half j) as
+                            // two fp16 planes in A-operand order -- k-step 2 w + ((lane & 7) >> 2), pixel m, 16-byte half ((lane & 3) >> 1) swapped for pixels 8-15
+                            const int m = 32 * i + (lane >> 3) + 8 * k;
+                            float xn[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) xn[c] = fmaxf(fmaf(o[c], nsc[c], nsh[c]), 0.f);
+                            tmax = fmaxf(fmaxf(tmax, fmaxf(xn[0], xn[1])), fmaxf(xn[2], xn[3]));
+                            const unsigned h0 = s2_pack_rn(xn[0], xn[1]), h1 = s2_pack_rn(xn[2], xn[3]);
+                            const unsigned l0 = s2_pack_rn(xn[0] - s2_lo(h0), xn[1] - s2_hi(h0)), l1 = s2_pack_rn(xn[2] - s2_lo(h1), xn[3] - s2_hi(h1));
+                            unsigned char* d = AP + (2 * w + ((lane & 7) >> 2)) * KS_STRIDE + m * 32 + (((((lane & 3) >> 1) ^ ((m >> 3) & 1))) * 16) + (lane & 1) * 8;
+                            *reinterpret_cast<x_u32x2*>(d) = x_u32x2{h0, h1};
+                            *reinterpret_cast<x_u32x2*>(d + PL_STRIDE) = x_u32x2{l0, l1};
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-            if (h == 0) __syncthreads();                      // every wave is done with the A planes of pass 0
+                if constexpr (NEXT) {
+                    // K half j of conv1 (channels [128 j, 128 j + 128) = k-steps 8 j .. 8 j + 7, ascending: the order of gemm_bf16x3_kernel): wave w -> n-tile w
+                    const __amdgpu_buffer_rsrc_t n1_srd = make_srd(a.n_W1, (size_t)128 * 256 * 2 * sizeof(uint16_t));
+                    auto n1load = [&](int q, x_u32x4 (&b)[2]) {
+                        const int ksg = 8 * j + (q < 8 ? q : 7);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(n1_srd, w3voff + p * 1024, ((ksg * 4 + w) * 2) * 1024));
+                    };
+                    constexpr int NR = 4;                     // weight k-steps in flight: a k-step is only 6 MFMAs (192 cycles), an L2 round trip three times that
+                    x_u32x4 nb[NR][2];
+#pragma unroll
+                    for (int q = 0; q < NR - 1; ++q) n1load(q, nb[q]);
+                    __syncthreads();                          // the four waves' planes of this K half are complete
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        n1load(q + NR - 1, nb[(q + NR - 1) % NR]);
+                        x_bf16x8 af[2][2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) af[i][p] = *(const x_bf16x8*)(AP + p * PL_STRIDE + q * KS_STRIDE + i * 1024 + aoff);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) mac6(acc1[i], af[i], nb[q % NR], false);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __syncthreads();                          // every wave has read the planes: the next K half / the next pass's conv2 tile may overwrite them
+                }
+            }
+            if constexpr (NEXT) {
+                // conv1's epilogue as gemm_bf16x3_kernel's: acc * oscale + bias, ReLU, 16-byte stores of the wave's 32 channels of the 64 pixels
+                const int col = w * 32 + (lane & 7) * 4;
+                const x_f32x4 b1 = *(const x_f32x4*)(a.n_b1 + col), o1 = *(const x_f32x4*)(a.n_osc1 + col);
+                const size_t cropn = (size_t)a.OH * a.OW * 128;
+                const __amdgpu_buffer_rsrc_t n_srd = make_srd(a.n_out + (size_t)l * cropn, cropn * sizeof(float));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) T[x_acc_row(r, lane) * 36 + (lane & 31)] = acc1[i][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = 32 * i + (lane >> 3) + 8 * k;
+                        const int oy = oy0 + 2 * (m >> 4) + h, ox = ox0 + (m & 15);
+                        x_f32x4 o = *(const x_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4];
+                        o *= o1;
+                        o += b1;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
+                        buf_store(o, n_srd, (oy < a.OH && ox < a.OW) ? ((oy * a.OW + ox) * 128 + col) * 4 : BUF_OOB);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (h == 0 && !NEXT) __syncthreads();             // every wave is done with the A planes of pass 0 (NEXT: the K half's closing barrier)
         }
         if constexpr (NP == 2) s2_raise(a.range_flag, tmax);
         return;
@@ -716,6 +802,11 @@ int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
+    if (a.n_W1) {                                      // ... with the next block's conv1 on the tile (all of n_* set)
+        if (!a.n_scale || !a.n_shift || !a.n_osc1 || !a.n_b1 || !a.n_out) { suo_set_error("conv3x3_wino_f16x2_fused: incomplete next-block arguments"); return SUO_ERR_ARG; }
+        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
+    } else
     if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());

@@ -69,7 +69,11 @@ private:
     void make_hourglass(const std::string& p, int n, HourglassW& h);
     float* alloc(size_t floats);
     // pool_out: also produce max_pool2d(out, 2, 2) (fused into the last GEMM where it can be, else a separate launch); `out` may then be nullptr
-    int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr, float* pool_out = nullptr);
+    // next: the Residual block that consumes `out` next at this resolution (or nullptr): where this block ends in the fused fp16 Winograd tail, that launch
+    // also computes next's conv1 (csrc/conv_wino_x3.hip, NEXT) and residual(*next, out, ...) finds it done (pre_*)
+    int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr, float* pool_out = nullptr,
+                 const ResidualW* next = nullptr);
+    bool next_conv1_fusable(const ResidualW& next, int L, int H, int W) const;
     int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const GemmW* gw = nullptr);
     bool residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const;
     int residual_in_one_launch(const ResidualW& r, int L, int H, int W) const;      // 0: no; 1: csrc/res_small.hip; 2: csrc/res_small_x3.hip
@@ -96,6 +100,8 @@ private:
     hipStream_t side_[kNumSide] = {}; hipStream_t own_stream_ = nullptr;
     hipEvent_t ev_[kNumEvents] = {}; int ev_next_ = 0;
     bool use_graph_ = true; bool dry_run_ = false;
+    struct PreConv1 { const float* x; const ResidualW* r; float* mid1; };      // conv1 of block r on input x, already computed by the producer's tail
+    std::vector<PreConv1> pre_;                                              // (several can be pending: up1[0]'s for up1[1] waits while the low branch runs)
     int pipe_ = 1, pipe_built_ = 1;                      // the pipe in use / the best one the weights were packed for
     unsigned* range_flag_ = nullptr;                     // mapped host memory: the f16x2 kernels raise it, the host reads it after any synchronisation
     // two executables per captured graph, launched alternately: hipGraphLaunch of an executable whose previous launch is still running blocks the host until

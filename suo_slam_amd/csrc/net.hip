@@ -438,8 +438,16 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
     (void)alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
     stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);
     ws_mark_ = ws_used_;
-    if (backbone(nullptr, IN_C, nullptr, max_crops_, nullptr) != SUO_OK) throw std::runtime_error("dry run failed");
-    ws_floats_ = ws_used_;
+    // (every pipe this network can run on: the forms pick different kernels -- per-layer launches with their intermediate tensors where another form
+    //  takes a one-launch block -- and a network that falls back to bf16x3 must find its workspace large enough)
+    size_t need = 0;
+    for (int p = pipe_built_; p >= (pipe_built_ == 0 ? 0 : 1); --p) {
+        pipe_ = p;
+        if (backbone(nullptr, IN_C, nullptr, max_crops_, nullptr) != SUO_OK) throw std::runtime_error("dry run failed");
+        need = std::max(need, ws_used_);
+    }
+    pipe_ = pipe_built_;
+    ws_floats_ = need;
     dry_run_ = false;
     if (hipMalloc(&ws_, ws_floats_ * sizeof(float)) != hipSuccess) throw std::runtime_error("hipMalloc(workspace) failed");
     if (hipMalloc(&d_mean_logit_, (size_t)max_crops_ * NUM_KP * sizeof(float)) != hipSuccess)
@@ -567,7 +575,16 @@ int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hi
     return SUO_OK;
 }
 
-int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, float* pool_out) {
+// The next block's conv1 can ride on this block's fused fp16 tail when the separate launch would have been the fp16 GEMM on the same operands
+// (256 -> 128 with a BatchNorm prologue, >= SUO_GEMM_X3_MIN_ROWS pixels, not a one-launch block): then the two are bit-identical (tests/test_gpu_f16x2.py)
+bool Net::next_conv1_fusable(const ResidualW& next, int L, int H, int W) const {
+    static const int on = getenv("SUO_FUSE_NEXT_CONV1") ? atoi(getenv("SUO_FUSE_NEXT_CONV1")) : 1;                // 0: A/B
+    static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+    return on && pipe_ == 2 && next.cin == 256 && next.c1.W16 && next.c1.osc16 && next.c1.N == 128 && next.c1.n_valid == 128 && next.c1.K1 == 256 && next.c1.K2 == 0 &&
+           (long)L * H * W >= x3_min_rows && !residual_in_one_launch(next, L, H, W);
+}
+
+int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, float* pool_out, const ResidualW* next) {
     const int M = L * H * W;
     if (residual_in_one_launch(r, L, H, W)) {
         if (!out) out = alloc((size_t)M * 256);
@@ -575,13 +592,22 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
         if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
         return SUO_OK;
     }
-    float* mid1 = alloc((size_t)M * r.c1.N);
+    float* mid1 = nullptr;
+    for (size_t i = 0; i < pre_.size(); ++i)
+        if (pre_[i].x == x && pre_[i].r == &r) {              // conv1 came with the producer block's tail (NEXT)
+            mid1 = pre_[i].mid1;
+            pre_.erase(pre_.begin() + i);
+            break;
+        }
+    if (!mid1) {
+        mid1 = alloc((size_t)M * r.c1.N);
+        GemmArgs g1 = {};
+        g1.A1 = x; g1.lda1 = r.cin; g1.K1 = r.c1.K1; g1.pro_scale = r.pro_scale; g1.pro_shift = r.pro_shift;
+        g1.Wp = r.c1.Wp; g1.bias = r.c1.bias; g1.out = mid1; g1.ldo = r.c1.N; g1.M = M; g1.N = r.c1.N; g1.n_valid = r.c1.n_valid; g1.relu = 1;
+        // large launches: on the bf16 pipe with 3-way split operands (464 vs 595 us at 256 crops / 64 x 64; below ~256 tiles the fp32 kernels' smaller tiles win)
+        SUO_TRY(gemm_maybe_pooled(g1, L, H, W, nullptr, s, &r.c1));
+    }
     float* mid2 = alloc((size_t)M * r.c2.N);
-    GemmArgs g1 = {};
-    g1.A1 = x; g1.lda1 = r.cin; g1.K1 = r.c1.K1; g1.pro_scale = r.pro_scale; g1.pro_shift = r.pro_shift;
-    g1.Wp = r.c1.Wp; g1.bias = r.c1.bias; g1.out = mid1; g1.ldo = r.c1.N; g1.M = M; g1.N = r.c1.N; g1.n_valid = r.c1.n_valid; g1.relu = 1;
-    // large launches: on the bf16 pipe with 3-way split operands (464 vs 595 us at 256 crops / 64 x 64; below ~256 tiles the fp32 kernels' smaller tiles win)
-    SUO_TRY(gemm_maybe_pooled(g1, L, H, W, nullptr, s, &r.c1));
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
     c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
@@ -604,6 +630,13 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
             c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256; c2.up = up;
             if (pipe_ == 2 && r.c2.Wq16 && r.c3x16) {        // both products as two fp16 terms (csrc/f16x2.h)
                 c2.Wp = r.c2.Wq16; c2.W3p = r.c3x16; c2.oscale = r.c2.osc16; c2.oscale3 = r.c3osc16; c2.range_flag = range_flag_;
+                // the next block's conv1 on the tile while it is in the CU: its 256-channel input is written once and not re-read by a GEMM launch.
+                // (Not with an up-sampled addend: that variant has no registers left -- measured no gain, tools/bench_f16x2.py.)
+                if (next && !up && !pool_out && next_conv1_fusable(*next, L, H, W)) {
+                    float* nm = alloc((size_t)M * 128);
+                    c2.n_scale = next->pro_scale; c2.n_shift = next->pro_shift; c2.n_W1 = next->c1.W16; c2.n_osc1 = next->c1.osc16; c2.n_b1 = next->c1.bias; c2.n_out = nm;
+                    pre_.push_back({out, next, nm});
+                }
                 SUO_LAUNCH(launch_conv3x3_wino_f16x2_fused(c2, s));
             } else if (r.c2.Wq3 && r.c3x) {                   // both products on the bf16 pipe, 3-way split operands
                 c2.Wp = r.c2.Wq3; c2.W3p = r.c3x; c2.w3_bf16x3 = 1;
@@ -658,7 +691,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     // wait for the low branch; its predecessor still runs beside it on the side stream.
     static const int fuse_up = getenv("SUO_FUSE_UPSAMPLE") ? atoi(getenv("SUO_FUSE_UPSAMPLE")) : 1;              // 0: A/B
     const bool up_in_tail = fuse_up && (residual_tail_is_fused(h.up1[1], L, H, W) || residual_in_one_launch(h.up1[1], L, H, W));
-    SUO_TRY(residual(h.up1[0], x, up_a, L, H, W, side));
+    SUO_TRY(residual(h.up1[0], x, up_a, L, H, W, side, nullptr, nullptr, &h.up1[1]));
     if (!up_in_tail) SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
     SUO_HIP_LIVE(hipEventRecord(ev_join, side));
 
@@ -674,19 +707,20 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     float* lo_a = alloc(n_lo);
     float* lo_b = alloc(n_lo);
     if (pool_by_block) SUO_TRY(residual_one_launch(h.low1[0], x, lo_a, L, H / 2, W / 2, s, nullptr, true));
-    else SUO_TRY(residual(h.low1[0], pooled, lo_a, L, H / 2, W / 2, s));
-    SUO_TRY(residual(h.low1[1], lo_a, lo_b, L, H / 2, W / 2, s));
+    else SUO_TRY(residual(h.low1[0], pooled, lo_a, L, H / 2, W / 2, s, nullptr, nullptr, &h.low1[1]));
+    // (lo_b has two readers -- the inner hourglass's up1[0] and, pooled, its low1[0]: the first one's conv1 rides along)
+    SUO_TRY(residual(h.low1[1], lo_a, lo_b, L, H / 2, W / 2, s, nullptr, nullptr, h.n > 1 ? &h.inner->up1[0] : &h.low2[0]));
     float* low2 = alloc(n_lo);
     if (h.n > 1) {
         SUO_TRY(hourglass(*h.inner, lo_b, low2, L, H / 2, W / 2, s, depth_idx + 1));
     } else {
         float* t = alloc(n_lo);
-        SUO_TRY(residual(h.low2[0], lo_b, t, L, H / 2, W / 2, s));
-        SUO_TRY(residual(h.low2[1], t, low2, L, H / 2, W / 2, s));
+        SUO_TRY(residual(h.low2[0], lo_b, t, L, H / 2, W / 2, s, nullptr, nullptr, &h.low2[1]));
+        SUO_TRY(residual(h.low2[1], t, low2, L, H / 2, W / 2, s, nullptr, nullptr, &h.low3[0]));
     }
     float* l3a = alloc(n_lo);
     float* l3b = alloc(n_lo);
-    SUO_TRY(residual(h.low3[0], low2, l3a, L, H / 2, W / 2, s));
+    SUO_TRY(residual(h.low3[0], low2, l3a, L, H / 2, W / 2, s, nullptr, nullptr, &h.low3[1]));
     SUO_TRY(residual(h.low3[1], l3a, l3b, L, H / 2, W / 2, s));
     SUO_HIP_LIVE(hipStreamWaitEvent(s, ev_join, 0));
     if (up_in_tail) SUO_TRY(residual(h.up1[1], up_a, out, L, H, W, s, l3b));
@@ -698,6 +732,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
 int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t s, bool stem_done) {
     ws_used_ = ws_mark_;
     ev_next_ = 0;
+    pre_.clear();
     float* stem = stem_slab_;
     if (!stem_done) {                                          // (the fused stem of the prior-less pass has filled the slab already: csrc/stem_x3.hip)
         ConvArgs c = {};
@@ -720,7 +755,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         SUO_TRY(hourglass(hg_[i], x, hg, L, 64, 64, s, 0, xp));
         float* ra = alloc((size_t)M * 256);
         float* rb = alloc((size_t)M * 256);
-        SUO_TRY(residual(post_[i][0], hg, ra, L, 64, 64, s));
+        SUO_TRY(residual(post_[i][0], hg, ra, L, 64, 64, s, nullptr, nullptr, &post_[i][1]));
         SUO_TRY(residual(post_[i][1], ra, rb, L, 64, 64, s));
         float* ll = alloc((size_t)M * 256);
         GemmArgs gl = {};
@@ -753,7 +788,15 @@ int Net::ensure_graph(float* in0, int in_c, float* logits, int L, hipStream_t s,
     if (it == graphs_.end()) {
         GraphEntry ge;
         SUO_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        int r = backbone(in0, in_c, logits, L, s, stem_done);
+        int r;
+        try {
+            r = backbone(in0, in_c, logits, L, s, stem_done);
+        } catch (...) {                                   // (an exception inside the schedule must not leave the stream capturing)
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(s, &dead);
+            if (dead) (void)hipGraphDestroy(dead);
+            throw;
+        }
         hipError_t e = hipStreamEndCapture(s, &ge.graph);
         if (r != SUO_OK) return r;
         SUO_HIP_CHECK(e);

@@ -72,6 +72,9 @@ struct ConvArgs {
     int w3_bf16x3;                                       // csrc/conv_wino_x3.hip only: W3p holds pack_tail_weight_bf16x3's uint16 planes
     // f16x2 form only (csrc/f16x2.h): per-channel factors 2^-(t_n + S2_XSHIFT) of the 3x3 convolution [N] and of the tail's conv3 [N2], range-guard flag
     const float* oscale; const float* oscale3; unsigned* range_flag;
+    // ... and, optional, the NEXT block's conv1 in the same launch (csrc/conv_wino_x3.hip, NEXT): its BatchNorm prologue [256], its weights as two fp16 planes
+    // (pack_gemm_weight_f16x2 of W1 [128][256]) with their factors [128], its folded bias [128]; n_out [L,OH,OW,128] = relu(bn1(conv1(relu(bn(out2)))))
+    const float* n_scale; const float* n_shift; const float* n_W1; const float* n_osc1; const float* n_b1; float* n_out;
 };
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 bool conv3x3_fusable(const ConvArgs& a);

@@ -331,6 +331,21 @@ def res_block_x3(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=Fals
     return out
 
 
+def conv3x3_wino_f16x2_tail_next(x_nhwc, w2, b2, w3, b3, skip_nhwc, up_nhwc, n_pro, n_w1, n_b1):
+    """The fused Residual tail on two fp16 terms WITH the next block's conv1 (csrc/conv_wino_x3.hip, NEXT): returns (out [L,H,W,256], next_mid1 [L,H,W,128], flag)."""
+    L, H, W, C = x_nhwc.shape
+    wq, o2, w3p, o3 = _pack_f16x2(w2, w3)
+    w1h, osc1, _ = pack_gemm_f16x2(n_w1)
+    out = torch.empty((L, H, W, 256), device="cuda")
+    nxt = torch.full((L, H, W, 128), -7.0, device="cuda")
+    b2d, b3d, ns, nt, nb = dev(b2), dev(b3), dev(n_pro[0]), dev(n_pro[1]), dev(n_b1)
+    flag = _flag()
+    _lib.check(_lib.lib().suo_conv3x3_wino_f16x2_conv1x1_skip_up_next(P(x_nhwc), L, H, W, P(wq), P(o2), P(b2d), P(w3p), P(o3), P(b3d), P(skip_nhwc), P(up_nhwc), P(out), P(ns), P(nt),
+                                                                      P(w1h), P(osc1), P(nb), P(nxt), P(flag), S()), "suo_conv3x3_wino_f16x2_conv1x1_skip_up_next")
+    torch.cuda.synchronize()
+    return out, nxt, int(flag.item())
+
+
 def res_block_f16x2(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=False):
     """csrc/res_small_x3.hip with NP = 2: the one-launch Residual block on two fp16 terms per operand; arguments as res_block.  Returns (out, range_flag)."""
     lib = _lib.lib()

@@ -319,3 +319,33 @@ def test_network_falls_back_when_activations_leave_the_fp16_range(monkeypatch, c
     out = n16(img, [torch.from_numpy(boxes)], None)
     torch.cuda.synchronize()
     assert np.array_equal(out["prob_logits"].cpu().numpy(), o3["prob_logits"]) and not n16.range_exceeded()
+
+
+@pytest.mark.parametrize("up", [False, True])
+@pytest.mark.parametrize("L,H,W", [(6, 32, 32), (3, 20, 24), (2, 64, 64)])
+def test_fused_tail_with_the_next_blocks_conv1_equals_the_separate_launches(ops, up, L, H, W):
+    """csrc/conv_wino_x3.hip, NEXT: the block's output is split for the next block's conv1 where it is stored and multiplied on the spot.  Bit for bit: `out` = the
+    fused tail without NEXT; `next` = suo_conv1x1_f16x2_ex (BN + ReLU prologue, ReLU) on that `out` -- the same products in the same order.  Ragged maps (tiles that
+    leave the map write nothing outside it), the up-sampled addend, and the range guard on the inner operand relu(bn_next(out))."""
+    rng = np.random.default_rng(31 + H + up)
+    x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
+    skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
+    upd = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda() if up else None
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+    b2 = (rng.standard_normal(128) * 0.3).astype(np.float32)
+    w3 = (rng.standard_normal((256, 128)) / np.sqrt(128)).astype(np.float32)
+    b3 = rng.standard_normal(256).astype(np.float32)
+    ns, nt = rng.uniform(0.5, 1.5, 256).astype(np.float32), (rng.standard_normal(256) * 0.3).astype(np.float32)
+    w1 = (rng.standard_normal((128, 256)) / 16).astype(np.float32)
+    b1 = (rng.standard_normal(128) * 0.2).astype(np.float32)
+    out, nxt, flag = ops.conv3x3_wino_f16x2_tail_next(x, w2, b2, w3, b3, skip, upd, (ns, nt), w1, b1)
+    ref_out, f0 = ops.conv3x3_wino_f16x2_conv1x1_skip_up(x, w2, b2, w3, b3, skip, upd)
+    assert flag == 0 and f0 == 0
+    assert torch.equal(out, ref_out)
+    ref_nxt, f1 = ops.conv1x1_f16x2(ref_out.reshape(-1, 256), w1, b1, pro=(ns, nt), relu=True)
+    assert f1 == 0
+    assert torch.equal(nxt.reshape(-1, 128), ref_nxt)
+    # the guard: a next-block BatchNorm scale that pushes relu(bn_next(out)) beyond 4094 raises the flag (out itself stays valid and in range)
+    ns_big = ns * np.float32(3000.0)
+    _, _, flag = ops.conv3x3_wino_f16x2_tail_next(x, w2, b2, w3, b3, skip, upd, (ns_big, nt), w1, b1)
+    assert flag == 1

@@ -77,8 +77,34 @@ def main():
             flop = 2.0 * L * HW * HW * C * C * 9
         t3, t2 = timed(f3), timed(f2)
         rows.append((name, t3, t2, "%.0f / %.0f algorithmic TFLOP/s" % (flop / t3 / 1e6, flop / t2 / 1e6)))
+    # ---- the next block's conv1 inside the tail (NEXT) against tail + separate conv1 launch ------------------------------------------------
+    nx = []
+    for HW in (64, 32):
+        for up in (False, True):
+            x = torch.rand((L, HW, HW, 128), device="cuda") - 0.3
+            skip = torch.rand((L, HW, HW, 256), device="cuda")
+            upd = torch.rand((L, HW // 2, HW // 2, 256), device="cuda") if up else None
+            w2 = (rng.standard_normal((128, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32)
+            w3 = (rng.standard_normal((256, 128)) / 11).astype(np.float32)
+            w1 = (rng.standard_normal((128, 256)) / 16).astype(np.float32)
+            b2, b3, b1 = ops.dev(np.zeros(128, np.float32)), ops.dev(np.zeros(256, np.float32)), ops.dev(np.zeros(128, np.float32))
+            wq, o2, w3p, o3 = ops._pack_f16x2(w2, w3)
+            w1h, o1, _ = ops.pack_gemm_f16x2(w1)
+            ns, nt = ops.dev(rng.uniform(0.5, 1.5, 256)), ops.dev(rng.standard_normal(256) * 0.1)
+            out = torch.empty((L, HW, HW, 256), device="cuda")
+            mid = torch.empty((L, HW, HW, 128), device="cuda")
+            M = L * HW * HW
+            tail = lambda: _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(x), L, HW, HW, P(wq), P(o2), P(b2), P(w3p), P(o3), P(b3), P(skip), P(upd), P(out), P(flag), S()))      # noqa: E731
+            gemm = lambda: _lib.check(lib.suo_conv1x1_f16x2_ex(P(out), 256, 256, P(ns), P(nt), None, 0, 0, P(w1h), P(o1), P(b1), None, 0, P(mid), 128, M, 128, 1, P(flag), S()))      # noqa: E731
+            fused = lambda: _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up_next(P(x), L, HW, HW, P(wq), P(o2), P(b2), P(w3p), P(o3), P(b3), P(skip), P(upd), P(out), P(ns), P(nt),      # noqa: E731
+                                                                                        P(w1h), P(o1), P(b1), P(mid), P(flag), S()))
+            both = lambda: (tail(), gemm())                 # noqa: E731
+            nx.append((HW, up, timed(tail), timed(gemm), timed(both), timed(fused)))
     torch.cuda.synchronize()
     assert int(flag.item()) == 0
+    print("next block's conv1 in the tail: map, up | tail alone | conv1 alone | tail + conv1 (two launches) | fused (one launch) | saved")
+    for HW, up, tt, tg, tb, tf in nx:
+        print(f"  {HW}x{HW} up={int(up)}   {tt:8.1f} {tg:8.1f} {tb:8.1f} {tf:8.1f}   {tb - tf:+7.1f} us ({100 * (tb - tf) / tb:.1f} %)")
     print(f"{L} crops per launch; us per launch: bf16x3 (6 MFMA) | f16x2 (3 MFMA) | ratio")
     for name, t3, t2, extra in rows:
         print(f"  {name:48s} {t3:9.1f} {t2:9.1f}   {t3 / t2:5.2f}x   {extra}")

@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (one gpurun call): bench lines, kernel traces, dominant-kernel stats, PMC passes.
 #   bash tools/profile_round.sh <round-tag>      -> gpurun_out/round_<tag>/...   (then: bash tools/install_profiles.sh <tag> <prefix>)
 # Every rocprofv3 command is written next to its output (cmd_*.txt) so that the installed files carry the command that made them.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
 rm -rf $OUT && mkdir -p $OUT
@@ -54,3 +54,11 @@ cp $R/profiles/pmc_dominant_conv.json $OUT/ 2>/dev/null
 SUO_PMC_GEMM_M=1048576 bash $R/tools/profile_gemm_pmc.sh conv1_f16 conv1_x3 conv1 > $OUT/pmc_gemm.txt 2>&1
 cp $R/profiles/pmc_gemm.json $OUT/ 2>/dev/null
 ls $OUT
+# 8. round 5: the matrix-pipe forms side by side at the network's launch shapes, and the host side of the batched evaluation
+python3 $R/tools/bench_f16x2.py 256 2>&1 | grep -v amdgpu.ids > $OUT/f16x2_ab.txt
+python3 $R/tools/time_views_single_host.py 16 2>&1 | grep -v amdgpu.ids | head -40 > $OUT/views_single_host.txt
+python3 $R/tools/time_frame_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/frame_chain.txt
+# gpurun merges gpurun_out/ back only when it is <= 64 MiB: the raw counter databases stay on the box (their summaries are in $OUT and profiles/*.json)
+rm -rf $R/gpurun_out/pmc
+find $R/gpurun_out -name "*.db" -delete 2>/dev/null
+du -sh $R/gpurun_out
