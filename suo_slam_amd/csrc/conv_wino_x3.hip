@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if constexpr (NP == 2) {                                  // hi = rn16(v), lo = rn16(v - hi) (the residual is exact)
             const unsigned h0 = s2_pack_rn(v[0], v[1]), h1 = s2_pack_rn(v[2], v[3]);
             *(x_u32x2*)&V[comp * 32 * VROW + vbase] = x_u32x2{h0, h1};
-            const unsigned l0 = s2_pack_rn(v[0] - s2_lo(h0), v[1] - s2_hi(h0)), l1 = s2_pack_rn(v[2] - s2_lo(h1), v[3] - s2_hi(h1));
+            const unsigned l0 = s2_lo_pack(v[0], v[1], h0), l1 = s2_lo_pack(v[2], v[3], h1);
             *(x_u32x2*)&V[VPL + comp * 32 * VROW + vbase] = x_u32x2{l0, l1};
             return;
         }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                             for (int c = 0; c < 4; ++c) xn[c] = fmaxf(fmaf(o[c], nsc[c], nsh[c]), 0.f);
                             tmax = fmaxf(fmaxf(tmax, fmaxf(xn[0], xn[1])), fmaxf(xn[2], xn[3]));
                             const unsigned h0 = s2_pack_rn(xn[0], xn[1]), h1 = s2_pack_rn(xn[2], xn[3]);
-                            const unsigned l0 = s2_pack_rn(xn[0] - s2_lo(h0), xn[1] - s2_hi(h0)), l1 = s2_pack_rn(xn[2] - s2_lo(h1), xn[3] - s2_hi(h1));
+                            const unsigned l0 = s2_lo_pack(xn[0], xn[1], h0), l1 = s2_lo_pack(xn[2], xn[3], h1);
                             unsigned char* d = AP + (2 * w + ((lane & 7) >> 2)) * KS_STRIDE + m * 32 + (((((lane & 3) >> 1) ^ ((m >> 3) & 1))) * 16) + (lane & 1) * 8;
                             *reinterpret_cast<x_u32x2*>(d) = x_u32x2{h0, h1};
                             *reinterpret_cast<x_u32x2*>(d + PL_STRIDE) = x_u32x2{l0, l1};

@@ -40,6 +40,22 @@ __device__ __forceinline__ unsigned s2_pack_rn(float a, float b) { return __buil
 // the two halves of such a pair as fp32 values (v_cvt_f32_f16, the upper half by SDWA)
 __device__ __forceinline__ float s2_lo(unsigned p) { return (float)__builtin_bit_cast(s2_f16x2, p)[0]; }
 __device__ __forceinline__ float s2_hi(unsigned p) { return (float)__builtin_bit_cast(s2_f16x2, p)[1]; }
+// the residual pair of (a, b) against their rounded pair h: fp16(a - hi_a) | fp16(b - hi_b) << 16.  v_fma_mixlo / mixhi_f16 read the fp16 half as an fp32 operand,
+// form fma(hi, -1, x) in fp32 (exact here) and round the result to fp16 in ONE instruction each -- 2 per pair where cvt_f32_f16 x 2 + v_pk_add_f32 + v_cvt_pk_f16_f32
+// take 4.  Same value bit for bit (tests/test_gpu_f16x2.py: test_device_split_equals_numpy_float16_rounding); -DSUO_S2_MIX=0 builds the four-instruction form.
+#ifndef SUO_S2_MIX
+#define SUO_S2_MIX 1
+#endif
+__device__ __forceinline__ unsigned s2_lo_pack(float a, float b, unsigned h) {
+#if SUO_S2_MIX
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(b));
+    return r;
+#else
+    return s2_pack_rn(a - s2_lo(h), b - s2_hi(h));
+#endif
+}
 // running max of magnitudes for the range guard: m <- max(m, |a|, |b|) (one v_max3_f32 with source modifiers)
 __device__ __forceinline__ float s2_track(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
 // raise the flag when the lane saw a value at or beyond the fp16 range

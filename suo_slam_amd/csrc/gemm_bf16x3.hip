@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? S
                 xmax = s2_track(s2_track(xmax, x[0], x[1]), x[2], x[3]);
                 const unsigned h0 = s2_pack_rn(x[0], x[1]), h1 = s2_pack_rn(x[2], x[3]);
                 *(u32x2*)&As[(X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{h0, h1};
-                const unsigned l0 = s2_pack_rn(x[0] - s2_lo(h0), x[1] - s2_hi(h0)), l1 = s2_pack_rn(x[2] - s2_lo(h1), x[3] - s2_hi(h1));      // exact residuals, rounded once
+                const unsigned l0 = s2_lo_pack(x[0], x[1], h0), l1 = s2_lo_pack(x[2], x[3], h1);      // exact residuals, rounded once
                 *(u32x2*)&As[PLANE + (X3_RPP * i + ar) * X3_PITCH + 4 * aq] = u32x2{l0, l1};
             }
         }

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void res_block_x3_kernel(const ResBlockArgs a)
                     gmax = s2_track(s2_track(gmax, x[0], x[1]), x[2], x[3]);
                     const unsigned h0 = s2_pack_rn(x[0], x[1]), h1 = s2_pack_rn(x[2], x[3]);
                     *(r3_u32x2*)(XA + row * XPB + q * 8) = r3_u32x2{h0, h1};
-                    *(r3_u32x2*)(XA + XPL + row * XPB + q * 8) = r3_u32x2{s2_pack_rn(x[0] - s2_lo(h0), x[1] - s2_hi(h0)), s2_pack_rn(x[2] - s2_lo(h1), x[3] - s2_hi(h1))};
+                    *(r3_u32x2*)(XA + XPL + row * XPB + q * 8) = r3_u32x2{s2_lo_pack(x[0], x[1], h0), s2_lo_pack(x[2], x[3], h1)};
                 } else {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {

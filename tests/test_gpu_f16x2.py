@@ -349,3 +349,24 @@ def test_fused_tail_with_the_next_blocks_conv1_equals_the_separate_launches(ops,
     ns_big = ns * np.float32(3000.0)
     _, _, flag = ops.conv3x3_wino_f16x2_tail_next(x, w2, b2, w3, b3, skip, upd, (ns_big, nt), w1, b1)
     assert flag == 1
+
+
+def test_device_split_equals_numpy_float16_rounding(ops):
+    """The device's operand split (v_cvt_pk_f16_f32 for hi, v_fma_mixlo / mixhi_f16 for the residual: csrc/f16x2.h s2_lo_pack) against numpy's float16 rounding,
+    bit for bit: with W = identity the kernel returns (hi + lo) / 16 of every input exactly (one product per output, powers of two everywhere), so the output
+    IS the split.  Inputs cover ties, the normal / subnormal boundary of both terms, and values whose residual is below fp16's smallest subnormal."""
+    rng = np.random.default_rng(5)
+    K = N = 128
+    M = 4096
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    a[:64] *= np.exp2(rng.integers(-24, 8, (64, K))).astype(np.float32)
+    a[64, :16] = np.array([1 + 2.0 ** -11, 1 + 3 * 2.0 ** -11, 2.0 ** -18, 2.0 ** -18 * (1 + 2.0 ** -10), 2.0 ** -28, 2.0 ** -29, 3 * 2.0 ** -29, 255.9375,
+                           -(1 + 2.0 ** -11), 4093.999, 2047.5 / 16, 65503.0 / 16, 1e-12, -1e-7, 0.0, 1023.5 * 2.0 ** -28], np.float32)
+    w = np.eye(N, K, dtype=np.float32)
+    out, flag = ops.conv1x1_f16x2(ops.dev(a), w, np.zeros(N, np.float32))
+    assert flag == 0
+    x = (a * np.float32(16.0)).astype(np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    want = ((hi.astype(np.float32) + lo.astype(np.float32)) / np.float32(16.0)).astype(np.float32) + np.float32(0.0)      # (+ 0: an input that vanishes in BOTH terms gives the accumulator's +0, not -0)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
