@@ -120,7 +120,9 @@ class HipPhases:
                 with torch.cuda.graph(g):                   # (capture only: nothing of the unit runs here)
                     self.unit(robust_on, rank, world, reduce_)
                 self._graphs[key] = g
-            except Exception:                               # capture is an optimisation: fall back to eager launches for good
+            except Exception as exc:                        # capture is an optimisation: fall back to eager launches for good -- and say why, once
+                import sys
+                print(f"suo_slam_amd.ba_dist: hipGraph capture of the LM unit failed ({type(exc).__name__}: {exc}); eager launches from here on", file=sys.stderr)
                 self._graph_failed = True
                 torch.cuda.synchronize()
                 return self.unit(robust_on, rank, world, reduce_)

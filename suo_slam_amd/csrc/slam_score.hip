@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void slam_score_kernel(const double* __restric
 
 struct SlamStore {
     double* rows = nullptr; int capacity = 0;
+    int written = 0;                                            // slots [0, written) have been uploaded; a pair may only name those (the rest of the buffer is uninitialised)
     char* dev = nullptr; char* host = nullptr; size_t cap = 0;   // per-call scratch (device, pinned host), grow-only
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -132,12 +133,14 @@ int suo_slam_store_put(void* h, int first_slot, int n, const double* rows_host) 
     if (!s || first_slot < 0 || n < 0 || (n && !rows_host)) { suo_set_error("suo_slam_store_put: bad arguments"); return SUO_ERR_ARG; }
     if (n == 0) return SUO_OK;
     std::lock_guard<std::mutex> lk(s->mu);
+    if (first_slot > s->written) { suo_set_error("suo_slam_store_put: slots %d..%d would leave a hole after %d written slots", first_slot, first_slot + n - 1, s->written); return SUO_ERR_ARG; }
     const size_t bytes = (size_t)n * suo::SS_ROW * sizeof(double);
     SS_TRY(suo::ss_reserve(s, first_slot + n));
     SS_TRY(suo::ss_scratch(s, bytes));
     memcpy(s->host, rows_host, bytes);
     SUO_HIP_CHECK(hipMemcpyAsync(s->rows + (size_t)first_slot * suo::SS_ROW, s->host, bytes, hipMemcpyHostToDevice, s->stream));
     SUO_HIP_CHECK(hipStreamSynchronize(s->stream));            // (the pinned scratch is the next call's too)
+    if (first_slot + n > s->written) s->written = first_slot + n;
     return SUO_OK;
 }
 
@@ -149,7 +152,7 @@ int suo_slam_score(void* h, int n_pairs, const double* pairs_host, double chi2_m
     for (int i = 0; i < n_pairs; ++i) {
         long long slot;
         memcpy(&slot, pairs_host + (size_t)i * suo::SS_PAIR + 13, 8);
-        if (slot < 0 || slot >= s->capacity) { suo_set_error("suo_slam_score: pair %d names slot %lld of %d", i, slot, s->capacity); return SUO_ERR_ARG; }
+        if (slot < 0 || slot >= s->written) { suo_set_error("suo_slam_score: pair %d names slot %lld, %d slots written", i, slot, s->written); return SUO_ERR_ARG; }
     }
     const size_t pb = (size_t)n_pairs * suo::SS_PAIR * sizeof(double), cb = (size_t)(n_pairs + 1) * sizeof(int32_t);
     const size_t co = (pb + 255) / 256 * 256;
