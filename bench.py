@@ -319,7 +319,7 @@ DTYPE_NOTE = {
 
 
 def dominant_kernel_name():
-    return {"f16x2": "wino3x3_x3_kernel<true,false,true,4,2>", "bf16x3": "wino3x3_x3_kernel<true,false,true,4,3>", "f32": "wino3x3_kernel<true"}[matrix_pipe()]
+    return {"f16x2": "wino3x3_x3_kernel<true,false,true,4,2,false>", "bf16x3": "wino3x3_x3_kernel<true,false,true,4,3,false>", "f32": "wino3x3_kernel<true"}[matrix_pipe()]
 
 
 def dominant_kernel_traffic(L):

@@ -370,3 +370,4 @@ def test_device_split_equals_numpy_float16_rounding(ops):
     lo = (x - hi.astype(np.float32)).astype(np.float16)
     want = ((hi.astype(np.float32) + lo.astype(np.float32)) / np.float32(16.0)).astype(np.float32) + np.float32(0.0)      # (+ 0: an input that vanishes in BOTH terms gives the accumulator's +0, not -0)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+

@@ -5,7 +5,8 @@
 TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
-rm -rf $OUT && mkdir -p $OUT
+[ -z "${SUO_PROFILE_ONLY_PMC:-}" ] && rm -rf $OUT
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_traced() {   # name, then the program and its arguments
   local name=$1; shift
@@ -14,6 +15,7 @@ run_traced() {   # name, then the program and its arguments
   python3 $R/tools/rocpd_stats.py $(find $OUT/${name}_trace -name "*.db" | head -1) grid > $OUT/${name}_kernel_stats.txt
   rm -rf $OUT/${name}_trace
 }
+if [ -z "${SUO_PROFILE_ONLY_PMC:-}" ]; then
 # 1. the bench line itself (all legs), and at the driver's flags
 python3 $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line_driver_flags.json 2>> $OUT/bench.err
@@ -42,6 +44,7 @@ printf 'import sys\nsys.path.insert(0, "%s")\nimport bench\nprint(bench.global_b
 rocprofv3 --kernel-trace -d $OUT/global_ba_trace -o trace -- python3 /tmp/gba.py > $OUT/global_ba.log 2>&1
 python3 $R/tools/rocpd_stats.py $(find $OUT/global_ba_trace -name "*.db" | head -1) grid > $OUT/global_ba_kernel_stats.txt
 rm -rf $OUT/global_ba_trace
+fi
 # 7. PMC passes (separate runs per counter group, nothing but --kernel-trace beside --pmc)
 mkdir -p $R/gpurun_out/pmc && rm -f $R/gpurun_out/pmc/*
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" \
@@ -54,10 +57,12 @@ cp $R/profiles/pmc_dominant_conv.json $OUT/ 2>/dev/null
 SUO_PMC_GEMM_M=1048576 bash $R/tools/profile_gemm_pmc.sh conv1_f16 conv1_x3 conv1 > $OUT/pmc_gemm.txt 2>&1
 cp $R/profiles/pmc_gemm.json $OUT/ 2>/dev/null
 ls $OUT
+if [ -z "${SUO_PROFILE_ONLY_PMC:-}" ]; then
 # 8. round 5: the matrix-pipe forms side by side at the network's launch shapes, and the host side of the batched evaluation
 python3 $R/tools/bench_f16x2.py 256 2>&1 | grep -v amdgpu.ids > $OUT/f16x2_ab.txt
 python3 $R/tools/time_views_single_host.py 16 2>&1 | grep -v amdgpu.ids | head -40 > $OUT/views_single_host.txt
 python3 $R/tools/time_frame_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/frame_chain.txt
+fi
 # gpurun merges gpurun_out/ back only when it is <= 64 MiB: the raw counter databases stay on the box (their summaries are in $OUT and profiles/*.json)
 rm -rf $R/gpurun_out/pmc
 find $R/gpurun_out -name "*.db" -delete 2>/dev/null
