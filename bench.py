@@ -604,18 +604,20 @@ def fp32_pipe_leg(args, L):
     import torch.nn.functional as Fn
     from suo_slam_amd import _lib
     out = {}
-    env = dict(os.environ, SUO_WINO_BF16X3="0")
     cmd = [sys.executable, os.path.abspath(__file__), "--no-legs", "--steps", "4", "--warmup", "2", "--objects", str(args.objects), "--frames-per-step",
            str(args.frames_per_step), "--depth", str(args.depth)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode == 0 and line:
-        j = json.loads(line[-1])
-        out["frames_per_s_fp32_pipe"] = j["value"]
-        out["ms_per_step_fp32_pipe"] = j["ms_per_step"]
-        out["steps"] = j["steps"]
-    else:
-        out["error"] = (r.stderr or r.stdout)[-300:]
+    for tag, env_add in (("fp32_pipe", {"SUO_WINO_BF16X3": "0"}), ("bf16x3", {"SUO_F16X2": "0"})):      # the same timed region on the other two forms, a child process each
+        if tag == "bf16x3" and matrix_pipe() != "f16x2":
+            continue
+        r = subprocess.run(cmd, env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=400)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            j = json.loads(line[-1])
+            out["frames_per_s_" + tag] = j["value"]
+            out["ms_per_step_" + tag] = j["ms_per_step"]
+            out["steps"] = j["steps"]
+        else:
+            out["error_" + tag] = (r.stderr or r.stdout)[-300:]
     # the dominant kernel (fused Residual tail @64x64) of both forms against fp64: 2 crops, same inputs
     lib = _lib.lib()
     rng = np.random.default_rng(3)
@@ -632,6 +634,9 @@ def fp32_pipe_leg(args, L):
     _lib.check(lib.suo_pack_wino_weight_bf16x3(w2.ctypes.data, 128, 128, wq3h.ctypes.data), "pack_wino_x3")
     w3xh = np.empty(3 * 256 * 128, np.uint16)
     _lib.check(lib.suo_pack_tail_weight_bf16x3(w3.ctypes.data, 256, 128, w3xh.ctypes.data), "pack_tail_x3")
+    wq16h, o2h, w3p16h, o3h = np.empty(2 * 16 * 128 * 128, np.uint16), np.empty(128, np.float32), np.empty(2 * 256 * 128, np.uint16), np.empty(256, np.float32)
+    _lib.check(lib.suo_pack_wino_weight_f16x2(w2.ctypes.data, 128, 128, wq16h.ctypes.data, o2h.ctypes.data), "pack_wino_f16x2")
+    _lib.check(lib.suo_pack_tail_weight_f16x2(w3.ctypes.data, 256, 128, w3p16h.ctypes.data, o3h.ctypes.data), "pack_tail_f16x2")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     xd, sd, wqd, wq3d, w3xd, wp3d, b2d, b3d = d(x), d(skip), d(wq), d(wq3h.view(np.int16)), d(w3xh.view(np.int16)), d(pack_gemm(w3, 256, 128)), d(b2), d(b3)
     o32, o3 = torch.empty((Lc, 64, 64, 256), device="cuda"), torch.empty((Lc, 64, 64, 256), device="cuda")
@@ -639,12 +644,18 @@ def fp32_pipe_leg(args, L):
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     _lib.check(lib.suo_conv3x3_wino_conv1x1_skip(P(xd), Lc, 64, 64, P(wqd), P(b2d), P(wp3d), P(b3d), P(sd), P(o32), s), "suo_conv3x3_wino_conv1x1_skip")
     _lib.check(lib.suo_conv3x3_wino_x3_conv1x1_skip_up(P(xd), Lc, 64, 64, P(wq3d), P(b2d), P(w3xd), 1, P(b3d), P(sd), None, P(o3), s), "suo_conv3x3_wino_x3_conv1x1_skip_up")
+    o16, rflag = torch.empty((Lc, 64, 64, 256), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    wq16d, o2d, w3p16d, o3d = d(wq16h.view(np.int16)), d(o2h), d(w3p16h.view(np.int16)), d(o3h)
+    _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(xd), Lc, 64, 64, P(wq16d), P(o2d), P(b2d), P(w3p16d), P(o3d), P(b3d), P(sd), None, P(o16), P(rflag), s),
+               "suo_conv3x3_wino_f16x2_conv1x1_skip_up")
     torch.cuda.synchronize()
     xm = torch.from_numpy(x).permute(0, 3, 1, 2).double()
     m = Fn.relu(Fn.conv2d(xm, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1))
     ref = (Fn.conv2d(m, torch.from_numpy(w3).double()[:, :, None, None], torch.from_numpy(b3).double())).permute(0, 2, 3, 1).numpy() + skip
     e32, e3 = float(np.abs(o32.cpu().numpy() - ref).max()), float(np.abs(o3.cpu().numpy() - ref).max())
-    out["dominant_kernel_max_abs_err_vs_fp64"] = {"fp32_pipe (wino3x3_kernel<true>)": float(f"{e32:.3e}"), "bf16x3 (wino3x3_x3_kernel<true,false,true>)": float(f"{e3:.3e}"),
+    e16 = float(np.abs(o16.cpu().numpy() - ref).max())
+    out["dominant_kernel_max_abs_err_vs_fp64"] = {"fp32_pipe (wino3x3_kernel<true>)": float(f"{e32:.3e}"), "bf16x3 (wino3x3_x3_kernel<true,false,true,4,3>)": float(f"{e3:.3e}"),
+                                                  "f16x2 (wino3x3_x3_kernel<true,false,true,4,2>, the default)": float(f"{e16:.3e}"), "f16x2_range_flag": int(rflag.item()),
                                                   "output_range": round(float(np.abs(ref).max()), 3), "crops": Lc}
     return out
 

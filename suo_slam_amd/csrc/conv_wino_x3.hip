@@ -804,8 +804,10 @@ int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s) {
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
     if (a.n_W1) {                                      // ... with the next block's conv1 on the tile (all of n_* set)
         if (!a.n_scale || !a.n_shift || !a.n_osc1 || !a.n_b1 || !a.n_out) { suo_set_error("conv3x3_wino_f16x2_fused: incomplete next-block arguments"); return SUO_ERR_ARG; }
-        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
+        // (with an up-sampled addend the kernel would need 14-23 registers more than the 256 a two-workgroup-per-CU kernel has: it spilled and measured
+        //  SLOWER than the two launches, profiles/REJECTED.md -- not built; csrc/net.hip does not ask for it)
+        if (a.up) { suo_set_error("conv3x3_wino_f16x2_fused: the next block's conv1 cannot ride on a tail with an up-sampled addend"); return SUO_ERR_ARG; }
+        hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
     } else
     if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);

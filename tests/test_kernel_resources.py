@@ -32,14 +32,15 @@ def _usage(src, tmp_path):
     return kernels
 
 
-@pytest.mark.parametrize("src,fused_tag,n_fused", [("conv_wino.hip", "wino3x3_kernelILb1E", 2), ("conv_wino_x3.hip", "wino3x3_x3_kernelILb1E", 4)])
+@pytest.mark.parametrize("src,fused_tag,n_fused", [("conv_wino.hip", "wino3x3_kernelILb1E", 2), ("conv_wino_x3.hip", "wino3x3_x3_kernelILb1E", 7)])
 def test_fused_winograd_tail_does_not_spill(tmp_path, src, fused_tag, n_fused):
-    """Both forms (fp32 pipe / bf16 pipe with split operands; the latter sits at 252-254 of its 256 registers)."""
+    """All forms: fp32 pipe (2) / split operands: bf16x3 with the tail on either pipe (4, at 252-254 of their 256 registers), fp16x2 (2, 246) and fp16x2 with the
+    next block's conv1 on the tile (1, 245)."""
     k = _usage(src, tmp_path)
     fused = {n: v for n, v in k.items() if fused_tag in n}
     assert len(fused) == n_fused, list(k)
     for name, v in k.items():
-        if "ELi2EEE" in name and src == "conv_wino_x3.hip":
+        if "ELb0ELi2ELi3E" in name and src == "conv_wino_x3.hip":
             # the 64-channel bf16x3 form keeps ONE loop-invariant value in scratch: stored before the channel loop, reloaded after it
             assert v["VGPRs Spill"] <= 1 and v["ScratchSize"] <= 8, (name, v)
         else:
