@@ -212,7 +212,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if constexpr (NP == 2) {                                  // hi = rn16(v), lo = rn16(v - hi) (the residual is exact)
             const unsigned h0 = s2_pack_rn(v[0], v[1]), h1 = s2_pack_rn(v[2], v[3]);
             *(x_u32x2*)&V[comp * 32 * VROW + vbase] = x_u32x2{h0, h1};
+#ifdef SUO_WX3_EXP_NOSPLIT                                    // timing experiment (wrong results): no residual
+            const unsigned l0 = h0, l1 = h1;
+#else
             const unsigned l0 = s2_lo_pack(v[0], v[1], h0), l1 = s2_lo_pack(v[2], v[3], h1);
+#endif
             *(x_u32x2*)&V[VPL + comp * 32 * VROW + vbase] = x_u32x2{l0, l1};
             return;
         }
@@ -294,7 +298,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if constexpr (NP == 2) {                                  // hi lo, lo hi, hi hi
             constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};
 #pragma unroll
+#ifdef SUO_WX3_EXP_MFMA1                                      // timing experiment (wrong results): one of the three cross terms
+            for (int t = 2; t < 3; ++t)
+#else
             for (int t = 0; t < 3; ++t)
+#endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x_f16x8, f[UI[t]]), __builtin_bit_cast(x_f16x8, bw[UJ[t]]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
             return;
         }
