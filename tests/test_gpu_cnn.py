@@ -454,6 +454,32 @@ def test_roi_align_concat_matches_oracle(ops):
                 assert np.array_equal(o[..., 3:44].transpose(0, 3, 1, 2), pri) and np.all(o[..., 44:] == 0)
 
 
+@pytest.mark.parametrize("H,W", [(540, 720), (480, 640)])
+def test_roi_align_kernels_match_the_grid_sample_reference_for_large_boxes(ops, H, W):
+    """Boxes beyond 256 px a side (2 and 3 samples per bin and axis: T-LESS 720x540 frames reach > 512 px, YCB-V 640x480 the whole frame) and boxes leaving the
+    image, against the implementation the builder did not write (tests/roi_ref.py: F.grid_sample at the positions RoIAlign's float32 arithmetic gives, 1e-6) --
+    the same reference the oracle is pinned to (tests/test_oracle_cnn.py).  Both device samplers: the staging kernel (roi_align_concat_kernel, uint8 and float
+    frames) and, through its output, the fused stem (stem_x3_kernel uses the same device function, csrc/roi_sample.h: tests/test_gpu_stem.py)."""
+    from suo_slam_amd import _lib
+    from tests import roi_ref as R
+    from oracle import cnn_oracle as O
+    rng = np.random.default_rng(41 + H)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    boxes = R.large_boxes(rng, 24, H, W)
+    boxes[0] = [3.25, 2.5, 3.25 + 700.0 * W / 720, 2.5 + 530.0 * H / 540]      # > 512 px on the T-LESS frame: three samples per bin and axis
+    _, _, gw, gh = R.sample_positions(boxes)
+    assert max(gw.max(), gh.max()) == 3 and min(gw.min(), gh.min()) == 1
+    chw = O.image_to_chw(img)
+    ref = R.roi_align_grid_sample(chw, boxes, 256, f32_positions=True)
+    for fmt, src in ((0, ops.dev(img, torch.uint8)), (1, ops.dev(chw))):
+        out = torch.full((len(boxes), 256, 256, 48), 7.0, device="cuda")
+        bx = ops.dev(boxes)
+        _lib.check(_lib.lib().suo_roi_align_concat(ops.P(src), fmt, H, W, ops.P(bx), len(boxes), None, ops.P(out), ops.S()))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()[..., :3].transpose(0, 3, 1, 2)
+        assert np.abs(got - ref).max() < 1e-6, (fmt, np.abs(got - ref).max())
+
+
 def test_decode_golden_and_masks(ops, cnn_golden, state_dict):
     from oracle import cnn_oracle as O
     from suo_slam_amd import _lib

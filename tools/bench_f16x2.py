@@ -80,7 +80,7 @@ def main():
     # ---- the next block's conv1 inside the tail (NEXT) against tail + separate conv1 launch ------------------------------------------------
     nx = []
     for HW in (64, 32):
-        for up in (False, True):
+        for up in (False,):                                  # (with an up-sampled addend the fused variant is not built: it spilled and measured slower, profiles/REJECTED.md)
             x = torch.rand((L, HW, HW, 128), device="cuda") - 0.3
             skip = torch.rand((L, HW, HW, 256), device="cuda")
             upd = torch.rand((L, HW // 2, HW // 2, 256), device="cuda") if up else None
@@ -101,7 +101,9 @@ def main():
             both = lambda: (tail(), gemm())                 # noqa: E731
             nx.append((HW, up, timed(tail), timed(gemm), timed(both), timed(fused)))
     torch.cuda.synchronize()
-    assert int(flag.item()) == 0
+    if int(flag.item()) != 0:                               # (timing-experiment builds compute wrong values on purpose: SUO_HIP_LIB=variants/...)
+        assert os.environ.get("SUO_HIP_LIB"), "range flag raised by the shipped kernels on in-range data"
+        print("(range flag raised: a timing-experiment build)")
     print("next block's conv1 in the tail: map, up | tail alone | conv1 alone | tail + conv1 (two launches) | fused (one launch) | saved")
     for HW, up, tt, tg, tb, tf in nx:
         print(f"  {HW}x{HW} up={int(up)}   {tt:8.1f} {tg:8.1f} {tb:8.1f} {tf:8.1f}   {tb - tf:+7.1f} us ({100 * (tb - tf) / tb:.1f} %)")
