@@ -255,6 +255,11 @@ int suo_res_block_f16x2(const float* x_dev, int L, int H, int W, int pool_in, co
 int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint16_t* out);
 int suo_stem_x3(const void* img_dev, int fmt, int H, int W, const float* boxes_dev, const int* box_img_dev, int L, const uint16_t* wx_dev,
                 const float* bias_dev, float* out_dev, void* stream);
+/* ... on two fp16 terms per operand (csrc/f16x2.h; the default of suo_net_forward): wh = suo_pack_stem_weight_f16x2 -> 14 * 2 * 2 * 64 * 8 uint16 and oscale [64];
+ * range_flag_dev as suo_conv1x1_f16x2_ex (a uint8 frame cannot raise it; a float frame holding values beyond 4094 does). */
+int suo_pack_stem_weight_f16x2(const float* w, int Cw, const float* scale, uint16_t* out, float* oscale_out);
+int suo_stem_f16x2(const void* img_dev, int fmt, int H, int W, const float* boxes_dev, const int* box_img_dev, int L, const uint16_t* wh_dev, const float* oscale_dev,
+                   const float* bias_dev, float* out_dev, unsigned* range_flag_dev, void* stream);
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 

@@ -378,6 +378,18 @@ int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint
     return SUO_OK;
 }
 
+int suo_pack_stem_weight_f16x2(const float* w, int Cw, const float* scale, uint16_t* out, float* oscale_out) {
+    if (!w || !out || !oscale_out || Cw < 3) { suo_set_error("suo_pack_stem_weight_f16x2: bad arguments"); return SUO_ERR_ARG; }
+    suo::pack_stem_weight_f16x2(w, Cw, scale, out, oscale_out);
+    return SUO_OK;
+}
+
+int suo_stem_f16x2(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* wh, const float* oscale, const float* bias,
+                   float* out, unsigned* range_flag_dev, void* stream) {
+    if (!oscale || !range_flag_dev) { suo_set_error("suo_stem_f16x2: null argument"); return SUO_ERR_ARG; }
+    return suo::launch_stem_x3(img, fmt, H, W, boxes, box_img, L, wh, bias, out, (hipStream_t)stream, oscale, range_flag_dev);
+}
+
 int suo_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* wx, const float* bias, float* out,
                 void* stream) {
     return suo::launch_stem_x3(img, fmt, H, W, boxes, box_img, L, wx, bias, out, (hipStream_t)stream);

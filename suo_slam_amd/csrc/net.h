@@ -88,6 +88,7 @@ private:
     std::map<std::string, HostTensor> tensors_;
     std::vector<float*> owned_;
     ConvW stem_, stem_img_;      // all 44 input channels | the 3 image channels only (no priors: SLAM_C = 16)
+    float* stem_h2_w_ = nullptr; float* stem_h2_osc_ = nullptr;       // ... as two fp16 planes + per-channel factors (csrc/f16x2.h)
     float* stem_x3_w_ = nullptr; float* stem_x3_bias_ = nullptr;      // the image-only stem as bf16x3 planes for the fused RoIAlign + stem launch (csrc/stem_x3.hip)
     float* stem_slab_ = nullptr;                                      // [max_crops,128,128,64] persistent slab of the stem's output
     ResidualW r1_, r4_, r5_, post_[2][2];

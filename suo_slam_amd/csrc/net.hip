@@ -366,6 +366,12 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
         for (int n = 0; n < 64; ++n) bias[n] = bb.data[n] * sc[n] + sh[n];
         stem_x3_w_ = upload(wx);
         stem_x3_bias_ = upload(bias);
+        if (pipe_f16x2()) {
+            std::vector<float> wh((size_t)14 * 2 * 2 * 64 * 8 / 2), osc(64);    // uint16 planes
+            pack_stem_weight_f16x2(w.data, (int)w.shape[1], sc.data(), reinterpret_cast<uint16_t*>(wh.data()), osc.data());
+            stem_h2_w_ = upload(wh);
+            stem_h2_osc_ = upload(osc);
+        }
     }
     make_residual(b + ".r1", r1_);
     make_residual(b + ".r4", r4_);
@@ -921,6 +927,9 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         if (in_c == IMG_C && fused_stem()) {
             // prior-less pass: RoIAlign + stem in one launch on the bf16 pipe (csrc/stem_x3.hip), ahead of the captured backbone (the frame and
             // the boxes are the caller's buffers: their addresses change from call to call, a captured launch could not take them)
+            if (pipe_ == 2 && stem_h2_w_)
+                SUO_LAUNCH(launch_stem_x3(img, fmt, H, W, boxes, box_img, L, reinterpret_cast<const uint16_t*>(stem_h2_w_), stem_x3_bias_, stem_slab_, s, stem_h2_osc_, range_flag_));
+            else
             SUO_LAUNCH(launch_stem_x3(img, fmt, H, W, boxes, box_img, L, reinterpret_cast<const uint16_t*>(stem_x3_w_), stem_x3_bias_, stem_slab_, s));
             SUO_TRY(run_backbone(in0, in_c, logits, L, s, true));
         } else {

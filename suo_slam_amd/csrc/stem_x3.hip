@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "bf16x3.h"
+#include "f16x2.h"
 #include "buffer_ops.h"
 #include "roi_sample.h"
 #include "suo_internal.h"
@@ -26,6 +27,7 @@ typedef float sx_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned sx_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned sx_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sx_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SX_STEPS = 14, SX_N = 64;
 // timing experiments only (tools/build_variant.sh -DSUO_SX_EXP=n; results are wrong): 1 no sampling (constants staged), 2 no products, 3 no output stores
@@ -51,6 +53,29 @@ void pack_stem_weight_bf16x3(const float* W, int Cw, const float* out_scale, uin
                 }
 }
 
+// host, two fp16 planes (csrc/f16x2.h): the same layout with 2 planes, output channel n times 2^t_n; oscale_out[n] = 2^-(t_n + S2_XSHIFT)
+void pack_stem_weight_f16x2(const float* W, int Cw, const float* out_scale, uint16_t* out, float* oscale_out) {
+    memset(out, 0, (size_t)SX_STEPS * 2 * 2 * 64 * 8 * sizeof(uint16_t));
+    for (int n = 0; n < SX_N; ++n) {
+        const float sc = out_scale ? out_scale[n] : 1.f;
+        float mx = 0.f;
+        for (int c = 0; c < 3; ++c)
+            for (int t = 0; t < 49; ++t) mx = fmaxf(mx, fabsf(W[((size_t)n * Cw + c) * 49 + t] * sc));
+        const int sh = s2_row_shift(mx);
+        oscale_out[n] = ldexpf(1.f, -(sh + S2_XSHIFT));
+        for (int ky = 0; ky < 7; ++ky)
+            for (int h = 0; h < 2; ++h)
+                for (int k = 0; k < 16; ++k) {
+                    const int j = k / 4, c = k % 4, kx = 2 * j + h;
+                    if (c == 3 || kx > 6) continue;
+                    const int st = ky * 2 + h, nb = n / 32, lane = (k / 8) * 32 + (n % 32), e = k % 8;
+                    uint16_t t[2];
+                    s2_split_host(ldexpf(W[(((size_t)n * Cw + c) * 7 + ky) * 7 + kx] * sc, sh), t);
+                    for (int p = 0; p < 2; ++p) out[((((size_t)(st * 2 + nb) * 2 + p) * 64) + lane) * 8 + e] = t[p];
+                }
+    }
+}
+
 #ifdef SUO_SX_PROF      // tools/build_variant.sh sxprof -DSUO_SX_PROF: per-workgroup phase stamps (s_memtime) + hardware ids, dumped by the launcher (tools/stem_phases.py)
 __device__ long long sx_prof[65536 * 6];
 #define SX_T(i) do { if (tid == 0 && blockIdx.x < 65536) sx_prof[blockIdx.x * 6 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -65,14 +90,16 @@ struct StemArgs {
     const float* boxes; const int* box_img; int L;      // [L,4] xyxy; optional frame index per crop
     const uint16_t* Wx; const float* bias;              // pack_stem_weight_bf16x3 planes, folded bias [64]
     float* out;                                         // [L,128,128,64]
+    const float* osc; unsigned* range_flag;             // NP = 2: per-channel factors 2^-(t_n + S2_XSHIFT), range-guard flag (a float frame may hold anything)
 };
 
-template <int FMT>
+// NP = operand planes: 3 = three bf16 terms (six MFMAs per product block), 2 = two fp16 terms (three; csrc/f16x2.h: samples times 2^S2_XSHIFT, weight rows times 2^t_n)
+template <int FMT, int NP = 3>
 __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
     constexpr int TH = 8, TW = 16, IR = 2 * TH + 5, IC = 2 * TW + 5;          // 21 x 37 input pixels
     constexpr int HALF_B = 160, ROW_B = 2 * HALF_B, PLANE_B = IR * ROW_B;    // bytes: 20 entries of 8 per half row
     constexpr int PP = SX_N + 4;                                             // epilogue patch pitch (floats)
-    constexpr int LDS_B = TH * TW * PP * 4 > 3 * PLANE_B ? TH * TW * PP * 4 : 3 * PLANE_B;
+    constexpr int LDS_B = TH * TW * PP * 4 > NP * PLANE_B ? TH * TW * PP * 4 : NP * PLANE_B;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_B];       // the staged planes, then (dead by then) the epilogue patch: 34 KB, 4 workgroups per CU
     unsigned char* A3 = lds;
     float* P = (float*)lds;
@@ -88,14 +115,15 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
 #ifdef SUO_SX_PROF
     if (tid == 0 && blockIdx.x < 65536) sx_prof[blockIdx.x * 6 + 5] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
 #endif
-    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wx, (size_t)SX_STEPS * 2 * 3 * 1024);
+    const __amdgpu_buffer_rsrc_t w_srd = make_srd(a.Wx, (size_t)SX_STEPS * 2 * NP * 1024);
     const int wv = lane * 16;
     constexpr int R = 4;
-    sx_u32x4 ring[R][3];
-    auto loadw = [&](int s, sx_u32x4 (&b)[3]) {
+    sx_u32x4 ring[R][NP];
+    float gmax = 0.f;                                                       // NP = 2: largest scaled sample this lane staged (range guard)
+    auto loadw = [&](int s, sx_u32x4 (&b)[NP]) {
         const int k = s < SX_STEPS ? s : SX_STEPS - 1;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = __builtin_bit_cast(sx_u32x4, buf_load(w_srd, wv + p * 1024, (k * 2 + wn) * 3072));
+        for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(sx_u32x4, buf_load(w_srd, wv + p * 1024, (k * 2 + wn) * NP * 1024));
     };
     // ---- stage: 21 rows x 2 halves x 20 entries; slot -> input pixel (r, xl = 2 j + h) ---------------------------------------------------
     if (FMT == 0) {
@@ -119,6 +147,14 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
         };
         auto store3 = [&](int r, int h, int j, float c0, float c1, float c2) {
             unsigned char* d = A3 + r * ROW_B + h * HALF_B + j * 8;
+            if constexpr (NP == 2) {
+                c0 *= S2_XSCALE; c1 *= S2_XSCALE; c2 *= S2_XSCALE;
+                gmax = fmaxf(s2_track(gmax, c0, c1), fabsf(c2));
+                const unsigned h0 = s2_pack_rn(c0, c1), h1 = s2_pack_rn(c2, 0.f);
+                *(sx_u32x2*)d = sx_u32x2{h0, h1};
+                *(sx_u32x2*)(d + PLANE_B) = sx_u32x2{s2_lo_pack(c0, c1, h0), s2_lo_pack(c2, 0.f, h1)};
+                return;
+            }
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const unsigned q0 = s3_pack_rn(c0, c1), q1 = s3_pack_rn(c2, 0.f);
@@ -176,6 +212,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};      // the six cross terms, smallest first
+    constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};                       // NP = 2: hi lo, lo hi, hi hi
     // this lane's pixels: m-tile i of the wave = tile pixels 64 wm + 32 i + (lane & 31)
     int abase[2];
 #pragma unroll
@@ -186,21 +223,25 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
 #pragma unroll
     for (int s = 0; s < (SUO_SX_EXP == 2 ? 1 : SX_STEPS); ++s) {                        // s = ky * 2 + h
         loadw(s + R - 1, ring[(s + R - 1) % R]);
-        sx_bf16x8 af[2][3];
+        sx_bf16x8 af[2][NP];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const unsigned char* src = A3 + p * PLANE_B + abase[i] + (s >> 1) * ROW_B + (s & 1) * HALF_B;
                 const sx_u32x2 lo = *(const sx_u32x2*)src, hi = *(const sx_u32x2*)(src + 8);      // (8-byte aligned runs: two ds_read_b64)
                 af[i][p] = __builtin_bit_cast(sx_bf16x8, sx_u32x4{lo[0], lo[1], hi[0], hi[1]});
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tt = 0; tt < 6; ++tt)
+        for (int tt = 0; tt < (NP == 2 ? 3 : 6); ++tt)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TI[tt]], __builtin_bit_cast(sx_bf16x8, ring[s % R][TJ[tt]]), acc[i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (NP == 2)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sx_f16x8, af[i][UI[tt]]), __builtin_bit_cast(sx_f16x8, ring[s % R][UJ[tt]]), acc[i], 0, 0, 0);
+                else
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TI[tt] % NP], __builtin_bit_cast(sx_bf16x8, ring[s % R][TJ[tt] % NP]), acc[i], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
     }
     // relu(acc + bias) -> patch [pixel][64], then 16-byte stores
@@ -209,10 +250,12 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
     {
         const int col = 32 * wn + (lane & 31);
         const float b = a.bias[col];
+        const float oc = NP == 2 ? a.osc[col] : 1.f;                        // back to scale: an exact power of two per channel
+        if constexpr (NP == 2) s2_raise(a.range_flag, gmax);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) P[(64 * wm + 32 * i + sx_acc_row(r, lane)) * PP + col] = fmaxf(acc[i][r] + b, 0.f);
+            for (int r = 0; r < 16; ++r) P[(64 * wm + 32 * i + sx_acc_row(r, lane)) * PP + col] = NP == 2 ? fmaxf(fmaf(acc[i][r], oc, b), 0.f) : fmaxf(acc[i][r] + b, 0.f);
     }
     __syncthreads();
     SX_T(3);
@@ -230,12 +273,15 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
 
 // frame(s) + boxes -> stem output [L,128,128,64] (prior-less pass); Wx = pack_stem_weight_bf16x3, bias = bn1-folded conv bias
 int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* Wx, const float* bias,
-                   float* out, hipStream_t s) {
-    if (L <= 0 || H <= 1 || W <= 1 || !img || !boxes || !Wx || !bias || !out) { suo_set_error("stem_x3: bad arguments"); return SUO_ERR_ARG; }
-    StemArgs a = {img, fmt, H, W, boxes, box_img, L, Wx, bias, out};
-    if (fmt == 0) hipLaunchKernelGGL(stem_x3_kernel<0>, dim3(L * 128), dim3(256), 0, s, a);
-    else if (fmt == 1) hipLaunchKernelGGL(stem_x3_kernel<1>, dim3(L * 128), dim3(256), 0, s, a);
-    else { suo_set_error("stem_x3: unknown image format %d", fmt); return SUO_ERR_ARG; }
+                   float* out, hipStream_t s, const float* osc, unsigned* range_flag) {
+    if (L <= 0 || H <= 1 || W <= 1 || !img || !boxes || !Wx || !bias || !out || ((osc == nullptr) != (range_flag == nullptr))) { suo_set_error("stem_x3: bad arguments"); return SUO_ERR_ARG; }
+    StemArgs a = {img, fmt, H, W, boxes, box_img, L, Wx, bias, out, osc, range_flag};
+    if (fmt != 0 && fmt != 1) { suo_set_error("stem_x3: unknown image format %d", fmt); return SUO_ERR_ARG; }
+    if (osc) {                                          // Wx = pack_stem_weight_f16x2 planes
+        if (fmt == 0) hipLaunchKernelGGL((stem_x3_kernel<0, 2>), dim3(L * 128), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((stem_x3_kernel<1, 2>), dim3(L * 128), dim3(256), 0, s, a);
+    } else if (fmt == 0) hipLaunchKernelGGL((stem_x3_kernel<0, 3>), dim3(L * 128), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((stem_x3_kernel<1, 3>), dim3(L * 128), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
 #ifdef SUO_SX_PROF
     {

@@ -68,6 +68,85 @@ def test_fused_stem_equals_roi_align_then_stem(ops, fmt):
         assert e3 <= 2.0 * e32 + 1e-7, (i, e3, e32)
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_fused_stem_on_two_fp16_terms(ops, fmt):
+    """The same launch with NP = 2 (csrc/f16x2.h; the network's default pipe since round 5): samples times 16 as hi + lo fp16, weight rows scaled into
+    [2^12, 2^13), three MFMAs per product block.  Same gate as the bf16 form against fp64 on the crop kernel's samples (5e-6 of each channel's range); the worst channel within 1.5x the bf16 form's
+    worst + 1e-7 and every channel within 2.5x its own bf16 error + 1e-7 (measured: 1.37e-6 against 1.36e-6 overall, worst single channel 1.95x); the guard
+    stays down for a frame in [0, 1]."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(41 + fmt)
+    imgd, boxes, idx = _stem_inputs(rng, fmt)
+    L = len(boxes)
+    w = (rng.standard_normal((64, 44, 7, 7)) / np.sqrt(49 * 3)).astype(np.float32)
+    w[5] *= 1e-3                                                 # channels of very different size: the per-channel shift
+    w[9] *= 40.0
+    w[11] = 0.0
+    scale = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    bias = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    wx = np.empty(14 * 2 * 3 * 64 * 8, np.uint16)
+    wh = np.empty(14 * 2 * 2 * 64 * 8, np.uint16)
+    osc = np.empty(64, np.float32)
+    _lib.check(lib.suo_pack_stem_weight_bf16x3(w.ctypes.data, 44, scale.ctypes.data, wx.ctypes.data), "suo_pack_stem_weight_bf16x3")
+    _lib.check(lib.suo_pack_stem_weight_f16x2(w.ctypes.data, 44, scale.ctypes.data, wh.ctypes.data, osc.ctypes.data), "suo_pack_stem_weight_f16x2")
+    assert np.all(np.log2(osc) == np.round(np.log2(osc)))        # exact powers of two
+    wxd, whd = torch.from_numpy(wx.view(np.int16)).cuda(), torch.from_numpy(wh.view(np.int16)).cuda()
+    bd, od, boxd, idxd = ops.dev(bias), ops.dev(osc), ops.dev(boxes), torch.from_numpy(idx).cuda()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    o3 = torch.full((L, 128, 128, 64), -7.0, device="cuda")
+    o2 = torch.full((L, 128, 128, 64), -7.0, device="cuda")
+    _lib.check(lib.suo_stem_x3(ops.P(imgd), fmt, 480, 640, ops.P(boxd), ops.P(idxd), L, ops.P(wxd), ops.P(bd), ops.P(o3), ops.S()), "suo_stem_x3")
+    _lib.check(lib.suo_stem_f16x2(ops.P(imgd), fmt, 480, 640, ops.P(boxd), ops.P(idxd), L, ops.P(whd), ops.P(od), ops.P(bd), ops.P(o2), ops.P(flag), ops.S()),
+               "suo_stem_f16x2")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    crops = []
+    for i in range(L):
+        st = torch.zeros((1, 256, 256, 48), device="cuda")
+        one = imgd[idx[i]].contiguous()
+        _lib.check(lib.suo_roi_align_concat(ops.P(one), fmt, 480, 640, ops.P(boxd[i:i + 1].contiguous()), 1, None, ops.P(st), ops.S()), "suo_roi_align_concat")
+        crops.append(st[..., :3])
+    torch.cuda.synchronize()
+    x = torch.cat(crops).permute(0, 3, 1, 2).double().cpu()
+    wf = (w[:, :3] * scale[:, None, None, None]).astype(np.float32)
+    ref = F.relu(F.conv2d(x, torch.from_numpy(wf).double(), torch.from_numpy(bias).double(), stride=2, padding=3)).permute(0, 2, 3, 1).numpy()
+    g2, g3 = o2.cpu().numpy(), o3.cpu().numpy()
+    # per output channel (their magnitudes differ by 4e4): error against that channel's own range
+    rng_c = np.maximum(np.abs(ref).max(axis=(0, 1, 2)), 1e-30)
+    e2 = np.abs(g2 - ref).max(axis=(0, 1, 2)) / rng_c
+    e3 = np.abs(g3 - ref).max(axis=(0, 1, 2)) / rng_c
+    assert e2.max() < 5e-6, e2.max()
+    print("stem f16x2 / bf16x3 per-channel max error / range:", e2.max(), e3.max(), "worst ratio", (e2 / np.maximum(e3, 1e-12)).max(), "at", int(np.argmax(e2 / np.maximum(e3, 1e-12))))
+    assert e2.max() <= 1.5 * e3.max() + 1e-7, (e2.max(), e3.max())
+    assert np.all(e2 <= 2.5 * e3 + 1e-7), (e2 / np.maximum(e3, 1e-12)).max()     # (a max over 1e5 outputs per channel: the ratio of two such maxima scatters)
+    assert np.array_equal(g2[..., 11], np.maximum(np.broadcast_to(bias[11], g2[..., 11].shape), 0))     # an all-zero channel: relu(bias) exactly
+
+
+def test_fused_stem_fp16_guard_rises_for_a_float_frame_beyond_range(ops):
+    """A float frame is whatever the caller hands over: one sample of 40000 (a bilinear weight of 1/4 or more of it, times 16, is beyond 65504) inside a box raises the flag; the same frame with the
+    sample outside every box does not."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 1, (1, 3, 480, 640)).astype(np.float32)
+    img[0, 1, 100, 200] = 40000.0
+    w = (rng.standard_normal((64, 3, 7, 7)) / 12).astype(np.float32)
+    wh, osc = np.empty(14 * 2 * 2 * 64 * 8, np.uint16), np.empty(64, np.float32)
+    _lib.check(lib.suo_pack_stem_weight_f16x2(w.ctypes.data, 3, None, wh.ctypes.data, osc.ctypes.data), "suo_pack_stem_weight_f16x2")
+    whd, od, bd = torch.from_numpy(wh.view(np.int16)).cuda(), ops.dev(osc), ops.dev(np.zeros(64, np.float32))
+    imgd = torch.from_numpy(img).cuda()
+    idxd = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = torch.empty((1, 128, 128, 64), device="cuda")
+    for box, want in (([150, 50, 300, 200], 1), ([300, 250, 500, 400], 0)):
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        boxd = ops.dev(np.array([box], np.float32))
+        _lib.check(lib.suo_stem_f16x2(ops.P(imgd), 1, 480, 640, ops.P(boxd), ops.P(idxd), 1, ops.P(whd), ops.P(od), ops.P(bd), ops.P(out), ops.P(flag), ops.S()),
+                   "suo_stem_f16x2")
+        torch.cuda.synchronize()
+        assert int(flag.item()) == want, box
+
+
 def test_network_with_and_without_the_fused_stem(monkeypatch):
     """SUO_STEM_X3 (read once per process: child processes) switches the prior-less pass between the fused stem and roi_align + fp32 stem; the
     network's outputs agree to the 1e-5 the path is held to (tests/test_gpu_cnn.py holds either against the reference's golden logits)."""

@@ -40,3 +40,8 @@ def timed(fn, n=30):
 
 us = timed(lambda: _lib.check(lib.suo_stem_x3(ops.P(img), 0, 480, 640, ops.P(boxes), ops.P(idx), L, ops.P(wxd), ops.P(bd), ops.P(out), ops.S())))
 print(f"stem_x3 (RoIAlign + stem, bf16 pipe) L={L}: {us:.1f} us  ({L * 128 * 128 * 64 * 147 * 2 / us / 1e6:.1f} TFLOP/s of the 147-term products; output {L * 128 * 128 * 64 * 4 / us / 1e3:.0f} GB/s)")
+wh, osc = np.empty(14 * 2 * 2 * 64 * 8, np.uint16), np.empty(64, np.float32)
+_lib.check(lib.suo_pack_stem_weight_f16x2(w.ctypes.data, 44, None, wh.ctypes.data, osc.ctypes.data))
+whd, od, flag = torch.from_numpy(wh.view(np.int16)).cuda(), ops.dev(osc), torch.zeros(1, dtype=torch.int32, device="cuda")
+us2 = timed(lambda: _lib.check(lib.suo_stem_f16x2(ops.P(img), 0, 480, 640, ops.P(boxes), ops.P(idx), L, ops.P(whd), ops.P(od), ops.P(bd), ops.P(out), ops.P(flag), ops.S())))
+print(f"stem f16x2 (two fp16 terms)          L={L}: {us2:.1f} us  ({L * 128 * 128 * 64 * 147 * 2 / us2 / 1e6:.1f} TFLOP/s; output {L * 128 * 128 * 64 * 4 / us2 / 1e3:.0f} GB/s)  flag {int(flag.item())}")
