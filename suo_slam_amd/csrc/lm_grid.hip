@@ -44,7 +44,7 @@ struct GridCtx {
 // L2 (buffer_wbl2 sc1 / buffer_inv sc1) -- ~45 us per barrier, i.e. most of an LM trial.  When all cooperating workgroups
 // sit on ONE XCD (verified at kernel start from the XCC_ID hardware register, not assumed) they share a single L2, so it is
 // enough that each wave's stores have reached L2 (s_waitcnt vmcnt(0): the vector L1 is write-through) before arriving and
-// that the CU's L1 is dropped (buffer_inv sc0) after leaving; the barrier words are only touched by L2 atomics.
+// that the CU's L1 is dropped (buffer_inv sc1, by one wave per workgroup) after leaving; the barrier words are only touched by L2 atomics.
 DEV void grid_sync(GridCtx& g) {
     if (g.same_xcd) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -60,7 +60,11 @@ DEV void grid_sync(GridCtx& g) {
             }
         }
         __syncthreads();
-        asm volatile("buffer_inv sc1" ::: "memory");
+        // the CU's vector L1 is dropped by ONE wave for all (the cache is the CU's, not the wave's): `buffer_inv sc1` from every wave of every workgroup costs
+        // ~15 us per barrier on this multi-XCD part, from one wave per workgroup ~1 us (tools/bench_res_chain.py: 16.6 / 3.2 / 2.2 us per barrier with all waves /
+        // one wave / no invalidate) -- round 5: it was most of this kernel's time
+        if (threadIdx.x < 64) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         return;
     }
     __threadfence();                                                         // release: every wave's writes -> L2 -> memory
