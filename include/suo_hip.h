@@ -248,24 +248,6 @@ int suo_pack_res_block_f16x2(const float* w1, const float* w2, const float* scal
 int suo_res_block_f16x2(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* w1h_dev,
                         const float* osc1_dev, const float* b1_dev, const uint16_t* w2h_dev, const float* osc2_dev, const float* b2_dev, const uint16_t* w3h_dev,
                         const float* osc3_dev, const float* b3_dev, const float* up_dev, float* out_dev, unsigned* range_flag_dev, void* stream);
-/* csrc/res_chain.hip: a CHAIN of up to 12 such blocks (the 8x8 / 4x4 levels of an Hourglass in a one-frame call: hg.py:37-58) in ONE cooperative launch on the CUs
- * of one XCD, layers separated by grid barriers -- what suo_net_forward launches for those levels of a call of few crops (SUO_RES_CHAIN=0: per-layer launches).
- * Blocks run in order; block i may read block j < i's `out` (as x, or as `up`: [L,H/2,W/2,256], added up-sampled).  Weights and factors exactly as
- * suo_res_block_f16x2 takes them.  scratch_dev: suo_res_chain_scratch_floats(max over the blocks of L*H*W) floats, ZEROED once when allocated (its last 16 floats
- * are the barrier words); launches that share a scratch must be stream-ordered.  xcd in 0..7 names the XCD whose CUs run the chain: AT MOST TWO chains may target
- * the same XCD at the same time (a grid barrier needs every workgroup resident; an XCD holds two whole chains) -- spread concurrent streams over xcd. */
-typedef struct suo_res_block_desc {
-    const float* x; int L, H, W, pool_in;
-    const float* pro_scale; const float* pro_shift;
-    const uint16_t* w1h; const float* osc1; const float* b1;
-    const uint16_t* w2h; const float* osc2; const float* b2;
-    const uint16_t* w3h; const float* osc3; const float* b3;
-    const float* up; float* out;
-} suo_res_block_desc;
-size_t suo_res_chain_scratch_floats(int max_pixels);
-int suo_res_chain_f16x2(const suo_res_block_desc* blocks_host, int n_blocks, float* scratch_dev, size_t scratch_floats, unsigned* range_flag_dev, int xcd, void* stream);
-/* (tools/bench_res_chain.py: an empty chain with n_barriers grid barriers on the grid a map of `pixels` pixels would get) */
-int suo_res_chain_probe(float* scratch_dev, size_t scratch_floats, unsigned* range_flag_dev, int xcd, int n_barriers, int pixels, void* stream);
 /* csrc/stem_x3.hip (what suo_net_forward launches for the prior-less pass unless SUO_STEM_X3=0): RoIAlign of the frame (pkpnet.py:93) + the stem
  * conv1_ 7x7 / stride 2 over the 3 image channels + bn1 + ReLU (hg.py:67-69,96-98) in one launch, products on the bf16 matrix pipe (3-way split);
  * the staged [L,256,256,*] crop tensor is never written.  wx = suo_pack_stem_weight_bf16x3(W[64][Cw][7][7], Cw, bn scale[64] or NULL) ->

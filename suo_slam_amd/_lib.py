@@ -79,9 +79,6 @@ SIGNATURES = {
     "suo_res_block_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_pack_res_block_f16x2": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_res_block_f16x2": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
-    "suo_res_chain_scratch_floats": (C.c_size_t, [C.c_int]),
-    "suo_res_chain_f16x2": (C.c_int, [VP, C.c_int, VP, C.c_size_t, VP, C.c_int, VP]),
-    "suo_res_chain_probe": (C.c_int, [VP, C.c_size_t, VP, C.c_int, C.c_int, C.c_int, VP]),
     "suo_pack_stem_weight_bf16x3": (C.c_int, [VP, C.c_int, VP, VP]),
     "suo_pack_stem_weight_f16x2": (C.c_int, [VP, C.c_int, VP, VP, VP]),
     "suo_stem_f16x2": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP]),
@@ -136,12 +133,6 @@ class BaProblem(C.Structure):
                 ("edge_inlier", VP), ("edge_chi2", VP),
                 ("its", C.c_int * 8), ("n_rounds", C.c_int), ("init_with_outliers", C.c_int),
                 ("chi2_thr", C.c_double), ("huber_delta", C.c_double), ("stats", C.c_int * 4)]
-
-
-class ResBlockDesc(C.Structure):
-    """ctypes mirror of suo_res_block_desc."""
-    _fields_ = [("x", VP), ("L", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pool_in", C.c_int), ("pro_scale", VP), ("pro_shift", VP),
-                ("w1h", VP), ("osc1", VP), ("b1", VP), ("w2h", VP), ("osc2", VP), ("b2", VP), ("w3h", VP), ("osc3", VP), ("b3", VP), ("up", VP), ("out", VP)]
 
 
 class FrameGeomParams(C.Structure):

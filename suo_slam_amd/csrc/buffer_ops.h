@@ -26,11 +26,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, size_t
 __device__ __forceinline__ bo_f32x4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(bo_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// the same load at DEVICE scope (sc1): served by L2, never by this CU's vector L1 -- for data another CU of the same XCD wrote earlier in this kernel
-// (csrc/res_chain.hip: `buffer_inv sc1` after a grid barrier costs ~15 us on this multi-XCD part; a load that does not look at L1 costs nothing extra)
-__device__ __forceinline__ bo_f32x4 buf_load_l2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(bo_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));
-}
 __device__ __forceinline__ void buf_store(bo_f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff = 0) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bo_u32x4, v), r, voff, soff, 0);
 }

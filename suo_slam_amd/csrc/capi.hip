@@ -372,24 +372,6 @@ int suo_res_block_f16x2(const float* x, int L, int H, int W, int pool_in, const 
     return suo::launch_res_block_f16x2(a, (hipStream_t)stream);
 }
 
-size_t suo_res_chain_scratch_floats(int max_pixels) { return suo::res_chain_scratch_floats(max_pixels); }
-
-int suo_res_chain_f16x2(const suo_res_block_desc* blocks, int n, float* scratch_dev, size_t scratch_floats, unsigned* range_flag_dev, int xcd, void* stream) {
-    if (!blocks || n < 1 || n > suo::RC_MAX_BLOCKS) { suo_set_error("suo_res_chain_f16x2: 1..%d blocks", suo::RC_MAX_BLOCKS); return SUO_ERR_ARG; }
-    suo::ResBlockArgs a[suo::RC_MAX_BLOCKS] = {};
-    for (int i = 0; i < n; ++i) {
-        const suo_res_block_desc& d = blocks[i];
-        a[i].x = d.x; a[i].L = d.L; a[i].H = d.H; a[i].W = d.W; a[i].pool_in = d.pool_in; a[i].pro_scale = d.pro_scale; a[i].pro_shift = d.pro_shift;
-        a[i].W1 = (const float*)d.w1h; a[i].b1 = d.b1; a[i].W2 = (const float*)d.w2h; a[i].b2 = d.b2; a[i].W3 = (const float*)d.w3h; a[i].b3 = d.b3;
-        a[i].up = d.up; a[i].out = d.out; a[i].osc1 = d.osc1; a[i].osc2 = d.osc2; a[i].osc3 = d.osc3; a[i].range_flag = range_flag_dev;
-    }
-    return suo::launch_res_chain(a, n, scratch_dev, scratch_floats, range_flag_dev, xcd, 0, 0, (hipStream_t)stream);
-}
-
-int suo_res_chain_probe(float* scratch_dev, size_t scratch_floats, unsigned* range_flag_dev, int xcd, int n_barriers, int pixels, void* stream) {
-    return suo::launch_res_chain(nullptr, 0, scratch_dev, scratch_floats, range_flag_dev, xcd, n_barriers, pixels, (hipStream_t)stream);
-}
-
 int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint16_t* out) {
     if (!w || !out || Cw < 3) { suo_set_error("suo_pack_stem_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
     suo::pack_stem_weight_bf16x3(w, Cw, scale, out);

@@ -113,18 +113,6 @@ int launch_res_block_x3(const ResBlockArgs& a, hipStream_t s);
 void pack_res_conv3x3_f16x2(const float* W, const float* out_scale, uint16_t* out, float* oscale_out);
 int launch_res_block_f16x2(const ResBlockArgs& a, hipStream_t s);
 
-// csrc/res_chain.hip: a chain of such blocks (f16x2 weights, as launch_res_block_f16x2 takes them) in ONE cooperative launch on the CUs of one XCD
-constexpr int RC_MAX_BLOCKS = 12, RC_MAX_WGS = 32;
-struct ResChainArgs {
-    ResBlockArgs b[RC_MAX_BLOCKS]; int n;
-    float* mid1; float* mid2;                            // [max pixels, 128] each: relu(conv1), relu(conv2) of the block in flight
-    unsigned* bar;                                       // [0] arrivals [1] generation [2] XCC mask of the launch [3] launches that fell back to the general barrier
-    unsigned* range_flag; int G, xcd, extra_barriers, bar_mode;
-};
-size_t res_chain_scratch_floats(int max_pixels);
-bool res_chain_takes(const ResBlockArgs& a);
-int launch_res_chain(const ResBlockArgs* blocks, int n, float* scratch, size_t scratch_floats, unsigned* range_flag, int xcd, int extra_barriers, int min_pixels, hipStream_t s);
-
 int launch_maxpool2(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);
 int launch_upsample2_add(const float* up1, const float* low, float* out, int L, int H, int W, int C, hipStream_t s);
 int launch_roi_align_concat(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, int out_c,

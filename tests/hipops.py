@@ -367,42 +367,3 @@ def res_block_f16x2(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=F
     torch.cuda.synchronize()
     return out, int(flag.item())
 
-
-class ChainWeights:
-    """One Residual block's f16x2 planes / factors / biases on the device (suo_pack_res_block_f16x2), for res_block_f16x2-style launches and chains."""
-    def __init__(self, B):
-        lib = _lib.lib()
-        w1, w2, w3 = (np.ascontiguousarray(B[k], np.float32) for k in ("w1", "w2", "w3"))
-        p1, p2, p3 = np.empty(2 * 128 * 256, np.uint16), np.empty(2 * 128 * 128 * 9, np.uint16), np.empty(2 * 256 * 128, np.uint16)
-        o1, o2, o3 = np.empty(128, np.float32), np.empty(128, np.float32), np.empty(256, np.float32)
-        _lib.check(lib.suo_pack_res_block_f16x2(w1.ctypes.data, w2.ctypes.data, None, w3.ctypes.data, p1.ctypes.data, p2.ctypes.data, p3.ctypes.data, o1.ctypes.data,
-                                                o2.ctypes.data, o3.ctypes.data), "suo_pack_res_block_f16x2")
-        self.w = [torch.from_numpy(t.view(np.int16)).cuda() for t in (p1, p2, p3)]
-        self.osc = [dev(t) for t in (o1, o2, o3)]
-        self.pro = [dev(B["pro"][0]), dev(B["pro"][1])]
-        self.b = [dev(B["b1"]), dev(B["b2"]), dev(B["b3"])]
-
-    def launch(self, x, out, L, H, W, pool_in, up, flag):
-        _lib.check(_lib.lib().suo_res_block_f16x2(P(x), L, H, W, int(pool_in), P(self.pro[0]), P(self.pro[1]), P(self.w[0]), P(self.osc[0]), P(self.b[0]), P(self.w[1]),
-                                                  P(self.osc[1]), P(self.b[1]), P(self.w[2]), P(self.osc[2]), P(self.b[2]), P(up), P(out), P(flag), S()), "suo_res_block_f16x2")
-
-    def desc(self, x, out, L, H, W, pool_in, up):
-        d = _lib.ResBlockDesc()
-        d.x, d.L, d.H, d.W, d.pool_in = x.data_ptr(), L, H, W, int(pool_in)
-        d.pro_scale, d.pro_shift = self.pro[0].data_ptr(), self.pro[1].data_ptr()
-        d.w1h, d.osc1, d.b1 = self.w[0].data_ptr(), self.osc[0].data_ptr(), self.b[0].data_ptr()
-        d.w2h, d.osc2, d.b2 = self.w[1].data_ptr(), self.osc[1].data_ptr(), self.b[1].data_ptr()
-        d.w3h, d.osc3, d.b3 = self.w[2].data_ptr(), self.osc[2].data_ptr(), self.b[2].data_ptr()
-        d.up, d.out = (up.data_ptr() if up is not None else None), out.data_ptr()
-        return d
-
-
-def chain_scratch(max_pixels):
-    n = int(_lib.lib().suo_res_chain_scratch_floats(int(max_pixels)))
-    return torch.zeros(n, device="cuda")
-
-
-def res_chain(descs, scratch, flag, xcd=0):
-    """csrc/res_chain.hip: the blocks of `descs` (ChainWeights.desc) in one cooperative launch on the current stream."""
-    arr = (_lib.ResBlockDesc * len(descs))(*descs)
-    _lib.check(_lib.lib().suo_res_chain_f16x2(C.byref(arr), len(descs), P(scratch), scratch.numel(), P(flag), int(xcd), S()), "suo_res_chain_f16x2")
