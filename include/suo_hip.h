@@ -248,6 +248,12 @@ int suo_pack_res_block_f16x2(const float* w1, const float* w2, const float* scal
 int suo_res_block_f16x2(const float* x_dev, int L, int H, int W, int pool_in, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* w1h_dev,
                         const float* osc1_dev, const float* b1_dev, const uint16_t* w2h_dev, const float* osc2_dev, const float* b2_dev, const uint16_t* w3h_dev,
                         const float* osc3_dev, const float* b3_dev, const float* up_dev, float* out_dev, unsigned* range_flag_dev, void* stream);
+/* csrc/gemm_bf16x3.hip (gemm_chain_head_kernel): TWO 1x1 convolutions in one launch -- the last stack's  logits = tmpOut(relu(bn(lin(x))))  (hg.py:106-111) -- with the
+ * 256-channel tensor between them kept in LDS instead of written and read back (what suo_net_forward launches for it at >= 32768 pixels; SUO_CHAIN_HEAD=0: two launches).
+ * a_dev [M, lda >= 256] rows; w1h / osc1 = suo_pack_gemm_weight_f16x2 of W1 [256][256] (BatchNorm folded), bias1 [256]; w2h / osc2 of W2 [64][256] (rows >= n_valid zero),
+ * bias2 [64]; out_nchw_dev [M / hw, n_valid, hw].  M a multiple of 64, hw a multiple of 64 dividing M.  Bit-identical to suo_conv1x1_f16x2_ex twice. */
+int suo_conv1x1_chain_head_f16x2(const float* a_dev, int lda, int M, const uint16_t* w1h_dev, const float* osc1_dev, const float* bias1_dev, const uint16_t* w2h_dev,
+                                 const float* osc2_dev, const float* bias2_dev, float* out_nchw_dev, int n_valid, int hw, unsigned* range_flag_dev, void* stream);
 /* csrc/stem_x3.hip (what suo_net_forward launches for the prior-less pass unless SUO_STEM_X3=0): RoIAlign of the frame (pkpnet.py:93) + the stem
  * conv1_ 7x7 / stride 2 over the 3 image channels + bn1 + ReLU (hg.py:67-69,96-98) in one launch, products on the bf16 matrix pipe (3-way split);
  * the staged [L,256,256,*] crop tensor is never written.  wx = suo_pack_stem_weight_bf16x3(W[64][Cw][7][7], Cw, bn scale[64] or NULL) ->

@@ -79,6 +79,7 @@ SIGNATURES = {
     "suo_res_block_bf16x3": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_pack_res_block_f16x2": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_res_block_f16x2": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "suo_conv1x1_chain_head_f16x2": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP, VP]),
     "suo_pack_stem_weight_bf16x3": (C.c_int, [VP, C.c_int, VP, VP]),
     "suo_pack_stem_weight_f16x2": (C.c_int, [VP, C.c_int, VP, VP, VP]),
     "suo_stem_f16x2": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP]),

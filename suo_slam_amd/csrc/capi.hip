@@ -372,6 +372,11 @@ int suo_res_block_f16x2(const float* x, int L, int H, int W, int pool_in, const 
     return suo::launch_res_block_f16x2(a, (hipStream_t)stream);
 }
 
+int suo_conv1x1_chain_head_f16x2(const float* a, int lda, int M, const uint16_t* w1h, const float* osc1, const float* bias1, const uint16_t* w2h, const float* osc2,
+                                 const float* bias2, float* out_nchw, int n_valid, int hw, unsigned* range_flag_dev, void* stream) {
+    return suo::launch_gemm_chain_head(a, lda, M, w1h, osc1, bias1, w2h, osc2, bias2, out_nchw, n_valid, hw, range_flag_dev, (hipStream_t)stream);
+}
+
 int suo_pack_stem_weight_bf16x3(const float* w, int Cw, const float* scale, uint16_t* out) {
     if (!w || !out || Cw < 3) { suo_set_error("suo_pack_stem_weight_bf16x3: bad arguments"); return SUO_ERR_ARG; }
     suo::pack_stem_weight_bf16x3(w, Cw, scale, out);

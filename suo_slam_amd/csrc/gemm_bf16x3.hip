@@ -340,6 +340,196 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? S
     }
 }
 
+// Two 1x1 convolutions in ONE launch where the tensor between them has a single reader: the last stack's  logits = tmpOut(relu(bn(lin(x))))  (hg.py:106-111; 256 -> 256 -> 41
+// channels at 64x64).  Separately the 256-channel tensor is written (1 GB at 256 crops) and read back by the second launch; here a workgroup keeps its 64 rows of it in LDS
+// as the two fp16 planes the second product wants anyway.  Two-term fp16 form only (csrc/f16x2.h).
+//   stage 1, per 128-column half tn = 0, 1: exactly gemm_bf16x3_kernel<false, false, false, false, 2, 1, 2>'s loop and epilogue arithmetic (same k order, same term order:
+//            y1 is bit-identical to that launch's output); relu(y1) times 16, split, into Y[plane][64 rows][128 columns] (16-byte chunks XOR-swizzled by the row);
+//   stage 2: acc2 (64 rows x 64 columns, one 32 x 32 block per wave) += Y-half (K = 128, eight k-steps) x W2 -- over the two halves in ascending k: bit-identical to the
+//            fp16 GEMM launched on the stored tensor;  epilogue: per-channel rescale + bias, NCHW store of the first n_valid channels.
+// LDS 18 + 32 KB, three workgroups per CU like the plain fp16 GEMM.
+struct GemmChainArgs {
+    const float* A; int lda, M;                           // [M, 256] rows
+    const float* bias1; const float* osc1;                // [256]: stage 1 (BatchNorm folded), its per-column factors
+    const float* bias2; const float* osc2;                // [64]
+    float* out; int n_valid, hw;                          // out[(row / hw) * n_valid * hw + ch * hw + row % hw], ch < n_valid
+    unsigned* range_flag;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_chain_head_kernel(const GemmChainArgs g, const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W2) {
+    static_assert(X3_BK == 16, "written for the 16-wide k-step");
+    constexpr int NP = 2, NCB = 2, BM = 64, K1 = 256, N1 = 256, NBT1 = N1 / 32, NB2 = 2;
+    constexpr int PLANE = BM * X3_PITCH;
+    constexpr int SFL = 4 * 32 * 36 * 4 / 4;                                  // uint16 per stage: the two stages together hold the epilogue's four transposition patches (18 KB)
+    static_assert(NP * PLANE <= SFL, "stage");
+    __shared__ __attribute__((aligned(16))) uint16_t S[2][SFL];
+    __shared__ __attribute__((aligned(16))) uint16_t Y[NP][BM * 128];         // relu(y1) * 16 of the current half: [plane][row][16 chunks of 8, chunk ^ (row & 15)]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int M = g.M;
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order
+    const int m0 = bid * BM;
+    const __amdgpu_buffer_rsrc_t a_srd = make_srd(g.A, (size_t)M * g.lda * sizeof(float));
+    const __amdgpu_buffer_rsrc_t w1_srd = make_srd(W1, (size_t)N1 * K1 * NP * sizeof(uint16_t));
+    const __amdgpu_buffer_rsrc_t w2_srd = make_srd(W2, (size_t)64 * N1 * NP * sizeof(uint16_t));
+    const int ar = tid / X3_LPR, aq = tid % X3_LPR;                           // staging: row ar, the 4 floats at k = 4 aq of a k-step
+    const int arow = m0 + ar;
+    const int avoff = arow < M ? (arow * g.lda + 4 * aq) * 4 : BUF_OOB;
+    const int wvoff = lane * 16;
+    constexpr int BSL = SUO_X3_F16_BSLOTS, nsteps = K1 / X3_BK;
+    constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};                       // hi lo, lo hi, hi hi
+    const int ko = 8 * (lane >> 5);
+    float xmax = 0.f;
+    x3_f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    for (int tn = 0; tn < 2; ++tn) {
+        x3_f32x4 araw[X3_ASLOTS];
+        x3_u32x4 braw[BSL][NCB][NP];
+        auto requestA = [&](int ks, int slot) { araw[slot] = buf_load(a_srd, avoff, ks * X3_BK * 4); };
+        auto requestB = [&](int kg, int slot) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    braw[slot][cb][p] = __builtin_bit_cast(x3_u32x4, buf_load(w1_srd, wvoff + p * 1024, ((kg * NBT1 + 2 * NCB * tn + NCB * wn + cb) * NP) * 1024));
+        };
+        auto split_store = [&](int slot, int stage) {
+            uint16_t* As = &S[stage][0];
+            float x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = araw[slot][t] * S2_XSCALE;
+            xmax = s2_track(s2_track(xmax, x[0], x[1]), x[2], x[3]);
+            const unsigned h0 = s2_pack_rn(x[0], x[1]), h1 = s2_pack_rn(x[2], x[3]);
+            *(u32x2*)&As[ar * X3_PITCH + 4 * aq] = u32x2{h0, h1};
+            const unsigned l0 = s2_lo_pack(x[0], x[1], h0), l1 = s2_lo_pack(x[2], x[3], h1);
+            *(u32x2*)&As[PLANE + ar * X3_PITCH + 4 * aq] = u32x2{l0, l1};
+        };
+        x3_f32x16 acc[NCB];
+#pragma unroll
+        for (int j = 0; j < NCB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < X3_ASLOTS; ++u) requestA(u, u);
+#pragma unroll
+        for (int u = 0; u < BSL; ++u) requestB(u, u);
+        split_store(0, 0);
+        for (int ks0 = 0; ks0 < nsteps; ks0 += X3_ASLOTS) {
+#pragma unroll
+            for (int u = 0; u < X3_ASLOTS; ++u) {
+                const int ks = ks0 + u;
+                __syncthreads();
+                const uint16_t* As = &S[u & 1][0];
+                x3_f16x8 af[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[p] = *(const x3_f16x8*)&As[p * PLANE + (32 * wm + (lane & 31)) * X3_PITCH + ko];
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < nsteps) split_store((u + 1) % X3_ASLOTS, (u + 1) & 1);
+                requestA(ks + X3_ASLOTS < nsteps ? ks + X3_ASLOTS : nsteps - 1, u);
+                const int slot = u % BSL;
+                x3_u32x4 bw[NCB][NP];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bw[cb][p] = braw[slot][cb][p];
+                requestB(ks + BSL < nsteps ? ks + BSL : nsteps - 1, slot);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[UI[t]], __builtin_bit_cast(x3_f16x8, bw[cb][UJ[t]]), acc[cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                                      // the stages are free (the epilogue's patches live there); the previous half's Y has been consumed
+        // the second product's weights for this half (k-steps 8 tn .. 8 tn + 7 of W2, n-tile wn), requested now: they arrive under the epilogue
+        x3_u32x4 b2[8][NP];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) b2[kk][p] = __builtin_bit_cast(x3_u32x4, buf_load(w2_srd, wvoff + p * 1024, (((8 * tn + kk) * NB2 + wn) * NP) * 1024));
+        float* T = reinterpret_cast<float*>(&S[0][0]) + w * (32 * 36);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int lcol = 32 * NCB * wn + 32 * cb + (lane & 7) * 4;       // column within the half
+            const x3_f32x4 bv = *(const x3_f32x4*)(g.bias1 + 128 * tn + lcol), osc = *(const x3_f32x4*)(g.osc1 + 128 * tn + lcol);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[x3_acc_row(r, lane) * 36 + (lane & 31)] = acc[cb][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = 32 * wm + (lane >> 3) + 8 * k;               // row of the tile
+                x3_f32x4 o = *(const x3_f32x4*)&T[((lane >> 3) + 8 * k) * 36 + (lane & 7) * 4];
+                o *= osc;
+                o += bv;
+                float y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[q] = fmaxf(o[q], 0.f) * S2_XSCALE;       // what the separate launch stores, times 2^S2_XSHIFT for the split
+                xmax = s2_track(s2_track(xmax, y[0], y[1]), y[2], y[3]);
+                const unsigned h0 = s2_pack_rn(y[0], y[1]), h1 = s2_pack_rn(y[2], y[3]);
+                const unsigned l0 = s2_lo_pack(y[0], y[1], h0), l1 = s2_lo_pack(y[2], y[3], h1);
+                const int at = row * 128 + (((lcol >> 3) ^ (row & 15)) << 3) + (lcol & 7);
+                *(u32x2*)&Y[0][at] = u32x2{h0, h1};
+                *(u32x2*)&Y[1][at] = u32x2{l0, l1};
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                                      // Y of this half complete
+        {
+            const int yrow = 32 * wm + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int chunk = (2 * kk + (lane >> 5)) ^ (yrow & 15);
+                x3_f16x8 af[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[p] = *(const x3_f16x8*)&Y[p][yrow * 128 + chunk * 8];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[UI[t]], __builtin_bit_cast(x3_f16x8, b2[kk][UJ[t]]), acc2, 0, 0, 0);
+            }
+        }
+        // (the next half's first barrier inside its k-loop comes after its first split_store into stage 0 / its reads of nothing of Y: Y is rewritten only in the next
+        //  epilogue, behind the k-loop's barriers; the patches T of this epilogue are dead)
+    }
+    s2_raise(g.range_flag, xmax);
+    // NCHW store straight from the accumulator: register group q holds 4 consecutive rows (pixels) of channel ch
+    const int ch = 32 * wn + (lane & 31);
+    if (ch < g.n_valid) {
+        const float oc = g.osc2[ch], bb = g.bias2[ch];
+        const __amdgpu_buffer_rsrc_t o_srd = make_srd(g.out, (size_t)(M / g.hw) * g.n_valid * g.hw * sizeof(float));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + 32 * wm + 8 * q + 4 * (lane >> 5);
+            x3_f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(acc2[4 * q + j], oc, bb);
+            const int img = row / g.hw, pix = row - img * g.hw;
+            buf_store(o, o_srd, row < M ? ((img * g.n_valid + ch) * g.hw + pix) * 4 : BUF_OOB);
+        }
+    }
+}
+
+bool gemm_chain_head_takes(int M, int lda, int n_valid, int hw) {
+    return M > 0 && M % 64 == 0 && lda % 4 == 0 && n_valid > 0 && n_valid <= 64 && hw > 0 && hw % 64 == 0 && M % hw == 0 && (size_t)M * lda * 4 < ((size_t)1 << 31);
+}
+
+// logits (NCHW, n_valid channels) = W2 relu(W1 A^T + bias1) + bias2 for A [M, 256]; W1h / W2h = pack_gemm_weight_f16x2 of [256][256] / [64][256] (rows beyond n_valid zero)
+int launch_gemm_chain_head(const float* A, int lda, int M, const uint16_t* W1h, const float* osc1, const float* bias1, const uint16_t* W2h, const float* osc2, const float* bias2,
+                           float* out, int n_valid, int hw, unsigned* range_flag, hipStream_t s) {
+    if (!A || !W1h || !osc1 || !bias1 || !W2h || !osc2 || !bias2 || !out || !range_flag || !gemm_chain_head_takes(M, lda, n_valid, hw)) {
+        suo_set_error("gemm_chain_head: unsupported arguments (M=%d lda=%d n_valid=%d hw=%d)", M, lda, n_valid, hw);
+        return SUO_ERR_ARG;
+    }
+    GemmChainArgs g = {A, lda, M, bias1, osc1, bias2, osc2, out, n_valid, hw, range_flag};
+    hipLaunchKernelGGL(gemm_chain_head_kernel, dim3(M / 64), dim3(256), 0, s, g, W1h, W2h);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
+}
+
 // out[M, N] = [relu]( [relu(A1 * scale + shift) or A1] W1^T + A2 W2^T + bias + R ): N a multiple of 128 (or 64, un-pooled), K1 and K2 multiples of 64 (K2 may be 0),
 // the prologue only without a second segment; Wx3 = pack_gemm_weight_bf16x3 of the row-concatenated [W1 | W2] (N rows, K1 + K2 columns)
 bool gemm_bf16x3_takes(const GemmArgs& g) {

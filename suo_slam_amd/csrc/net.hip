@@ -185,6 +185,12 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
             g.W16 = upload(h2);
             g.osc16 = upload(osc);
         }
+    } else if (Np == 64 && K1 == 256 && K1p == K1 && K2 == 0 && pipe_f16x2()) {
+        // the output head (tmpOut: 256 -> 41, padded to 64 rows of zeros): fp16 planes for the lin + head launch (csrc/gemm_bf16x3.hip: gemm_chain_head_kernel)
+        std::vector<float> h2((size_t)Np * Kp), osc(Np);
+        pack_gemm_weight_f16x2(full.data(), Np, Kp, reinterpret_cast<uint16_t*>(h2.data()), osc.data());
+        g.W16 = upload(h2);
+        g.osc16 = upload(osc);
     }
 }
 
@@ -763,6 +769,15 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         float* rb = alloc((size_t)M * 256);
         SUO_TRY(residual(post_[i][0], hg, ra, L, 64, 64, s, nullptr, nullptr, &post_[i][1]));
         SUO_TRY(residual(post_[i][1], ra, rb, L, 64, 64, s));
+        // the last stack's lin -> head pair: `ll` has one reader, so it never leaves the CU (one launch, 1.2 GB of traffic instead of 3.3 at 256 crops)
+        static const int chain_head = getenv("SUO_CHAIN_HEAD") ? atoi(getenv("SUO_CHAIN_HEAD")) : 1;            // 0: A/B
+        static const long chain_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+        if (i == 1 && chain_head && pipe_ == 2 && lin_[i].W16 && head_[i].W16 && lin_[i].N == 256 && lin_[i].K1 == 256 && M >= chain_min_rows &&
+            gemm_chain_head_takes(M, 256, NUM_KP, HEAT * HEAT)) {
+            SUO_LAUNCH(launch_gemm_chain_head(rb, 256, M, reinterpret_cast<const uint16_t*>(lin_[i].W16), lin_[i].osc16, lin_[i].bias, reinterpret_cast<const uint16_t*>(head_[i].W16),
+                                              head_[i].osc16, head_[i].bias, logits, NUM_KP, HEAT * HEAT, range_flag_, s));
+            continue;
+        }
         float* ll = alloc((size_t)M * 256);
         GemmArgs gl = {};
         gl.A1 = rb; gl.lda1 = 256; gl.K1 = 256; gl.Wp = lin_[i].Wp; gl.bias = lin_[i].bias; gl.out = ll; gl.ldo = 256;

@@ -128,6 +128,10 @@ int launch_gemm_bf16x3(const float* A, int lda, int K, const float* pro_scale, c
 // GemmArgs.range_flag must name the guard flag; out = 2 * N * K uint16
 void pack_gemm_weight_f16x2(const float* W, int N, int K, uint16_t* out, float* oscale_out);
 int launch_gemm_f16x2_args(const GemmArgs& g, const uint16_t* W16, hipStream_t s);
+// two 1x1 convolutions in one launch, the 256-channel tensor between them kept in LDS (csrc/gemm_bf16x3.hip: gemm_chain_head_kernel): NCHW logits = W2 relu(W1 A + b1) + b2
+bool gemm_chain_head_takes(int M, int lda, int n_valid, int hw);
+int launch_gemm_chain_head(const float* A, int lda, int M, const uint16_t* W1h, const float* osc1, const float* bias1, const uint16_t* W2h, const float* osc2, const float* bias2,
+                           float* out, int n_valid, int hw, unsigned* range_flag, hipStream_t s);
 // experimental: Winograd 3x3 with its products on the bf16 matrix pipe at fp32 accuracy (csrc/conv_wino_x3.hip); ConvArgs.Wp = packed uint16
 void pack_tail_weight_bf16x3(const float* W3, int N2, int K, uint16_t* out);
 void pack_wino_weight_bf16x3(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out);

@@ -367,3 +367,16 @@ def res_block_f16x2(x_nhwc, pro, w1, b1, w2, b2, w3, b3, up_nhwc=None, pool_in=F
     torch.cuda.synchronize()
     return out, int(flag.item())
 
+
+def conv1x1_chain_head_f16x2(a, w1, b1, w2, b2, n_valid, hw):
+    """csrc/gemm_bf16x3.hip: gemm_chain_head_kernel.  a [M,256] cuda; w1 [256,256], b1 [256]; w2 [64,256] (rows >= n_valid zero), b2 [64] -> (NCHW [M/hw, n_valid, hw], flag)."""
+    M = a.shape[0]
+    w1h, o1, _ = pack_gemm_f16x2(w1)
+    w2h, o2, _ = pack_gemm_f16x2(w2)
+    b1d, b2d = dev(b1), dev(b2)
+    out = torch.full((M // hw, n_valid, hw), float("nan"), device="cuda")
+    flag = _flag()
+    _lib.check(_lib.lib().suo_conv1x1_chain_head_f16x2(P(a), a.stride(0), M, P(w1h), P(o1), P(b1d), P(w2h), P(o2), P(b2d), P(out), n_valid, hw, P(flag), S()),
+               "suo_conv1x1_chain_head_f16x2")
+    torch.cuda.synchronize()
+    return out, int(flag.item())

@@ -376,3 +376,49 @@ def test_device_split_equals_numpy_float16_rounding(ops):
     want = ((hi.astype(np.float32) + lo.astype(np.float32)) / np.float32(16.0)).astype(np.float32) + np.float32(0.0)      # (+ 0: an input that vanishes in BOTH terms gives the accumulator's +0, not -0)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
+
+
+# ---- lin -> head in one launch (csrc/gemm_bf16x3.hip: gemm_chain_head_kernel) -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,hw,lda", [(8192, 4096, 256), (64, 64, 256), (4096 * 5, 4096, 256), (1024, 256, 320)])
+def test_chain_head_is_bit_identical_to_the_two_launches(ops, M, hw, lda):
+    """logits = W2 relu(W1 a + b1) + b2 with the 256-channel tensor kept in LDS: the same products in the same order as suo_conv1x1_f16x2_ex launched twice (the second
+    on the stored tensor) -- every bit equal; NCHW, only the first 41 of the 64 padded channels written; the flag down."""
+    rng = np.random.default_rng(M + hw)
+    a_full = torch.from_numpy(rng.standard_normal((M, lda)).astype(np.float32)).cuda()
+    a = a_full[:, :256]
+    w1 = (rng.standard_normal((256, 256)) / 16).astype(np.float32)
+    b1 = (rng.standard_normal(256) * 0.2).astype(np.float32)
+    w2 = np.zeros((64, 256), np.float32)
+    w2[:41] = (rng.standard_normal((41, 256)) / 16).astype(np.float32)
+    w2[7] *= 300.0                                                 # rows of very different size: the per-row shift
+    w2[9] *= 1e-3
+    b2 = np.zeros(64, np.float32)
+    b2[:41] = rng.standard_normal(41).astype(np.float32)
+    got, flag = ops.conv1x1_chain_head_f16x2(a, w1, b1, w2, b2, 41, hw)
+    assert flag == 0 and torch.isfinite(got).all()
+    ll, f1 = ops.conv1x1_f16x2(a, w1, b1, relu=True)
+    two, f2 = ops.conv1x1_f16x2(ll, w2, b2)
+    assert f1 == 0 and f2 == 0
+    want = two.reshape(M // hw, hw, 64)[:, :, :41].permute(0, 2, 1).contiguous()
+    assert torch.equal(got, want)
+    # and against fp64
+    ref = (np.maximum(a.double().cpu().numpy() @ w1.astype(np.float64).T + b1, 0) @ w2.astype(np.float64).T + b2)[:, :41]
+    ref = ref.reshape(M // hw, hw, 41).transpose(0, 2, 1)
+    scale = np.abs(ref).max(axis=(0, 2), keepdims=True)
+    assert (np.abs(got.cpu().numpy() - ref) / scale).max() < 5e-6
+
+
+def test_chain_head_range_guard(ops):
+    """The tensor that never leaves the CU is covered by the guard: relu(lin) of 4094 or more raises the flag, as does the input."""
+    rng = np.random.default_rng(2)
+    M, hw = 4096, 4096
+    a = torch.from_numpy(np.abs(rng.standard_normal((M, 256))).astype(np.float32)).cuda()
+    w1 = np.abs(rng.standard_normal((256, 256)) / 16).astype(np.float32)
+    w2 = np.zeros((64, 256), np.float32)
+    w2[:41] = (rng.standard_normal((41, 256)) / 16).astype(np.float32)
+    b = np.zeros(256, np.float32)
+    assert ops.conv1x1_chain_head_f16x2(a, w1, b, w2, np.zeros(64, np.float32), 41, hw)[1] == 0
+    assert ops.conv1x1_chain_head_f16x2(a, w1 * np.float32(400.0), b, w2, np.zeros(64, np.float32), 41, hw)[1] == 1       # the inner tensor
+    a2 = a.clone()
+    a2[100, 3] = 5000.0
+    assert ops.conv1x1_chain_head_f16x2(a2, w1, b, w2, np.zeros(64, np.float32), 41, hw)[1] == 1                          # the input
