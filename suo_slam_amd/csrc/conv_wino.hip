@@ -456,9 +456,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 
 // Measured at 128 -> 128 channels (tools/bench_wino.py): 1.46-1.75x the direct kernel from 256 tiles of 8 x 16 pixels up
 // (64x64 maps of 8 crops, 16x16 maps of 128 crops), 0.5x at 64 tiles -- there the direct kernel's smaller tiles fill more CUs.
-bool conv3x3_wino_pays(const ConvArgs& a) {
+bool conv3x3_wino_pays(const ConvArgs& a, long min_tiles_arg) {
     static const int on = getenv("SUO_CONV_WINO") ? atoi(getenv("SUO_CONV_WINO")) : 1;                  // 0: A/B against the direct kernels
-    static const long min_tiles = getenv("SUO_CONV_WINO_TILES") ? atol(getenv("SUO_CONV_WINO_TILES")) : 256;
+    static const long min_tiles_env = getenv("SUO_CONV_WINO_TILES") ? atol(getenv("SUO_CONV_WINO_TILES")) : -1;
+    const long min_tiles = min_tiles_env >= 0 ? min_tiles_env : (min_tiles_arg >= 0 ? min_tiles_arg : 256);
     const long tiles = (long)((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
     return on && ((a.N == 128 && a.C == 128) || (a.N == 64 && a.C == 64)) && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && tiles >= min_tiles;
 }

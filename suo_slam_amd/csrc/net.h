@@ -73,6 +73,8 @@ private:
     // also computes next's conv1 (csrc/conv_wino_x3.hip, NEXT) and residual(*next, out, ...) finds it done (pre_*)
     int residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up = nullptr, float* pool_out = nullptr,
                  const ResidualW* next = nullptr);
+    long wino_min_tiles() const;
+    long x3_min_rows() const;
     bool next_conv1_fusable(const ResidualW& next, int L, int H, int W) const;
     int gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const GemmW* gw = nullptr);
     bool residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const;

@@ -497,12 +497,26 @@ float* Net::alloc(size_t floats) {
 
 // Residual.forward: three fused launches
 // true when residual() ends in the fused Winograd tail (the only epilogue that can add an up-sampled tensor)
+// Launch-size thresholds of the split-operand kernels.  The Winograd kernels and the bf16x3 GEMM were introduced for batched calls and measured against the fp32-pipe
+// kernels' smaller tiles: from 256 tiles of 8 x 16 pixels / 32768 rows up.  The fp16 forms changed the balance for calls of FEW crops (SLAM passes run 2-7): a fused fp16
+// tail takes ~50 us whatever the crop count below 8 (one workgroup per CU) where direct 3x3 + conv3 take 84-106; measured per network call of L crops (bench.py --only cnn
+// --objects L --frames-per-step 1, ms, thresholds 256 / 32768 -> 32 / 4096): L = 1 1.544 -> 1.531, 2 1.631 -> 1.567, 3 1.886 -> 1.678, 4 1.921 -> 1.726, 5 2.155 -> 1.759,
+// 6 2.218 -> 1.800, 7 2.435 -> 1.832, 8 and up unchanged.
+long Net::wino_min_tiles() const {
+    static const long env = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : -1;      // (0: never fuse)
+    return env >= 0 ? env : (pipe_ == 2 ? 32 : 256);
+}
+long Net::x3_min_rows() const {
+    static const long env = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : -1;
+    return env >= 0 ? env : (pipe_ == 2 ? 4096 : 32768);
+}
+
 bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const {
-    static const long fuse_tiles = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : 256;
+    const long fuse_tiles = wino_min_tiles();
     ConvArgs c2 = {};
     c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.OH = H; c2.OW = W; c2.N = r.c2.N;
     const long tiles = (long)((W + 15) / 16) * ((H + 7) / 8) * L;
-    return r.c2.Wq && conv3x3_wino_pays(c2) && fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 &&
+    return r.c2.Wq && conv3x3_wino_pays(c2, pipe_ == 2 ? 32 : -1) && fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 &&
            r.c3.K1 == 128 && r.cin == 256;
 }
 
@@ -561,7 +575,7 @@ int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hi
     const float* Wx3 = gw ? gw->Wx3 : nullptr;
     static const int fuse_pool = getenv("SUO_FUSE_POOL") ? atoi(getenv("SUO_FUSE_POOL")) : 1;                    // 0: A/B
     // large launches with a bf16x3 form of the weights: on the bf16 pipe (csrc/gemm_bf16x3.hip)
-    static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+    const long x3_min_rows = this->x3_min_rows();
     if (Wx3 && g.M >= x3_min_rows) {
         GemmArgs gx = g;
         gx.pool_out = pool_out; gx.pool_H = H; gx.pool_W = W;                  // the pool in the epilogue (maps of 64-column multiples), `out` optional
@@ -591,7 +605,7 @@ int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hi
 // (256 -> 128 with a BatchNorm prologue, >= SUO_GEMM_X3_MIN_ROWS pixels, not a one-launch block): then the two are bit-identical (tests/test_gpu_f16x2.py)
 bool Net::next_conv1_fusable(const ResidualW& next, int L, int H, int W) const {
     static const int on = getenv("SUO_FUSE_NEXT_CONV1") ? atoi(getenv("SUO_FUSE_NEXT_CONV1")) : 1;                // 0: A/B
-    static const long x3_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+    const long x3_min_rows = this->x3_min_rows();
     return on && pipe_ == 2 && next.cin == 256 && next.c1.W16 && next.c1.osc16 && next.c1.N == 128 && next.c1.n_valid == 128 && next.c1.K1 == 256 && next.c1.K2 == 0 &&
            (long)L * H * W >= x3_min_rows && !residual_in_one_launch(next, L, H, W);
 }
@@ -623,7 +637,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     ConvArgs c2 = {};
     c2.in = mid1; c2.L = L; c2.H = H; c2.W = W; c2.C = r.c2.C; c2.Wp = r.c2.Wp; c2.bias = r.c2.bias;
     c2.out = mid2; c2.OH = H; c2.OW = W; c2.N = r.c2.N; c2.relu = 1;
-    const bool wino = r.c2.Wq && conv3x3_wino_pays(c2);       // 2.25x fewer MFMA MACs (csrc/conv_wino.hip)
+    const bool wino = r.c2.Wq && conv3x3_wino_pays(c2, pipe_ == 2 ? 32 : -1);       // 2.25x fewer MFMA MACs (csrc/conv_wino.hip)
     if (!wino && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256 && conv3x3_fusable(c2)) {
         // conv2 -> conv3 + skip in one launch: the 128-channel tensor between them never leaves the CU (csrc/conv.hip: FUSE)
         if (!out) out = alloc((size_t)M * 256);
@@ -634,7 +648,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     }
     if (wino) {
         c2.Wp = r.c2.Wq;
-        static const long fuse_tiles = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : 256;       // (0: never)
+        const long fuse_tiles = wino_min_tiles();
         const long tiles = (long)((W + 15) / 16) * ((H + 7) / 8) * L;
         if (fuse_tiles > 0 && tiles >= fuse_tiles && !r.has_skip_conv && r.c3.N == 256 && r.c3.n_valid == 256 && r.c3.K1 == 128 && r.cin == 256) {
             // conv2 -> conv3 + skip in one launch (933 vs 713 + 346 us at 64x64 / 128 crops, 257 vs 195 + 91 at 32x32)
@@ -771,7 +785,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         SUO_TRY(residual(post_[i][1], ra, rb, L, 64, 64, s));
         // the last stack's lin -> head pair: `ll` has one reader, so it never leaves the CU (one launch, 1.2 GB of traffic instead of 3.3 at 256 crops)
         static const int chain_head = getenv("SUO_CHAIN_HEAD") ? atoi(getenv("SUO_CHAIN_HEAD")) : 1;            // 0: A/B
-        static const long chain_min_rows = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : 32768;
+        const long chain_min_rows = x3_min_rows();
         if (i == 1 && chain_head && pipe_ == 2 && lin_[i].W16 && head_[i].W16 && lin_[i].N == 256 && lin_[i].K1 == 256 && M >= chain_min_rows &&
             gemm_chain_head_takes(M, 256, NUM_KP, HEAT * HEAT)) {
             SUO_LAUNCH(launch_gemm_chain_head(rb, 256, M, reinterpret_cast<const uint16_t*>(lin_[i].W16), lin_[i].osc16, lin_[i].bias, reinterpret_cast<const uint16_t*>(head_[i].W16),

@@ -82,7 +82,7 @@ bool conv3x3_fusable(const ConvArgs& a);
 void pack_wino_weight(const float* W, int N, int C, int Np, int Cp, const float* out_scale, float* out);
 int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_wino_fused(const ConvArgs& a, hipStream_t s);
-bool conv3x3_wino_pays(const ConvArgs& a);             // enough 8 x 16-pixel tiles to fill the chip (measured: >= 256)
+bool conv3x3_wino_pays(const ConvArgs& a, long min_tiles = -1);      // enough 8 x 16-pixel tiles (min_tiles < 0: SUO_CONV_WINO_TILES, default 256 -- measured on the fp32-pipe kernel)
 int launch_conv3x3_fused(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_small(const ConvArgs& a, hipStream_t s);
 int launch_gemm_small(const GemmArgs& a, hipStream_t s);
