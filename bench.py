@@ -2,8 +2,9 @@
 """Headline benchmark of the suo_slam hot path on MI355X (contract: see the task statement).
 
 One STEP = `--frames-per-step` (32) consecutive synthetic YCB-V-shaped frames (640x480 uint8, 8 object boxes each = 256 crops)
-through the whole per-frame path of BASELINE.json configs[1] (single-view eval, no SLAM), everything inside the timed region:
-    host: boxes -> K_bbox (fix_K_for_bbox_ndc, float32 container) -> inv(K_bbox) terms; pinned frames, boxes, model keypoints H2D
+through the whole per-frame path of BASELINE.json configs[1] (single-view eval, no SLAM).  The frames are resident in HBM when the timed region starts (the bench
+contract; `--frames-from-host` and the `frames_from_pinned_host` leg time the same region with the frames uploaded inside it -- rounds 1-4's `value`); inside it:
+    host: boxes -> K_bbox (fix_K_for_bbox_ndc, float32 container) -> inv(K_bbox) terms; boxes, model keypoints H2D
     -> RoI crop + prior concat -> stacked-hourglass keypoint CNN (fp32 MFMA) -> heat-map decode -> validity masks
     -> [device-resident, csrc/frame_geom.hip] compaction of the valid keypoints -> batched P3P-RANSAC PnP -> acceptance
     -> pose graph -> uncertainty-weighted LM, rounds [10,10,40,40] -> ONE read-back of poses / inlier flags / keypoints.
@@ -17,7 +18,7 @@ frames that are counted.  Frames of the single-view stream are independent (eval
 batching them; the reference's own call shape (one frame per call) is timed separately (`latency`).
 
 Legs after the timed region, never part of `value` and each fenced (an exception or a time-out in one costs only that leg):
-`roofline` (dominant kernel + the largest 1x1 GEMM + the latency-mode launch under HIP events), `pose_check`, `latency`,
+`roofline` (dominant kernel + the largest 1x1 GEMM + the latency-mode launch under HIP events), `frames_from_pinned_host`, `pose_check`, `latency`,
 `drop_in` (ObjectSLAM.process_view, the thing evaluate.py calls, one frame per call), `slam` (BASELINE configs[2]: a 60-view
 sequence through ObjectSLAM.process_view, the reference's two timing meters), `global_ba` (BASELINE configs[4]'s exchange
 step over RCCL -- on one GPU over a ONE-rank RCCL group with every collective issued), `fp32_pipe` (the same timed region with every
@@ -81,6 +82,7 @@ def parse():
     ap.add_argument("--frames-per-step", "--frames-per-forward", dest="frames_per_step", type=int, default=32,
                     help="frames of the stream batched into one network call = one step (--objects crops each)")
     ap.add_argument("--only", choices=["all", "cnn"], default="all", help="diagnostic: network half of the step only")
+    ap.add_argument("--frames-from-host", action="store_true", help="frames in pinned host memory, uploaded inside the timed region (rounds 1-4's `value`); default: resident in HBM")
     ap.add_argument("--no-legs", action="store_true", help="timed region only (profiling runs)")
     ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--no-global-ba-leg", action="store_true")
@@ -610,7 +612,7 @@ def fp32_pipe_leg(args, L):
     from suo_slam_amd import _lib
     out = {}
     cmd = [sys.executable, os.path.abspath(__file__), "--no-legs", "--steps", "4", "--warmup", "2", "--objects", str(args.objects), "--frames-per-step",
-           str(args.frames_per_step), "--depth", str(args.depth)]
+           str(args.frames_per_step), "--depth", str(args.depth)] + (["--frames-from-host"] if args.frames_from_host else [])
     for tag, env_add in (("fp32_pipe", {"SUO_WINO_BF16X3": "0"}), ("bf16x3", {"SUO_F16X2": "0"})):      # the same timed region on the other two forms, a child process each
         if tag == "bf16x3" and matrix_pipe() != "f16x2":
             continue
@@ -755,11 +757,12 @@ def cpu_quota():
         return None
 
 
-def frames_resident_leg(L, pool, F, use_graph, depth, steps, warmup, fps_value):
-    """The timed region again with the pool's frames ALREADY IN HBM when a step starts (no frame H2D inside it; boxes / model keypoints still come from the host
-    per step, 0.2 MB): `value` itself counts the frames' H2D from pinned memory (0.92 MB per frame over PCIe, a copy kernel on the step's stream)."""
+def frames_from_host_leg(L, pool, F, use_graph, depth, steps, warmup, fps_value):
+    """The timed region again with the frames handed over in PINNED HOST memory and uploaded inside it (0.92 MB per frame over PCIe, a copy kernel on the step's
+    stream) -- the rate rounds 1-4 reported as `value`.  `value` itself follows the bench contract: inputs resident in HBM when the timed region starts (the C ABI
+    takes device pointers for the frames: include/suo_hip.h, suo_net_forward_frames); the boxes / model keypoints (0.2 MB per step) come from the host either way."""
     import torch
-    pipe = FramePipeline(L, pool, F, use_graph=use_graph, depth=depth, resident=True)
+    pipe = FramePipeline(L, pool, F, use_graph=use_graph, depth=depth, resident=False)
     for i in range(warmup):
         pipe.step(i)
     pipe.drain(warmup)
@@ -775,7 +778,7 @@ def frames_resident_leg(L, pool, F, use_graph, depth, steps, warmup, fps_value):
     fps = steps * F / dt
     return {"frames_per_s": round(fps, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "warmup": warmup,
             "over_value": round(fps / fps_value, 4),
-            "note": "`value` is the PCIe-inclusive rate (frames handed over in pinned host memory, as a loader thread does); this is the same region with the frames resident"}
+            "note": "the PCIe-inclusive rate (frames in pinned host memory, H2D inside the timed region): what `value` was in rounds 1-4; `value` has the frames resident in HBM"}
 
 
 def pose_check_leg(L, pool, use_graph):
@@ -1116,7 +1119,7 @@ def main():
     # frames shard embarrassingly: rank r processes its own stream (weak scaling: K steps = K*F frames per GPU)
     n_pool = args.pool if args.pool > 0 else 2 * F
     pool = make_pool(np.random.default_rng(1000 + rank), n_pool, L)
-    pipe = FramePipeline(L, pool, F, use_graph=not args.no_graph, only=args.only, depth=args.depth)
+    pipe = FramePipeline(L, pool, F, use_graph=not args.no_graph, only=args.only, depth=args.depth, resident=not args.frames_from_host)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1176,14 +1179,15 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "dtype_note": DTYPE_NOTE[matrix_pipe()], "matrix_pipe": matrix_pipe(),
             "data": "synthetic", "n_ranks_seen": n_ranks_seen, "rccl_backend": rccl_backend,
-            "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> H2D, RoI crop, hourglass keypoint "
+            "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> RoI crop, hourglass keypoint "
                                    "CNN fp32, decode, masks, device-resident compaction -> batched PnP -> acceptance -> LM rounds [10,10,40,40], "
                                    "one read-back" % L,
-                       "step": "frames_per_step consecutive frames: host K_bbox terms + H2D of the frames + one network call + the geometry of "
-                               "those frames on the network's own output",
+                       "step": "frames_per_step consecutive frames (resident in HBM%s): host K_bbox terms + H2D of the boxes / model keypoints + one network "
+                               "call + the geometry of those frames on the network's own output" % (" -- NO: --frames-from-host, uploaded inside the step" if args.frames_from_host else ""),
                        "frames_per_step": F, "objects_per_frame": L, "crops_per_step": L * F, "crops_per_s": round(fps * L, 2),
                        "frames_timed": frames, "timed_region_s": round(dt, 4), "steps_in_flight": args.depth,
-                       "inside_timed_region": "fix_K_for_bbox_ndc + inv(K_bbox) per crop (host), pinned-frame H2D (0.92 MB per frame), boxes / model "
+                       "frames": "pinned host memory, H2D inside the timed region" if args.frames_from_host else "resident in HBM when the timed region starts (bench contract); the PCIe-inclusive rate is the frames_from_pinned_host leg",
+                       "inside_timed_region": "fix_K_for_bbox_ndc + inv(K_bbox) per crop (host), boxes / model "
                                               "keypoints H2D, network, masks, compaction, PnP, acceptance, graph build, LM, read-back",
                        "weights": "seeded random, classifier bias + 4, thresholds bbox %.1f / var %.1f so the masks pass: the geometry runs on "
                                   "whatever the network emitted (worst case: RANSAC at its iteration cap)" % (BBOX_THRESH, KP_VAR_THRESH),
@@ -1263,7 +1267,8 @@ def main():
             if world == 1 and wino_bf16x3_enabled():
                 leg("fp32_pipe", fp32_pipe_leg, args, L)
             if world == 1:
-                leg("frames_resident_in_hbm", frames_resident_leg, L, pool, F, not args.no_graph, args.depth, args.steps, args.warmup, base["value"])
+                if not args.frames_from_host:
+                    leg("frames_from_pinned_host", frames_from_host_leg, L, pool, F, not args.no_graph, args.depth, args.steps, args.warmup, base["value"])
                 leg("pose_check", pose_check_leg, L, pool, not args.no_graph)
                 if not args.no_latency_leg:
                     leg("latency", latency_leg, L, pool, not args.no_graph)
