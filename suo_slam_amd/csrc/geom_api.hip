@@ -34,12 +34,13 @@ size_t lm_problem_struct_size();
 int launch_ba_init(const void* P, hipStream_t s);
 size_t ba_scratch_doubles();
 int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch, hipStream_t s);
-int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl = nullptr);
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl = nullptr, double* copy_to = nullptr,
+                        int copy_n = 0);
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s, const double* ctl = nullptr);
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
                            double* scratch, double* big, hipStream_t s, const double* ctl = nullptr);
 int launch_ba_ctl_begin(double* ctl, int its, int world, hipStream_t s);
-int launch_ba_ctl_lin(const void* P, double* ctl, const double* lin, hipStream_t s);
+int launch_ba_ctl_lin(const void* P, double* ctl, const double* lin, double* scratch, hipStream_t s);
 int launch_ba_ctl_decide(const void* P, double* ctl, const double* red, hipStream_t s);
 int launch_ba_copy(const double* src, double* dst, int n, hipStream_t s);
 int launch_ba_restore(const void* P, hipStream_t s);
@@ -662,15 +663,13 @@ int suo_ba_lm_begin_dev(suo_ba_ctx* c, double* ctl_dev, int its, int world, void
 }
 int suo_ba_lm_linearize_dev(suo_ba_ctx* c, int robust_on, int rank, int world, const double* ctl_dev, double* lin_local_dev, double* lin_dev, void* stream) {
     if (!c || !ctl_dev || !lin_local_dev || !lin_dev || rank < 0 || rank >= world) { suo_set_error("suo_ba_lm_linearize_dev: bad arguments"); return SUO_ERR_ARG; }
-    int rc = launch_ba_linearize(c->dev_problem(), robust_on, lin_local_dev, c->scratch(), rank, world, (hipStream_t)stream, ctl_dev);
-    if (rc != SUO_OK) return rc;
     // the reduce works in place and runs every unit: it starts from this rank's own totals every time (a trial on a standing linearisation
-    // re-reduces the same numbers instead of reducing the already reduced ones)
-    return launch_ba_copy(lin_local_dev, lin_dev, 1 + 27 * c->n_obj + world, (hipStream_t)stream);
+    // re-reduces the same numbers instead of reducing the already reduced ones) -- the tail kernel copies them over, live unit or not
+    return launch_ba_linearize(c->dev_problem(), robust_on, lin_local_dev, c->scratch(), rank, world, (hipStream_t)stream, ctl_dev, lin_dev, 1 + 27 * c->n_obj + world);
 }
 int suo_ba_lm_schur_dev(suo_ba_ctx* c, double* ctl_dev, const double* lin_dev, double* sch_dev, void* stream) {
     if (!c || !ctl_dev || !lin_dev || !sch_dev) { suo_set_error("suo_ba_lm_schur_dev: null argument"); return SUO_ERR_ARG; }
-    int rc = launch_ba_ctl_lin(c->dev_problem(), ctl_dev, lin_dev, (hipStream_t)stream);
+    int rc = launch_ba_ctl_lin(c->dev_problem(), ctl_dev, lin_dev, c->scratch(), (hipStream_t)stream);
     if (rc != SUO_OK) return rc;
     return launch_ba_schur(c->dev_problem(), 0.0, c->ns, sch_dev, c->scratch(), (hipStream_t)stream, ctl_dev);
 }

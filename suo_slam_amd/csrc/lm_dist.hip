@@ -95,31 +95,52 @@ __global__ __launch_bounds__(LM_THREADS) void ba_accumulate_kernel(const LmProbl
     accumulate_pairs_range(*Pp, 0, Pp->n_pair, GT, GS);
 }
 // own cameras: Hcc / bc; objects: this rank's share of (Hoo 21 + bo 6) -> out[1 + 27 o + k]
+// Eight lanes per entry, each walking every eighth pair of the vertex's list (two dependent index loads per pair are pure latency: one lane per entry took 17.5 us for
+// 32 cameras x 16 objects), the eight partial sums combined by an xor butterfly -- the same tree on every lane, the same bits on every run.
 __global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ out, const double* __restrict__ ctl, int want) {
     BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
-    for (int idx = GT; idx < P.n_cam * 27; idx += GS) {
-        const int c = idx / 27, k = idx - c * 27;
-        if (P.cam_fixed[c]) continue;
-        double s = 0;
-        for (int j = P.cam_pair_ptr[c]; j < P.cam_pair_ptr[c + 1]; ++j)
-            s += P.pair_part[90 * (size_t)P.cam_pair_idx[j] + (k < 21 ? k : 78 + (k - 21))];
-        if (k < 21) P.Hcc[36 * c + k] = s; else P.bc[6 * c + (k - 21)] = s;
-    }
-    for (int idx = GT; idx < P.n_obj * 27; idx += GS) {
-        const int o = idx / 27, k = idx - o * 27;
-        double s = 0;
-        if (!P.obj_fixed[o])
-            for (int j = P.obj_pair_ptr[o]; j < P.obj_pair_ptr[o + 1]; ++j)
-                s += P.pair_part[90 * (size_t)P.obj_pair_idx[j] + (k < 21 ? 21 + k : 84 + (k - 21))];
-        out[1 + idx] = s;
+    constexpr int SL = 8;
+    auto sum8 = [](double v) {
+#pragma unroll
+        for (int o = 1; o < SL; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    const int nc = P.n_cam * 27, no = P.n_obj * 27;
+    // (whole groups of eight lanes run the same trip count: the shuffles are executed by all of them)
+    for (int t = GT; t < (nc + no) * SL; t += GS) {
+        const int item = t / SL, sl = t - item * SL;
+        if (item < nc) {
+            const int c = item / 27, k = item - c * 27;
+            double s = 0;
+            if (!P.cam_fixed[c])
+                for (int j = P.cam_pair_ptr[c] + sl; j < P.cam_pair_ptr[c + 1]; j += SL)
+                    s += P.pair_part[90 * (size_t)P.cam_pair_idx[j] + (k < 21 ? k : 78 + (k - 21))];
+            s = sum8(s);
+            if (sl == 0 && !P.cam_fixed[c]) { if (k < 21) P.Hcc[36 * c + k] = s; else P.bc[6 * c + (k - 21)] = s; }
+        } else {
+            const int idx = item - nc, o = idx / 27, k = idx - o * 27;
+            double s = 0;
+            if (!P.obj_fixed[o])
+                for (int j = P.obj_pair_ptr[o] + sl; j < P.obj_pair_ptr[o + 1]; j += SL)
+                    s += P.pair_part[90 * (size_t)P.obj_pair_idx[j] + (k < 21 ? 21 + k : 84 + (k - 21))];
+            s = sum8(s);
+            if (sl == 0) out[1 + idx] = s;
+        }
     }
 }
 // out[0] = chi2_local, out[1 + 27 n_obj + rank] = max |diag Hcc| over the local free cameras (the other ranks' slots are
 // zeroed: a SUM all-reduce then carries every rank's maximum, so the max needs no collective of its own)
+// copy_to (device-resident schedule): afterwards out[0 .. copy_n) is copied there -- ALSO when the unit does not linearise: the in-place reduce of the exchange buffer
+// starts from this rank's own totals every unit (a launch of its own until round 5)
 __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ partial, int n,
-                                                                        double* __restrict__ out, int rank, int world, const double* __restrict__ ctl, int want) {
-    BA_GUARD(ctl, want);
+                                                                        double* __restrict__ out, int rank, int world, const double* __restrict__ ctl, int want,
+                                                                        double* __restrict__ copy_to, int copy_n) {
+    const bool live = !(ctl && (int)ctl[CTL_STATE] != want);
+    if (!live) {
+        if (copy_to) for (int i = threadIdx.x; i < copy_n; i += LM_THREADS) copy_to[i] = out[i];
+        return;
+    }
     const LmProblem& P = *Pp;
     __shared__ double red[LM_THREADS / 64];
     double md = 0;
@@ -133,6 +154,10 @@ __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmP
         for (int i = 0; i < n; ++i) chi += partial[i];
         out[0] = chi;
         for (int r = 0; r < world; ++r) out[1 + 27 * P.n_obj + r] = r == rank ? md : 0.0;
+    }
+    if (copy_to) {
+        __syncthreads();                                       // thread 0's entries are written (same workgroup; the gather kernel's are from an earlier launch)
+        for (int i = threadIdx.x; i < copy_n; i += LM_THREADS) copy_to[i] = out[i];
     }
 }
 
@@ -341,34 +366,33 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_big_kernel(const LmProble
     }
     if (tid == 0 && sh_ok == 0) atomicAdd(bad, 1);
 }
-// x_c = y_c - sum_o Y(c,o) x_o for the own cameras, then T <- exp(x) T for cameras and objects (one thread per pose)
-// x_c = y_c - sum_o Y(c,o) x_o and the pose updates.  Six threads per camera (one per row of x_c): the dependent index chain of a
-// camera's pair list runs once per row in parallel instead of six times in a row (one thread per camera: 47 us for 32 cameras).
+// x_c = y_c - sum_o Y(c,o) x_o for the own cameras, then T <- exp(x) T for cameras and objects.  24 threads per camera: the six rows of x_c times four slices of the
+// camera's pair list (its dependent index chain is pure latency: one thread per camera took 47 us for 32 cameras, six 14), the slices summed by an xor butterfly.
 __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* __restrict__ Pp, const int* __restrict__ bad, const double* __restrict__ ctl, int want) {
     BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
     const bool ok = *bad == 0;
-    constexpr int CPW = LM_THREADS / 6;                       // cameras per workgroup and sweep
-    const int tid = threadIdx.x, cl = tid / 6, r = tid - cl * 6;
+    constexpr int SLU = 4, TPC = 6 * SLU, CPW = LM_THREADS / TPC;      // cameras per workgroup and sweep
+    const int tid = threadIdx.x, cl = tid / TPC, rs = tid - cl * TPC, r = rs / SLU, sl = rs - r * SLU;
     for (int c0 = blockIdx.x * CPW; c0 < P.n_cam; c0 += gridDim.x * CPW) {
         const int c = c0 + cl;
         const bool mine = cl < CPW && c < P.n_cam;
-        if (mine) {
-            double s = 0;
-            if (!P.cam_fixed[c]) {
-                s = P.yc[6 * c + r];
-                for (int b = P.cam_pair_ptr[c]; b < P.cam_pair_ptr[c + 1]; ++b) {
-                    const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
-                    if (P.obj_fixed[o]) continue;
-                    const double* Yr = P.Y + 36 * (size_t)p + r * 6;
-                    const double* xo = P.xo + 6 * o;
-                    for (int k = 0; k < 6; ++k) s -= Yr[k] * xo[k];
-                }
+        const bool free_cam = mine && !P.cam_fixed[c];
+        double s = 0;
+        if (free_cam) {
+            for (int b = P.cam_pair_ptr[c] + sl; b < P.cam_pair_ptr[c + 1]; b += SLU) {
+                const int p = P.cam_pair_idx[b], o = P.pair_obj[p];
+                if (P.obj_fixed[o]) continue;
+                const double* Yr = P.Y + 36 * (size_t)p + r * 6;
+                const double* xo = P.xo + 6 * o;
+                for (int k = 0; k < 6; ++k) s -= Yr[k] * xo[k];
             }
-            P.xc[6 * c + r] = s;
         }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (mine && sl == 0) P.xc[6 * c + r] = free_cam ? P.yc[6 * c + r] + s : 0.0;
         __syncthreads();                                      // the six rows of a camera are written (same workgroup)
-        if (mine && r == 0 && ok && !P.cam_fixed[c]) pose_oplus(P.cam[c], P.xc + 6 * c);
+        if (free_cam && rs == 0 && ok) pose_oplus(P.cam[c], P.xc + 6 * c);
     }
     if (ok)
         for (int o = GT; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
@@ -425,8 +449,10 @@ __global__ void ba_ctl_begin_kernel(double* __restrict__ ctl, int its, int world
 }
 // after the linearisation totals are reduced: chi2 of the iteration; in the first iteration computeLambdaInit (tau * max |diag H| over ALL
 // free vertices: the cameras' maxima travel in per-rank slots of the same SUM, the objects' diagonals are in the totals)
-__global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ ctl, const double* __restrict__ lin) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || (int)ctl[CTL_STATE] != ST_LINEARIZE) return;
+__global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ ctl, const double* __restrict__ lin, int* __restrict__ bad) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (bad) *bad = 0;                                         // the Schur phase's failure counter (a memset node of its own until round 5)
+    if ((int)ctl[CTL_STATE] != ST_LINEARIZE) return;
     const LmProblem& P = *Pp;
     ctl[CTL_CHI] = lin[0];
     if ((int)ctl[CTL_IT] == 0) {
@@ -444,8 +470,9 @@ __global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __re
 }
 // after the step's [chi2 | scale over cameras | ok-count] are reduced (red[3] = scale over objects, identical on every rank): the gain ratio,
 // accept / reject, lambda / ni, the trial and iteration counters, what the next unit is
-__global__ void ba_ctl_decide_kernel(double* __restrict__ ctl, const double* __restrict__ red) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// ... and pop() when the trial was rejected: one workgroup restores the poses saved by the Schur phase behind thread 0's decision (a grid-strided launch of its own
+// until round 5; a rank's few thousand poses are a few microseconds for 256 threads)
+__device__ void ba_decide(double* __restrict__ ctl, const double* __restrict__ red) {
     ctl[CTL_RESTORE] = 0;
     if ((int)ctl[CTL_STATE] != ST_TRIAL) return;
     const int world = (int)ctl[CTL_WORLD];
@@ -476,6 +503,15 @@ __global__ void ba_ctl_decide_kernel(double* __restrict__ ctl, const double* __r
     ctl[CTL_IT] = it;
     ctl[CTL_STATE] = (qmax == 10 || rho == 0 || !lam_finite || it >= (int)ctl[CTL_ITS]) ? ST_DONE : ST_LINEARIZE;
 }
+__global__ __launch_bounds__(LM_THREADS) void ba_ctl_decide_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ ctl, const double* __restrict__ red) {
+    __shared__ int sh_restore;
+    if (threadIdx.x == 0) { ba_decide(ctl, red); sh_restore = ctl[CTL_RESTORE] != 0.0; }
+    __syncthreads();
+    if (!sh_restore) return;
+    const LmProblem& P = *Pp;
+    for (int c = threadIdx.x; c < P.n_cam; c += LM_THREADS) P.cam[c] = P.cam_bak[c];
+    for (int o = threadIdx.x; o < P.n_obj; o += LM_THREADS) P.obj[o] = P.obj_bak[o];
+}
 __global__ void ba_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -492,16 +528,16 @@ int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch
     hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)scratch, BA_WGS, out, 0);
     BA_DONE
 }
-int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl) {
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl, double* copy_to, int copy_n) {
     BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch, ctl, ST_LINEARIZE);
     BA_GRID(ba_accumulate_kernel, ctl, ST_LINEARIZE);
     BA_GRID(ba_gather_kernel, out, ctl, ST_LINEARIZE);
-    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world, ctl, ST_LINEARIZE);
+    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world, ctl, ST_LINEARIZE, copy_to, copy_n);
     BA_DONE
 }
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s, const double* ctl) {
     int* bad = (int*)(scratch + BA_WGS);
-    SUO_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
+    if (!ctl) SUO_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));      // (device-resident schedule: ba_ctl_lin_kernel has cleared it)
     BA_GRID(ba_schur_cams_kernel, lambda, bad, ctl, ST_TRIAL);
     BA_GRID(ba_schur_y_kernel, ctl, ST_TRIAL);
     {   // one workgroup per 6 x 6 block of S
@@ -526,14 +562,13 @@ int launch_ba_ctl_begin(double* ctl, int its, int world, hipStream_t s) {
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
-int launch_ba_ctl_lin(const void* P, double* ctl, const double* lin, hipStream_t s) {
-    hipLaunchKernelGGL(ba_ctl_lin_kernel, dim3(1), dim3(64), 0, s, (const LmProblem*)P, ctl, lin);
+int launch_ba_ctl_lin(const void* P, double* ctl, const double* lin, double* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(ba_ctl_lin_kernel, dim3(1), dim3(64), 0, s, (const LmProblem*)P, ctl, lin, (int*)(scratch + BA_WGS));
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
 int launch_ba_ctl_decide(const void* P, double* ctl, const double* red, hipStream_t s) {
-    hipLaunchKernelGGL(ba_ctl_decide_kernel, dim3(1), dim3(64), 0, s, ctl, red);
-    BA_GRID(ba_restore_kernel, (const double*)ctl);            // pop() when the trial was rejected
+    BA_ONE(ba_ctl_decide_kernel, ctl, red);                    // the decision + pop() when the trial was rejected
     BA_DONE
 }
 int launch_ba_copy(const double* src, double* dst, int n, hipStream_t s) {
