@@ -198,18 +198,18 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem*
     }
 }
 // out = [S_g (ns x ns) | r_g (ns) | ok]
-// One workgroup per 6 x 6 block (s1, s2) of S (grid-strided), the block's 36 elements x 7 slices of object o1's camera list over 252
-// threads, slices summed in slice order through LDS (deterministic).  (One thread per element walking the whole list: 45 us -- its
-// three dependent index loads per camera are pure latency.)  The right-hand side rows follow, one thread per row.
+// One workgroup per 6 x 6 block (s1, s2) of S (grid-strided): 42 slices of object o1's camera list x the block's six rows over 252 threads (a thread keeps a row's six
+// columns: one camera per slice at 32 cameras -- the three dependent index loads per camera are pure latency: one thread per element walking the whole list took 45 us,
+// seven slices of 36 threads 19), slices summed in slice order through LDS (deterministic).  The right-hand side rows follow, one thread per row.
 __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem* __restrict__ Pp, int ns, const int* __restrict__ bad,
                                                                  double* __restrict__ out, const double* __restrict__ ctl, int want) {
     BA_GUARD(ctl, want);
     const LmProblem& P = *Pp;
-    constexpr int NSL = LM_THREADS / 36;                      // camera slices (7 with 256 threads)
+    constexpr int NSL = LM_THREADS / 6;                       // camera slices (42 with 256 threads): six threads per slice, one per row of the block
     __shared__ double part[NSL * 36];
     __shared__ int sh_o[2];
     const int tid = threadIdx.x, nb = ns / 6;
-    const int sl = tid / 36, e = tid - sl * 36, i = e / 6, j = e - i * 6;
+    const int sl = tid / 6, i = tid - sl * 6;
     for (int blk = blockIdx.x; blk < nb * nb; blk += gridDim.x) {
         const int s1 = blk / nb, s2 = blk - s1 * nb;
         if (tid < 2) {
@@ -221,16 +221,22 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
         __syncthreads();
         const int o1 = sh_o[0], o2 = sh_o[1];
         if (sl < NSL) {
-            double acc = 0;
+            double acc[6] = {0, 0, 0, 0, 0, 0};
             for (int a = P.obj_pair_ptr[o1] + sl; a < P.obj_pair_ptr[o1 + 1]; a += NSL) {
                 const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
                 const int p2 = P.cam_obj_pair[(size_t)c * P.n_obj + o2];
                 if (P.cam_fixed[c] || p2 < 0) continue;
                 const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
                 const double* Y2 = P.Y + 36 * (size_t)p2;
-                for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i] * Y2[k * 6 + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double h = H1[k * 6 + i];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[j] += h * Y2[k * 6 + j];
+                }
             }
-            part[sl * 36 + e] = acc;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) part[sl * 36 + i * 6 + j] = acc[j];
         }
         __syncthreads();
         if (tid < 36) {
@@ -240,18 +246,24 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
         }
         __syncthreads();
     }
-    for (int row = GT; row < ns; row += GS) {
+    // the right-hand side rows: 32 lanes per row, each walking every 32nd camera of the object's list (one lane per row: 32 dependent index chains in a row, ~19 us --
+    // it WAS this kernel's time), summed by an xor butterfly (the same tree on every lane)
+    constexpr int RSL = 32;
+    for (int t = GT; t < ns * RSL; t += GS) {
+        const int row = t / RSL, rsl = t - row * RSL;
         const int s1 = row / 6, i2 = row - s1 * 6;
         int o1 = -1;
         for (int o = 0; o < P.n_obj; ++o) if (P.obj_slot[o] == s1) o1 = o;
         double acc = 0;
-        for (int a = P.obj_pair_ptr[o1]; a < P.obj_pair_ptr[o1 + 1]; ++a) {
+        for (int a = P.obj_pair_ptr[o1] + rsl; a < P.obj_pair_ptr[o1 + 1]; a += RSL) {
             const int p1 = P.obj_pair_idx[a], c = P.pair_cam[p1];
             if (P.cam_fixed[c]) continue;
             const double* H1 = P.pair_part + 90 * (size_t)p1 + 42;
             for (int k = 0; k < 6; ++k) acc += H1[k * 6 + i2] * P.yc[6 * c + k];
         }
-        out[ns * ns + row] = acc;
+#pragma unroll
+        for (int o = 1; o < RSL; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (rsl == 0) out[ns * ns + row] = acc;
     }
     if (GT == 0) out[ns * ns + ns] = *bad == 0 ? 1.0 : 0.0;
 }
@@ -272,8 +284,18 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
     const double* rt = St + ns * ns;
     if (tid == 0) sh_ok = 1;
     if (tid == 0 && expect_ok > 0 && (int)(rt[ns] + 0.5) != expect_ok) atomicAdd(bad, 1);      // some rank's camera block was singular
-    for (int row = tid >> 6; row < ns; row += LM_THREADS / 64)          // a wave per row, lanes over the columns of the lower triangle
-        for (int col = tid & 63; col <= row; col += 64) S[row * sp + col] = -St[row * ns + col];
+    // the reduced system into LDS (lower triangle): eight independent loads in flight per thread (a wave per row, one row after the other, was 24 dependent
+    // round trips to L2 -- a third of this kernel)
+    for (int base = 0; base < ns * ns; base += 8 * LM_THREADS) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int idx = base + u * LM_THREADS + tid; v[u] = idx < ns * ns ? St[idx] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * LM_THREADS + tid, row = idx / ns, col = idx - row * ns;
+            if (idx < ns * ns && col <= row) S[row * sp + col] = -v[u];
+        }
+    }
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
         const int o = idx / 36, rc = idx - o * 36, r = rc / 6, cc = rc - r * 6;
