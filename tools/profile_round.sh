@@ -62,6 +62,14 @@ if [ -z "${SUO_PROFILE_ONLY_PMC:-}" ]; then
 python3 $R/tools/bench_f16x2.py 256 2>&1 | grep -v amdgpu.ids > $OUT/f16x2_ab.txt
 python3 $R/tools/time_views_single_host.py 16 2>&1 | grep -v amdgpu.ids | head -40 > $OUT/views_single_host.txt
 python3 $R/tools/time_frame_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/frame_chain.txt
+# 9. round 5, late: lin -> head as one launch; a network call of L = 1 .. 9 crops with the round's launch-size thresholds against the former ones
+python3 $R/tools/bench_chain_head.py 256 2>&1 | grep -v amdgpu.ids > $OUT/chain_head.txt
+python3 $R/tools/bench_chain_head.py 8 2>&1 | grep -v amdgpu.ids >> $OUT/chain_head.txt
+ms() { python3 $R/bench.py --no-legs --only cnn --depth 1 --objects $1 --frames-per-step 1 --steps 200 --warmup 20 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
+for L in 1 2 3 4 5 6 7 8 9; do
+  echo "crops per call $L: $(ms $L) ms | thresholds of rounds 1-4 (SUO_CONV_WINO_TILES=256 SUO_WINO_FUSE_TILES=256 SUO_GEMM_X3_MIN_ROWS=32768): $(SUO_CONV_WINO_TILES=256 SUO_WINO_FUSE_TILES=256 SUO_GEMM_X3_MIN_ROWS=32768 ms $L) ms"
+done > $OUT/network_by_crops.txt
+python3 $R/tools/bench_global_ba.py 60 8 2>&1 | grep -v amdgpu.ids > $OUT/global_ba_tool.txt
 fi
 # gpurun merges gpurun_out/ back only when it is <= 64 MiB: the raw counter databases stay on the box (their summaries are in $OUT and profiles/*.json)
 rm -rf $R/gpurun_out/pmc
