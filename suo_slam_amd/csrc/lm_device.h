@@ -262,7 +262,10 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
 #pragma unroll
             for (int c = 0; c <= r; ++c) L[r][c] = S[(k0 + r) * sp + k0 + c];
     };
-    for (int k0 = 0; k0 < ns; k0 += 6) {
+#ifndef SUO_CHOL_EXP          // timing experiments (wrong results): 1 = no factorisation, 2 = no substitutions, 4 = no trailing update
+#define SUO_CHOL_EXP 0
+#endif
+    for (int k0 = 0; k0 < ((SUO_CHOL_EXP & 1) ? 0 : ns); k0 += 6) {
         double L[6][6], rd[6];
         load_diag(k0, L);
         bool good = true;
@@ -317,7 +320,7 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
         // trailing update of the lower triangle, 16 x 16 tiles of (row a, column b <= a) over the threads
         const int m = ns - k0 - 6, base = k0 + 6;
         const int ty = (tid >> 4) & 15, tx = tid & 15;
-        if (tid < 256) {
+        if (tid < 256 && !(SUO_CHOL_EXP & 4)) {
             for (int a0 = 0; a0 < m; a0 += 16) {
                 const int a = a0 + ty;
                 double la[6];
@@ -336,51 +339,56 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
         }
         __syncthreads();
     }
-    // L y = rhs, block by block: every thread solves the 6 x 6 block redundantly, thread t then updates row t below it
-    for (int k0 = 0; k0 < ns; k0 += 6) {
-        double L[6][6], y[6];
-        load_diag(k0, L);
+    // The substitutions by ONE wave (round 5): 2 ns / 6 block steps whose only parallel work is ns rows of six multiply-adds -- with the whole workgroup each step paid a
+    // workgroup barrier and four redundant copies of the 6 x 6 solve (16 of the 56 us of a 96-row solve); a wave's LDS operations execute in order, so it needs none.
+    // L y = rhs, block by block: every lane solves the 6 x 6 block redundantly, lane t then updates rows t, t + 64 below it
+    if (tid < 64 && !(SUO_CHOL_EXP & 2)) {
+        for (int k0 = 0; k0 < ns; k0 += 6) {
+            double L[6][6], y[6];
+            load_diag(k0, L);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double v = rhs[k0 + c];
+            for (int c = 0; c < 6; ++c) {
+                double v = rhs[k0 + c];
 #pragma unroll
-            for (int q = 0; q < c; ++q) v -= L[c][q] * y[q];
-            y[c] = v * S[(k0 + c) * sp + k0 + c + 1];
+                for (int q = 0; q < c; ++q) v -= L[c][q] * y[q];
+                y[c] = v * S[(k0 + c) * sp + k0 + c + 1];
+            }
+            for (int i = k0 + 6 + tid; i < ns; i += 64) {
+                double v = rhs[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v -= S[i * sp + k0 + c] * y[c];
+                rhs[i] = v;
+            }
+            __builtin_amdgcn_wave_barrier();               // (every lane has read rhs[k0 ..] before lane 0 overwrites it)
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) rhs[k0 + c] = y[c];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        for (int i = k0 + 6 + tid; i < ns; i += nthreads) {
-            double v = rhs[i];
+        // L^T x = y, from the last block up
+        for (int k0 = ns - 6; k0 >= 0; k0 -= 6) {
+            double L[6][6], x[6];
+            load_diag(k0, L);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) v -= S[i * sp + k0 + c] * y[c];
-            rhs[i] = v;
-        }
-        __syncthreads();                                   // every thread has read rhs[k0 ..]; rows below are updated
-        if (tid == 0) {
+            for (int c = 5; c >= 0; --c) {
+                double v = rhs[k0 + c];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) rhs[k0 + c] = y[c];
-        }
-    }
-    __syncthreads();
-    // L^T x = y, from the last block up
-    for (int k0 = ns - 6; k0 >= 0; k0 -= 6) {
-        double L[6][6], x[6];
-        load_diag(k0, L);
+                for (int q = c + 1; q < 6; ++q) v -= L[q][c] * x[q];
+                x[c] = v * S[(k0 + c) * sp + k0 + c + 1];
+            }
+            for (int i = tid; i < k0; i += 64) {
+                double v = rhs[i];
 #pragma unroll
-        for (int c = 5; c >= 0; --c) {
-            double v = rhs[k0 + c];
+                for (int c = 0; c < 6; ++c) v -= S[(k0 + c) * sp + i] * x[c];
+                rhs[i] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) {
 #pragma unroll
-            for (int q = c + 1; q < 6; ++q) v -= L[q][c] * x[q];
-            x[c] = v * S[(k0 + c) * sp + k0 + c + 1];
-        }
-        for (int i = tid; i < k0; i += nthreads) {
-            double v = rhs[i];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) v -= S[(k0 + c) * sp + i] * x[c];
-            rhs[i] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) rhs[k0 + c] = x[c];
+                for (int c = 0; c < 6; ++c) rhs[k0 + c] = x[c];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
