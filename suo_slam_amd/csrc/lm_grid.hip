@@ -218,21 +218,28 @@ __global__ __launch_bounds__(LG_THREADS) void lm_grid_kernel(const LmProblem* __
             accumulate_pairs_range(P, 0, P.n_pair, gt, GS);
             grid_sync(g);
             LGPROF(1);
-            for (int idx = gt; idx < P.n_cam * 27; idx += GS) {
-                const int c = idx / 27, k = idx - c * 27;
-                if (P.cam_fixed[c]) continue;
-                double s = 0;
-                for (int j = P.cam_pair_ptr[c]; j < P.cam_pair_ptr[c + 1]; ++j)
-                    s += P.pair_part[90 * (size_t)P.cam_pair_idx[j] + (k < 21 ? k : 78 + (k - 21))];
-                if (k < 21) P.Hcc[36 * c + k] = s; else P.bc[6 * c + (k - 21)] = s;
-            }
-            for (int idx = gt; idx < P.n_obj * 27; idx += GS) {
-                const int o = idx / 27, k = idx - o * 27;
-                if (P.obj_fixed[o]) continue;
-                double s = 0;
-                for (int j = P.obj_pair_ptr[o]; j < P.obj_pair_ptr[o + 1]; ++j)
-                    s += P.pair_part[90 * (size_t)P.obj_pair_idx[j] + (k < 21 ? 21 + k : 84 + (k - 21))];
-                if (k < 21) P.Hoo[36 * o + k] = s; else P.bo[6 * o + (k - 21)] = s;
+            {   // diagonal blocks / gradients of every vertex from its pairs: eight lanes per entry, each walking every eighth pair of the list (two dependent index
+                // loads per pair are pure latency: an object seen from 60 views was 60 round trips in a row), combined by an xor butterfly (csrc/lm_dist.hip: ba_gather_kernel)
+                constexpr int SL = 8;
+                const int nc = P.n_cam * 27, no = P.n_obj * 27;
+                for (int t = gt; t < (nc + no) * SL; t += GS) {
+                    const int item = t / SL, sl = t - item * SL;
+                    const bool is_cam = item < nc;
+                    const int v = is_cam ? item / 27 : (item - nc) / 27, k = is_cam ? item - v * 27 : item - nc - v * 27;
+                    const bool fixed = is_cam ? P.cam_fixed[v] != 0 : P.obj_fixed[v] != 0;
+                    const int* ptr = is_cam ? P.cam_pair_ptr : P.obj_pair_ptr;
+                    const int* lst = is_cam ? P.cam_pair_idx : P.obj_pair_idx;
+                    const int off = is_cam ? (k < 21 ? k : 78 + (k - 21)) : (k < 21 ? 21 + k : 84 + (k - 21));
+                    double sacc = 0;
+                    if (!fixed)
+                        for (int j = ptr[v] + sl; j < ptr[v + 1]; j += SL) sacc += P.pair_part[90 * (size_t)lst[j] + off];
+#pragma unroll
+                    for (int o = 1; o < SL; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+                    if (sl == 0 && !fixed) {
+                        if (is_cam) { if (k < 21) P.Hcc[36 * v + k] = sacc; else P.bc[6 * v + (k - 21)] = sacc; }
+                        else { if (k < 21) P.Hoo[36 * v + k] = sacc; else P.bo[6 * v + (k - 21)] = sacc; }
+                    }
+                }
             }
             grid_sync(g);
             LGPROF(2);
