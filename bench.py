@@ -54,13 +54,16 @@ BBOX_THRESH, KP_VAR_THRESH = 1.0, 0.5      # evaluate.py:66-74 (the T-LESS pair)
 
 def winograd_saved_gflop_per_crop(crops_per_call):
     """MACs the Winograd F(2x2,3x3) form does not execute (csrc/conv_wino.hip): the 3x3 convolution of a Residual block (128 -> 128,
-    or 64 -> 64 in r1 / r4) runs in that form when its launch has >= 256 tiles of 8 x 16 pixels (conv3x3_wino_pays), at 16 instead
-    of 36 products per 2x2 tile.  Such convolutions per crop (hg.py:7-58, 2 stacks): 128 channels -- 9 at 64x64 (r5, up1 and the
+    or 64 -> 64 in r1 / r4) runs in that form when its launch has enough tiles of 8 x 16 pixels (csrc/net.hip: 32 on the fp16 pipe, 256 on the
+    others) and is not taken by the one-launch block kernels (maps of <= 32 pixels a side up to 768 tiles of 4 x 8: direct products), at 16
+    instead of 36 products per 2x2 tile.  Such convolutions per crop (hg.py:7-58, 2 stacks): 128 channels -- 9 at 64x64 (r5, up1 and the
     post-hourglass blocks), 12 at 32x32, 12 at 16x16; 64 channels -- r1 at 128x128, r4 at 64x64."""
+    min_tiles = 32 if matrix_pipe() == "f16x2" else 256
     saved = 0.0
     for hw, count, ch in ((64, 9, 128), (32, 12, 128), (16, 12, 128), (128, 1, 64), (64, 1, 64)):
         tiles = crops_per_call * (hw // 8) * (hw // 16)
-        if tiles >= 256:
+        one_launch = hw <= 32 and crops_per_call * (hw // 4) * (hw // 8) <= 768
+        if tiles >= min_tiles and not one_launch:
             saved += count * 2.0 * hw * hw * ch * ch * 9 * (1 - 1 / 2.25) / 1e9
     return saved
 
