@@ -301,40 +301,50 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
             for (int c = 0; c < 6; ++c) S[i * sp + k0 + c] = x[c];
         }
         __syncthreads();                                   // panel complete; every thread has read the diagonal block
-        if (tid < 6) {
+        if (tid == 0) {
+            // the factored diagonal block back to LDS -- by ONE lane with compile-time indices (27 stores).  Six lanes, each selecting "its" row of L out of
+            // registers with a runtime index, were 72 conditional moves in six divergent blocks on wave 0's way into the trailing update (0.4 us per block step).
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
-                if (c <= tid) {
-                    double v = 0;
+            for (int r = 0; r < 6; ++r) {
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) v = r == tid ? L[r][c] : v;      // (static indexing: L stays in registers)
-                    S[(k0 + tid) * sp + k0 + c] = v;
-                }
-            // 1 / L_qq for the substitutions, kept in the never-referenced element right of the diagonal (sp > ns: the last row's is
-            // the pad column) -- six fp64 divisions per block step and thread otherwise
-            double rdv = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) rdv = r == tid ? rd[r] : rdv;
-            S[(k0 + tid) * sp + k0 + tid + 1] = rdv;
+                for (int c = 0; c <= r; ++c) S[(k0 + r) * sp + k0 + c] = L[r][c];
+                // 1 / L_rr for the substitutions, kept in the never-referenced element right of the diagonal (sp > ns: the last row's is
+                // the pad column) -- six fp64 divisions per block step and thread otherwise
+                S[(k0 + r) * sp + k0 + r + 1] = rd[r];
+            }
         }
-        // trailing update of the lower triangle, 16 x 16 tiles of (row a, column b <= a) over the threads
+        // Trailing update of the lower triangle, 16 x 16 tiles of (row a, column b <= a) over the threads.  Per tile row: the (at most six) tiles of the row are
+        // loaded together, updated as INDEPENDENT chains and stored together -- the loads are unconditional (clamped rows, results selected) and the six-term
+        // chains of a row's tiles interleave; as a loop over tiles with a predicated body every element was its own basic block: LDS round trip -> twelve dependent
+        // fp64 operations -> store, one after the other (22 of the 56 us of a 96-row solve, thread 0's wall clock).  Same operations per element: same bits.
         const int m = ns - k0 - 6, base = k0 + 6;
         const int ty = (tid >> 4) & 15, tx = tid & 15;
         if (tid < 256 && !(SUO_CHOL_EXP & 4)) {
             for (int a0 = 0; a0 < m; a0 += 16) {
                 const int a = a0 + ty;
+                const bool a_ok = a < m;
+                const double* rowa = S + (base + (a_ok ? a : m - 1)) * sp;         // (a row of the system whatever the lane: no predicated loads)
                 double la[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) la[c] = a < m ? S[(base + a) * sp + k0 + c] : 0.0;
-                for (int b0 = 0; b0 <= a0; b0 += 16) {
-                    const int b = b0 + tx;
-                    if (a < m && b <= a) {
-                        double acc = S[(base + a) * sp + base + b];
+                for (int c = 0; c < 6; ++c) la[c] = rowa[k0 + c];
+                double acc[6], lbv[6][6];
+                bool ok[6];
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) acc -= la[c] * S[(base + b) * sp + k0 + c];
-                        S[(base + a) * sp + base + b] = acc;
-                    }
+                for (int j = 0; j < 6; ++j) {
+                    const int b = 16 * j + tx;
+                    ok[j] = 16 * j <= a0 && a_ok && b <= a;
+                    const int bb = b < m ? b : m - 1;
+                    acc[j] = rowa[base + bb];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) lbv[j][c] = S[(base + bb) * sp + k0 + c];
                 }
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[j] -= la[c] * lbv[j][c];
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (ok[j]) S[(base + a) * sp + base + 16 * j + tx] = acc[j];
             }
         }
         __syncthreads();
