@@ -415,6 +415,9 @@ int suo_ba_lm_schur_dev(suo_ba_ctx* ctx, double* ctl_dev, const double* lin_dev,
 int suo_ba_lm_solve_update_dev(suo_ba_ctx* ctx, int robust_on, int world, const double* ctl_dev, const double* lin_dev, const double* sch_dev,
                                double* red_dev, void* stream);
 int suo_ba_lm_decide_dev(suo_ba_ctx* ctx, double* ctl_dev, const double* red_dev, void* stream);
+/* The same unit on ONE rank, where nothing is exchanged between its phases: one call, the control steps folded into the kernels in front of them (12 launches
+ * instead of 14), bit-identical to the four calls above back to back. */
+int suo_ba_lm_unit_one_rank_dev(suo_ba_ctx* ctx, int robust_on, double* ctl_dev, double* lin_local_dev, double* lin_dev, double* sch_dev, double* red_dev, void* stream);
 /* Test entry (finite-difference checks of what the KERNELS linearise, not of the oracle): after suo_ba_linearize, per edge in
  * the caller's order jac_out[e][29] = [J_cam 2x6 | J_obj 2x6 | w*info (xx,xy,yy) | -w*info*err (2)] (EdgeSE3ProjectFromObject::
  * linearizeOplus, types_object_slam.cpp:70-123, columns = [omega, upsilon]) and err_out[e][2] (computeError, :45-60). */

@@ -92,6 +92,11 @@ class HipPhases:
         """One unit of the device-resident schedule: [linearise] -> reduce -> [lambda init] Schur -> reduce -> solve + update + chi2 -> reduce ->
         decide [+ restore]; the phases that the control block does not call for return at once.  No host synchronisation."""
         s = self._stream()
+        if world == 1 and not _collectives_forced() and os.environ.get("SUO_BA_FOLD_CTL", "1") not in ("", "0"):
+            # nothing is exchanged between the phases: the control steps ride in the tail kernels (csrc/geom_api.hip: suo_ba_lm_unit_one_rank_dev)
+            _lib.check(self.lib.suo_ba_lm_unit_one_rank_dev(self._h, int(robust_on), self._p(self.ctl), self._p(self.lin_loc), self._p(self.lin), self._p(self.sch),
+                                                            self._p(self.red), s), "suo_ba_lm_unit_one_rank_dev")
+            return
         _lib.check(self.lib.suo_ba_lm_linearize_dev(self._h, int(robust_on), rank, world, self._p(self.ctl), self._p(self.lin_loc), self._p(self.lin), s),
                    "suo_ba_lm_linearize_dev")
         reduce_(self.lin)

@@ -35,10 +35,10 @@ int launch_ba_init(const void* P, hipStream_t s);
 size_t ba_scratch_doubles();
 int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch, hipStream_t s);
 int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl = nullptr, double* copy_to = nullptr,
-                        int copy_n = 0);
+                        int copy_n = 0, double* fold_ctl = nullptr);
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s, const double* ctl = nullptr);
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
-                           double* scratch, double* big, hipStream_t s, const double* ctl = nullptr);
+                           double* scratch, double* big, hipStream_t s, const double* ctl = nullptr, double* fold_ctl = nullptr);
 int launch_ba_ctl_begin(double* ctl, int its, int world, hipStream_t s);
 int launch_ba_ctl_lin(const void* P, double* ctl, const double* lin, double* scratch, hipStream_t s);
 int launch_ba_ctl_decide(const void* P, double* ctl, const double* red, hipStream_t s);
@@ -678,6 +678,17 @@ int suo_ba_lm_solve_update_dev(suo_ba_ctx* c, int robust_on, int world, const do
     if (!c || !ctl_dev || !lin_dev || !sch_dev || !red_dev) { suo_set_error("suo_ba_lm_solve_update_dev: null argument"); return SUO_ERR_ARG; }
     return launch_ba_solve_update(c->dev_problem(), 0.0, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), c->d_big, (hipStream_t)stream,
                                   ctl_dev);
+}
+// One unit on ONE rank (no exchange between its phases): the control steps run inside the tail kernels in front of them -- 12 launches instead of 14.  Same arithmetic
+// in the same order as the four calls above with nothing in between: bit-identical (tests/test_gpu_geometry.py).
+int suo_ba_lm_unit_one_rank_dev(suo_ba_ctx* c, int robust_on, double* ctl_dev, double* lin_local_dev, double* lin_dev, double* sch_dev, double* red_dev, void* stream) {
+    if (!c || !ctl_dev || !lin_local_dev || !lin_dev || !sch_dev || !red_dev) { suo_set_error("suo_ba_lm_unit_one_rank_dev: null argument"); return SUO_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_ba_linearize(c->dev_problem(), robust_on, lin_local_dev, c->scratch(), 0, 1, s, ctl_dev, lin_dev, 1 + 27 * c->n_obj + 1, ctl_dev);
+    if (rc != SUO_OK) return rc;
+    rc = launch_ba_schur(c->dev_problem(), 0.0, c->ns, sch_dev, c->scratch(), s, ctl_dev);
+    if (rc != SUO_OK) return rc;
+    return launch_ba_solve_update(c->dev_problem(), 0.0, c->ns, robust_on, lin_dev + 1, sch_dev, 1, red_dev, c->scratch(), c->d_big, s, ctl_dev, ctl_dev);
 }
 int suo_ba_lm_decide_dev(suo_ba_ctx* c, double* ctl_dev, const double* red_dev, void* stream) {
     if (!c || !ctl_dev || !red_dev) { suo_set_error("suo_ba_lm_decide_dev: null argument"); return SUO_ERR_ARG; }

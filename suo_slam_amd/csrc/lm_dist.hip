@@ -40,6 +40,10 @@ constexpr int CTL_LAMBDA = 0, CTL_NI = 1, CTL_CHI = 2, CTL_STATE = 3, CTL_IT = 4
               CTL_RESTORE = 10, CTL_WORLD = 11;
 constexpr int ST_LINEARIZE = 0, ST_TRIAL = 1, ST_DONE = 2;
 #define BA_GUARD(ctl, want) do { if ((ctl) && (int)(ctl)[CTL_STATE] != (want)) return; } while (0)
+__device__ void ba_ctl_lin(const LmProblem& P, double* __restrict__ ctl, const double* __restrict__ lin, int* __restrict__ bad);
+__device__ void ba_decide(double* __restrict__ ctl, const double* __restrict__ red);
+// ONE rank, no collective between the phases of a unit: the one-thread control steps fold into the one-workgroup tail kernels in front of them (fold_ctl of
+// ba_linearize_tail_kernel / ba_update_tail_kernel; 14 -> 12 launches per unit).  With an all-reduce between tail and control step they stay launches of their own.
 
 // ---- phase 0: poses from the 3x4 matrices, reset levels ---------------------------------------------------
 __global__ __launch_bounds__(LM_THREADS) void ba_init_kernel(const LmProblem* __restrict__ Pp) {
@@ -135,10 +139,11 @@ __global__ __launch_bounds__(LM_THREADS) void ba_gather_kernel(const LmProblem* 
 // starts from this rank's own totals every unit (a launch of its own until round 5)
 __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ partial, int n,
                                                                         double* __restrict__ out, int rank, int world, const double* __restrict__ ctl, int want,
-                                                                        double* __restrict__ copy_to, int copy_n) {
+                                                                        double* __restrict__ copy_to, int copy_n, double* __restrict__ fold_ctl, int* __restrict__ bad) {
     const bool live = !(ctl && (int)ctl[CTL_STATE] != want);
     if (!live) {
         if (copy_to) for (int i = threadIdx.x; i < copy_n; i += LM_THREADS) copy_to[i] = out[i];
+        if (fold_ctl && threadIdx.x == 0) ba_ctl_lin(*Pp, fold_ctl, copy_to, bad);      // (clears the failure counter; the state is not "linearise": nothing else)
         return;
     }
     const LmProblem& P = *Pp;
@@ -158,6 +163,10 @@ __global__ __launch_bounds__(LM_THREADS) void ba_linearize_tail_kernel(const LmP
     if (copy_to) {
         __syncthreads();                                       // thread 0's entries are written (same workgroup; the gather kernel's are from an earlier launch)
         for (int i = threadIdx.x; i < copy_n; i += LM_THREADS) copy_to[i] = out[i];
+        if (fold_ctl) {
+            __syncthreads();                                   // the totals are in place (one rank: they ARE the reduced ones)
+            if (threadIdx.x == 0) ba_ctl_lin(P, fold_ctl, copy_to, bad);
+        }
     }
 }
 
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* 
 // (the first three are summed over ranks; the object part is identical on every rank)
 __global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProblem* __restrict__ Pp, double lambda, const double* __restrict__ partial,
                                                                      int n, const double* __restrict__ HB, const int* __restrict__ bad,
-                                                                     double* __restrict__ out, const double* __restrict__ ctl, int want) {
+                                                                     double* __restrict__ out, const double* __restrict__ ctl, int want, double* __restrict__ fold_ctl) {
     BA_GUARD(ctl, want);
     if (ctl) lambda = ctl[CTL_LAMBDA];
     const LmProblem& P = *Pp;
@@ -443,6 +452,15 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_tail_kernel(const LmProb
         double chi = 0;
         for (int i = 0; i < n; ++i) chi += partial[i];
         out[0] = chi; out[1] = sc_c; out[2] = ok ? 1.0 : 0.0; out[3] = sc_o;
+    }
+    if (fold_ctl) {                                            // one rank: `out` is the reduced result -- decide, and pop() a rejected step, right here
+        __shared__ int sh_restore;
+        if (tid == 0) { ba_decide(fold_ctl, out); sh_restore = fold_ctl[CTL_RESTORE] != 0.0; }
+        __syncthreads();
+        if (sh_restore) {
+            for (int c = tid; c < P.n_cam; c += LM_THREADS) P.cam[c] = P.cam_bak[c];
+            for (int o = tid; o < P.n_obj; o += LM_THREADS) P.obj[o] = P.obj_bak[o];
+        }
     }
 }
 
@@ -471,11 +489,9 @@ __global__ void ba_ctl_begin_kernel(double* __restrict__ ctl, int its, int world
 }
 // after the linearisation totals are reduced: chi2 of the iteration; in the first iteration computeLambdaInit (tau * max |diag H| over ALL
 // free vertices: the cameras' maxima travel in per-rank slots of the same SUM, the objects' diagonals are in the totals)
-__global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ ctl, const double* __restrict__ lin, int* __restrict__ bad) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void ba_ctl_lin(const LmProblem& P, double* __restrict__ ctl, const double* __restrict__ lin, int* __restrict__ bad) {
     if (bad) *bad = 0;                                         // the Schur phase's failure counter (a memset node of its own until round 5)
     if ((int)ctl[CTL_STATE] != ST_LINEARIZE) return;
-    const LmProblem& P = *Pp;
     ctl[CTL_CHI] = lin[0];
     if ((int)ctl[CTL_IT] == 0) {
         double maxd = 0;
@@ -489,6 +505,10 @@ __global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __re
     }
     ctl[CTL_QMAX] = 0; ctl[CTL_RHO] = 0;
     ctl[CTL_STATE] = ST_TRIAL;
+}
+__global__ void ba_ctl_lin_kernel(const LmProblem* __restrict__ Pp, double* __restrict__ ctl, const double* __restrict__ lin, int* __restrict__ bad) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ba_ctl_lin(*Pp, ctl, lin, bad);
 }
 // after the step's [chi2 | scale over cameras | ok-count] are reduced (red[3] = scale over objects, identical on every rank): the gain ratio,
 // accept / reject, lambda / ni, the trial and iteration counters, what the next unit is
@@ -550,11 +570,12 @@ int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch
     hipLaunchKernelGGL(ba_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)scratch, BA_WGS, out, 0);
     BA_DONE
 }
-int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl, double* copy_to, int copy_n) {
+int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl, double* copy_to, int copy_n,
+                        double* fold_ctl) {
     BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch, ctl, ST_LINEARIZE);
     BA_GRID(ba_accumulate_kernel, ctl, ST_LINEARIZE);
     BA_GRID(ba_gather_kernel, out, ctl, ST_LINEARIZE);
-    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world, ctl, ST_LINEARIZE, copy_to, copy_n);
+    BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world, ctl, ST_LINEARIZE, copy_to, copy_n, fold_ctl, (int*)(scratch + BA_WGS));
     BA_DONE
 }
 int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* scratch, hipStream_t s, const double* ctl) {
@@ -569,14 +590,14 @@ int launch_ba_schur(const void* P, double lambda, int ns, double* out, double* s
     BA_DONE
 }
 int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, const double* HB, const double* St, int expect_ok, double* out,
-                           double* scratch, double* big, hipStream_t s, const double* ctl) {
+                           double* scratch, double* big, hipStream_t s, const double* ctl, double* fold_ctl) {
     int* bad = (int*)(scratch + BA_WGS);          // carries over from the Schur phase of the same trial
     if (ns <= LM_NS) BA_ONE(ba_solve_kernel, lambda, ns, HB, St, expect_ok, bad, ctl, ST_TRIAL);
     else if (!big) { suo_set_error("bundle adjustment: reduced system of %d rows needs the big-system scratch", ns); return SUO_ERR_ARG; }
     else BA_ONE(ba_solve_big_kernel, lambda, ns, HB, St, expect_ok, bad, big, big + (size_t)ns * ns, ctl, ST_TRIAL);
     BA_GRID(ba_update_kernel, (const int*)bad, ctl, ST_TRIAL);
     BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch, ctl, ST_TRIAL);
-    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out, ctl, ST_TRIAL);
+    BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out, ctl, ST_TRIAL, fold_ctl);
     BA_DONE
 }
 int launch_ba_ctl_begin(double* ctl, int its, int world, hipStream_t s) {

@@ -388,6 +388,22 @@ def test_device_resident_lm_schedule_equals_the_host_schedule(ba, monkeypatch, n
     assert np.array_equal(a.inlier, b.inlier) and np.array_equal(a.chi2, b.chi2)
 
 
+def test_one_rank_unit_with_folded_control_steps_equals_the_four_calls(ba, monkeypatch):
+    """On one rank nothing is exchanged between the phases of an LM unit and the control steps ride in the tail kernels (suo_ba_lm_unit_one_rank_dev: 12 launches instead
+    of 14); SUO_BA_FOLD_CTL=0 keeps the four calls a multi-rank run makes.  Same arithmetic, same order: every output bit-identical."""
+    from suo_slam_amd import ba_dist
+    rng = np.random.default_rng(404)
+    P, _ = _multi_view_scene(rng, 24, 12)
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SUO_BA_FOLD_CTL", mode)
+        out[mode] = ba_dist.optimize_distributed(ba.Problem(*[P[k].copy() for k in keys]))
+    a, b = out["1"], out["0"]
+    assert np.array_equal(a.stats, b.stats) and a.stats[2] > 4
+    assert np.array_equal(a.cam_T, b.cam_T) and np.array_equal(a.obj_T, b.obj_T) and np.array_equal(a.inlier, b.inlier) and np.array_equal(a.chi2, b.chi2)
+
+
 def test_single_view_frame_with_many_edges_per_object_leaves_the_one_wave_kernel(ba):
     """csrc/lm_frame2.hip keeps a lane's outlier flags in a 32-bit mask: at most 32 edges per lane = 256 per object with 8 lanes.
     A two-object frame with 300 keypoints each fits its edge budget (656) but not that cap -- the dispatcher must hand it to the general
