@@ -207,6 +207,41 @@ __device__ bool spd_inverse6(const double* A, double* Ainv) {
     return true;
 }
 
+// column `col` of the same inverse (the factorisation repeated, ONE of the six solves): the operations of spd_inverse6 for that column, bit for bit -- for kernels that
+// give a lane to each column (csrc/lm_dist.hip: ba_schur_cams_kernel)
+__device__ bool spd_inverse6_col(const double* A, int col, double* x) {
+    double L[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) L[i] = 0;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (!(s > 0) || !isfinite(s)) ok = false; L[i * 6 + i] = sqrt(ok ? s : 1.0); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return ok;
+}
+
 struct LmProblem {
     // sizes
     int n_cam, n_obj, n_edge, n_pair;

@@ -178,18 +178,32 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_cams_kernel(const LmProbl
     const LmProblem& P = *Pp;
     for (int c = GT; c < P.n_cam; c += GS) P.cam_bak[c] = P.cam[c];
     for (int o = GT; o < P.n_obj; o += GS) P.obj_bak[o] = P.obj[o];
-    for (int c = GT; c < P.n_cam; c += GS) {
-        if (P.cam_fixed[c]) continue;
-        double A[36], Ai[36];
-        unpack_sym21(P.Hcc + 36 * c, A);
-        for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
-        if (!spd_inverse6(A, Ai)) { atomicAdd(bad, 1); for (int i = 0; i < 36; ++i) Ai[i] = 0; }
-        for (int i = 0; i < 36; ++i) P.Hcc_inv[36 * c + i] = Ai[i];
-        for (int r = 0; r < 6; ++r) {
-            double s = 0;
-            for (int k = 0; k < 6; ++k) s += Ai[r * 6 + k] * P.bc[6 * c + k];
-            P.yc[6 * c + r] = s;
+    // (Hcc + lambda I)^-1 and y_c = (Hcc + lambda I)^-1 b_c: an octet of lanes per camera, lane col < 6 factors the block and solves for COLUMN col of the inverse -- the
+    // operations of spd_inverse6 for that column (one thread per camera ran the factorisation and six solves in a row: 7.7 us for 32 cameras); row r of y_c is summed by lane r
+    // over the columns in ascending order, each taken from its lane by a shuffle: bit-identical to the one-thread form.
+    for (int t = GT; t < P.n_cam * 8; t += GS) {              // GS is a multiple of 8: an octet stays together
+        const int c = t >> 3, col = t & 7;
+        const bool work = !P.cam_fixed[c] && col < 6;
+        double x[6] = {0, 0, 0, 0, 0, 0};
+        bool okc = true;
+        if (work) {
+            double A[36];
+            unpack_sym21(P.Hcc + 36 * c, A);
+            for (int d = 0; d < 6; ++d) A[d * 7] += lambda;
+            okc = spd_inverse6_col(A, col, x);
+            if (!okc) { for (int i = 0; i < 6; ++i) x[i] = 0; if (col == 0) atomicAdd(bad, 1); }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) P.Hcc_inv[36 * c + i * 6 + col] = x[i];
         }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double xr = 0;                                      // element (row col, column k) of the inverse: lane k's x[col]
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const double v = __shfl(x[i], k, 8); xr = i == col ? v : xr; }
+            if (work) s += xr * P.bc[6 * c + k];
+        }
+        if (work) P.yc[6 * c + col] = s;
     }
 }
 __global__ __launch_bounds__(LM_THREADS) void ba_schur_y_kernel(const LmProblem* __restrict__ Pp, const double* __restrict__ ctl, int want) {
@@ -573,7 +587,8 @@ int launch_ba_classify(const void* P, int keep_all, double* out, double* scratch
 int launch_ba_linearize(const void* P, int robust_on, double* out, double* scratch, int rank, int world, hipStream_t s, const double* ctl, double* copy_to, int copy_n,
                         double* fold_ctl) {
     BA_GRID(ba_edge_pass_kernel, robust_on, 1, scratch, ctl, ST_LINEARIZE);
-    BA_GRID(ba_accumulate_kernel, ctl, ST_LINEARIZE);
+    // (one (pair, entry) item per thread up to 256 workgroups: with the 64 of the other steps a thread walked three items' edge lists one after the other)
+    hipLaunchKernelGGL(ba_accumulate_kernel, dim3(BA_WGS * 4), dim3(LM_THREADS), 0, s, (const LmProblem*)P, ctl, ST_LINEARIZE);
     BA_GRID(ba_gather_kernel, out, ctl, ST_LINEARIZE);
     BA_ONE(ba_linearize_tail_kernel, (const double*)scratch, BA_WGS, out, rank, world, ctl, ST_LINEARIZE, copy_to, copy_n, fold_ctl, (int*)(scratch + BA_WGS));
     BA_DONE
