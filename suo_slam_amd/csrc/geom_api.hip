@@ -487,30 +487,68 @@ struct suo_ba_ctx {
     Staged st;
     int n_cam = 0, n_obj = 0, ns = 0;
     double* d_io = nullptr; double* h_io = nullptr; size_t io_doubles = 0;   // [out | in | workgroup partials (device only)]
+    size_t io_cap = 0, big_cap = 0;                                           // capacities of the (possibly recycled) buffers, in doubles
     double* d_big = nullptr;     // reduced system + right-hand side in global memory when it has more than 96 rows (> 16 free objects)
     double* scratch() const { return d_io + io_doubles; }
     const void* dev_problem() const { return arena.dev + st.o_structs; }
 };
 
+// A context's buffers outlive it: a global adjustment of a SLAM run is create -> optimise -> destroy every few views, and creating / freeing its device arena, pinned
+// staging, stream and exchange buffers cost 1.6-2 ms of a 10 ms adjustment (hipFree and hipHostFree synchronise the device).  suo_ba_ctx_destroy parks them here (at most
+// four sets), suo_ba_ctx_create takes the first set back and grows what is too small.  Nothing read from them relies on their previous contents.
+struct BaCtxBuffers {
+    char* dev = nullptr; char* host = nullptr; size_t cap = 0; hipStream_t stream = nullptr;
+    double* d_io = nullptr; double* h_io = nullptr; size_t io_cap = 0;      // io_cap: doubles of h_io; d_io holds io_cap + ba_scratch_doubles()
+    double* d_big = nullptr; size_t big_cap = 0;
+};
+static std::mutex g_ba_pool_mu;
+static std::vector<BaCtxBuffers> g_ba_pool;
+static void ba_buffers_free(BaCtxBuffers& b) {
+    if (b.d_io) (void)hipFree(b.d_io);
+    if (b.d_big) (void)hipFree(b.d_big);
+    if (b.h_io) (void)hipHostFree(b.h_io);
+    if (b.dev) (void)hipFree(b.dev);
+    if (b.host) (void)hipHostFree(b.host);
+    if (b.stream) (void)hipStreamDestroy(b.stream);
+    b = BaCtxBuffers();
+}
+
 int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
     if (!p || !out) { suo_set_error("suo_ba_ctx_create: null argument"); return SUO_ERR_ARG; }
     suo_ba_ctx* c = new suo_ba_ctx();
+    BaCtxBuffers b;
+    {
+        std::lock_guard<std::mutex> lock(g_ba_pool_mu);
+        if (!g_ba_pool.empty()) { b = g_ba_pool.back(); g_ba_pool.pop_back(); }
+    }
+    c->arena.dev = b.dev; c->arena.host = b.host; c->arena.cap = b.cap; c->arena.stream = b.stream;      // (Arena::ensure keeps what is large enough)
+    c->d_io = b.d_io; c->h_io = b.h_io; c->io_cap = b.io_cap; c->d_big = b.d_big; c->big_cap = b.big_cap;
     int rc = stage_problems(p, 1, c->arena, c->st);
-    if (rc != SUO_OK) { delete c; return rc; }
+    if (rc != SUO_OK) { suo_ba_ctx_destroy(c); return rc; }
     c->n_cam = p->n_cam; c->n_obj = p->n_obj;
     int nfo = 0;
     for (int o = 0; o < p->n_obj; ++o) nfo += p->obj_fixed[o] ? 0 : 1;
     c->ns = 6 * nfo;
-    if (nfo > 16 && hipMalloc((void**)&c->d_big, ((size_t)c->ns * c->ns + c->ns) * sizeof(double)) != hipSuccess) {
-        suo_set_error("suo_ba_ctx_create: allocation failed"); delete c; return SUO_ERR_HIP;
+    const size_t big_need = nfo > 16 ? (size_t)c->ns * c->ns + c->ns : 0;
+    if (big_need > c->big_cap) {
+        if (c->d_big) (void)hipFree(c->d_big);
+        c->d_big = nullptr; c->big_cap = 0;
+        if (hipMalloc((void**)&c->d_big, big_need * sizeof(double)) != hipSuccess) { suo_set_error("suo_ba_ctx_create: allocation failed"); suo_ba_ctx_destroy(c); return SUO_ERR_HIP; }
+        c->big_cap = big_need;
     }
     c->io_doubles = 2 * ((size_t)c->ns * c->ns + c->ns + 27 * (size_t)p->n_obj + 16);
-    if (hipMalloc((void**)&c->d_io, (c->io_doubles + ba_scratch_doubles()) * sizeof(double)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_io, c->io_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
-        suo_set_error("suo_ba_ctx_create: allocation failed"); delete c; return SUO_ERR_HIP;
+    if (c->io_doubles > c->io_cap) {
+        if (c->d_io) (void)hipFree(c->d_io);
+        if (c->h_io) (void)hipHostFree(c->h_io);
+        c->d_io = nullptr; c->h_io = nullptr; c->io_cap = 0;
+        if (hipMalloc((void**)&c->d_io, (c->io_doubles + ba_scratch_doubles()) * sizeof(double)) != hipSuccess ||
+            hipHostMalloc((void**)&c->h_io, c->io_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            suo_set_error("suo_ba_ctx_create: allocation failed"); suo_ba_ctx_destroy(c); return SUO_ERR_HIP;
+        }
+        c->io_cap = c->io_doubles;
     }
     rc = launch_ba_init(c->dev_problem(), c->arena.stream);
-    if (rc != SUO_OK) { delete c; return rc; }
+    if (rc != SUO_OK) { suo_ba_ctx_destroy(c); return rc; }
     SUO_HIP_CHECK(hipStreamSynchronize(c->arena.stream));
     *out = c;
     return SUO_OK;
@@ -518,13 +556,18 @@ int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
 
 void suo_ba_ctx_destroy(suo_ba_ctx* c) {
     if (!c) return;
-    if (c->d_io) (void)hipFree(c->d_io);
-    if (c->d_big) (void)hipFree(c->d_big);
-    if (c->h_io) (void)hipHostFree(c->h_io);
-    if (c->arena.dev) (void)hipFree(c->arena.dev);
-    if (c->arena.host) (void)hipHostFree(c->arena.host);
-    if (c->arena.stream) (void)hipStreamDestroy(c->arena.stream);
+    if (c->arena.stream) (void)hipStreamSynchronize(c->arena.stream);
+    BaCtxBuffers b;
+    b.dev = c->arena.dev; b.host = c->arena.host; b.cap = c->arena.cap; b.stream = c->arena.stream;
+    b.d_io = c->d_io; b.h_io = c->h_io; b.io_cap = c->io_cap; b.d_big = c->d_big; b.big_cap = c->big_cap;
+    c->arena.dev = nullptr; c->arena.host = nullptr; c->arena.stream = nullptr;
     delete c;
+    static const size_t keep = getenv("SUO_BA_CTX_POOL") ? (size_t)atoi(getenv("SUO_BA_CTX_POOL")) : 4;      // 0: free at once
+    {
+        std::lock_guard<std::mutex> lock(g_ba_pool_mu);
+        if (g_ba_pool.size() < keep) { g_ba_pool.push_back(b); return; }
+    }
+    ba_buffers_free(b);
 }
 
 int suo_ba_ctx_ns(const suo_ba_ctx* c) { return c ? c->ns : -1; }

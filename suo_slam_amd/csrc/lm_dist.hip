@@ -439,8 +439,9 @@ __global__ __launch_bounds__(LM_THREADS) void ba_update_kernel(const LmProblem* 
         __syncthreads();                                      // the six rows of a camera are written (same workgroup)
         if (free_cam && rs == 0 && ok) pose_oplus(P.cam[c], P.xc + 6 * c);
     }
+    // the objects' updates by the LAST threads of the grid: the first ones have just walked a camera each (another exponential map in the same thread's way)
     if (ok)
-        for (int o = GT; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
+        for (int o = GS - 1 - GT; o < P.n_obj; o += GS) if (!P.obj_fixed[o]) pose_oplus(P.obj[o], P.xo + 6 * o);
 }
 // out = [chi2_local after the step | sum x_c (lambda x_c + b_c) over own cameras | ok | the same sum over the objects]
 // (the first three are summed over ranks; the object part is identical on every rank)
