@@ -29,6 +29,17 @@ COLLECTIVES_PER_TRIAL = 2          # [S | r | ok] and [chi2 | scale | ok]; +1 pe
 _DIAG21 = (0, 6, 11, 15, 18, 20)
 
 
+_PINNED = {}
+
+
+def _pinned(n):
+    """A pinned read-back buffer of >= n doubles, kept for the process: pinning one per adjustment is a hipHostMalloc (0.2-0.5 ms) per call."""
+    cap = 1 << max(6, (int(n) - 1).bit_length())
+    if cap not in _PINNED:
+        _PINNED[cap] = torch.empty(cap, dtype=torch.float64).pin_memory()
+    return _PINNED[cap]
+
+
 class HipPhases:
     """One rank's share of the graph, resident on its GPU (suo_ba_ctx_* of include/suo_hip.h), with the exchange buffers
     of the LM schedule as DEVICE tensors that the collectives reduce in place:
@@ -54,7 +65,7 @@ class HipPhases:
         self.sch = torch.zeros(self.ns * self.ns + self.ns + 1, dtype=torch.float64, device=dev)
         self.red = torch.zeros(4, dtype=torch.float64, device=dev)
         self.good = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._pin = torch.empty(max(self.lin.numel(), 16), dtype=torch.float64).pin_memory()
+        self._pin = _pinned(max(self.lin.numel(), 16))
         # device-resident LM schedule (csrc/lm_dist.hip: ctl): this rank's own linearisation totals (the in-place reduce starts from them every
         # unit) and the control block g2o's accept / reject arithmetic lives in
         self.lin_loc = torch.zeros_like(self.lin)
