@@ -574,6 +574,30 @@ def test_full_network_golden_on_the_winograd_path(ops, cnn_golden, state_dict, m
         np.testing.assert_array_equal(idx[i][sure], cnn_golden["backbone_argmax"][0][sure])
 
 
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 7])
+def test_full_network_golden_at_slam_call_sizes(ops, cnn_golden, state_dict, monkeypatch, L):
+    """A SLAM pass is a call of 2-7 crops.  Since round 5 the fp16 pipe takes such calls on the Winograd 3x3 / fused tail / fp16 GEMM kernels as well (csrc/net.hip:
+    from 32 tiles / 4096 rows; rounds 1-4 sent them to the direct fp32-pipe kernels below 8 crops), the 32x32 / 16x16 levels on the one-launch blocks, lin -> head as one
+    launch: every copy of the crop against the REFERENCE's own logits at 1e-5, with and without the captured graph, the range flag down."""
+    from suo_slam_amd.pkpnet import PkpNet
+    from tests.gpu_backbone import run_backbone_from_staged
+    monkeypatch.delenv("SUO_WINO_BF16X3", raising=False)
+    monkeypatch.delenv("SUO_F16X2", raising=False)
+    net = PkpNet(state_dict=state_dict, max_crops=8)
+    assert net.pipe() == 2
+    rng = np.random.Generator(np.random.PCG64(int(cnn_golden["backbone_in_seed"])))
+    x = rng.uniform(0, 1, (1, 44, 256, 256)).astype(np.float32)
+    xin = np.zeros((L, 256, 256, 48), np.float32)
+    xin[..., :44] = x.transpose(0, 2, 3, 1)
+    ref = cnn_golden["backbone_logits"]
+    for graph in (False, True):
+        net.set_graph(graph)
+        logits = run_backbone_from_staged(net, xin)
+        assert logits.shape == (L, 41, 64, 64) and not net.range_exceeded() and net.pipe() == 2
+        rel = np.abs(logits - ref).max() / np.abs(ref).max()
+        assert rel < 1e-5, (L, graph, rel)
+
+
 def test_the_two_matrix_pipe_forms_are_both_reachable_and_agree(ops, state_dict, monkeypatch):
     """SUO_WINO_BF16X3 / SUO_F16X2 select the form when a network is built; "1" below = the split forms with the default SUO_F16X2, i.e. the fp16 one.
     The networks' logits on the same input agree to fp32-rounding level but are not bit-identical (= different kernels really ran)."""
