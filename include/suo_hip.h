@@ -266,6 +266,12 @@ int suo_stem_x3(const void* img_dev, int fmt, int H, int W, const float* boxes_d
 int suo_pack_stem_weight_f16x2(const float* w, int Cw, const float* scale, uint16_t* out, float* oscale_out);
 int suo_stem_f16x2(const void* img_dev, int fmt, int H, int W, const float* boxes_dev, const int* box_img_dev, int L, const uint16_t* wh_dev, const float* oscale_dev,
                    const float* bias_dev, float* out_dev, unsigned* range_flag_dev, void* stream);
+/* ... with the first Residual block's conv1 computed on the tile as well (what suo_net_forward launches; SUO_STEM_NEXT=0: conv1 as its own launch):
+ * n_out [L,128,128,64] = relu(W1 relu(n_scale * out + n_shift) * n_osc1 + n_b1), n_w1h / n_osc1 = suo_pack_gemm_weight_f16x2 of W1 [64][64] (BatchNorm folded).
+ * Bit-identical to suo_stem_f16x2 followed by suo_conv1x1_f16x2_ex on its output. */
+int suo_stem_f16x2_next(const void* img_dev, int fmt, int H, int W, const float* boxes_dev, const int* box_img_dev, int L, const uint16_t* wh_dev, const float* oscale_dev,
+                        const float* bias_dev, float* out_dev, const float* n_scale_dev, const float* n_shift_dev, const uint16_t* n_w1h_dev, const float* n_osc1_dev,
+                        const float* n_b1_dev, float* n_out_dev, unsigned* range_flag_dev, void* stream);
 int suo_maxpool2(const float* in_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 int suo_upsample2_add(const float* up1_dev, const float* low_dev, float* out_dev, int L, int H, int W, int C, void* stream);
 

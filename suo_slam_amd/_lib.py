@@ -83,6 +83,7 @@ SIGNATURES = {
     "suo_pack_stem_weight_bf16x3": (C.c_int, [VP, C.c_int, VP, VP]),
     "suo_pack_stem_weight_f16x2": (C.c_int, [VP, C.c_int, VP, VP, VP]),
     "suo_stem_f16x2": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP]),
+    "suo_stem_f16x2_next": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_stem_x3": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP]),
     "suo_maxpool2": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "suo_upsample2_add": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),

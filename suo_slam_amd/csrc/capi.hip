@@ -395,6 +395,14 @@ int suo_stem_f16x2(const void* img, int fmt, int H, int W, const float* boxes, c
     return suo::launch_stem_x3(img, fmt, H, W, boxes, box_img, L, wh, bias, out, (hipStream_t)stream, oscale, range_flag_dev);
 }
 
+int suo_stem_f16x2_next(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* wh, const float* oscale, const float* bias,
+                        float* out, const float* n_scale, const float* n_shift, const uint16_t* n_w1h, const float* n_osc1, const float* n_b1, float* n_out,
+                        unsigned* range_flag_dev, void* stream) {
+    if (!oscale || !range_flag_dev) { suo_set_error("suo_stem_f16x2_next: null argument"); return SUO_ERR_ARG; }
+    const suo::StemNext nx = {n_scale, n_shift, n_w1h, n_osc1, n_b1, n_out};
+    return suo::launch_stem_x3(img, fmt, H, W, boxes, box_img, L, wh, bias, out, (hipStream_t)stream, oscale, range_flag_dev, &nx);
+}
+
 int suo_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* wx, const float* bias, float* out,
                 void* stream) {
     return suo::launch_stem_x3(img, fmt, H, W, boxes, box_img, L, wx, bias, out, (hipStream_t)stream);

@@ -93,6 +93,8 @@ private:
     float* stem_h2_w_ = nullptr; float* stem_h2_osc_ = nullptr;       // ... as two fp16 planes + per-channel factors (csrc/f16x2.h)
     float* stem_x3_w_ = nullptr; float* stem_x3_bias_ = nullptr;      // the image-only stem as bf16x3 planes for the fused RoIAlign + stem launch (csrc/stem_x3.hip)
     float* stem_slab_ = nullptr;                                      // [max_crops,128,128,64] persistent slab of the stem's output
+    float* stem_mid1_slab_ = nullptr;                                 // ... and of r1's conv1 when the fused stem launch computes it (csrc/stem_x3.hip: NEXT)
+    bool stem_computes_r1_conv1() const;
     ResidualW r1_, r4_, r5_, post_[2][2];
     HourglassW hg_[2];
     GemmW lin_[2], head_[2], reinject_;

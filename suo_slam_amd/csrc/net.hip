@@ -185,6 +185,12 @@ void Net::make_gemm(const std::string& conv, const std::string& bn_after, const 
             g.W16 = upload(h2);
             g.osc16 = upload(osc);
         }
+    } else if (Np == 64 && N == 64 && K1 == 64 && K1p == K1 && K2 == 0 && pipe_f16x2()) {
+        // r1's conv1 (64 -> 64): fp16 planes for the stem launch that computes it on the tile (csrc/stem_x3.hip: NEXT)
+        std::vector<float> h2((size_t)Np * Kp), osc(Np);
+        pack_gemm_weight_f16x2(full.data(), Np, Kp, reinterpret_cast<uint16_t*>(h2.data()), osc.data());
+        g.W16 = upload(h2);
+        g.osc16 = upload(osc);
     } else if (Np == 64 && K1 == 256 && K1p == K1 && K2 == 0 && pipe_f16x2()) {
         // the output head (tmpOut: 256 -> 41, padded to 64 rows of zeros): fp16 planes for the lin + head launch (csrc/gemm_bf16x3.hip: gemm_chain_head_kernel)
         std::vector<float> h2((size_t)Np * Kp), osc(Np);
@@ -449,6 +455,7 @@ Net::Net(int n, const char* const* names, const float* const* data, const int64_
     (void)alloc((size_t)max_crops_ * CROP * CROP * IN_C);
     (void)alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
     stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);
+    stem_mid1_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);
     ws_mark_ = ws_used_;
     // (every pipe this network can run on: the forms pick different kernels -- per-layer launches with their intermediate tensors where another form
     //  takes a one-launch block -- and a network that falls back to bf16x3 must find its workspace large enough)
@@ -760,6 +767,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
     ev_next_ = 0;
     pre_.clear();
     float* stem = stem_slab_;
+    if (stem_done && stem_computes_r1_conv1()) pre_.push_back({stem, &r1_, stem_mid1_slab_});      // (the fused stem launch leaves r1's conv1 there)
     if (!stem_done) {                                          // (the fused stem of the prior-less pass has filled the slab already: csrc/stem_x3.hip)
         ConvArgs c = {};
         const ConvW& sw = in_c == IMG_C ? stem_img_ : stem_;
@@ -885,6 +893,12 @@ int Net::range_exceeded() {
 }
 
 // SUO_STEM_X3=0: the prior-less pass stages the crop (roi_align_concat_kernel) and runs the stem on the fp32 pipe inside the backbone, as rounds 1-3 did
+// the fused stem launch of the fp16 pipe also computes r1's conv1 on its tile (csrc/stem_x3.hip: NEXT); a function of the network's state only -- suo_net_prepare captures the
+// backbone without launching the stem
+bool Net::stem_computes_r1_conv1() const {
+    static const int on = getenv("SUO_STEM_NEXT") ? atoi(getenv("SUO_STEM_NEXT")) : 1;              // 0: A/B
+    return on && fused_stem() && pipe_ == 2 && stem_h2_w_ && r1_.c1.W16 && r1_.c1.osc16 && r1_.cin == 64 && r1_.c1.N == 64 && r1_.c1.K1 == 64 && r1_.c1.K2 == 0;
+}
 bool Net::fused_stem() const {
     static const int on = getenv("SUO_STEM_X3") ? atoi(getenv("SUO_STEM_X3")) : 1;
     return on != 0 && stem_x3_w_ != nullptr;
@@ -902,6 +916,7 @@ int Net::prepare(int L, int with_priors, hipStream_t s) {
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
         stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);          // the stem's output: persistent, the fused stem writes it OUTSIDE the captured graph
+        stem_mid1_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);     // ... and r1's conv1 of it, when the stem launch computes that too
         ws_mark_ = ws_used_;
         hipGraphExec_t exec = nullptr;
         SUO_TRY(ensure_graph(in0, with_priors ? IN_C : IMG_C, logits, L, s, &exec, !with_priors && fused_stem()));
@@ -922,6 +937,7 @@ int Net::forward_staged(const float* in0_user, int L, float* logits_out, hipStre
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
         stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);          // the stem's output: persistent, the fused stem writes it OUTSIDE the captured graph
+        stem_mid1_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);     // ... and r1's conv1 of it, when the stem launch computes that too
         ws_mark_ = ws_used_;
         if (in0_user)
             SUO_HIP_CHECK(hipMemcpyAsync(in0, in0_user, (size_t)L * CROP * CROP * IN_C * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -951,12 +967,17 @@ int Net::forward(const void* img, int fmt, int H, int W, const float* boxes, con
         float* in0 = alloc((size_t)max_crops_ * CROP * CROP * IN_C);
         float* logits = alloc((size_t)max_crops_ * NUM_KP * HEAT * HEAT);
         stem_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);          // the stem's output: persistent, the fused stem writes it OUTSIDE the captured graph
+        stem_mid1_slab_ = alloc((size_t)max_crops_ * 128 * 128 * 64);     // ... and r1's conv1 of it, when the stem launch computes that too
         ws_mark_ = ws_used_;
         const int in_c = (priors || prior_uv) ? IN_C : IMG_C;     // the slab is sized for IN_C; the prior-less layout uses a sixth of it
         if (in_c == IMG_C && fused_stem()) {
             // prior-less pass: RoIAlign + stem in one launch on the bf16 pipe (csrc/stem_x3.hip), ahead of the captured backbone (the frame and
             // the boxes are the caller's buffers: their addresses change from call to call, a captured launch could not take them)
-            if (pipe_ == 2 && stem_h2_w_)
+            if (stem_computes_r1_conv1()) {
+                // r1's conv1 on the tile while the stem has it (the stem's output is read by r1's skip convolution only)
+                const StemNext nx = {r1_.pro_scale, r1_.pro_shift, reinterpret_cast<const uint16_t*>(r1_.c1.W16), r1_.c1.osc16, r1_.c1.bias, stem_mid1_slab_};
+                SUO_LAUNCH(launch_stem_x3(img, fmt, H, W, boxes, box_img, L, reinterpret_cast<const uint16_t*>(stem_h2_w_), stem_x3_bias_, stem_slab_, s, stem_h2_osc_, range_flag_, &nx));
+            } else if (pipe_ == 2 && stem_h2_w_)
                 SUO_LAUNCH(launch_stem_x3(img, fmt, H, W, boxes, box_img, L, reinterpret_cast<const uint16_t*>(stem_h2_w_), stem_x3_bias_, stem_slab_, s, stem_h2_osc_, range_flag_));
             else
             SUO_LAUNCH(launch_stem_x3(img, fmt, H, W, boxes, box_img, L, reinterpret_cast<const uint16_t*>(stem_x3_w_), stem_x3_bias_, stem_slab_, s));

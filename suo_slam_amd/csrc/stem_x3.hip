@@ -91,11 +91,17 @@ struct StemArgs {
     const uint16_t* Wx; const float* bias;              // pack_stem_weight_bf16x3 planes, folded bias [64]
     float* out;                                         // [L,128,128,64]
     const float* osc; unsigned* range_flag;             // NP = 2: per-channel factors 2^-(t_n + S2_XSHIFT), range-guard flag (a float frame may hold anything)
+    // NEXT (NP = 2 only): the first Residual block's conv1 on the tile while it is in the CU -- relu(bn(out)) x W1 (64 -> 64, BatchNorm folded) + b1, ReLU -> n_out [L,128,128,64]
+    const float* n_scale; const float* n_shift; const uint16_t* n_W1; const float* n_osc1; const float* n_b1; float* n_out;
 };
 
 // NP = operand planes: 3 = three bf16 terms (six MFMAs per product block), 2 = two fp16 terms (three; csrc/f16x2.h: samples times 2^S2_XSHIFT, weight rows times 2^t_n)
-template <int FMT, int NP = 3>
+// NEXT: the stem's output has two readers, r1's conv1 (1x1, 64 -> 64 behind a BatchNorm + ReLU) and r1's skip convolution; conv1 is computed here, on the tile in the epilogue
+// patch (one 32-pixel m-tile per wave, K = 64 in four k-steps, both 32-channel n-tiles) -- its launch (a 1.07 GB read at 256 crops) is gone.  Same products in the same order as
+// gemm_bf16x3_kernel<NP = 2> on the stored tensor: bit-identical (tests/test_gpu_stem.py).
+template <int FMT, int NP = 3, bool NEXT = false>
 __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
+    static_assert(!NEXT || NP == 2, "the next block's conv1 rides on the fp16 form");
     constexpr int TH = 8, TW = 16, IR = 2 * TH + 5, IC = 2 * TW + 5;          // 21 x 37 input pixels
     constexpr int HALF_B = 160, ROW_B = 2 * HALF_B, PLANE_B = IR * ROW_B;    // bytes: 20 entries of 8 per half row
     constexpr int PP = SX_N + 4;                                             // epilogue patch pitch (floats)
@@ -269,15 +275,81 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
         }
     }
     SX_T(4);
+    if constexpr (NEXT) {
+        // A fragments straight out of the patch (fp32 -> prologue -> split in registers); wave w owns pixels [32 w, 32 w + 32) and all 64 output channels
+        constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};
+        const __amdgpu_buffer_rsrc_t n_srd = make_srd(a.n_W1, (size_t)64 * 64 * 2 * sizeof(uint16_t));
+        sx_u32x4 nb[4][2][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) nb[ks][n][pl] = __builtin_bit_cast(sx_u32x4, buf_load(n_srd, wv + pl * 1024, ((ks * 2 + n) * 2) * 1024));
+        sx_f32x16 acc2[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+        float gmax2 = 0.f;
+        const float* prow = P + (32 * w + (lane & 31)) * PP + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c0 = 16 * ks + 8 * (lane >> 5);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const sx_f32x4 x = *(const sx_f32x4*)(prow + 16 * ks + 4 * q);
+                const sx_f32x4 sc = *(const sx_f32x4*)(a.n_scale + c0 + 4 * q), sh = *(const sx_f32x4*)(a.n_shift + c0 + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * q + j] = fmaxf(fmaf(x[j], sc[j] * S2_XSCALE, sh[j] * S2_XSCALE), 0.f);      // (the GEMM's prologue, scale folded in the same way)
+            }
+            sx_u32x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gmax2 = s2_track(gmax2, v[2 * j], v[2 * j + 1]);
+                hi[j] = s2_pack_rn(v[2 * j], v[2 * j + 1]);
+                lo[j] = s2_lo_pack(v[2 * j], v[2 * j + 1], hi[j]);
+            }
+            const sx_f16x8 af[2] = {__builtin_bit_cast(sx_f16x8, hi), __builtin_bit_cast(sx_f16x8, lo)};
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[UI[tt]], __builtin_bit_cast(sx_f16x8, nb[ks][n][UJ[tt]]), acc2[n], 0, 0, 0);
+        }
+        s2_raise(a.range_flag, gmax2);
+        __syncthreads();                                        // every wave has read its rows of the patch (and the first output's stores have read theirs)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = 32 * n + (lane & 31);
+            const float oc = a.n_osc1[col], b = a.n_b1[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[(32 * w + sx_acc_row(r, lane)) * PP + col] = fmaxf(fmaf(acc2[n][r], oc, b), 0.f);
+        }
+        __syncthreads();
+        float* o2 = a.n_out + (size_t)l * 128 * 128 * SX_N;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid + 256 * k, p = idx >> 4, q = idx & 15;
+            const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+            *(sx_f32x4*)(o2 + ((size_t)oy * 128 + ox) * SX_N + 4 * q) = *(const sx_f32x4*)&P[p * PP + 4 * q];
+        }
+    }
 }
 
 // frame(s) + boxes -> stem output [L,128,128,64] (prior-less pass); Wx = pack_stem_weight_bf16x3, bias = bn1-folded conv bias
 int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* Wx, const float* bias,
-                   float* out, hipStream_t s, const float* osc, unsigned* range_flag) {
+                   float* out, hipStream_t s, const float* osc, unsigned* range_flag, const StemNext* next) {
     if (L <= 0 || H <= 1 || W <= 1 || !img || !boxes || !Wx || !bias || !out || ((osc == nullptr) != (range_flag == nullptr))) { suo_set_error("stem_x3: bad arguments"); return SUO_ERR_ARG; }
-    StemArgs a = {img, fmt, H, W, boxes, box_img, L, Wx, bias, out, osc, range_flag};
+    if (next && (!osc || !next->scale || !next->shift || !next->W1 || !next->osc1 || !next->b1 || !next->out)) { suo_set_error("stem_x3: the next block's conv1 needs the fp16 form and all of its operands"); return SUO_ERR_ARG; }
+    StemArgs a = {img, fmt, H, W, boxes, box_img, L, Wx, bias, out, osc, range_flag, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (next) { a.n_scale = next->scale; a.n_shift = next->shift; a.n_W1 = next->W1; a.n_osc1 = next->osc1; a.n_b1 = next->b1; a.n_out = next->out; }
     if (fmt != 0 && fmt != 1) { suo_set_error("stem_x3: unknown image format %d", fmt); return SUO_ERR_ARG; }
-    if (osc) {                                          // Wx = pack_stem_weight_f16x2 planes
+    if (osc && next) {
+        if (fmt == 0) hipLaunchKernelGGL((stem_x3_kernel<0, 2, true>), dim3(L * 128), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((stem_x3_kernel<1, 2, true>), dim3(L * 128), dim3(256), 0, s, a);
+    } else if (osc) {                                   // Wx = pack_stem_weight_f16x2 planes
         if (fmt == 0) hipLaunchKernelGGL((stem_x3_kernel<0, 2>), dim3(L * 128), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((stem_x3_kernel<1, 2>), dim3(L * 128), dim3(256), 0, s, a);
     } else if (fmt == 0) hipLaunchKernelGGL((stem_x3_kernel<0, 3>), dim3(L * 128), dim3(256), 0, s, a);

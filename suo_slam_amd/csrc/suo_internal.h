@@ -145,8 +145,10 @@ int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s);
 // RoIAlign + stem 7x7 / 2 (+ BN + ReLU) of the prior-less pass in one launch on the bf16 pipe (csrc/stem_x3.hip)
 void pack_stem_weight_bf16x3(const float* W, int Cw, const float* out_scale, uint16_t* out);
 // osc / range_flag: both null = Wx holds three bf16 planes; both set = two fp16 planes (pack_stem_weight_f16x2) with their per-channel factors and the guard flag
+// next (fp16 form only): the first Residual block's conv1 on the tile -- relu(scale x + shift) W1^T (64 -> 64, pack_gemm_weight_f16x2 planes) * osc1 + b1, ReLU -> out
+struct StemNext { const float* scale; const float* shift; const uint16_t* W1; const float* osc1; const float* b1; float* out; };
 int launch_stem_x3(const void* img, int fmt, int H, int W, const float* boxes, const int* box_img, int L, const uint16_t* Wx, const float* bias,
-                   float* out, hipStream_t s, const float* osc = nullptr, unsigned* range_flag = nullptr);
+                   float* out, hipStream_t s, const float* osc = nullptr, unsigned* range_flag = nullptr, const StemNext* next = nullptr);
 void pack_stem_weight_f16x2(const float* W, int Cw, const float* out_scale, uint16_t* out, float* oscale_out);
 int launch_upload(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
 int launch_decode(const float* logits, int L, float* uv, float* cov, float* mean_logit, int* argmax_idx, float* prob, hipStream_t s);

@@ -123,6 +123,43 @@ def test_fused_stem_on_two_fp16_terms(ops, fmt):
     assert np.array_equal(g2[..., 11], np.maximum(np.broadcast_to(bias[11], g2[..., 11].shape), 0))     # an all-zero channel: relu(bias) exactly
 
 
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_fused_stem_with_the_first_blocks_conv1_is_bit_identical_to_the_two_launches(ops, fmt):
+    """csrc/stem_x3.hip, NEXT: r1's conv1 (BatchNorm + ReLU prologue, 1x1 64 -> 64, folded BatchNorm, ReLU) computed on the tile in the stem's epilogue patch.  The stem's
+    own output is unchanged bit for bit; the second tensor equals suo_conv1x1_f16x2_ex launched on the stored stem output (same products, same order)."""
+    from suo_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(61 + fmt)
+    imgd, boxes, idx = _stem_inputs(rng, fmt)
+    L = len(boxes)
+    w = (rng.standard_normal((64, 44, 7, 7)) / np.sqrt(49 * 3)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    bias = (rng.standard_normal(64) * 0.3).astype(np.float32)
+    wh, osc = np.empty(14 * 2 * 2 * 64 * 8, np.uint16), np.empty(64, np.float32)
+    _lib.check(lib.suo_pack_stem_weight_f16x2(w.ctypes.data, 44, scale.ctypes.data, wh.ctypes.data, osc.ctypes.data), "suo_pack_stem_weight_f16x2")
+    w1 = (rng.standard_normal((64, 64)) / 8).astype(np.float32)
+    w1[3] *= 50.0
+    b1 = (rng.standard_normal(64) * 0.2).astype(np.float32)
+    ps, pt = rng.uniform(0.5, 1.5, 64).astype(np.float32), (rng.standard_normal(64) * 0.2).astype(np.float32)
+    w1h, o1, _ = ops.pack_gemm_f16x2(w1)
+    whd, od, bd = torch.from_numpy(wh.view(np.int16)).cuda(), ops.dev(osc), ops.dev(bias)
+    boxd, idxd = ops.dev(boxes), torch.from_numpy(idx).cuda()
+    psd, ptd, b1d = ops.dev(ps), ops.dev(pt), ops.dev(b1)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plain = torch.empty((L, 128, 128, 64), device="cuda")
+    _lib.check(lib.suo_stem_f16x2(ops.P(imgd), fmt, 480, 640, ops.P(boxd), ops.P(idxd), L, ops.P(whd), ops.P(od), ops.P(bd), ops.P(plain), ops.P(flag), ops.S()), "suo_stem_f16x2")
+    out = torch.full((L, 128, 128, 64), -7.0, device="cuda")
+    mid = torch.full((L, 128, 128, 64), -7.0, device="cuda")
+    _lib.check(lib.suo_stem_f16x2_next(ops.P(imgd), fmt, 480, 640, ops.P(boxd), ops.P(idxd), L, ops.P(whd), ops.P(od), ops.P(bd), ops.P(out), ops.P(psd), ops.P(ptd),
+                                       ops.P(w1h), ops.P(o1), ops.P(b1d), ops.P(mid), ops.P(flag), ops.S()), "suo_stem_f16x2_next")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    assert torch.equal(out, plain)
+    want, f2 = ops.conv1x1_f16x2(plain.reshape(-1, 64), w1, b1, pro=(ps, pt), relu=True)
+    assert f2 == 0
+    assert torch.equal(mid.reshape(-1, 64), want)
+
+
 def test_fused_stem_fp16_guard_rises_for_a_float_frame_beyond_range(ops):
     """A float frame is whatever the caller hands over: one sample of 40000 (a bilinear weight of 1/4 or more of it, times 16, is beyond 65504) inside a box raises the flag; the same frame with the
     sample outside every box does not."""

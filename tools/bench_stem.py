@@ -45,3 +45,14 @@ _lib.check(lib.suo_pack_stem_weight_f16x2(w.ctypes.data, 44, None, wh.ctypes.dat
 whd, od, flag = torch.from_numpy(wh.view(np.int16)).cuda(), ops.dev(osc), torch.zeros(1, dtype=torch.int32, device="cuda")
 us2 = timed(lambda: _lib.check(lib.suo_stem_f16x2(ops.P(img), 0, 480, 640, ops.P(boxes), ops.P(idx), L, ops.P(whd), ops.P(od), ops.P(bd), ops.P(out), ops.P(flag), ops.S())))
 print(f"stem f16x2 (two fp16 terms)          L={L}: {us2:.1f} us  ({L * 128 * 128 * 64 * 147 * 2 / us2 / 1e6:.1f} TFLOP/s; output {L * 128 * 128 * 64 * 4 / us2 / 1e3:.0f} GB/s)  flag {int(flag.item())}")
+w1 = (rng.standard_normal((64, 64)) / 8).astype(np.float32)
+w1h, o1, _ = ops.pack_gemm_f16x2(w1)
+ps, pt, b1 = ops.dev(np.ones(64, np.float32)), ops.dev(np.zeros(64, np.float32)), ops.dev(np.zeros(64, np.float32))
+mid = torch.empty((L, 128, 128, 64), device="cuda")
+us3 = timed(lambda: _lib.check(lib.suo_stem_f16x2_next(ops.P(img), 0, 480, 640, ops.P(boxes), ops.P(idx), L, ops.P(whd), ops.P(od), ops.P(bd), ops.P(out), ops.P(ps), ops.P(pt),
+                                                       ops.P(w1h), ops.P(o1), ops.P(b1), ops.P(mid), ops.P(flag), ops.S())))
+a2 = out.reshape(-1, 64)
+mid2 = torch.empty((L * 128 * 128, 64), device="cuda")
+us4 = timed(lambda: _lib.check(lib.suo_conv1x1_f16x2_ex(ops.P(a2), 64, 64, ops.P(ps), ops.P(pt), None, 0, 0, ops.P(w1h), ops.P(o1), ops.P(b1), None, 0, ops.P(mid2), 64, L * 128 * 128, 64, 1,
+                                                        ops.P(flag), ops.S())))
+print(f"stem f16x2 + r1's conv1 on the tile  L={L}: {us3:.1f} us  (the stem alone {us2:.1f}; conv1 as its own fp16 GEMM launch {us4:.1f}; the network's former conv1: the fp32-pipe persistent kernel, 440 at 256 crops)")
