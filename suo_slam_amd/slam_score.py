@@ -21,7 +21,10 @@ def _ptr(a):
 
 
 class DetectionStore:
-    """Device rows of the detections scored so far (grow-only: a SLAM sequence re-scores the detections of its last 15 views, SfM of all views)."""
+    """Device rows of the detections scored so far.  A SLAM sequence re-scores the detections of its last 15 views only, so the store is a soft-bounded ring: when a call
+    would take it past ``max_slots`` rows (SUO_SLAM_STORE_SLOTS, default 4096 = 12 MB) every tag is invalidated, the store starts over at row 0 and the call's detections are
+    written again -- device memory no longer grows with the length of the sequence.  A single call naming more distinct detections than that (SfM over all
+    views) still gets the rows it needs."""
 
     _uids = 0
 
@@ -33,6 +36,9 @@ class DetectionStore:
         if not self._h:
             _lib.check(-1, "suo_slam_store_create")
         self.n_slots = 0
+        import os
+        self.max_slots = int(os.environ.get("SUO_SLAM_STORE_SLOTS", "4096"))
+        self.recycled = 0                               # times the ring started over
 
     def clear(self):
         """Forget every detection (ObjectSLAM.reset: a new scene); the device allocation is kept, stale ``_slot`` tags no longer match."""
@@ -70,6 +76,11 @@ class DetectionStore:
         """Store slot and keypoint count of every detection; detections not in the store yet are written in one upload."""
         out = np.empty(len(dets), dtype=np.int64)
         ns = np.empty(len(dets), dtype=np.int64)
+        if self.n_slots > 0 and self.max_slots > 0:
+            fresh = {id(d) for d in dets if not (d.get("_slot") is not None and d["_slot"][0] == self.uid and d["_slot"][3] is d["uv_pred"])}
+            if self.n_slots + len(fresh) > self.max_slots:
+                self.clear()                            # every tag is stale now: this call's detections are written again from row 0
+                self.recycled += 1
         new = []
         for i, d in enumerate(dets):
             s = d.get("_slot")

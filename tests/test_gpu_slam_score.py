@@ -90,6 +90,25 @@ def test_store_grows_and_keeps_old_rows():
     assert SC.chi2_counts(own, np.stack(Ts[:1]), [d], False, 0.005, CHI2_2DOF_95)[0] == HS._chi2_inliers(Ts[0], d, False, 0.005)
 
 
+def test_store_is_a_soft_bounded_ring(monkeypatch):
+    """A long sequence does not grow the store: a call that would take it past max_slots rows invalidates every tag, starts over at row 0 and writes the call's own
+    detections again -- counts unchanged; a single call naming more distinct detections than the bound still gets its rows."""
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("SUO_SLAM_STORE_SLOTS", "12")
+    own = Owner()
+    Ts, dets = _cases(rng, True)
+    want = [HS._chi2_inliers(T, d, False, 0.005) for T, d in zip(Ts, dets)]
+    st = None
+    for lo in range(0, len(dets) - 8, 4):                           # a sliding window of 8 detections, 4 new per call
+        got = SC.chi2_counts(own, np.stack(Ts[lo:lo + 8]), dets[lo:lo + 8], False, 0.005, CHI2_2DOF_95)
+        st = own._score_store
+        assert list(got) == want[lo:lo + 8], lo
+        assert st.n_slots <= 12
+    assert st.recycled >= 1
+    got = SC.chi2_counts(own, np.stack(Ts), dets, False, 0.005, CHI2_2DOF_95)            # one call beyond the bound: served in full
+    assert list(got) == want and st.n_slots == len(dets)
+
+
 def test_reset_starts_a_new_scene_in_the_same_store():
     """ObjectSLAM.reset() (evaluate.py:338: once per scene) rewinds the store: slots are reused, detections of the previous scene are not found by tag."""
     from suo_slam_amd.object_slam import ObjectSLAM
