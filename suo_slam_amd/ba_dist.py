@@ -260,7 +260,9 @@ def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
             # `its` of them cover a round whose every trial is accepted, a rejected trial costs one more -- and looks at the control block
             # once per batch.  Every rank enqueues the same units: the decisions are taken on all-reduced quantities.
             ph.begin_round(int(its), world)
-            batch = int(os.environ.get("SUO_BA_UNITS_PER_LOOK", "12"))      # units between two looks at the control block (a dead unit costs ~50 us of empty launches)
+            # units between two looks at the control block: a dead unit (enqueued past the end of a round) costs ~50 us of empty launches on one rank, and three
+            # all-reduces more on several -- there the batches are half as long
+            batch = int(os.environ.get("SUO_BA_UNITS_PER_LOOK", "12" if world == 1 else "6"))
             budget, done = min(int(its), batch), int(its) <= 0
             while not done:
                 for _ in range(budget):
