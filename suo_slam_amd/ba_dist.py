@@ -122,7 +122,9 @@ class HipPhases:
         """The same unit as a captured hipGraph (one per robust_on): its launches are identical from trial to trial -- lambda and the
         live / dead decision of every phase come from the control block -- so 17 launches become one graph launch (host 10-16 us instead
         of ~80, kernel boundaries ~1.5 us).  SUO_BA_GRAPH=0: eager; 1 (default): captured when the unit holds no collective (one rank);
-        2: captured with its collectives (RCCL inside hipGraph capture)."""
+        2: captured with its collectives (RCCL inside hipGraph capture).  The graphs live on this object, i.e. for ONE adjustment: capture + instantiation + first replay
+        measure 0.30 + 0.25 ms of a 9 ms adjustment (two graphs: robust kernel on / off) -- keeping them across adjustments would need the exchange tensors and the
+        context at fixed addresses, for 5 %; not done."""
         mode = int(os.environ.get("SUO_BA_GRAPH", "1"))
         has_collectives = world > 1 or _collectives_forced()
         if mode <= 0 or (has_collectives and mode < 2) or self._graph_failed:
