@@ -143,7 +143,7 @@ int suo_conv1x1_pool(const float* a1_dev, int lda1, int K1, const float* pro_sca
                      float* pool_out_dev, void* stream);
 /* The same 1x1 convolution (N = 128 or 64, K a multiple of 64 up to 512, optional BN + ReLU prologue, bias, optional ReLU) at fp32 accuracy on the
  * bf16 matrix pipe: both operands are split into three bf16 terms and 6 of the 9 cross products are accumulated in fp32
- * (csrc/gemm_bf16x3.hip; what suo_net_forward launches for conv1 of its Residual blocks at >= 32768 pixels unless SUO_WINO_BF16X3=0).
+ * (csrc/gemm_bf16x3.hip; what suo_net_forward launches for conv1 of its Residual blocks at >= 4096 pixels on the fp16 pipe, >= 32768 on the bf16x3 pipe (csrc/net.hip: x3_min_rows) unless SUO_WINO_BF16X3=0).
  * wp3 = suo_pack_gemm_weight_bf16x3(W[N][K]) -> 3*N*K uint16 (MFMA B-operand order). */
 int suo_pack_gemm_weight_bf16x3(const float* w, int N, int K, uint16_t* out);
 int suo_conv1x1_bf16x3(const float* a_dev, int lda, int K, const float* pro_scale_dev, const float* pro_shift_dev, const uint16_t* wp3_dev,
@@ -249,7 +249,7 @@ int suo_res_block_f16x2(const float* x_dev, int L, int H, int W, int pool_in, co
                         const float* osc1_dev, const float* b1_dev, const uint16_t* w2h_dev, const float* osc2_dev, const float* b2_dev, const uint16_t* w3h_dev,
                         const float* osc3_dev, const float* b3_dev, const float* up_dev, float* out_dev, unsigned* range_flag_dev, void* stream);
 /* csrc/gemm_bf16x3.hip (gemm_chain_head_kernel): TWO 1x1 convolutions in one launch -- the last stack's  logits = tmpOut(relu(bn(lin(x))))  (hg.py:106-111) -- with the
- * 256-channel tensor between them kept in LDS instead of written and read back (what suo_net_forward launches for it at >= 32768 pixels; SUO_CHAIN_HEAD=0: two launches).
+ * 256-channel tensor between them kept in LDS instead of written and read back (what suo_net_forward launches for it at >= 4096 pixels on the fp16 pipe (csrc/net.hip: x3_min_rows); SUO_CHAIN_HEAD=0: two launches).
  * a_dev [M, lda >= 256] rows; w1h / osc1 = suo_pack_gemm_weight_f16x2 of W1 [256][256] (BatchNorm folded), bias1 [256]; w2h / osc2 of W2 [64][256] (rows >= n_valid zero),
  * bias2 [64]; out_nchw_dev [M / hw, n_valid, hw].  M a multiple of 64, hw a multiple of 64 dividing M.  Bit-identical to suo_conv1x1_f16x2_ex twice. */
 int suo_conv1x1_chain_head_f16x2(const float* a_dev, int lda, int M, const uint16_t* w1h_dev, const float* osc1_dev, const float* bias1_dev, const uint16_t* w2h_dev,

@@ -237,104 +237,108 @@ def optimize_distributed(full: _ba.Problem, phases_factory=HipPhases):
     rank, world = _world()
     local, cams, sel = split_problem(full, rank, world)
     ph = phases_factory(local, world)
-    O = len(full.obj_T)
-    n_edge_total = len(full.edge_cam)
-    free_obj = [o for o in range(O) if not full.obj_fixed[o]]
-    rounds = lm_its = lm_trials = 0
+    try:
+        O = len(full.obj_T)
+        n_edge_total = len(full.edge_cam)
+        free_obj = [o for o in range(O) if not full.obj_fixed[o]]
+        rounds = lm_its = lm_trials = 0
 
-    def classify(keep_all):
-        ph.classify(keep_all)
-        return int(round(float(ph.read(_reduce_(ph.good))[0])))
-    if full.init_with_outliers:
-        classify(True)
-        num_good = n_edge_total
-    else:
-        num_good = classify(False)
-    robust_on = True
-    drop = max(1, len(full.its) // 2)
-    device_schedule = hasattr(ph, "unit") and not host_schedule_forced()
-    for rnd, its in enumerate(full.its):
-        if n_edge_total < 4 or num_good < 4:
-            break
-        rounds += 1
-        if device_schedule:
-            # g2o's lambda / nu / gain-ratio logic runs on the device (csrc/lm_dist.hip: ba_ctl_*_kernel); the host enqueues units blindly --
-            # `its` of them cover a round whose every trial is accepted, a rejected trial costs one more -- and looks at the control block
-            # once per batch.  Every rank enqueues the same units: the decisions are taken on all-reduced quantities.
-            ph.begin_round(int(its), world)
-            # units between two looks at the control block: a dead unit (enqueued past the end of a round) costs ~50 us of empty launches on one rank, and three
-            # all-reduces more on several -- there the batches are half as long
-            batch = int(os.environ.get("SUO_BA_UNITS_PER_LOOK", "12" if world == 1 else "6"))
-            budget, done = min(int(its), batch), int(its) <= 0
-            while not done:
-                for _ in range(budget):
-                    (ph.unit_replay if hasattr(ph, "unit_replay") else ph.unit)(robust_on, rank, world, _reduce_)
-                ctl = ph.read(ph.ctl)
-                done = int(ctl[3]) == 2
-                budget = min(max(1, int(its) - int(ctl[4])) + 1, batch)
-            lm_its, lm_trials = int(ctl[7]), int(ctl[8])
+        def classify(keep_all):
+            ph.classify(keep_all)
+            return int(round(float(ph.read(_reduce_(ph.good))[0])))
+        if full.init_with_outliers:
+            classify(True)
+            num_good = n_edge_total
+        else:
+            num_good = classify(False)
+        robust_on = True
+        drop = max(1, len(full.its) // 2)
+        device_schedule = hasattr(ph, "unit") and not host_schedule_forced()
+        for rnd, its in enumerate(full.its):
+            if n_edge_total < 4 or num_good < 4:
+                break
+            rounds += 1
+            if device_schedule:
+                # g2o's lambda / nu / gain-ratio logic runs on the device (csrc/lm_dist.hip: ba_ctl_*_kernel); the host enqueues units blindly --
+                # `its` of them cover a round whose every trial is accepted, a rejected trial costs one more -- and looks at the control block
+                # once per batch.  Every rank enqueues the same units: the decisions are taken on all-reduced quantities.
+                ph.begin_round(int(its), world)
+                # units between two looks at the control block: a dead unit (enqueued past the end of a round) costs ~50 us of empty launches on one rank, and three
+                # all-reduces more on several -- there the batches are half as long
+                batch = int(os.environ.get("SUO_BA_UNITS_PER_LOOK", "12" if world == 1 else "6"))
+                budget, done = min(int(its), batch), int(its) <= 0
+                while not done:
+                    for _ in range(budget):
+                        (ph.unit_replay if hasattr(ph, "unit_replay") else ph.unit)(robust_on, rank, world, _reduce_)
+                    ctl = ph.read(ph.ctl)
+                    done = int(ctl[3]) == 2
+                    budget = min(max(1, int(its) - int(ctl[4])) + 1, batch)
+                lm_its, lm_trials = int(ctl[7]), int(ctl[8])
+                num_good = classify(False)
+                if rnd == drop:
+                    robust_on = False
+                continue
+            lam, ni = -1.0, 2.0
+            for it in range(int(its)):
+                ph.linearize(robust_on, rank, world)
+                lin = ph.read(_reduce_(ph.lin))
+                current_chi, HB = float(lin[0]), lin[1:1 + 27 * O]
+                if it == 0:                                        # computeLambdaInit: tau * max |diag H| over all free vertices
+                    maxd = float(lin[1 + 27 * O:].max())
+                    for o in free_obj:
+                        maxd = max(maxd, max(abs(HB[27 * o + d]) for d in _DIAG21))
+                    lam, ni = 1e-5 * maxd, 2.0
+                rho, qmax, lam_finite = 0.0, 0, True
+                while True:
+                    ph.schur(lam)
+                    _reduce_(ph.sch)                               # the pose-graph reduce: [S | r | ok-count], in place
+                    ph.solve_update(lam, robust_on, world)         # refuses the step unless every rank's Schur phase was ok
+                    _reduce_(ph.red[:3])
+                    red = ph.read(ph.red)                          # [chi2 | scale_cams | ok-count | scale_objs]
+                    temp_chi, scale = DBL_MAX, 0.0
+                    if int(round(red[2])) == world:
+                        temp_chi, scale = float(red[0]), float(red[1]) + float(red[3])
+                    rho = (current_chi - temp_chi) / (scale + 1e-3)
+                    if rho > 0 and math.isfinite(temp_chi):
+                        r21 = 2 * rho - 1
+                        alpha = min(1.0 - r21 * r21 * r21, 2.0 / 3.0)        # (the products as the kernels form them: the two schedules agree bit for bit)
+                        lam *= max(1.0 / 3.0, alpha)
+                        ni = 2.0
+                        current_chi = temp_chi
+                    else:
+                        lam *= ni
+                        ni *= 2
+                        ph.restore()
+                        if not math.isfinite(lam):
+                            lam_finite = False
+                            break
+                    qmax += 1
+                    lm_trials += 1
+                    if not (rho < 0 and qmax < 10):
+                        break
+                lm_its += 1
+                if qmax == 10 or rho == 0 or not lam_finite:
+                    break
             num_good = classify(False)
             if rnd == drop:
                 robust_on = False
-            continue
-        lam, ni = -1.0, 2.0
-        for it in range(int(its)):
-            ph.linearize(robust_on, rank, world)
-            lin = ph.read(_reduce_(ph.lin))
-            current_chi, HB = float(lin[0]), lin[1:1 + 27 * O]
-            if it == 0:                                        # computeLambdaInit: tau * max |diag H| over all free vertices
-                maxd = float(lin[1 + 27 * O:].max())
-                for o in free_obj:
-                    maxd = max(maxd, max(abs(HB[27 * o + d]) for d in _DIAG21))
-                lam, ni = 1e-5 * maxd, 2.0
-            rho, qmax, lam_finite = 0.0, 0, True
-            while True:
-                ph.schur(lam)
-                _reduce_(ph.sch)                               # the pose-graph reduce: [S | r | ok-count], in place
-                ph.solve_update(lam, robust_on, world)         # refuses the step unless every rank's Schur phase was ok
-                _reduce_(ph.red[:3])
-                red = ph.read(ph.red)                          # [chi2 | scale_cams | ok-count | scale_objs]
-                temp_chi, scale = DBL_MAX, 0.0
-                if int(round(red[2])) == world:
-                    temp_chi, scale = float(red[0]), float(red[1]) + float(red[3])
-                rho = (current_chi - temp_chi) / (scale + 1e-3)
-                if rho > 0 and math.isfinite(temp_chi):
-                    r21 = 2 * rho - 1
-                    alpha = min(1.0 - r21 * r21 * r21, 2.0 / 3.0)        # (the products as the kernels form them: the two schedules agree bit for bit)
-                    lam *= max(1.0 / 3.0, alpha)
-                    ni = 2.0
-                    current_chi = temp_chi
-                else:
-                    lam *= ni
-                    ni *= 2
-                    ph.restore()
-                    if not math.isfinite(lam):
-                        lam_finite = False
-                        break
-                qmax += 1
-                lm_trials += 1
-                if not (rho < 0 and qmax < 10):
-                    break
-            lm_its += 1
-            if qmax == 10 or rho == 0 or not lam_finite:
-                break
-        num_good = classify(False)
-        if rnd == drop:
-            robust_on = False
-    loc = ph.download()
-    # assemble the full result on every rank: each camera / edge is owned by exactly one rank
-    cam = np.zeros((len(full.cam_T), 12))
-    cam[cams] = loc.cam_T
-    inl = np.zeros(n_edge_total)
-    chi = np.zeros(n_edge_total)
-    inl[sel] = loc.inlier
-    chi[sel] = loc.chi2[:len(sel)]
-    packed = _allreduce(np.concatenate([cam.ravel(), inl, chi]))
-    full.cam_T[:] = packed[:cam.size].reshape(cam.shape)
-    full.obj_T[:] = loc.obj_T
-    full.inlier[:] = np.round(packed[cam.size:cam.size + n_edge_total]).astype(np.uint8)
-    full.chi2 = packed[cam.size + n_edge_total:]
-    full.stats[:] = [rounds, lm_its, lm_trials, num_good]
-    if hasattr(ph, "close"):
-        ph.close()
-    return full
+        loc = ph.download()
+        # assemble the full result on every rank: each camera / edge is owned by exactly one rank
+        cam = np.zeros((len(full.cam_T), 12))
+        cam[cams] = loc.cam_T
+        inl = np.zeros(n_edge_total)
+        chi = np.zeros(n_edge_total)
+        inl[sel] = loc.inlier
+        chi[sel] = loc.chi2[:len(sel)]
+        packed = _allreduce(np.concatenate([cam.ravel(), inl, chi]))
+        full.cam_T[:] = packed[:cam.size].reshape(cam.shape)
+        full.obj_T[:] = loc.obj_T
+        full.inlier[:] = np.round(packed[cam.size:cam.size + n_edge_total]).astype(np.uint8)
+        full.chi2 = packed[cam.size + n_edge_total:]
+        full.stats[:] = [rounds, lm_its, lm_trials, num_good]
+        return full
+    finally:
+        # (also on an exception between two phases: the context's kernels run on the CURRENT stream -- suo_ba_ctx_destroy drains the device before it
+        #  parks the buffers, csrc/geom_api.hip)
+        if hasattr(ph, "close"):
+            ph.close()

@@ -1,5 +1,5 @@
 // fp32-accurate 1x1 convolution on the bf16 matrix pipe by 3-way operand splitting: what the network launches for its 1x1 convolutions with
-// 128 / 256 output channels at >= 32768 pixels (csrc/net.hip: gemm_maybe_pooled; SUO_WINO_BF16X3=0 keeps the fp32-pipe kernels).
+// 128 / 256 output channels at >= 4096 pixels on the fp16 pipe, >= 32768 on the bf16x3 pipe (csrc/net.hip: x3_min_rows, gemm_maybe_pooled; SUO_WINO_BF16X3=0 keeps the fp32-pipe kernels).
 //
 // gfx950 runs fp32 MFMAs at the vector rate (157 TFLOP/s) and bf16 MFMAs 16x faster (2.5 PFLOP/s dense).  An fp32 number is exactly
 // the sum of three bf16 numbers (8 significand bits each: x0 = rn(x), x1 = rn(x - x0), x2 = x - x0 - x1, every subtraction exact: csrc/bf16x3.h),

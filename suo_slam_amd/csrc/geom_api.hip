@@ -489,14 +489,20 @@ struct suo_ba_ctx {
     double* d_io = nullptr; double* h_io = nullptr; size_t io_doubles = 0;   // [out | in | workgroup partials (device only)]
     size_t io_cap = 0, big_cap = 0;                                           // capacities of the (possibly recycled) buffers, in doubles
     double* d_big = nullptr;     // reduced system + right-hand side in global memory when it has more than 96 rows (> 16 free objects)
+    int device = 0;              // the device its buffers live on (hipGetDevice at creation)
+    bool on_caller_stream = false;      // a *_dev entry has enqueued work on a stream this context does not own: destroy must not park the buffers under it
+    hipStream_t on(void* stream) { on_caller_stream = true; return (hipStream_t)stream; }
     double* scratch() const { return d_io + io_doubles; }
     const void* dev_problem() const { return arena.dev + st.o_structs; }
 };
 
 // A context's buffers outlive it: a global adjustment of a SLAM run is create -> optimise -> destroy every few views, and creating / freeing its device arena, pinned
 // staging, stream and exchange buffers cost 1.6-2 ms of a 10 ms adjustment (hipFree and hipHostFree synchronise the device).  suo_ba_ctx_destroy parks them here (at most
-// four sets), suo_ba_ctx_create takes the first set back and grows what is too small.  Nothing read from them relies on their previous contents.
+// four sets), suo_ba_ctx_create takes the first set OF ITS DEVICE back and grows what is too small.  Nothing read from them relies on their previous contents.
+// The phase entries (suo_ba_*_dev) run on the CALLER's stream: a context that has used one is parked only after the whole device has drained (hipFree / hipHostFree
+// used to imply that), so the next context never restages buffers a queued kernel still reads.
 struct BaCtxBuffers {
+    int device = -1;
     char* dev = nullptr; char* host = nullptr; size_t cap = 0; hipStream_t stream = nullptr;
     double* d_io = nullptr; double* h_io = nullptr; size_t io_cap = 0;      // io_cap: doubles of h_io; d_io holds io_cap + ba_scratch_doubles()
     double* d_big = nullptr; size_t big_cap = 0;
@@ -517,9 +523,11 @@ int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
     if (!p || !out) { suo_set_error("suo_ba_ctx_create: null argument"); return SUO_ERR_ARG; }
     suo_ba_ctx* c = new suo_ba_ctx();
     BaCtxBuffers b;
+    if (hipGetDevice(&c->device) != hipSuccess) { delete c; suo_set_error("suo_ba_ctx_create: no current device"); return SUO_ERR_HIP; }
     {
         std::lock_guard<std::mutex> lock(g_ba_pool_mu);
-        if (!g_ba_pool.empty()) { b = g_ba_pool.back(); g_ba_pool.pop_back(); }
+        for (size_t i = g_ba_pool.size(); i-- > 0;)
+            if (g_ba_pool[i].device == c->device) { b = g_ba_pool[i]; g_ba_pool.erase(g_ba_pool.begin() + i); break; }
     }
     c->arena.dev = b.dev; c->arena.host = b.host; c->arena.cap = b.cap; c->arena.stream = b.stream;      // (Arena::ensure keeps what is large enough)
     c->d_io = b.d_io; c->h_io = b.h_io; c->io_cap = b.io_cap; c->d_big = b.d_big; c->big_cap = b.big_cap;
@@ -556,18 +564,24 @@ int suo_ba_ctx_create(suo_ba_problem* p, suo_ba_ctx** out) {
 
 void suo_ba_ctx_destroy(suo_ba_ctx* c) {
     if (!c) return;
-    if (c->arena.stream) (void)hipStreamSynchronize(c->arena.stream);
+    int cur = -1;
+    const bool switched = hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess;
+    if (c->on_caller_stream) (void)hipDeviceSynchronize();          // work may still be queued on a stream that is not ours
+    else if (c->arena.stream) (void)hipStreamSynchronize(c->arena.stream);
     BaCtxBuffers b;
+    b.device = c->device;
     b.dev = c->arena.dev; b.host = c->arena.host; b.cap = c->arena.cap; b.stream = c->arena.stream;
     b.d_io = c->d_io; b.h_io = c->h_io; b.io_cap = c->io_cap; b.d_big = c->d_big; b.big_cap = c->big_cap;
     c->arena.dev = nullptr; c->arena.host = nullptr; c->arena.stream = nullptr;
     delete c;
     static const size_t keep = getenv("SUO_BA_CTX_POOL") ? (size_t)atoi(getenv("SUO_BA_CTX_POOL")) : 4;      // 0: free at once
+    bool parked = false;
     {
         std::lock_guard<std::mutex> lock(g_ba_pool_mu);
-        if (g_ba_pool.size() < keep) { g_ba_pool.push_back(b); return; }
+        if (g_ba_pool.size() < keep) { g_ba_pool.push_back(b); parked = true; }
     }
-    ba_buffers_free(b);
+    if (!parked) ba_buffers_free(b);
+    if (switched) (void)hipSetDevice(cur);
 }
 
 int suo_ba_ctx_ns(const suo_ba_ctx* c) { return c ? c->ns : -1; }
@@ -683,50 +697,50 @@ static int optimize_phasewise(suo_ba_problem* q) {
 // ---- the same phases on caller-owned DEVICE buffers, stream-ordered, no host synchronisation: the buffers are what RCCL
 // all-reduces in place between the phases (suo_slam_amd/ba_dist.py) ------------------------------------------------
 int suo_ba_classify_dev(suo_ba_ctx* c, int keep_all, double* num_good_dev, void* stream) {
-    return launch_ba_classify(c->dev_problem(), keep_all, num_good_dev, c->scratch(), (hipStream_t)stream);
+    return launch_ba_classify(c->dev_problem(), keep_all, num_good_dev, c->scratch(), c->on(stream));
 }
 int suo_ba_linearize_dev(suo_ba_ctx* c, int robust_on, int rank, int world, double* lin_dev, void* stream) {
     if (rank < 0 || rank >= world) { suo_set_error("suo_ba_linearize_dev: rank %d of %d", rank, world); return SUO_ERR_ARG; }
-    return launch_ba_linearize(c->dev_problem(), robust_on, lin_dev, c->scratch(), rank, world, (hipStream_t)stream);
+    return launch_ba_linearize(c->dev_problem(), robust_on, lin_dev, c->scratch(), rank, world, c->on(stream));
 }
 int suo_ba_schur_dev(suo_ba_ctx* c, double lambda, double* sch_dev, void* stream) {
-    return launch_ba_schur(c->dev_problem(), lambda, c->ns, sch_dev, c->scratch(), (hipStream_t)stream);
+    return launch_ba_schur(c->dev_problem(), lambda, c->ns, sch_dev, c->scratch(), c->on(stream));
 }
 int suo_ba_solve_update_dev(suo_ba_ctx* c, double lambda, int robust_on, int world, const double* lin_dev, const double* sch_dev, double* red_dev,
                             void* stream) {
     return launch_ba_solve_update(c->dev_problem(), lambda, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), c->d_big,
-                                  (hipStream_t)stream);
+                                  c->on(stream));
 }
-int suo_ba_restore_dev(suo_ba_ctx* c, void* stream) { return launch_ba_restore(c->dev_problem(), (hipStream_t)stream); }
+int suo_ba_restore_dev(suo_ba_ctx* c, void* stream) { return launch_ba_restore(c->dev_problem(), c->on(stream)); }
 
 // ---- the same phases under the device-resident LM schedule (csrc/lm_dist.hip: ctl) ------------------------------------------------------
 int suo_ba_lm_begin_dev(suo_ba_ctx* c, double* ctl_dev, int its, int world, void* stream) {
     if (!c || !ctl_dev || world < 1) { suo_set_error("suo_ba_lm_begin_dev: bad arguments"); return SUO_ERR_ARG; }
-    return launch_ba_ctl_begin(ctl_dev, its, world, (hipStream_t)stream);
+    return launch_ba_ctl_begin(ctl_dev, its, world, c->on(stream));
 }
 int suo_ba_lm_linearize_dev(suo_ba_ctx* c, int robust_on, int rank, int world, const double* ctl_dev, double* lin_local_dev, double* lin_dev, void* stream) {
     if (!c || !ctl_dev || !lin_local_dev || !lin_dev || rank < 0 || rank >= world) { suo_set_error("suo_ba_lm_linearize_dev: bad arguments"); return SUO_ERR_ARG; }
     // the reduce works in place and runs every unit: it starts from this rank's own totals every time (a trial on a standing linearisation
     // re-reduces the same numbers instead of reducing the already reduced ones) -- the tail kernel copies them over, live unit or not
-    return launch_ba_linearize(c->dev_problem(), robust_on, lin_local_dev, c->scratch(), rank, world, (hipStream_t)stream, ctl_dev, lin_dev, 1 + 27 * c->n_obj + world);
+    return launch_ba_linearize(c->dev_problem(), robust_on, lin_local_dev, c->scratch(), rank, world, c->on(stream), ctl_dev, lin_dev, 1 + 27 * c->n_obj + world);
 }
 int suo_ba_lm_schur_dev(suo_ba_ctx* c, double* ctl_dev, const double* lin_dev, double* sch_dev, void* stream) {
     if (!c || !ctl_dev || !lin_dev || !sch_dev) { suo_set_error("suo_ba_lm_schur_dev: null argument"); return SUO_ERR_ARG; }
-    int rc = launch_ba_ctl_lin(c->dev_problem(), ctl_dev, lin_dev, c->scratch(), (hipStream_t)stream);
+    int rc = launch_ba_ctl_lin(c->dev_problem(), ctl_dev, lin_dev, c->scratch(), c->on(stream));
     if (rc != SUO_OK) return rc;
-    return launch_ba_schur(c->dev_problem(), 0.0, c->ns, sch_dev, c->scratch(), (hipStream_t)stream, ctl_dev);
+    return launch_ba_schur(c->dev_problem(), 0.0, c->ns, sch_dev, c->scratch(), c->on(stream), ctl_dev);
 }
 int suo_ba_lm_solve_update_dev(suo_ba_ctx* c, int robust_on, int world, const double* ctl_dev, const double* lin_dev, const double* sch_dev, double* red_dev,
                                void* stream) {
     if (!c || !ctl_dev || !lin_dev || !sch_dev || !red_dev) { suo_set_error("suo_ba_lm_solve_update_dev: null argument"); return SUO_ERR_ARG; }
-    return launch_ba_solve_update(c->dev_problem(), 0.0, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), c->d_big, (hipStream_t)stream,
+    return launch_ba_solve_update(c->dev_problem(), 0.0, c->ns, robust_on, lin_dev + 1, sch_dev, world, red_dev, c->scratch(), c->d_big, c->on(stream),
                                   ctl_dev);
 }
 // One unit on ONE rank (no exchange between its phases): the control steps run inside the tail kernels in front of them -- 12 launches instead of 14.  Same arithmetic
 // in the same order as the four calls above with nothing in between: bit-identical (tests/test_gpu_geometry.py).
 int suo_ba_lm_unit_one_rank_dev(suo_ba_ctx* c, int robust_on, double* ctl_dev, double* lin_local_dev, double* lin_dev, double* sch_dev, double* red_dev, void* stream) {
     if (!c || !ctl_dev || !lin_local_dev || !lin_dev || !sch_dev || !red_dev) { suo_set_error("suo_ba_lm_unit_one_rank_dev: null argument"); return SUO_ERR_ARG; }
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = c->on(stream);
     int rc = launch_ba_linearize(c->dev_problem(), robust_on, lin_local_dev, c->scratch(), 0, 1, s, ctl_dev, lin_dev, 1 + 27 * c->n_obj + 1, ctl_dev);
     if (rc != SUO_OK) return rc;
     rc = launch_ba_schur(c->dev_problem(), 0.0, c->ns, sch_dev, c->scratch(), s, ctl_dev);
@@ -735,7 +749,7 @@ int suo_ba_lm_unit_one_rank_dev(suo_ba_ctx* c, int robust_on, double* ctl_dev, d
 }
 int suo_ba_lm_decide_dev(suo_ba_ctx* c, double* ctl_dev, const double* red_dev, void* stream) {
     if (!c || !ctl_dev || !red_dev) { suo_set_error("suo_ba_lm_decide_dev: null argument"); return SUO_ERR_ARG; }
-    return launch_ba_ctl_decide(c->dev_problem(), ctl_dev, red_dev, (hipStream_t)stream);
+    return launch_ba_ctl_decide(c->dev_problem(), ctl_dev, red_dev, c->on(stream));
 }
 
 // Test entry: what the LM kernels linearise.  After suo_ba_linearize (edge_pass_partial of csrc/lm_device.h, shared by every LM

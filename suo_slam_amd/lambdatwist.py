@@ -39,7 +39,7 @@ class ReferenceSampler:
     (utils/random.h:112-116) until it holds four values, read in ascending order; randui is std::uniform_int_distribution<int> over the PROCESS-GLOBAL
     std::default_random_engine seeded once with RANDOM_SEED_VALUE = 0 (random.h:40-42,65-86) -- the stream continues from one pnp call to the next.
     libstdc++: default_random_engine = minstd_rand0 (x <- 16807 x mod 2^31 - 1, seed 0 -> 1); the distribution scales down by rejection
-    (scaling = (2^31 - 3) / n; draw x - 1 until < n * scaling; divide).  Pinned against the reference's header compiled in the build container
+    (scaling = (max - min) / n = (2^31 - 3) / n; draw x - 1 until < n * scaling; divide).  Pinned against the reference's header compiled in the build container
     (tests/test_ref_sampler.py, tests/golden/sampler_golden.npz)."""
     M = 2147483647
 
@@ -49,7 +49,7 @@ class ReferenceSampler:
 
     def randui(self, lo, hi):
         uerange = hi - lo + 1
-        scaling = (self.M - 3) // uerange                                       # urngrange = max - min = (M - 1) - 1 - ... = 2^31 - 3
+        scaling = (self.M - 2) // uerange                                       # urngrange = max() - min() = (M - 1) - 1 = 2^31 - 3 = M - 2
         past = uerange * scaling
         while True:
             self.state = (self.state * 16807) % self.M

@@ -307,6 +307,8 @@ class ObjectSLAM:
     def process_view(self, view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt=None, cam_pose=None):
         """object_slam.py:327-451."""
         assert view_id not in self.cam_poses, f"Repeat view_id {view_id}"
+        if self.views_in_flight():                          # (their results carry PnP sampler keys that continue from _pnp_seed: a view in between would reuse them)
+            raise RuntimeError("process_view: batches of submit_views_single are still in flight -- collect them first")
         import torch
         self._frame_key = self._frame_dev = None            # (the frame is uploaded once per view: _frame_on_device)
         if self.model is not None:
@@ -452,7 +454,12 @@ class ObjectSLAM:
         loop advances its seed, csrc/pnp.hip); the shared network call picks its kernels by launch size, so its keypoints agree with the
         per-view calls' to the network's tolerance (1e-5 of the reference either way).  tests/test_gpu_evaluator.py holds both.
         = submit_views_single + collect_views_single; a caller with more batches to come submits the next one BEFORE collecting this one
-        (Evaluator.run does), so that the host's share of a batch -- bookkeeping of the results, preparation of the next -- runs under the device's."""
+        (Evaluator.run does), so that the host's share of a batch -- bookkeeping of the results, preparation of the next -- runs under the device's.
+        Refuses to run with batches of an earlier submit_views_single still in flight: collect_views_single hands back the OLDEST batch, which would be zipped
+        against these views."""
+        if self.views_in_flight():
+            raise RuntimeError("process_views_single: %d batch(es) submitted earlier are still in flight -- collect_views_single() / drain_views_single() them first"
+                               % self.views_in_flight())
         if not self.single_views_take_the_device_chain(views):
             self.drain_views_single()
             out = []

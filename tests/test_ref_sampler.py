@@ -65,3 +65,45 @@ def test_oracle_ransac_under_a_draw_table():
         s.get4(len(xs), its)                                                # the reference's stream after this call
         T2, best2, its2, win2 = G.pnp_with_draws(xs, ys, np.concatenate([tab[win:win + 1], tab]), 1e-3, refine=False)
         assert win2 == 0 and best2 == best and np.array_equal(T, T2)
+
+
+def _libstdcxx_draw(state, n):
+    """std::uniform_int_distribution<int>(0, n - 1) on a std::minstd_rand0 whose state is `state` -- libstdc++ itself, compiled here (None without g++)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("g++") is None:
+        return None
+    src = ("#include <random>\n#include <sstream>\n#include <cstdio>\nint main(int c, char** v) { std::minstd_rand0 e; std::istringstream(v[1]) >> e;\n"
+           "std::uniform_int_distribution<int> d(0, atoi(v[2]) - 1); printf(\"%d\\n\", d(e)); return 0; }\n")
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "d.cpp"), "w").write(src)
+        exe = os.path.join(td, "d")
+        subprocess.check_call(["g++", "-O1", "-o", exe, os.path.join(td, "d.cpp")])
+        return int(subprocess.check_output([exe, str(state), str(n)]).split()[0])
+
+
+@pytest.mark.parametrize("n", [5, 19])
+def test_draws_on_the_scaling_boundary(n):
+    """n divides the engine's range 2^31 - 3 = 5 * 19 * 22605091 for objects of 5 or 19 keypoints, so `scaling` is exact and a one-off range
+    ((M - 3) / n instead of (M - 2) / n) shifts the bucket edges by one draw each.  States searched to land ON the edges: both restatements and libstdc++ agree."""
+    M = 2147483647
+    scaling = (M - 2) // n
+    assert scaling * n == M - 2
+    inv = pow(16807, -1, M)
+    for edge in (1, 2, n - 1):
+        for r in (edge * scaling - 1, edge * scaling):                      # the draw's value x - 1, last of bucket edge - 1 and first of bucket edge
+            pre = ((r + 1) * inv) % M                                         # the engine state whose next step yields x = r + 1
+            assert (pre * 16807) % M == r + 1
+            p, o = lt.ReferenceSampler(), G.RefSampler()
+            p.state = pre
+            o.state.value = pre
+            got_p, got_o = p.randui(0, n - 1), o.randui(0, n - 1)
+            assert got_p == got_o == r // scaling
+            ref = _libstdcxx_draw(pre, n)
+            if ref is not None:
+                assert got_p == ref
+    # the state the advisor checked against g++: uniform_int_distribution(0, 4) returns 0
+    p = lt.ReferenceSampler()
+    p.state = 1584412847
+    assert p.randui(0, 4) == 0
