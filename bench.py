@@ -42,33 +42,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_CROP = 31.495          # conv FLOPs, hook-counted on the reference module
-# Without priors (this workload: single-view frames, lib/object_slam.py:1094-1097 feeds zeros) 41 of the stem's 44 input
-# channels are structural zeros and their MACs are never issued (csrc/net.hip: stem_img_): 2*128*128*64*49*41 per crop.
-GFLOP_SKIPPED_PER_CROP = 2 * 128 * 128 * 64 * 49 * 41 / 1e9
-FP32_MFMA_PEAK_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md chip table
-BF16_MFMA_PEAK_TF = 2500.0       # dense, same table (the fp32 pipe is 1/16 of it); fp16 runs at the bf16 rate
-HBM_PEAK_GBPS = 8000.0           # HBM3E spec, same table (~6.3 TB/s achievable)
-BBOX_THRESH, KP_VAR_THRESH = 1.0, 0.5      # evaluate.py:66-74 (the T-LESS pair): with random weights the YCB-V pair masks everything
-
-
-def winograd_saved_gflop_per_crop(crops_per_call):
-    """MACs the Winograd F(2x2,3x3) form does not execute (csrc/conv_wino.hip): the 3x3 convolution of a Residual block (128 -> 128,
-    or 64 -> 64 in r1 / r4) runs in that form when its launch has enough tiles of 8 x 16 pixels (csrc/net.hip: 32 on the fp16 pipe, 256 on the
-    others) and is not taken by the one-launch block kernels (maps of <= 32 pixels a side up to 768 tiles of 4 x 8: direct products), at 16
-    instead of 36 products per 2x2 tile.  Such convolutions per crop (hg.py:7-58, 2 stacks): 128 channels -- 9 at 64x64 (r5, up1 and the
-    post-hourglass blocks), 12 at 32x32, 12 at 16x16; 64 channels -- r1 at 128x128, r4 at 64x64."""
-    min_tiles = 32 if matrix_pipe() == "f16x2" else 256
-    saved = 0.0
-    for hw, count, ch in ((64, 9, 128), (32, 12, 128), (16, 12, 128), (128, 1, 64), (64, 1, 64)):
-        tiles = crops_per_call * (hw // 8) * (hw // 16)
-        one_launch = hw <= 32 and crops_per_call * (hw // 4) * (hw // 8) <= 768
-        if tiles >= min_tiles and not one_launch:
-            saved += count * 2.0 * hw * hw * ch * ch * 9 * (1 - 1 / 2.25) / 1e9
-    return saved
-
-
-N_OBJ = 8
+from bench_legs.common import (BBOX_THRESH, BF16_MFMA_PEAK_TF, DTYPE, DTYPE_NOTE, FP32_MFMA_PEAK_TF, GFLOP_PER_CROP, GFLOP_SKIPPED_PER_CROP, HBM_PEAK_GBPS,  # noqa: E402,F401
+                               KP_VAR_THRESH, N_OBJ, _timed, committed_pmc, committed_traffic, confident_state_dict, dominant_kernel_name, dominant_kernel_traffic,
+                               make_pool, matrix_pipe, pack_conv, pack_gemm, wino_bf16x3_enabled, winograd_saved_gflop_per_crop)
+from bench_legs.host import cpu_baseline, cpu_quota, sample_power  # noqa: E402,F401
+from bench_legs.path import drop_in_leg, frames_from_host_leg, global_ba_leg, latency_leg, pose_check_leg, slam_leg, tless_leg  # noqa: E402,F401
+from bench_legs.pipeline import FramePipeline  # noqa: E402,F401
+from bench_legs.roofline import bf16x3_leg, conv_roofline, fp32_pipe_leg, gemm_roofline, latency_roofline  # noqa: E402,F401
 
 
 def parse():
@@ -90,10 +70,14 @@ def parse():
     ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--no-global-ba-leg", action="store_true")
     ap.add_argument("--no-slam-leg", action="store_true")
+    ap.add_argument("--no-tless-leg", action="store_true")
     ap.add_argument("--legs-timeout", type=int, default=600, help="seconds the legs after the timed region may take before the line is printed without the rest")
     ap.add_argument("--no-power-sample", action="store_true", help="do not run rocm-smi beside the timed region")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only: print the number of ranks seen and leave (no GPU work)")
     return ap.parse_args()
+
+
+# ---- N > 1 without a launcher: become the launcher's parent (nothing below this line has touched the GPU yet) ------------------
 
 
 # ---- N > 1 without a launcher: become the launcher's parent (nothing below this line has touched the GPU yet) ------------------
@@ -110,902 +94,6 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def make_pool(rng, n, L):
-    """Synthetic frames: pixels, boxes, class masks, model keypoints, diameters (what the dataset hands process_view) plus the
-    ground truth the pose check needs.  Nothing derived from them is precomputed."""
-    from suo_slam_amd import synthetic as S
-    return [S.make_frame(rng, L, noise=0.01, outlier_frac=0.05) for _ in range(n)]
-
-
-def confident_state_dict():
-    """Seeded random weights whose validity head says yes (bias + 4): the decode / mask / compaction path then hands real,
-    data-dependent keypoint sets to PnP and LM (tests/test_gpu_sixteen_objects.py uses the same construction)."""
-    from suo_slam_amd import weights
-    sd = weights.make_random_state_dict(0, 8.0)
-    sd["classifier.2.bias"] = (np.asarray(sd["classifier.2.bias"]) + 4.0).astype(np.float32)
-    return sd
-
-
-class FramePipeline:
-    """The per-frame product path through the C ABI.  One STEP on a slot's stream, no host wait anywhere inside:
-        host prep of the step's small arrays (K_bbox terms) -> async H2D of the F frames (pinned) + boxes + model keypoints / masks ->
-        suo_net_forward_frames -> suo_keypoint_masks -> suo_frame_geom_launch (compaction, PnP, acceptance, graph, LM, one D2H).
-    `depth` steps are in flight: step i runs on slot i % depth (own network workspace, hipGraph, stream, geometry context,
-    device + pinned staging); before a slot is reused the host fetches the results of the step that used it.  Every call
-    processes exactly the frames that are counted; nothing is cached across steps."""
-
-    def __init__(self, L, pool, F, use_graph=True, only="all", depth=2, state_dict=None, gt_keypoints=False, resident=False):
-        import torch
-        from suo_slam_amd import _lib
-        from suo_slam_amd.frame_geom import FrameGeometry
-        from suo_slam_amd.pkpnet import PkpNet
-        self.torch, self.lib, self._lib = torch, _lib.lib(), _lib
-        self.only, self.L, self.F, self.depth, self.gt = only, L, F, depth, gt_keypoints
-        sd = state_dict if state_dict is not None else confident_state_dict()
-        self.pool = pool
-        assert len(pool) % F == 0, "--pool must be a multiple of --frames-per-step"
-        self.n_groups = len(pool) // F
-        LF = L * F
-        # the dataset side: frames in pinned host memory (what a loader thread would hand over)
-        self.h_imgs = torch.from_numpy(np.stack([fr["image"] for fr in pool])).pin_memory()
-        dev = "cuda"
-        # resident: the pool's frames already in HBM when a step starts (the frames_resident_in_hbm leg); the network reads them where they lie
-        self.d_imgs = self.h_imgs.to(dev) if resident else None
-        self.slots = []
-        for _ in range(depth):
-            net = PkpNet(state_dict=sd, max_crops=LF)
-            net.set_graph(use_graph)
-            ts = torch.cuda.Stream()      # a real (non-NULL) stream: hipGraph replay is then fully asynchronous
-            S = {"net": net, "tstream": ts, "stream": C.c_void_p(ts.cuda_stream), "busy": None, "fg": FrameGeometry(LF, F),
-                 "imgs": torch.empty((F, 480, 640, 3), dtype=torch.uint8, device=dev),
-                 "uv": torch.empty((LF, 41, 2), device=dev), "cov": torch.empty((LF, 41, 2, 2), device=dev),
-                 "kp": torch.empty((LF, 41), device=dev), "mask": torch.empty((LF, 41), dtype=torch.uint8, device=dev),
-                 "boxes": torch.empty((LF, 4), device=dev), "box_img": torch.arange(F, dtype=torch.int32, device=dev).repeat_interleave(L),
-                 "mm": torch.empty((LF, 41), dtype=torch.uint8, device=dev), "kps": torch.empty((LF, 41, 3), device=dev),
-                 "h_boxes": torch.empty((LF, 4)).pin_memory(), "h_mm": torch.empty((LF, 41), dtype=torch.uint8).pin_memory(),
-                 "h_kps": torch.empty((LF, 41, 3)).pin_memory()}
-            self.slots.append(S)
-        self.first = np.arange(F + 1, dtype=np.int32) * L
-        self.reset_metrics()
-
-    def reset_metrics(self):
-        self.n_frames = self.n_crops = self.n_kp = self.n_pose = self.n_inl = self.n_trials = 0
-        self.pose_err, self.n_pose_gt = 0.0, 0
-
-    def step(self, i):
-        from suo_slam_amd import geometry as geo
-        from suo_slam_amd.frame_geom import kbbox_terms
-        torch = self.torch
-        S = self.slots[i % self.depth]
-        self.retire(S)
-        g = i % self.n_groups
-        frames = self.pool[g * self.F:(g + 1) * self.F]
-        L, LF = self.L, self.L * self.F
-        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        # ---- host side of the step (lib/object_slam.py:1082-1098): per-box intrinsics in the reference's float32 container
-        boxes = np.concatenate([fr["boxes"] for fr in frames]).astype(np.float32)
-        K_bbox = np.concatenate([geo.fix_K_for_bbox_ndc_many(fr["K"], fr["boxes"].astype(np.float64)) for fr in frames]).astype(np.float32)
-        kinv, camk = kbbox_terms(K_bbox)
-        min_depth = 0.5 * np.concatenate([fr["diameter"] for fr in frames])
-        S["h_boxes"].numpy()[:] = boxes
-        S["h_mm"].numpy()[:] = np.concatenate([fr["model_kps_masks"] for fr in frames])
-        S["h_kps"].numpy()[:] = np.concatenate([fr["model_kps"] for fr in frames])
-        # the frames' H2D (0.92 MB each) and the small per-crop arrays, from pinned memory, stream-ordered (suo_upload: a copy kernel --
-        # an asynchronous hipMemcpy in front of the network makes the next host-side wait on this stack take 10-20 ms)
-        src = self.h_imgs[g * self.F:(g + 1) * self.F]
-        imgs = S["imgs"] if self.d_imgs is None else self.d_imgs[g * self.F:(g + 1) * self.F]
-        for dst, h in ((S["imgs"], src), (S["boxes"], S["h_boxes"]), (S["mm"], S["h_mm"]), (S["kps"], S["h_kps"])):
-            if dst is S["imgs"] and self.d_imgs is not None:
-                continue
-            self._lib.check(self.lib.suo_upload(P(dst), C.c_void_p(h.data_ptr()), dst.numel() * dst.element_size(), S["stream"]), "suo_upload")
-        self._lib.check(self.lib.suo_net_forward_frames(S["net"]._h, P(imgs), 0, 480, 640, P(S["boxes"]), P(S["box_img"]), LF, None,
-                                                        P(S["uv"]), P(S["cov"]), P(S["kp"]), None, None, S["stream"]), "suo_net_forward_frames")
-        self._lib.check(self.lib.suo_keypoint_masks(P(S["uv"]), P(S["cov"]), P(S["kp"]), P(S["mm"]), LF, BBOX_THRESH, KP_VAR_THRESH, P(S["mask"]),
-                                                    S["stream"]), "suo_keypoint_masks")
-        if self.gt:
-            # pose check only: overwrite what the network said with the frames' projected ground-truth keypoints + noise
-            with torch.cuda.stream(S["tstream"]):
-                S["uv"].copy_(torch.from_numpy(np.concatenate([fr["uv"] for fr in frames])), non_blocking=False)
-                S["cov"].copy_(torch.from_numpy(np.concatenate([fr["cov"] for fr in frames])), non_blocking=False)
-                S["mask"].copy_(S["mm"])
-        if self.only != "cnn":
-            gs = S["tstream"]
-            mode = os.environ.get("SUO_BENCH_GEOM_STREAM", "0")
-            if mode != "0":
-                if not hasattr(self, "gstreams"):
-                    n = {"1": 1, "2": 2}.get(mode, 1)
-                    self.gstreams = [torch.cuda.Stream(priority=-1) for _ in range(n)]
-                if "nev" not in S:
-                    S["nev"] = torch.cuda.Event()
-                gs = self.gstreams[(i % self.depth) % len(self.gstreams)]
-                S["nev"].record(S["tstream"])
-                gs.wait_event(S["nev"])
-            S["fg"].launch(self.first, S["uv"], S["cov"], S["mask"], S["kps"], kinv, camk, min_depth, seed=i, use_cov=True, do_lm=True,
-                           its=(10, 10, 40, 40), stream=gs.cuda_stream)
-        else:
-            S["ev"] = torch.cuda.Event()
-            S["ev"].record(S["tstream"])
-        S["busy"] = (g, i)
-
-    def retire(self, S):
-        """Fetch the results of the step that last used this slot (the ONE read-back of the step) and account for them."""
-        if S["busy"] is None:
-            return None
-        (g, i), S["busy"] = S["busy"], None
-        self.n_frames += self.F
-        self.n_crops += self.L * self.F
-        if self.only == "cnn":
-            S["ev"].synchronize()
-            self.check_range(S)
-            return None
-        r = S["fg"].fetch(copy=False)
-        self.check_range(S)
-        assert np.isfinite(r["uv"]).all() and np.isfinite(r["T_opt"][r["accepted"]]).all()
-        self.n_kp += int(r["n_kp"].sum())
-        self.n_pose += int(r["accepted"].sum())
-        self.n_inl += int(np.count_nonzero(r["inlier"][r["accepted"]] & (np.arange(41)[None, :] < r["n_kp"][r["accepted"], None])))
-        self.n_trials += int(r["lm_stats"][:, 2].sum())
-        if self.gt:
-            frames = self.pool[g * self.F:(g + 1) * self.F]
-            gt = np.concatenate([fr["T_OtoC"] for fr in frames])
-            ok = r["accepted"]
-            d = np.linalg.norm(r["T_opt"][:, :, 3] - gt[:, :3, 3], axis=1) / gt[:, 2, 3]
-            self.pose_err += float(d[ok].sum())
-            self.n_pose_gt += int(ok.sum())
-        return r
-
-    @staticmethod
-    def check_range(S):
-        """The fp16 form's contract (include/suo_hip.h: suo_net_range_exceeded): a step whose activations left fp16's range has invalid outputs and would have
-        to be re-issued on bf16x3.  The synthetic weights sit 200x inside the range (profiles/r05_activation_range.txt): if this fires the measurement is void."""
-        if S["net"].range_exceeded():
-            raise RuntimeError("an activation left the fp16 range inside the timed region: the line would not be a measurement of the fp16 form")
-
-    def drain(self, next_step):
-        """Retire every step still in flight, oldest first."""
-        for k in range(self.depth):
-            self.retire(self.slots[(next_step + k) % self.depth])
-
-
-def pack_conv(w, Np, Cp, CK):
-    from suo_slam_amd import _lib
-    w = np.ascontiguousarray(w, np.float32)
-    out = np.empty(2 * Np * ((Cp * w.shape[2] * w.shape[3] + 15) // 16 * 16), np.float32)
-    _lib.check(_lib.lib().suo_pack_conv_weight(w.ctypes.data, w.shape[0], w.shape[1], w.shape[2], Np, Cp, CK, out.ctypes.data), "pack_conv")
-    return out
-
-
-def pack_gemm(w, Np, Kp):
-    from suo_slam_amd import _lib
-    w = np.ascontiguousarray(w, np.float32)
-    out = np.empty(2 * Np * Kp, np.float32)
-    _lib.check(_lib.lib().suo_pack_gemm_weight(w.ctypes.data, w.shape[0], w.shape[1], Np, Kp, out.ctypes.data), "pack_gemm")
-    return out
-
-
-def committed_traffic(name, L, kernel_prefix):
-    """HBM bytes per launch from a committed PMC summary (tools/profile_round.sh -> tools/pmc_to_json.py), or None when the summary is
-    for another launch shape / kernel."""
-    pmc = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(pmc):
-        return None
-    rec = json.load(open(pmc))
-    if rec.get("crops_per_launch") == L and rec.get("kernel", "").replace(" ", "").startswith(kernel_prefix):
-        return rec.get("hbm_bytes_per_launch")
-    return None
-
-
-def committed_pmc(name, L, kernel_prefix):
-    """The committed PMC summary itself (tools/profile_round.sh -> tools/pmc_to_json.py) when it is for this launch shape / kernel."""
-    pmc = os.path.join(ROOT, "profiles", name)
-    if not os.path.exists(pmc):
-        return None
-    rec = json.load(open(pmc))
-    if rec.get("crops_per_launch") == L and rec.get("kernel", "").replace(" ", "").startswith(kernel_prefix):
-        return rec
-    return None
-
-
-def wino_bf16x3_enabled():
-    """csrc/net.hip: the Residual blocks' 3x3 convolution + fused tail run on the bf16 matrix pipe with 3-way split operands unless SUO_WINO_BF16X3=0."""
-    return os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
-
-
-def matrix_pipe():
-    """csrc/net.hip, read when a network is built: "f32" (SUO_WINO_BF16X3=0), "bf16x3" (SUO_F16X2=0: three bf16 terms per operand, six MFMAs per product block)
-    or "f16x2" (default: two fp16 terms, three MFMAs, range-guarded -- csrc/f16x2.h)."""
-    if not wino_bf16x3_enabled():
-        return "f32"
-    return "bf16x3" if os.environ.get("SUO_F16X2", "1") in ("0", "") else "f16x2"
-
-
-DTYPE_NOTE = {
-    "f16x2": ("fp32 tensors and fp32 accuracy end to end; the Residual blocks' 3x3 + tail and the large 1x1 convolutions form their products on the fp16 matrix "
-              "pipe from operands split into two fp16 terms (hi*lo + lo*hi + hi*hi, fp32 accumulate; operands scaled into fp16's range by exact powers of two, "
-              "a range guard re-issues a call that leaves it on the bf16x3 form): suo_slam_amd/csrc/f16x2.h, DESIGN.md section 4"),
-    "bf16x3": ("fp32 tensors and fp32 accuracy end to end; the Residual blocks' 3x3 + tail and the large 1x1 convolutions form their products on "
-               "the bf16 matrix pipe from operands split into three bf16 terms (6 cross terms, fp32 accumulate; SUO_F16X2=0): DESIGN.md section 4"),
-    "f32": "fp32 MFMA throughout (SUO_WINO_BF16X3=0)"}
-
-
-def dominant_kernel_name():
-    return {"f16x2": "wino3x3_x3_kernel<true,false,true,4,2,false>", "bf16x3": "wino3x3_x3_kernel<true,false,true,4,3,false>", "f32": "wino3x3_kernel<true"}[matrix_pipe()]
-
-
-def dominant_kernel_traffic(L):
-    return committed_traffic("pmc_dominant_conv.json", L, dominant_kernel_name())
-
-
-def _timed(f, st, iters):
-    import torch
-    try:
-        f()
-    except Exception:
-        return float("nan")
-    for _ in range(10):                                      # (the first launches of a kernel in a process run 5-25 % slow)
-        f()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        f()
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
-
-
-def conv_roofline(L, iters=30):
-    """Live HIP-event timing of the dominant kernel at the launch shape of the timed region: the tail of a 256 -> 256 Residual block
-    at 64x64 in ONE launch -- conv2 (3x3, 128 -> 128, Winograd F(2x2,3x3)) + ReLU, conv3 (1x1, 128 -> 256) + skip (8 launches per network
-    call, about a third of its kernel time).  What the network launches (csrc/net.hip):
-      * default: wino3x3_x3_kernel<true,*,true> (csrc/conv_wino_x3.hip) -- every product on the BF16 matrix pipe, both operands split into
-        three bf16 terms, 6 of the 9 cross terms accumulated in fp32 (fp32 accuracy: tests/test_gpu_cnn.py).  `achieved` / `frac` count
-        the bf16 FLOPs the kernel EXECUTES (6 MFMAs of 32x32x16 per component / k-step) against the dense bf16 MFMA peak; the fp32-equivalent
-        rates (what an fp32 kernel would have to sustain for the same launch time) are beside it: `f32_equivalent_executed_tflops` (Winograd-
-        counted, / 157.3 = `f32_equivalent_over_f32_peak`) and the reference-counted `algorithmic_tflops`;
-      * SUO_WINO_BF16X3=0: wino3x3_kernel<true> (csrc/conv_wino.hip) on the fp32 pipe: `achieved` / `frac` = executed fp32 FLOPs (16 products
-        per 2x2 tile and channel pair where the direct form issues 36) against the fp32 MFMA peak.
-    The other kernel of the pair, the 3x3 alone and the direct forms are timed in the same process under `same_process`."""
-    import torch
-    from suo_slam_amd import _lib
-    rng = np.random.default_rng(0)
-    x = torch.rand((L, 64, 64, 128), device="cuda") - 0.5
-    skip = torch.rand((L, 64, 64, 256), device="cuda") - 0.5
-    w2 = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
-    w3 = (rng.standard_normal((256, 128)) / 11.0).astype(np.float32)
-    lib = _lib.lib()
-    wq = np.empty(16 * 128 * 128, np.float32)
-    _lib.check(lib.suo_pack_wino_weight(np.ascontiguousarray(w2).ctypes.data, 128, 128, 128, 128, wq.ctypes.data), "pack_wino")
-    wq2 = torch.from_numpy(wq).cuda()
-    wq3h = np.empty(3 * 16 * 128 * 128, np.uint16)
-    _lib.check(lib.suo_pack_wino_weight_bf16x3(np.ascontiguousarray(w2).ctypes.data, 128, 128, wq3h.ctypes.data), "pack_wino_x3")
-    wq3 = torch.from_numpy(wq3h.view(np.int16)).cuda()
-    w3xh = np.empty(3 * 256 * 128, np.uint16)
-    _lib.check(lib.suo_pack_tail_weight_bf16x3(np.ascontiguousarray(w3).ctypes.data, 256, 128, w3xh.ctypes.data), "pack_tail_x3")
-    w3x = torch.from_numpy(w3xh.view(np.int16)).cuda()
-    wq16h, o2h, w3p16h, o3h = np.empty(2 * 16 * 128 * 128, np.uint16), np.empty(128, np.float32), np.empty(2 * 256 * 128, np.uint16), np.empty(256, np.float32)
-    _lib.check(lib.suo_pack_wino_weight_f16x2(np.ascontiguousarray(w2).ctypes.data, 128, 128, wq16h.ctypes.data, o2h.ctypes.data), "pack_wino_f16x2")
-    _lib.check(lib.suo_pack_tail_weight_f16x2(np.ascontiguousarray(w3).ctypes.data, 256, 128, w3p16h.ctypes.data, o3h.ctypes.data), "pack_tail_f16x2")
-    wq16, o2, w3p16, o3 = torch.from_numpy(wq16h.view(np.int16)).cuda(), torch.from_numpy(o2h).cuda(), torch.from_numpy(w3p16h.view(np.int16)).cuda(), torch.from_numpy(o3h).cuda()
-    rflag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    wp2 = torch.from_numpy(pack_conv(w2, 128, 128, 32)).cuda()
-    wp3 = torch.from_numpy(pack_gemm(w3, 256, 128)).cuda()
-    b2 = torch.zeros(128, device="cuda")
-    b3 = torch.zeros(256, device="cuda")
-    mid = torch.empty((L, 64, 64, 128), device="cuda")
-    out = torch.empty((L, 64, 64, 256), device="cuda")
-    st = torch.cuda.current_stream()
-    s = C.c_void_p(st.cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-
-    def f16_fused():
-        _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(x), L, 64, 64, P(wq16), P(o2), P(b2), P(w3p16), P(o3), P(b3), P(skip), None, P(out), P(rflag), s),
-                   "suo_conv3x3_wino_f16x2_conv1x1_skip_up")
-
-    def f16_plain():
-        _lib.check(lib.suo_conv3x3_wino_f16x2_n(P(x), L, 64, 64, 128, P(wq16), P(o2), P(b2), P(mid), 1, P(rflag), s), "suo_conv3x3_wino_f16x2_n")
-
-    def x3_fused():
-        _lib.check(lib.suo_conv3x3_wino_x3_conv1x1_skip_up(P(x), L, 64, 64, P(wq3), P(b2), P(w3x), 1, P(b3), P(skip), None, P(out), s), "suo_conv3x3_wino_x3_conv1x1_skip_up")
-
-    def x3_plain():
-        _lib.check(lib.suo_conv3x3_wino_x3(P(x), L, 64, 64, P(wq3), P(b2), P(mid), 1, s), "suo_conv3x3_wino_x3")
-
-    def wino_fused():
-        _lib.check(lib.suo_conv3x3_wino_conv1x1_skip(P(x), L, 64, 64, P(wq2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "suo_conv3x3_wino_conv1x1_skip")
-
-    def wino_plain():
-        _lib.check(lib.suo_conv3x3_wino(P(x), L, 64, 64, 128, P(wq2), P(b2), P(mid), 128, 1, s), "suo_conv3x3_wino")
-
-    def direct_fused():
-        _lib.check(lib.suo_conv3x3_conv1x1_skip(P(x), L, 64, 64, P(wp2), P(b2), P(wp3), P(b3), P(skip), P(out), s), "suo_conv3x3_conv1x1_skip")
-
-    def direct_plain():
-        _lib.check(lib.suo_conv_kxk(3, P(x), L, 64, 64, 128, P(wp2), P(b2), P(mid), 128, 1, s), "suo_conv_kxk")
-    us_h, us_hp = (_timed(f, st, iters) for f in (f16_fused, f16_plain))
-    us_x, us_xp, us_w, us_wp, us_df, us_dp = (_timed(f, st, iters) for f in (x3_fused, x3_plain, wino_fused, wino_plain, direct_fused, direct_plain))
-    px = float(L) * 64 * 64
-    flop3, flop1 = 2.0 * px * 128 * 128 * 9, 2.0 * px * 128 * 256
-    flop = flop3 + flop1
-    flop_exec = flop3 / 2.25 + flop1                               # 16 products per 2x2 tile and channel pair instead of 36
-    flop_exec_bf16 = 6.0 * flop_exec                               # every product as 6 bf16 cross terms
-    flop_exec_f16 = 3.0 * flop_exec                                # ... as 3 fp16 cross terms
-    tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
-    fr = lambda f, t, pk=FP32_MFMA_PEAK_TF: round(f / (t * 1e-6) / 1e12 / pk, 4) if t == t else None  # noqa: E731
-    f32_entry = {"avg_launch_us": round(us_w, 2), "frac": fr(flop_exec, us_w), "achieved_tflops": tf(flop_exec, us_w), "peak": FP32_MFMA_PEAK_TF,
-                 "algorithmic_tflops": tf(flop, us_w), "algorithmic_over_peak": fr(flop, us_w)}
-    x3_entry = {"avg_launch_us": round(us_x, 2), "frac": fr(flop_exec_bf16, us_x, BF16_MFMA_PEAK_TF), "achieved_tflops": tf(flop_exec_bf16, us_x),
-                "peak": BF16_MFMA_PEAK_TF, "f32_equivalent_executed_tflops": tf(flop_exec, us_x), "f32_equivalent_over_f32_peak": fr(flop_exec, us_x),
-                "algorithmic_tflops": tf(flop, us_x)}
-    f16_entry = {"avg_launch_us": round(us_h, 2), "frac": fr(flop_exec_f16, us_h, BF16_MFMA_PEAK_TF), "achieved_tflops": tf(flop_exec_f16, us_h),
-                 "peak": BF16_MFMA_PEAK_TF, "f32_equivalent_executed_tflops": tf(flop_exec, us_h), "f32_equivalent_over_f32_peak": fr(flop_exec, us_h),
-                 "algorithmic_tflops": tf(flop, us_h)}
-    same = {"wino3x3_x3_kernel<false,false,false,4,2> (f16x2, 3x3 alone)": {"avg_launch_us": round(us_hp, 2), "frac": fr(3.0 * flop3 / 2.25, us_hp, BF16_MFMA_PEAK_TF),
-                                                                            "f32_equivalent_over_f32_peak": fr(flop3 / 2.25, us_hp), "algorithmic_tflops": tf(flop3, us_hp)},
-            "wino3x3_kernel<false> (fp32 pipe, 3x3 alone)": {"avg_launch_us": round(us_wp, 2), "frac": fr(flop3 / 2.25, us_wp), "algorithmic_tflops": tf(flop3, us_wp)},
-            "wino3x3_x3_kernel<false> (bf16x3, 3x3 alone)": {"avg_launch_us": round(us_xp, 2), "frac": fr(6.0 * flop3 / 2.25, us_xp, BF16_MFMA_PEAK_TF),
-                                                             "f32_equivalent_over_f32_peak": fr(flop3 / 2.25, us_xp), "algorithmic_tflops": tf(flop3, us_xp)},
-            "convk_kernel<3,1,32,8,16,2,2,2,2,true> (direct, fused tail)": {"avg_launch_us": round(us_df, 2) if us_df == us_df else None, "frac": fr(flop, us_df)},
-            "convk_kernel<3,1,32,8,16,2,2,2,2,false> (direct 3x3 alone)": {"avg_launch_us": round(us_dp, 2), "frac": fr(flop3, us_dp)}}
-    # `achieved` / `frac` follow SURVEY.md 8(d): ALGORITHMIC FLOPs of the launch (the direct-form count the reference's hooks give:
-    # 2 px (128*128*9 + 128*256)) over the launch's duration, against the dense peak of the pipe the kernel RUNS on.  Beside it, so that the
-    # number cannot be misread: the FLOPs the kernel executes on that pipe over the same peak (`executed_frac`: Winograd issues 16 of 36
-    # products, the bf16x3 form six MFMAs per product block), the fp32-equivalent rate over the fp32 peak, and from the committed PMC pass of
-    # this very launch shape the share of cycles the matrix pipe was busy and the shader clock under this kernel's load (the peaks are quoted
-    # at 2.4 GHz; `*_at_measured_clock` rescale them to what the chip actually ran).
-    rec = committed_pmc("pmc_dominant_conv.json", L, dominant_kernel_name())
-    clock = rec.get("shader_clock_ghz") if rec else None
-    pmc = {"traffic": rec.get("hbm_bytes_per_launch") if rec else None, "traffic_source": "profiles/pmc_dominant_conv.json (rocprofv3 --pmc, tools/profile_round.sh)" if rec else None,
-           "traffic_over_algorithmic_bytes": round(rec["hbm_bytes_per_launch"] / rec["algorithmic_bytes"], 3) if rec else None,
-           "mfma_busy": round(rec["mfma_util"], 4) if rec else None, "shader_clock_ghz": clock, "pmc_pass_avg_launch_us": rec.get("pmc_pass_avg_launch_us") if rec else None}
-    at_clock = lambda v: round(v * 2.4 / clock, 4) if (clock and v is not None) else None  # noqa: E731
-    common = dict(pmc, bound="mfma", unit="TFLOP/s", algorithmic_flop_per_launch=flop,
-                  algorithmic_bytes_per_launch=4.0 * px * (128 + 256 + 256) + 4.0 * (128 * 128 * 16 + 128 * 256),
-                  flop_basis="SURVEY.md 8(d): algorithmic FLOPs 2*px*(128*128*9 + 128*256) per launch / avg launch duration / dense peak of the pipe the kernel runs on")
-    shape = "fused Residual tail: 3x3 128->128 (Winograd F(2x2,3x3)) + ReLU, 1x1 128->256 + skip @64x64, %d crops/launch" % L
-    if matrix_pipe() == "f16x2":
-        same["wino3x3_kernel<true> (fp32 pipe, SUO_WINO_BF16X3=0)"] = f32_entry
-        same["wino3x3_x3_kernel<true,false,true,4,3> (bf16x3, SUO_F16X2=0)"] = x3_entry
-        frac = fr(flop, us_h, BF16_MFMA_PEAK_TF)
-        return dict(common, kernel="wino3x3_x3_kernel<true,false,true,4,2> " + shape, dtype="f32 as 2 x fp16 (3 cross terms, fp32 accumulate)", pipe="fp16 MFMA",
-                    achieved=tf(flop, us_h), peak=BF16_MFMA_PEAK_TF, frac=frac, frac_at_measured_clock=at_clock(frac), avg_launch_us=f16_entry["avg_launch_us"],
-                    executed_flop_per_launch=flop_exec_f16, executed_tflops=f16_entry["achieved_tflops"], executed_frac=f16_entry["frac"],
-                    executed_frac_at_measured_clock=at_clock(f16_entry["frac"]),
-                    executed_flop_basis="fp16 FLOPs issued to the MFMA pipe: 3 * (2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1)); dense fp16 peak = the bf16 one",
-                    f32_equivalent_executed_tflops=f16_entry["f32_equivalent_executed_tflops"], f32_equivalent_over_f32_peak=f16_entry["f32_equivalent_over_f32_peak"],
-                    algorithmic_over_f32_peak=fr(flop, us_h), same_process=same)
-    same["wino3x3_x3_kernel<true,false,true,4,2> (f16x2, default)"] = f16_entry
-    if wino_bf16x3_enabled():
-        same["wino3x3_kernel<true> (fp32 pipe, SUO_WINO_BF16X3=0)"] = f32_entry
-        frac = fr(flop, us_x, BF16_MFMA_PEAK_TF)
-        return dict(common, kernel="wino3x3_x3_kernel<true,false,true> " + shape, dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)", pipe="bf16 MFMA",
-                    achieved=tf(flop, us_x), peak=BF16_MFMA_PEAK_TF, frac=frac, frac_at_measured_clock=at_clock(frac), avg_launch_us=x3_entry["avg_launch_us"],
-                    executed_flop_per_launch=flop_exec_bf16, executed_tflops=x3_entry["achieved_tflops"], executed_frac=x3_entry["frac"],
-                    executed_frac_at_measured_clock=at_clock(x3_entry["frac"]),
-                    executed_flop_basis="bf16 FLOPs issued to the MFMA pipe: 6 * (2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1))",
-                    f32_equivalent_executed_tflops=x3_entry["f32_equivalent_executed_tflops"], f32_equivalent_over_f32_peak=x3_entry["f32_equivalent_over_f32_peak"],
-                    algorithmic_over_f32_peak=fr(flop, us_x), same_process=same)
-    same["wino3x3_x3_kernel<true,false,true> (bf16x3, default)"] = x3_entry
-    frac = fr(flop, us_w)
-    return dict(common, kernel="wino3x3_kernel<true> " + shape, dtype="f32", pipe="fp32 MFMA", achieved=tf(flop, us_w), peak=FP32_MFMA_PEAK_TF, frac=frac,
-                frac_at_measured_clock=at_clock(frac), avg_launch_us=round(us_w, 2), executed_flop_per_launch=flop_exec, executed_tflops=tf(flop_exec, us_w),
-                executed_frac=fr(flop_exec, us_w), executed_frac_at_measured_clock=at_clock(fr(flop_exec, us_w)),
-                executed_flop_basis="fp32 FLOPs issued to the MFMA pipe: 2*px*128*128*9/2.25 (Winograd 3x3) + 2*px*128*256 (1x1)", same_process=same)
-
-
-def gemm_roofline(L, iters=30):
-    """The largest 1x1 convolution of a network call: conv1 of a 256 -> 256 Residual block at 64x64 -- BN + ReLU prologue (the
-    pre-activation, layers/Residual.py:22-24), K = 256 -> N = 128, M = L * 4096 pixels.  2*M*N*K FLOPs against 4*(M*K + M*N) bytes = 42 FLOP/B.
-    What the network launches (csrc/net.hip: residual): by default gemm_bf16x3_kernel (csrc/gemm_bf16x3.hip: bf16 matrix pipe, both operands
-    split into three bf16 terms, 6 cross terms, fp32 accumulate) -- `achieved` / `frac` = executed bf16 FLOPs (6 x 2*M*N*K) against the dense
-    bf16 peak, with the fp32-equivalent rate beside it; with SUO_WINO_BF16X3=0 the persistent fp32 GEMM (gemm_persist_kernel) against the
-    fp32 MFMA peak.  The other form is timed in the same process."""
-    import torch
-    from suo_slam_amd import _lib
-    rng = np.random.default_rng(1)
-    M, K, N = L * 4096, 256, 128
-    a = torch.rand((M, K), device="cuda") - 0.5
-    out = torch.empty((M, N), device="cuda")
-    w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
-    wp = torch.from_numpy(pack_gemm(w, N, K)).cuda()
-    lib = _lib.lib()
-    w3 = np.empty(3 * N * K, np.uint16)
-    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data), "pack_bf16x3")
-    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
-    sc = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32)).cuda()
-    sh = torch.from_numpy((rng.standard_normal(K) * 0.1).astype(np.float32)).cuda()
-    b = torch.zeros(N, device="cuda")
-    st = torch.cuda.current_stream()
-    s = C.c_void_p(st.cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-
-    def gemm():
-        _lib.check(lib.suo_conv1x1(P(a), K, K, P(sc), P(sh), None, 0, 0, P(wp), P(b), None, 0, P(out), N, M, N, N, 1, 0, s), "suo_conv1x1")
-
-    def gemm_x3():
-        _lib.check(lib.suo_conv1x1_bf16x3(P(a), K, K, P(sc), P(sh), P(w3d), P(b), P(out), N, M, N, 1, s), "suo_conv1x1_bf16x3")
-    w16h, osch = np.empty(2 * N * K, np.uint16), np.empty(N, np.float32)
-    _lib.check(lib.suo_pack_gemm_weight_f16x2(w.ctypes.data, N, K, w16h.ctypes.data, osch.ctypes.data), "pack_f16x2")
-    w16d, oscd = torch.from_numpy(w16h.view(np.int16)).cuda(), torch.from_numpy(osch).cuda()
-    rflag = torch.zeros(1, dtype=torch.int32, device="cuda")
-
-    def gemm_f16():
-        _lib.check(lib.suo_conv1x1_f16x2_ex(P(a), K, K, P(sc), P(sh), None, 0, 0, P(w16d), P(oscd), P(b), None, 0, P(out), N, M, N, 1, P(rflag), s), "suo_conv1x1_f16x2_ex")
-    us, us3, us16 = _timed(gemm, st, iters), _timed(gemm_x3, st, iters), _timed(gemm_f16, st, iters)
-    flop = 2.0 * M * N * K
-    tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t == t else None  # noqa: E731
-    shape = "1x1 conv K256->N128 with BN+ReLU prologue, + ReLU, M = %d pixels (%d crops @64x64)" % (M, L)
-    f32 = {"kernel": "gemm_persist_kernel: " + shape, "avg_launch_us": round(us, 2), "achieved_tflops": tf(flop, us), "peak": FP32_MFMA_PEAK_TF,
-           "frac": round(flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
-    x3 = {"kernel": "gemm_bf16x3_kernel: " + shape, "avg_launch_us": round(us3, 2), "achieved_tflops": tf(6.0 * flop, us3), "peak": BF16_MFMA_PEAK_TF,
-          "frac": round(6.0 * flop / (us3 * 1e-6) / 1e12 / BF16_MFMA_PEAK_TF, 4), "f32_equivalent_tflops": tf(flop, us3),
-          "f32_equivalent_over_f32_peak": round(flop / (us3 * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
-    abytes = 4.0 * (M * K + M * N) + 4.0 * N * K
-    # 42.7 FLOP per byte: below the ridge of either split form (six / three MFMAs per product block: 2500 / 6 / 6.3 TB/s = 66, 2500 / 3 / 6.3 = 132 FLOP/B) --
-    # the split-form launches are HBM-bound: `achieved` = algorithmic bytes / time against the HBM peak (8 TB/s spec; ~6.3 achievable), the matrix-pipe rates beside it
-    hbm = lambda t: {"bound": "hbm", "unit": "GB/s", "achieved": round(abytes / t / 1e3, 1), "peak": HBM_PEAK_GBPS, "frac": round(abytes / t / 1e3 / HBM_PEAK_GBPS, 4),  # noqa: E731
-                     "frac_of_achievable_6300": round(abytes / t / 1e3 / 6300.0, 4), "flop_per_launch": flop, "algorithmic_bytes_per_launch": abytes,
-                     "intensity_flop_per_byte": round(flop / abytes, 1)}
-    f16 = {"kernel": "gemm_bf16x3_kernel<...,NP=2>: " + shape, "avg_launch_us": round(us16, 2), "executed_tflops": tf(3.0 * flop, us16),
-           "executed_over_fp16_peak": round(3.0 * flop / (us16 * 1e-6) / 1e12 / BF16_MFMA_PEAK_TF, 4), "f32_equivalent_tflops": tf(flop, us16),
-           "f32_equivalent_over_f32_peak": round(flop / (us16 * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4), "hbm_gbps_algorithmic": round(abytes / us16 / 1e3, 1)}
-    common = {"bound": "mfma", "unit": "TFLOP/s", "flop_per_launch": flop, "algorithmic_bytes_per_launch": abytes}
-    if matrix_pipe() == "f16x2":
-        x3["hbm_gbps_algorithmic"] = round(abytes / us3 / 1e3, 1)
-        return dict(hbm(us16), kernel=f16["kernel"], dtype="f32 as 2 x fp16 (3 cross terms, fp32 accumulate)", avg_launch_us=f16["avg_launch_us"],
-                    executed_flop_per_launch=3.0 * flop, executed_tflops=f16["executed_tflops"], executed_over_fp16_peak=f16["executed_over_fp16_peak"],
-                    f32_equivalent_tflops=f16["f32_equivalent_tflops"], f32_equivalent_over_f32_peak=f16["f32_equivalent_over_f32_peak"],
-                    traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"), same_process={"bf16x3 (SUO_F16X2=0)": x3, "fp32 pipe (SUO_WINO_BF16X3=0)": f32})
-    if wino_bf16x3_enabled():
-        return dict(hbm(us3), kernel=x3["kernel"], dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)", avg_launch_us=x3["avg_launch_us"],
-                    executed_flop_per_launch=6.0 * flop, executed_tflops=x3["achieved_tflops"], executed_over_bf16_peak=x3["frac"],
-                    f32_equivalent_tflops=x3["f32_equivalent_tflops"], f32_equivalent_over_f32_peak=x3["f32_equivalent_over_f32_peak"],
-                    traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"), same_process={"f16x2 (default)": f16, "fp32 pipe (SUO_WINO_BF16X3=0)": f32})
-    if False:
-        return dict(common, kernel=x3["kernel"], dtype="f32 as 3 x bf16 (6 cross terms, fp32 accumulate)", achieved=x3["achieved_tflops"], peak=BF16_MFMA_PEAK_TF,
-                    frac=x3["frac"], avg_launch_us=x3["avg_launch_us"], executed_flop_per_launch=6.0 * flop, f32_equivalent_tflops=x3["f32_equivalent_tflops"],
-                    f32_equivalent_over_f32_peak=x3["f32_equivalent_over_f32_peak"], traffic=committed_traffic("pmc_gemm.json", L, "gemm_bf16x3_kernel"),
-                    hbm_gbps_algorithmic=round(common["algorithmic_bytes_per_launch"] / us3 / 1e3, 1), same_process={"fp32 pipe (SUO_WINO_BF16X3=0)": f32})
-    return dict(common, kernel=f32["kernel"], dtype="f32", achieved=f32["achieved_tflops"], peak=FP32_MFMA_PEAK_TF, frac=f32["frac"], avg_launch_us=f32["avg_launch_us"],
-                traffic=committed_traffic("pmc_gemm.json", L, "gemm_persist_kernel"), same_process={"bf16x3 (default)": x3})
-
-
-def bf16x3_leg(L, iters=30):
-    """Accuracy of the bf16x3 form next to its speed: the largest 1x1 convolution of a call (as gemm_roofline) on the bf16 matrix pipe -- both
-    operands split into three bf16 terms, 6 of the 9 cross products accumulated in fp32 (csrc/gemm_bf16x3.hip, what the network launches
-    for conv1 of its Residual blocks) -- against the fp32 MFMA kernel: error of both against fp64 on the same inputs, and time."""
-    import torch
-    from suo_slam_amd import _lib
-    lib = _lib.lib()
-    rng = np.random.default_rng(1)
-    M, K, N = L * 4096, 256, 128
-    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
-    w = (rng.standard_normal((N, K)) / 16.0).astype(np.float32)
-    sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), (rng.standard_normal(K) * 0.1).astype(np.float32)
-    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
-    wp = torch.from_numpy(pack_gemm(w, N, K)).cuda()
-    w3 = np.empty(3 * N * K, np.uint16)
-    _lib.check(lib.suo_pack_gemm_weight_bf16x3(w.ctypes.data, N, K, w3.ctypes.data), "pack_bf16x3")
-    w3d = torch.from_numpy(w3.view(np.int16)).cuda()
-    scd, shd, bd = torch.from_numpy(sc).cuda(), torch.from_numpy(sh).cuda(), torch.from_numpy(b).cuda()
-    o32, o3 = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
-    st = torch.cuda.current_stream()
-    s = C.c_void_p(st.cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    f32 = lambda: _lib.check(lib.suo_conv1x1(P(a), K, K, P(scd), P(shd), None, 0, 0, P(wp), P(bd), None, 0, P(o32), N, M, N, N, 1, 0, s), "suo_conv1x1")  # noqa: E731
-    x3 = lambda: _lib.check(lib.suo_conv1x1_bf16x3(P(a), K, K, P(scd), P(shd), P(w3d), P(bd), P(o3), N, M, N, 1, s), "suo_conv1x1_bf16x3")  # noqa: E731
-    us32, us3 = _timed(f32, st, iters), _timed(x3, st, iters)
-    rows = slice(0, 4096)
-    pre = np.maximum(a[rows].cpu().numpy() * sc + sh, 0).astype(np.float32).astype(np.float64)      # the prologue is float32 in both kernels
-    ref = np.maximum(pre @ w.astype(np.float64).T + b, 0)
-    e32, e3 = np.abs(o32[rows].cpu().numpy() - ref).max(), np.abs(o3[rows].cpu().numpy() - ref).max()
-    flop = 2.0 * M * N * K
-    return {"kernel": "gemm_bf16x3_kernel vs gemm_persist_kernel: 1x1 conv K256->N128, BN+ReLU prologue, + ReLU, M = %d" % M, "dtype": "f32 via bf16x3",
-            "f32_mfma_us": round(us32, 1), "bf16x3_us": round(us3, 1), "speedup": round(us32 / us3, 3),
-            "bf16x3_tflops_f32_equivalent": round(flop / us3 / 1e6, 1), "bf16x3_over_f32_mfma_peak": round(flop / us3 / 1e6 / FP32_MFMA_PEAK_TF, 3),
-            "max_abs_err_vs_fp64": {"f32_mfma": float(f"{e32:.3e}"), "bf16x3": float(f"{e3:.3e}")}, "output_range": round(float(np.abs(ref).max()), 3),
-            "algorithmic_bytes_per_launch": 4.0 * (M * K + M * N), "note": "fp32 accuracy holds (tests/test_gpu_cnn.py); see DESIGN.md section 4"}
-
-
-def fp32_pipe_leg(args, L):
-    """Why the line says dtype "f32" although most products are formed on the bf16 matrix pipe: the SAME benchmark with every product on the fp32
-    matrix pipe (SUO_WINO_BF16X3=0, read when the network is built: a child process, 4 timed steps), and the dominant kernel of both forms
-    against fp64 on the same inputs -- measured here, by whoever runs this file."""
-    import torch
-    import torch.nn.functional as Fn
-    from suo_slam_amd import _lib
-    out = {}
-    cmd = [sys.executable, os.path.abspath(__file__), "--no-legs", "--steps", "4", "--warmup", "2", "--objects", str(args.objects), "--frames-per-step",
-           str(args.frames_per_step), "--depth", str(args.depth)] + (["--frames-from-host"] if args.frames_from_host else [])
-    for tag, env_add in (("fp32_pipe", {"SUO_WINO_BF16X3": "0"}), ("bf16x3", {"SUO_F16X2": "0"})):      # the same timed region on the other two forms, a child process each
-        if tag == "bf16x3" and matrix_pipe() != "f16x2":
-            continue
-        r = subprocess.run(cmd, env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=400)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode == 0 and line:
-            j = json.loads(line[-1])
-            out["frames_per_s_" + tag] = j["value"]
-            out["ms_per_step_" + tag] = j["ms_per_step"]
-            out["steps"] = j["steps"]
-        else:
-            out["error_" + tag] = (r.stderr or r.stdout)[-300:]
-    # the dominant kernel (fused Residual tail @64x64) of both forms against fp64: 2 crops, same inputs
-    lib = _lib.lib()
-    rng = np.random.default_rng(3)
-    Lc = 2
-    x = rng.standard_normal((Lc, 64, 64, 128)).astype(np.float32)
-    skip = rng.standard_normal((Lc, 64, 64, 256)).astype(np.float32)
-    w2 = (rng.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
-    w3 = (rng.standard_normal((256, 128)) / 11.0).astype(np.float32)
-    b2 = (rng.standard_normal(128) * 0.3).astype(np.float32)
-    b3 = rng.standard_normal(256).astype(np.float32)
-    wq = np.empty(16 * 128 * 128, np.float32)
-    _lib.check(lib.suo_pack_wino_weight(w2.ctypes.data, 128, 128, 128, 128, wq.ctypes.data), "pack_wino")
-    wq3h = np.empty(3 * 16 * 128 * 128, np.uint16)
-    _lib.check(lib.suo_pack_wino_weight_bf16x3(w2.ctypes.data, 128, 128, wq3h.ctypes.data), "pack_wino_x3")
-    w3xh = np.empty(3 * 256 * 128, np.uint16)
-    _lib.check(lib.suo_pack_tail_weight_bf16x3(w3.ctypes.data, 256, 128, w3xh.ctypes.data), "pack_tail_x3")
-    wq16h, o2h, w3p16h, o3h = np.empty(2 * 16 * 128 * 128, np.uint16), np.empty(128, np.float32), np.empty(2 * 256 * 128, np.uint16), np.empty(256, np.float32)
-    _lib.check(lib.suo_pack_wino_weight_f16x2(w2.ctypes.data, 128, 128, wq16h.ctypes.data, o2h.ctypes.data), "pack_wino_f16x2")
-    _lib.check(lib.suo_pack_tail_weight_f16x2(w3.ctypes.data, 256, 128, w3p16h.ctypes.data, o3h.ctypes.data), "pack_tail_f16x2")
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    xd, sd, wqd, wq3d, w3xd, wp3d, b2d, b3d = d(x), d(skip), d(wq), d(wq3h.view(np.int16)), d(w3xh.view(np.int16)), d(pack_gemm(w3, 256, 128)), d(b2), d(b3)
-    o32, o3 = torch.empty((Lc, 64, 64, 256), device="cuda"), torch.empty((Lc, 64, 64, 256), device="cuda")
-    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(lib.suo_conv3x3_wino_conv1x1_skip(P(xd), Lc, 64, 64, P(wqd), P(b2d), P(wp3d), P(b3d), P(sd), P(o32), s), "suo_conv3x3_wino_conv1x1_skip")
-    _lib.check(lib.suo_conv3x3_wino_x3_conv1x1_skip_up(P(xd), Lc, 64, 64, P(wq3d), P(b2d), P(w3xd), 1, P(b3d), P(sd), None, P(o3), s), "suo_conv3x3_wino_x3_conv1x1_skip_up")
-    o16, rflag = torch.empty((Lc, 64, 64, 256), device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
-    wq16d, o2d, w3p16d, o3d = d(wq16h.view(np.int16)), d(o2h), d(w3p16h.view(np.int16)), d(o3h)
-    _lib.check(lib.suo_conv3x3_wino_f16x2_conv1x1_skip_up(P(xd), Lc, 64, 64, P(wq16d), P(o2d), P(b2d), P(w3p16d), P(o3d), P(b3d), P(sd), None, P(o16), P(rflag), s),
-               "suo_conv3x3_wino_f16x2_conv1x1_skip_up")
-    torch.cuda.synchronize()
-    xm = torch.from_numpy(x).permute(0, 3, 1, 2).double()
-    m = Fn.relu(Fn.conv2d(xm, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1))
-    ref = (Fn.conv2d(m, torch.from_numpy(w3).double()[:, :, None, None], torch.from_numpy(b3).double())).permute(0, 2, 3, 1).numpy() + skip
-    e32, e3 = float(np.abs(o32.cpu().numpy() - ref).max()), float(np.abs(o3.cpu().numpy() - ref).max())
-    e16 = float(np.abs(o16.cpu().numpy() - ref).max())
-    out["dominant_kernel_max_abs_err_vs_fp64"] = {"fp32_pipe (wino3x3_kernel<true>)": float(f"{e32:.3e}"), "bf16x3 (wino3x3_x3_kernel<true,false,true,4,3>)": float(f"{e3:.3e}"),
-                                                  "f16x2 (wino3x3_x3_kernel<true,false,true,4,2>, the default)": float(f"{e16:.3e}"), "f16x2_range_flag": int(rflag.item()),
-                                                  "output_range": round(float(np.abs(ref).max()), 3), "crops": Lc}
-    return out
-
-
-def latency_roofline(L=8, iters=50):
-    """The dominant kernel of the reference's call shape (one frame = 8 crops per network call): the same fused Winograd tail at
-    256 tiles -- one workgroup per CU, a quarter of the chip's wave slots."""
-    r = conv_roofline(L, iters)
-    keep = ("bound", "kernel", "dtype", "pipe", "achieved", "peak", "unit", "frac", "avg_launch_us", "executed_flop_per_launch", "executed_tflops", "executed_frac",
-            "f32_equivalent_executed_tflops", "f32_equivalent_over_f32_peak", "algorithmic_over_f32_peak", "flop_basis")
-    out = {k: r[k] for k in keep if k in r}
-    out["same_process"] = {k: v for k, v in r["same_process"].items() if k.startswith("wino3x3_kernel<true>") or k.startswith("wino3x3_x3_kernel<true")}
-    return out
-
-
-def cpu_baseline(pool, L):
-    """The oracle (CPU restatement) timed on this box's host cores on a bounded sample of the same workload: the CNN of one 8-crop
-    frame per thread count of a sweep (the best is reported), PnP + LM of the pool's frames on one thread (the reference's geometry
-    is single-threaded, lib/object_slam.py:440-442)."""
-    import torch
-    from oracle import cnn_oracle as O
-    from oracle import geometry as G
-    from suo_slam_amd import geometry as geo
-    from suo_slam_amd import synthetic as S
-    from suo_slam_amd import weights
-    cores = len(os.sched_getaffinity(0))
-    quota = cpu_quota()
-    sd = weights.make_random_state_dict(0, 8.0)
-    Pw = O.to_torch(sd)
-    sweep, frames_per_point = {}, {}
-    t_start = time.perf_counter()
-    # thread counts up to every core the process may run on (8, 16, 32, 64, 128, all); per point: one untimed frame (the intra-op pool's start-up at
-    # that size), then up to 3 timed frames, the median reported.  torch's intra-op pool is OpenMP-free (its own work-stealing pool): thread placement
-    # is the kernel's, memory is first-touch -- no OMP_PLACES / interleave policy is set, and none would be honoured.  Bounded at ~30 s in all.
-    for n in sorted({min(c, cores) for c in (8, 16, 32, 64, 128, cores)}):
-        torch.set_num_threads(n)
-        fr = pool[0]
-        O.pkpnet_forward(fr["image"], fr["boxes"], None, sd, Pw)                      # first call with a thread count: pool start-up
-        ts = []
-        for k in range(3):
-            fk = pool[(1 + k) % len(pool)]
-            t0 = time.perf_counter()
-            O.pkpnet_forward(fk["image"], fk["boxes"], None, sd, Pw)
-            ts.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > 30.0:
-                break
-        sweep[n] = float(np.median(ts))
-        frames_per_point[n] = len(ts)
-        if time.perf_counter() - t_start > 30.0:
-            break
-    n_best = min(sweep, key=sweep.get)
-    t_cnn = sweep[n_best]
-    geo_in = []
-    for fr in pool[:16]:
-        xs = [fr["model_kps"][o][fr["model_kps_masks"][o]].astype(np.float64) for o in range(L)]
-        ys = [geo.normalize_uv(fr["uv"][o][fr["model_kps_masks"][o]].astype(np.float64), fr["K_bbox"][o].astype(np.float32).astype(np.float64)) for o in range(L)]
-        geo_in.append((xs, ys, fr))
-    t0 = time.perf_counter()
-    n_geo = 0
-    for rep in range(3):
-        for xs, ys, fr in geo_in:
-            init = [G.pnp(xs[o], ys[o], 1e-3, seed=o)[0][:3] for o in range(L)]
-            B = S.frame_to_ba_problem(fr, np.tile(np.eye(4)[None], (L, 1, 1)))
-            G.optimize(B["cam_T"], B["cam_fixed"], np.array(init), B["obj_fixed"], B["edge_cam"], B["edge_obj"], B["edge_camk"], B["edge_p"],
-                       B["edge_uv"], B["edge_info"], B["edge_inlier"])
-            n_geo += 1
-    t_geo = (time.perf_counter() - t0) / n_geo
-    # the CPU figures beside the `global_ba` and `slam` legs: the same 32-camera x 16-object pose graph through the dense C oracle (one thread, as the
-    # reference's g2o call), and a SLAM view's tracking as the oracle would do it -- two network passes of the frame + the frame's geometry
-    from suo_slam_amd import synthetic as S2
-    Pg = S2.make_pose_graph(np.random.default_rng(5), 32, 16)
-    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
-    t0 = time.perf_counter()
-    G.optimize(*[Pg[k].copy() for k in keys])
-    t_gba = time.perf_counter() - t0
-    return {"value": round(1.0 / (t_cnn + t_geo), 4), "unit": "frames/s", "cores": n_best, "kind": "port",
-            "cnn_ms_per_frame_by_threads": {str(k): round(1e3 * v, 1) for k, v in sweep.items()}, "frames_timed_per_thread_count": {str(k): v for k, v in frames_per_point.items()},
-            "host_cores_available": cores, "cpu_quota_cores": quota,
-            "thread_placement": "torch intra-op pool (not OpenMP): no OMP_PLACES / NUMA interleave policy applies; kernel placement, first-touch memory",
-            "global_ba_32x16_ms": round(1e3 * t_gba, 1), "slam_tracking_ms_per_view": round(1e3 * (2 * t_cnn + t_geo), 1),
-            "slam_tracking_basis": "2 network passes of an 8-crop frame at the best thread count + PnP/LM of the frame (both measured above); hypotheses / re-initialisation scoring not included",
-            "sample": f"up to 3 frames x {L} crops through the torch-CPU CNN oracle per thread count of the sweep (median; best: {n_best} threads, {t_cnn * 1e3:.0f} ms/frame) + "
-                      f"{n_geo} frames through the C PnP/LM oracle (1 thread, {t_geo * 1e3:.2f} ms/frame) + one 32 x 16 global adjustment through the C LM oracle (1 thread)"}
-
-
-def cpu_quota():
-    """CPUs the cgroup actually grants (the GPU boxes show 256 and grant 16), or None."""
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if q == "max" else round(int(q) / int(per), 2)
-    except Exception:
-        return None
-
-
-def frames_from_host_leg(L, pool, F, use_graph, depth, steps, warmup, fps_value):
-    """The timed region again with the frames handed over in PINNED HOST memory and uploaded inside it (0.92 MB per frame over PCIe, a copy kernel on the step's
-    stream) -- the rate rounds 1-4 reported as `value`.  `value` itself follows the bench contract: inputs resident in HBM when the timed region starts (the C ABI
-    takes device pointers for the frames: include/suo_hip.h, suo_net_forward_frames); the boxes / model keypoints (0.2 MB per step) come from the host either way."""
-    import torch
-    pipe = FramePipeline(L, pool, F, use_graph=use_graph, depth=depth, resident=False)
-    for i in range(warmup):
-        pipe.step(i)
-    pipe.drain(warmup)
-    pipe.reset_metrics()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        pipe.step(warmup + i)
-    pipe.drain(warmup + steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert pipe.n_frames == steps * F
-    fps = steps * F / dt
-    return {"frames_per_s": round(fps, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "warmup": warmup,
-            "over_value": round(fps / fps_value, 4),
-            "note": "the PCIe-inclusive rate (frames in pinned host memory, H2D inside the timed region): what `value` was in rounds 1-4; `value` has the frames resident in HBM"}
-
-
-def pose_check_leg(L, pool, use_graph):
-    """Is the geometry RIGHT?  The same device chain on good measurements (projected ground-truth keypoints + N(0, 0.01^2) NDC noise,
-    5 % gross outliers, random SPD covariances -- the reference's --debug_gt_kp mode, lib/object_slam.py:1129-1131) against the ground
-    truth, and on a sample of frames against the CPU oracle on identical inputs (PnP: same sampler keys)."""
-    import torch
-    from oracle import geometry as G
-    from suo_slam_amd import geometry as geo
-    F = 8
-    pipe = FramePipeline(L, pool[:F], F, use_graph=use_graph, depth=1, gt_keypoints=True)
-    pipe.step(0)
-    r = pipe.retire(pipe.slots[0])
-    torch.cuda.synchronize()
-    out = {"mean_rel_translation_err": round(pipe.pose_err / max(pipe.n_pose_gt, 1), 5), "poses": pipe.n_pose_gt, "of_objects": L * F,
-           "inlier_edges": pipe.n_inl, "lm_trials": pipe.n_trials}
-    dT = dR = 0.0
-    flags_differ = n_cmp = 0
-    rank = 0
-    for j in range(min(F, 4)):
-        fr = pool[j]
-        Kb = fr["K_bbox"].astype(np.float32).astype(np.float64)
-        init, objs = [], []
-        for o in range(L):
-            m = fr["model_kps_masks"][o]
-            g = j * L + o
-            To = G.pnp(fr["model_kps"][o][m].astype(np.float64), geo.normalize_uv(fr["uv"][o][m].astype(np.float64), Kb[o]), 1e-3,
-                       seed=(rank + o * 0x9E3779B97F4A7C15) % 2 ** 64)[0]
-            dT = max(dT, float(np.abs(r["T_pnp"][g] - To).max()))
-            if r["accepted"][g]:
-                init.append(To[:3])
-                objs.append(o)
-        rank += L
-        if not objs:
-            continue
-        e_obj = np.concatenate([np.full(int(fr["model_kps_masks"][o].sum()), k, np.int32) for k, o in enumerate(objs)])
-        sel = [fr["model_kps_masks"][o] for o in objs]
-        camk = np.concatenate([np.tile([Kb[o][0, 0], Kb[o][1, 1], Kb[o][0, 2], Kb[o][1, 2]], (int(m.sum()), 1)) for o, m in zip(objs, sel)])
-        p = np.concatenate([fr["model_kps"][o][m].astype(np.float64) for o, m in zip(objs, sel)])
-        uv = np.concatenate([fr["uv"][o][m].astype(np.float64) for o, m in zip(objs, sel)])
-        c = np.concatenate([fr["cov"][o][m].astype(np.float64) for o, m in zip(objs, sel)])
-        det = c[:, 0, 0] * c[:, 1, 1] - c[:, 0, 1] * c[:, 1, 0]
-        info = np.stack([c[:, 1, 1] / det, 0.5 * (-c[:, 0, 1] / det + -c[:, 1, 0] / det), c[:, 0, 0] / det], 1)
-        ref = G.optimize(np.eye(4)[None, :3], np.array([1], np.uint8), np.array(init), np.zeros(len(objs), np.uint8), np.zeros(len(p), np.int32), e_obj,
-                         camk, p, uv, info, np.ones(len(p), np.uint8))
-        k = 0
-        for i, o in enumerate(objs):
-            g = j * L + o
-            n = int(fr["model_kps_masks"][o].sum())
-            dR = max(dR, float(np.abs(r["T_opt"][g][:, :3] - ref[1][i][:, :3]).max()))
-            dT = max(dT, float(np.abs(r["T_opt"][g][:, 3] - ref[1][i][:, 3]).max() / np.abs(ref[1][i][:, 3]).max()))
-            flags_differ += int(np.count_nonzero(r["inlier"][g, :n] != ref[2][k:k + n].astype(bool)))
-            k += n
-            n_cmp += 1
-    out["vs_oracle"] = {"objects": n_cmp, "max_abs_dR_entry": float(f"{dR:.3e}"), "max_rel_dt": float(f"{dT:.3e}"), "inlier_flags_differing": flags_differ}
-    return out
-
-
-def latency_leg(L, pool, use_graph, seconds=0.6):
-    """The reference's call shape (evaluate.py:338-395: one frame per network call).  ONE frame in flight: launch -> results on the host,
-    nothing overlapped (the latency of a frame); four in flight: the same calls pipelined."""
-    import torch
-    out = {}
-    for depth, only in ((1, "cnn"), (1, "all"), (4, "all")):
-        pipe = FramePipeline(L, pool, 1, use_graph=use_graph, depth=depth, only=only)
-        for i in range(8):
-            pipe.step(i)
-        pipe.drain(8)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 0
-        while n < 16 or time.perf_counter() - t0 < seconds:
-            pipe.step(8 + n)
-            n += 1
-        pipe.drain(8 + n)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if only == "cnn":
-            out["network_ms_per_frame"] = round(1e3 * dt / n, 3)          # H2D + network + decode + masks of one 8-crop frame, nothing else
-        elif depth == 1:
-            out["one_in_flight_ms_per_frame"] = round(1e3 * dt / n, 3)
-            out["one_in_flight_fps"] = round(n / dt, 2)
-        else:
-            out["four_in_flight_fps"] = round(n / dt, 2)
-        del pipe
-    return out
-
-
-def drop_in_leg(L, pool, n=40):
-    """The call path evaluate.py takes (evaluate.py:338-395): ObjectSLAM(single_view_mode, sfm_mode) -- reset(), process_view(...),
-    collect_results() per frame, synchronous, one frame in flight -- on network output (confident random weights)."""
-    import torch
-    from suo_slam_amd.object_slam import ObjectSLAM
-    fr0 = pool[0]
-    mesh = lambda fr: {o: {"diameter": float(fr["diameter"][k]), "is_symmetric": False} for k, o in enumerate(fr["obj_ids"])}  # noqa: E731
-    slam = ObjectSLAM(None, mesh(fr0), sfm_mode=True, single_view_mode=True, state_dict=confident_state_dict(), max_crops=max(16, L),
-                      kp_var_thresh=KP_VAR_THRESH, bbox_thresh=BBOX_THRESH)
-    n_pose = 0
-    for it in range(n + 6):
-        if it == 6:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        fr = pool[it % len(pool)]
-        slam.reset()
-        slam.mesh_db = mesh(fr)
-        slam.process_view(it, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
-                          fr["model_kps_masks"])
-        res = slam.collect_results(no_viz=True)
-        n_pose += sum(r["T_OtoC"] is not None for r in res[it]["poses"].values())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = {"call": "ObjectSLAM.reset / process_view / collect_results per frame (evaluate.py:338-395), device chain", "frames": n,
-           "process_view_ms": round(1e3 * dt / n, 3), "evaluator_fps": round(n / dt, 2), "poses_returned": n_pose,
-           "tracking_meter_ms": round(1e3 * slam.track_time_meter.average(), 3)}
-    # the same loop with B views per device call (Evaluator(frames_per_call=B) -> ObjectSLAM.process_views_single): the views of a single-view
-    # evaluation are independent, so they can share a network call and a geometry launch; object ids made unique per frame (one mesh table)
-    B = 16
-    del slam
-    frames = [pool[i % len(pool)] for i in range(B)]
-    mesh_all = {100 * i + o: {"diameter": float(fr["diameter"][k]), "is_symmetric": False} for i, fr in enumerate(frames) for k, o in enumerate(fr["obj_ids"])}
-    slam = ObjectSLAM(None, mesh_all, sfm_mode=True, single_view_mode=True, state_dict=confident_state_dict(), max_crops=B * max(16, L),
-                      kp_var_thresh=KP_VAR_THRESH, bbox_thresh=BBOX_THRESH)
-    # as Evaluator.run drives it: batch i + 1 is submitted before batch i is collected (ObjectSLAM.submit_views_single / collect_views_single), so the
-    # host's bookkeeping of one batch runs under the device work of the next; every batch's results are collected inside the timed region
-    n_calls, n_pose_b = 6, 0
-
-    def collect():
-        res = slam.collect_views_single()
-        return sum(r["T_OtoC"] is not None for rv in res for v in rv.values() for r in v["poses"].values())
-    for it in range(n_calls + 2):
-        if it == 2:
-            slam.drain_views_single()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        views = [(it * B + i, fr["image"], fr["K"], 100 * i + np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
-                  fr["model_kps_masks"]) for i, fr in enumerate(frames)]
-        slam.submit_views_single(views)
-        if slam.views_in_flight() == 2:
-            n_pose_b += collect()
-    while slam.views_in_flight():
-        n_pose_b += collect()
-    torch.cuda.synchronize()
-    dtb = time.perf_counter() - t0
-    out["views_per_call_%d" % B] = {"call": "ObjectSLAM.submit_views_single / collect_views_single, two batches in flight (Evaluator(frames_per_call=%d))" % B, "frames": n_calls * B,
-                                    "ms_per_frame": round(1e3 * dtb / (n_calls * B), 3), "evaluator_fps": round(n_calls * B / dtb, 2),
-                                    "poses_returned_per_frame": round(n_pose_b / ((n_calls + 2) * B), 2)}
-    return out
-
-
-def slam_leg(n_views=60, n_obj=8):
-    """BASELINE configs[2]: one synthetic sequence through ObjectSLAM.process_view in SLAM mode, the reference's two meters
-    (lib/object_slam.py:155-164, 421-427, 444-451): tracking = network pass without priors + camera-pose hypotheses + network pass with
-    device-rendered priors for the symmetric objects + PnP + re-initialisation checks + current-view LM; global optimisation = the
-    pose-graph adjustment every 10 views.  The network runs on the frame's pixels (both passes, timed), its output is read back and
-    then replaced by the projected ground-truth keypoints + noise (--debug_gt_kp, :1129-1131): random weights cannot track."""
-    from suo_slam_amd import synthetic as S
-    from suo_slam_amd import weights
-    from suo_slam_amd.object_slam import ObjectSLAM
-    seq = S.make_slam_sequence(np.random.default_rng(3), n_views, n_obj)
-    sd = weights.make_random_state_dict(0, 8.0)
-    out = None
-    for rep in range(2):                        # the first pass pays graph captures / first launches
-        slam = ObjectSLAM(None, seq["mesh_db"], debug_gt_kp=True, manual_kp_std=0.01, state_dict=sd, max_crops=max(16, n_obj), run_network_in_debug=True)
-        t0 = time.perf_counter()
-        for vw in seq["views"]:
-            slam.process_view(vw["view_id"], vw["image"], vw["K"], vw["obj_ids"].copy(), vw["bboxes"].copy(), vw["model_kps"], vw["model_kps_masks"],
-                              vw["kp_masks"], uv_gt=vw["uv_gt"])
-        res = slam.collect_results(no_viz=True, final=True)
-        dt = time.perf_counter() - t0
-        err = []
-        for vw in seq["views"]:
-            for o in vw["obj_ids"]:
-                T = res.get(vw["view_id"], {}).get("poses", {}).get(int(o), {}).get("T_OtoC")
-                if T is not None:
-                    gt = vw["T_GtoC_gt"] @ seq["T_OtoG_gt"][int(o)]
-                    err.append(np.linalg.norm(T[:3, 3] - gt[:3, 3]) / gt[2, 3])
-        out = {"views": n_views, "objects": n_obj, "tracking_ms_per_view": round(1e3 * slam.track_time_meter.average(), 3),
-               "global_opt_ms": round(1e3 * slam.opt_time_meter.average(), 3), "global_opts": slam.opt_time_meter.count,
-               "wall_ms_per_view": round(1e3 * dt / n_views, 3), "camera_poses": len(slam.cam_poses), "poses": len(err),
-               "median_rel_translation_err": round(float(np.median(err)), 5) if err else None,
-               "keypoints": "network run on the frame's pixels (both passes), output replaced by projected GT + N(0,0.01^2) (debug_gt_kp)"}
-    return out
-
-
-def global_ba_leg(world, L, n_cam_per_rank=32, reps=3):
-    """BASELINE configs[4]'s exchange step: ONE global pose-graph adjustment (first camera fixed, all other cameras and all
-    L objects free, lib/object_slam.py:746-778) whose cameras are partitioned over the ranks; each LM trial all-reduces the
-    reduced object system over RCCL (suo_slam_amd/ba_dist.py).  Weak scaling: n_cam_per_rank cameras per GPU."""
-    from suo_slam_amd import ba, ba_dist
-    from suo_slam_amd import synthetic as S
-    import torch.distributed as dist
-    n_cam = n_cam_per_rank * world
-    P = S.make_pose_graph(np.random.default_rng(5), n_cam, L)
-    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
-
-    def run():
-        ts = []
-        for _ in range(reps):
-            full = ba.Problem(*[P[k].copy() for k in keys])
-            t0 = time.perf_counter()
-            ba_dist.optimize_distributed(full)
-            ts.append(time.perf_counter() - t0)
-        return full, min(ts)
-    extra = {}
-    if world == 1 and dist.is_initialized():
-        # one rank: the collectives of the schedule are identities and ba_dist skips them -- time that, then the SAME call with every
-        # all-reduce really issued on the one-rank RCCL group (what an 8-GPU node executes per trial), and compare the results bit for bit
-        os.environ["SUO_FORCE_COLLECTIVES"] = "0"
-        plain, t_plain = run()
-        os.environ["SUO_FORCE_COLLECTIVES"] = "1"
-        full, t = run()
-        os.environ["SUO_FORCE_COLLECTIVES"] = "0"
-        extra = {"ms_collectives_skipped": round(1e3 * t_plain, 2), "collectives": "every all-reduce issued on a one-rank %s group (SUO_FORCE_COLLECTIVES=1), in place on device buffers" % dist.get_backend(),
-                 "identical_to_skipped": bool(np.array_equal(plain.cam_T, full.cam_T) and np.array_equal(plain.obj_T, full.obj_T) and np.array_equal(plain.inlier, full.inlier))}
-    else:
-        full, t = run()
-    ts = [t]
-    err = float(max(np.linalg.norm(full.obj_T.reshape(-1, 3, 4)[o][:, 3] - P["obj_gt"][o][:, 3]) for o in range(L)))
-    return {**extra, "ranks": world, "cameras": n_cam, "objects": L, "edges": int(len(P["edge_cam"])), "ms": round(1e3 * min(ts), 2),
-            "lm_trials": int(full.stats[2]), "collectives_per_trial": ba_dist.COLLECTIVES_PER_TRIAL,
-            "reduce_bytes_per_trial": int(8 * ((6 * L) ** 2 + 6 * L + 4)),
-            "max_object_translation_err_mm": round(err, 3), "inlier_edges": int(full.inlier.sum())}
-
-
 _LINE_FD = None
 
 
@@ -1017,43 +105,6 @@ def print_line(text):
         sys.stdout.flush()
     else:
         os.write(_LINE_FD, data)
-
-
-def sample_power(out, stop=None, bdf=None):
-    """Package power / shader clock of GPU 0 while the caller's timed region runs, into `out`: amdgpu's hwmon files every 50 ms until `stop` is set
-    (mean / max over the samples), else ONE rocm-smi reading (a child process; it answers ~0.3 s in).  Silent when neither is there."""
-    import glob
-    import re
-    import subprocess
-    try:
-        hw = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if os.path.exists(os.path.join(h, "power1_average")) or os.path.exists(os.path.join(h, "power1_input"))]
-        if bdf:                                              # the card of THIS process's GPU (a box shows every card of the node in sysfs)
-            hw = [h for h in hw if os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).lower() == bdf.lower()]
-        if hw and stop is not None:
-            h = hw[0]
-            pf = os.path.join(h, "power1_average") if os.path.exists(os.path.join(h, "power1_average")) else os.path.join(h, "power1_input")
-            cap = os.path.join(h, "power1_cap")
-            w, f = [], []
-            while not stop.is_set():
-                w.append(int(open(pf).read()) / 1e6)
-                if os.path.exists(os.path.join(h, "freq1_input")):
-                    f.append(int(open(os.path.join(h, "freq1_input")).read()) / 1e6)
-                stop.wait(0.05)
-            if w:
-                out.update(package_w_mean=round(sum(w) / len(w), 1), package_w_max=round(max(w), 1), samples=len(w),
-                           cap_w=int(open(cap).read()) / 1e6 if os.path.exists(cap) else None, sclk_mhz_mean=round(sum(f) / len(f)) if f else None,
-                           source=f"{pf} ({bdf}) every 50 ms while the timed region ran")
-            return
-        t = time.perf_counter()
-        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
-        m = re.search(r"GPU\[0\][^\n]*Current Socket Graphics Package Power \(W\): ([0-9.]+)", r) or re.search(r"GPU\[0\][^\n]*Average Graphics Package Power \(W\): ([0-9.]+)", r)
-        c = re.search(r"GPU\[0\][^\n]*Max Graphics Package Power \(W\): ([0-9.]+)", r)
-        k = re.search(r"GPU\[0\][^\n]*sclk clock level: \S+ \((\d+)Mhz\)", r)
-        if m:
-            out.update(package_w=float(m.group(1)), cap_w=float(c.group(1)) if c else None, sclk_mhz=int(k.group(1)) if k else None, t_done=time.perf_counter(),
-                       source="rocm-smi, one reading of GPU 0 requested %.2f s into the timed region" % 0.0, t_req=t)
-    except Exception:
-        pass
 
 
 def main():
@@ -1180,11 +231,14 @@ def main():
             "metric": "frames/sec (obj-crops/sec) YCB-V 640x480 8-obj; ADD(-S) vs ref",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "dtype_note": DTYPE_NOTE[matrix_pipe()], "matrix_pipe": matrix_pipe(),
+            "dtype": DTYPE[matrix_pipe()], "dtype_note": DTYPE_NOTE[matrix_pipe()], "matrix_pipe": matrix_pipe(),
+            # the PCIe-inclusive rate of the same region (frames in pinned host memory, uploaded inside it: the reference's tracking meter includes that copy,
+            # lib/object_slam.py:1096-1098): measured by the frames_from_pinned_host leg below, which fills this in; `value` itself follows the bench contract
+            "value_pcie_inclusive": round(fps, 3) if args.frames_from_host else None,
             "data": "synthetic", "n_ranks_seen": n_ranks_seen, "rccl_backend": rccl_backend,
             "config": {"workload": "YCB-V single-view eval (BASELINE configs[1]): 640x480 frame, %d objects -> RoI crop, hourglass keypoint "
-                                   "CNN fp32, decode, masks, device-resident compaction -> batched PnP -> acceptance -> LM rounds [10,10,40,40], "
-                                   "one read-back" % L,
+                                   "CNN (%s), decode, masks, device-resident compaction -> batched PnP -> acceptance -> LM rounds [10,10,40,40], "
+                                   "one read-back" % (L, DTYPE[matrix_pipe()]),
                        "step": "frames_per_step consecutive frames (resident in HBM%s): host K_bbox terms + H2D of the boxes / model keypoints + one network "
                                "call + the geometry of those frames on the network's own output" % (" -- NO: --frames-from-host, uploaded inside the step" if args.frames_from_host else ""),
                        "frames_per_step": F, "objects_per_frame": L, "crops_per_step": L * F, "crops_per_s": round(fps * L, 2),
@@ -1240,6 +294,16 @@ def main():
         with lock:
             (extra if into is None else extra.setdefault(into, {}))[name] = val
 
+    if rank == 0:
+        # the whole call against the HBM roof: algorithmic bytes of every launch of one step's network call (a dry run of the schedule that just ran) / step time
+        try:
+            from bench_legs.roofline import whole_call
+            nb = pipe.slots[0]["net"].schedule_bytes(L * F, F, 480, 640)
+            with lock:
+                extra.setdefault("roofline_all", {})["whole_call"] = whole_call(nb, base["ms_per_step"], args.depth)
+        except Exception as e:
+            with lock:
+                extra.setdefault("roofline_all", {})["whole_call"] = {"error": repr(e)[:300]}
     if not args.no_legs and args.only == "all":
         del pipe                                  # free the timed region's slots before the legs build their own
         if not args.no_global_ba_leg:
@@ -1272,7 +336,12 @@ def main():
             if world == 1:
                 if not args.frames_from_host:
                     leg("frames_from_pinned_host", frames_from_host_leg, L, pool, F, not args.no_graph, args.depth, args.steps, args.warmup, base["value"])
+                    with lock:
+                        if "frames_per_s" in extra.get("frames_from_pinned_host", {}):
+                            base["value_pcie_inclusive"] = extra["frames_from_pinned_host"]["frames_per_s"]
                 leg("pose_check", pose_check_leg, L, pool, not args.no_graph)
+                if not args.no_tless_leg:
+                    leg("tless", tless_leg, not args.no_graph, args.depth)
                 if not args.no_latency_leg:
                     leg("latency", latency_leg, L, pool, not args.no_graph)
                     leg("drop_in", drop_in_leg, L, pool)

@@ -47,6 +47,11 @@ int suo_net_set_graph(suo_net* net, int enable);          /* hipGraph replay of 
  * the graphs will be replayed on (capture is stream-agnostic; NULL = internal). */
 int suo_net_prepare(suo_net* net, int L, int with_priors, void* stream);
 size_t suo_net_workspace_bytes(const suo_net* net);
+/* Measurement aid (nothing is launched): the launch schedule of ONE call of L crops cut from n_frames frames of H x W pixels, walked as a dry run on the
+ * network's current matrix pipe.  bytes[0..5] = ALGORITHMIC HBM bytes (every operand read once, every result written once, the weights once) of the
+ * staging / stem launch, the 3x3 convolutions (+ fused Residual tails), the 1x1 GEMMs, the one-launch Residual blocks, the pool / up-sample launches,
+ * decode + classifier; *n_launches = kernels of the call.  bench.py's `roofline_all.whole_call` divides their sum by the measured step time. */
+int suo_net_schedule_bytes(suo_net* net, int L, int n_frames, int H, int W, int with_priors, double* bytes6, int* n_launches);
 
 /* Matrix pipe of the network's large launches (the reference runs cuDNN's fp32 convolutions, lib/models/layers/Residual.py:20-35; all three forms are held
  * to its outputs at 1e-5, tests/test_gpu_cnn.py).  Chosen when the network is created -- SUO_WINO_BF16X3=0: SUO_PIPE_F32; SUO_F16X2=0: SUO_PIPE_BF16X3;

@@ -31,6 +31,7 @@ SIGNATURES = {
     "suo_net_set_graph": (C.c_int, [VP, C.c_int]),
     "suo_net_prepare": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "suo_net_workspace_bytes": (C.c_size_t, [VP]),
+    "suo_net_schedule_bytes": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "suo_net_forward": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_net_forward_frames": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]),
     "suo_net_forward_prior_kp": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP]),

@@ -59,6 +59,10 @@ int suo_net_prepare(suo_net* net, int L, int with_priors, void* stream) {
 }
 
 size_t suo_net_workspace_bytes(const suo_net* net) { return net ? net->impl->workspace_bytes() : 0; }
+int suo_net_schedule_bytes(suo_net* net, int L, int n_frames, int H, int W, int with_priors, double* bytes6, int* n_launches) {
+    if (!net) return SUO_ERR_ARG;
+    return net->impl->schedule_bytes(L, n_frames, H, W, with_priors, bytes6, n_launches);
+}
 
 int suo_net_get_pipe(const suo_net* net) { return net ? net->impl->pipe() : -1; }
 int suo_net_set_pipe(suo_net* net, int pipe) { return net ? net->impl->set_pipe(pipe) : SUO_ERR_ARG; }

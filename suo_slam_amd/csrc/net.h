@@ -58,6 +58,7 @@ public:
     int range_exceeded();
     int max_crops() const { return max_crops_; }
     size_t workspace_bytes() const { return ws_floats_ * sizeof(float); }
+    int schedule_bytes(int L, int n_frames, int H, int W, int with_priors, double* out, int* n_launches);
     const HostTensor& T(const std::string& name) const;
 
 private:
@@ -105,6 +106,9 @@ private:
     hipStream_t side_[kNumSide] = {}; hipStream_t own_stream_ = nullptr;
     hipEvent_t ev_[kNumEvents] = {}; int ev_next_ = 0;
     bool use_graph_ = true; bool dry_run_ = false;
+    bool acct_on_ = false; double acct_[8] = {}; int acct_launches_ = 0;      // schedule_bytes: algorithmic HBM bytes per kind of launch, summed over a dry run
+    void acct(int kind, double bytes) { if (acct_on_) acct_[kind] += bytes; }
+    int maxpool(const float* in, float* out, int L, int H, int W, int C, hipStream_t s);
     struct PreConv1 { const float* x; const ResidualW* r; float* mid1; };      // conv1 of block r on input x, already computed by the producer's tail
     std::vector<PreConv1> pre_;                                              // (several can be pending: up1[0]'s for up1[1] waits while the low branch runs)
     int pipe_ = 1, pipe_built_ = 1;                      // the pipe in use / the best one the weights were packed for

@@ -499,8 +499,33 @@ float* Net::alloc(size_t floats) {
 }
 
 #define SUO_TRY(x) do { int _r = (x); if (_r != SUO_OK) return _r; } while (0)
-#define SUO_LAUNCH(x) do { if (!dry_run_) { int _r = (x); if (_r != SUO_OK) return _r; } } while (0)
+#define SUO_LAUNCH(x) do { if (acct_on_) ++acct_launches_; if (!dry_run_) { int _r = (x); if (_r != SUO_OK) return _r; } } while (0)
 #define SUO_HIP_LIVE(x) do { if (!dry_run_) SUO_HIP_CHECK(x); } while (0)
+
+// ---- algorithmic (compulsory) HBM bytes of a launch: every operand read once, every result written once, the weights once.  Summed per kind over the launch
+// schedule by Net::schedule_bytes (a dry run): what bench.py's `roofline_all.whole_call` divides by the step time.  wb = bytes per weight element in the form the
+// launch reads (4: fp32 or two fp16 planes; 6: three bf16 planes).
+enum { ACCT_STAGE = 0, ACCT_CONV3 = 1, ACCT_GEMM = 2, ACCT_BLOCK = 3, ACCT_ELTWISE = 4, ACCT_DECODE = 5, ACCT_KINDS = 6 };
+static double gemm_bytes(const GemmArgs& g, double wb) {
+    const double M = g.M, nv = g.nchw_hw > 0 ? g.n_valid : g.N;
+    double b = 4.0 * M * (g.K1 + g.K2) + (g.R ? 4.0 * M * g.N : 0.0) + wb * (double)g.N * (g.K1 + g.K2);
+    if (g.out) b += 4.0 * M * nv;
+    if (g.pool_out) b += 4.0 * (M / 4) * g.N;
+    return b;
+}
+static double conv_bytes(const ConvArgs& c, double wb, int taps, bool fused) {
+    const double pin = (double)c.L * c.H * c.W, pout = (double)c.L * c.OH * c.OW;
+    double b = 4.0 * pin * c.C + wb * (double)c.N * c.C * taps;
+    if (!fused) return b + 4.0 * pout * c.N;
+    b += 4.0 * pout * c.N2 * 2 + wb * (double)c.N2 * c.N;                   // skip read, out2 written, conv3's weights
+    if (c.up) b += 4.0 * (pout / 4) * c.N2;
+    if (c.n_out) b += 4.0 * pout * 128 + wb * 128.0 * 256.0;               // the next block's conv1 written, its weights
+    return b;
+}
+static double block_bytes(const ResBlockArgs& a, double wb) {
+    const double px = (double)a.L * a.H * a.W;
+    return 4.0 * px * 256 * (a.pool_in ? 4 : 1) + 4.0 * px * 256 + (a.up ? 4.0 * (px / 4) * 256 : 0.0) + wb * (256.0 * 128 + 128.0 * 128 * 9 + 128.0 * 256);
+}
 
 // Residual.forward: three fused launches
 // true when residual() ends in the fused Winograd tail (the only epilogue that can add an up-sampled tensor)
@@ -564,14 +589,23 @@ int Net::residual_one_launch(const ResidualW& r, const float* x, float* out, int
     if (kind == 2 && pipe_ == 2 && r.rbh_w[0]) {                      // two fp16 planes: a third less weight traffic per workgroup, half the MFMAs
         a.W1 = r.rbh_w[0]; a.W2 = r.rbh_w[1]; a.W3 = r.rbh_w[2];
         a.osc1 = r.rbh_osc[0]; a.osc2 = r.rbh_osc[1]; a.osc3 = r.rbh_osc[2]; a.range_flag = range_flag_;
+        acct(ACCT_BLOCK, block_bytes(a, 4));
         SUO_LAUNCH(launch_res_block_f16x2(a, s));
     } else if (kind == 2) {
         a.W1 = r.rbx_w[0]; a.W2 = r.rbx_w[1]; a.W3 = r.rbx_w[2];
+        acct(ACCT_BLOCK, block_bytes(a, 6));
         SUO_LAUNCH(launch_res_block_x3(a, s));
     } else {
         a.W1 = r.rb_w[0]; a.W2 = r.rb_w[1]; a.W3 = r.rb_w[2];
+        acct(ACCT_BLOCK, block_bytes(a, 4));
         SUO_LAUNCH(launch_res_block(a, s));
     }
+    return SUO_OK;
+}
+
+int Net::maxpool(const float* in, float* out, int L, int H, int W, int C, hipStream_t s) {
+    acct(ACCT_ELTWISE, 4.0 * L * H * W * C * 1.25);
+    SUO_LAUNCH(launch_maxpool2(in, out, L, H, W, C, s));
     return SUO_OK;
 }
 
@@ -589,23 +623,24 @@ int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hi
         const bool f16 = pipe_ == 2 && gw->W16;                              // the two-term fp16 form of the same kernel (csrc/f16x2.h)
         if (f16) { gx.oscale = gw->osc16; gx.range_flag = range_flag_; }
         auto launch = [&](const GemmArgs& a) { return f16 ? launch_gemm_f16x2_args(a, reinterpret_cast<const uint16_t*>(gw->W16), s) : launch_gemm_bf16x3_args(a, reinterpret_cast<const uint16_t*>(Wx3), s); };
-        if (gemm_bf16x3_takes(gx)) { SUO_LAUNCH(launch(gx)); return SUO_OK; }
+        if (gemm_bf16x3_takes(gx)) { acct(ACCT_GEMM, gemm_bytes(gx, f16 ? 4 : 6)); SUO_LAUNCH(launch(gx)); return SUO_OK; }
         gx.pool_out = nullptr;                                                // else the pool as its own launch
         if (g.out && gemm_bf16x3_takes(gx)) {
+            acct(ACCT_GEMM, gemm_bytes(gx, f16 ? 4 : 6));
             SUO_LAUNCH(launch(gx));
-            if (pool_out) SUO_LAUNCH(launch_maxpool2(g.out, pool_out, L, H, W, g.N, s));
+            if (pool_out) SUO_TRY(maxpool(g.out, pool_out, L, H, W, g.N, s));
             return SUO_OK;
         }
     }
-    if (!pool_out) { SUO_LAUNCH(launch_gemm1x1(g, s)); return SUO_OK; }
+    if (!pool_out) { acct(ACCT_GEMM, gemm_bytes(g, 4)); SUO_LAUNCH(launch_gemm1x1(g, s)); return SUO_OK; }
     GemmArgs gp = g;
     gp.pool_out = pool_out; gp.pool_H = H; gp.pool_W = W;
     const long tiles128 = (long)(g.M / 128) * (g.N / 128);
-    if (fuse_pool && g.M > 4096 && tiles128 >= 512 && gemm1x1_can_pool(gp)) { SUO_LAUNCH(launch_gemm1x1(gp, s)); return SUO_OK; }
+    if (fuse_pool && g.M > 4096 && tiles128 >= 512 && gemm1x1_can_pool(gp)) { acct(ACCT_GEMM, gemm_bytes(gp, 4)); SUO_LAUNCH(launch_gemm1x1(gp, s)); return SUO_OK; }
     if (!g.out) g.out = alloc((size_t)g.M * g.ldo);
+    acct(ACCT_GEMM, gemm_bytes(g, 4));
     SUO_LAUNCH(launch_gemm1x1(g, s));
-    SUO_LAUNCH(launch_maxpool2(g.out, pool_out, L, H, W, g.N, s));
-    return SUO_OK;
+    return maxpool(g.out, pool_out, L, H, W, g.N, s);
 }
 
 // The next block's conv1 can ride on this block's fused fp16 tail when the separate launch would have been the fp16 GEMM on the same operands
@@ -622,7 +657,7 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
     if (residual_in_one_launch(r, L, H, W)) {
         if (!out) out = alloc((size_t)M * 256);
         SUO_TRY(residual_one_launch(r, x, out, L, H, W, s, up, false));
-        if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
+        if (pool_out) SUO_TRY(maxpool(out, pool_out, L, H, W, 256, s));
         return SUO_OK;
     }
     float* mid1 = nullptr;
@@ -649,8 +684,9 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
         // conv2 -> conv3 + skip in one launch: the 128-channel tensor between them never leaves the CU (csrc/conv.hip: FUSE)
         if (!out) out = alloc((size_t)M * 256);
         c2.W3p = r.c3.Wp; c2.bias3 = r.c3.bias; c2.R = x; c2.out2 = out; c2.N2 = 256;
+        acct(ACCT_CONV3, conv_bytes(c2, 4, 9, true));
         SUO_LAUNCH(launch_conv3x3_fused(c2, s));
-        if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
+        if (pool_out) SUO_TRY(maxpool(out, pool_out, L, H, W, 256, s));
         return SUO_OK;
     }
     if (wino) {
@@ -670,19 +706,24 @@ int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, 
                     c2.n_scale = next->pro_scale; c2.n_shift = next->pro_shift; c2.n_W1 = next->c1.W16; c2.n_osc1 = next->c1.osc16; c2.n_b1 = next->c1.bias; c2.n_out = nm;
                     pre_.push_back({out, next, nm});
                 }
+                acct(ACCT_CONV3, conv_bytes(c2, 4, 16, true));
                 SUO_LAUNCH(launch_conv3x3_wino_f16x2_fused(c2, s));
             } else if (r.c2.Wq3 && r.c3x) {                   // both products on the bf16 pipe, 3-way split operands
                 c2.Wp = r.c2.Wq3; c2.W3p = r.c3x; c2.w3_bf16x3 = 1;
+                acct(ACCT_CONV3, conv_bytes(c2, 6, 16, true));
                 SUO_LAUNCH(launch_conv3x3_wino_x3_fused(c2, s));
-            } else
-            SUO_LAUNCH(launch_conv3x3_wino_fused(c2, s));
-            if (pool_out) SUO_LAUNCH(launch_maxpool2(out, pool_out, L, H, W, 256, s));
+            } else {
+                acct(ACCT_CONV3, conv_bytes(c2, 4, 16, true));
+                SUO_LAUNCH(launch_conv3x3_wino_fused(c2, s));
+            }
+            if (pool_out) SUO_TRY(maxpool(out, pool_out, L, H, W, 256, s));
             return SUO_OK;
         }
-        if (pipe_ == 2 && r.c2.Wq16) { c2.Wp = r.c2.Wq16; c2.oscale = r.c2.osc16; c2.range_flag = range_flag_; SUO_LAUNCH(launch_conv3x3_wino_f16x2(c2, s)); }
-        else if (r.c2.Wq3) { c2.Wp = r.c2.Wq3; SUO_LAUNCH(launch_conv3x3_wino_x3(c2, s)); }
-        else SUO_LAUNCH(launch_conv3x3_wino(c2, s));
+        if (pipe_ == 2 && r.c2.Wq16) { c2.Wp = r.c2.Wq16; c2.oscale = r.c2.osc16; c2.range_flag = range_flag_; acct(ACCT_CONV3, conv_bytes(c2, 4, 16, false)); SUO_LAUNCH(launch_conv3x3_wino_f16x2(c2, s)); }
+        else if (r.c2.Wq3) { c2.Wp = r.c2.Wq3; acct(ACCT_CONV3, conv_bytes(c2, 6, 16, false)); SUO_LAUNCH(launch_conv3x3_wino_x3(c2, s)); }
+        else { acct(ACCT_CONV3, conv_bytes(c2, 4, 16, false)); SUO_LAUNCH(launch_conv3x3_wino(c2, s)); }
     } else {
+        acct(ACCT_CONV3, conv_bytes(c2, 4, 9, false));
         SUO_LAUNCH(launch_conv3x3(c2, s));
     }
     if (up) { suo_set_error("residual: an up-sampled addend needs the fused Winograd tail"); return SUO_ERR_ARG; }
@@ -734,7 +775,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     const bool pool_by_block = !pooled && pool_in_block && residual_in_one_launch(h.low1[0], L, H / 2, W / 2) && (H % 2 == 0) && (W % 2 == 0);
     if (!pooled && !pool_by_block) {
         float* p = alloc(n_lo);
-        SUO_LAUNCH(launch_maxpool2(x, p, L, H, W, C, s));
+        SUO_TRY(maxpool(x, p, L, H, W, C, s));
         pooled = p;
     }
     float* lo_a = alloc(n_lo);
@@ -757,7 +798,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     SUO_TRY(residual(h.low3[1], l3a, l3b, L, H / 2, W / 2, s));
     SUO_HIP_LIVE(hipStreamWaitEvent(s, ev_join, 0));
     if (up_in_tail) SUO_TRY(residual(h.up1[1], up_a, out, L, H, W, s, l3b));
-    else SUO_LAUNCH(launch_upsample2_add(up_b, l3b, out, L, H, W, C, s));
+    else { acct(ACCT_ELTWISE, 4.0 * L * H * W * C * 2.25); SUO_LAUNCH(launch_upsample2_add(up_b, l3b, out, L, H, W, C, s)); }
     return SUO_OK;
 }
 
@@ -773,6 +814,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         const ConvW& sw = in_c == IMG_C ? stem_img_ : stem_;
         c.in = in0; c.L = L; c.H = CROP; c.W = CROP; c.C = in_c; c.Wp = sw.Wp; c.bias = sw.bias;
         c.out = stem; c.OH = 128; c.OW = 128; c.N = 64; c.relu = 1;
+        acct(ACCT_STAGE, conv_bytes(c, 4, 49, false));
         SUO_LAUNCH(launch_conv7x7s2(c, s));
     }
     // pool(r1(x)): the full-resolution r1 output has no other reader, so only its pooled form is written (csrc/gemm_persist.hip: POOL)
@@ -796,6 +838,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         const long chain_min_rows = x3_min_rows();
         if (i == 1 && chain_head && pipe_ == 2 && lin_[i].W16 && head_[i].W16 && lin_[i].N == 256 && lin_[i].K1 == 256 && M >= chain_min_rows &&
             gemm_chain_head_takes(M, 256, NUM_KP, HEAT * HEAT)) {
+            acct(ACCT_GEMM, 4.0 * M * 256 + 4.0 * M * NUM_KP + 4.0 * (256.0 * 256 + 64.0 * 256));
             SUO_LAUNCH(launch_gemm_chain_head(rb, 256, M, reinterpret_cast<const uint16_t*>(lin_[i].W16), lin_[i].osc16, lin_[i].bias, reinterpret_cast<const uint16_t*>(head_[i].W16),
                                               head_[i].osc16, head_[i].bias, logits, NUM_KP, HEAT * HEAT, range_flag_, s));
             continue;
@@ -819,6 +862,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
             x = xn;
         } else {
             gh.out = logits; gh.n_valid = NUM_KP; gh.nchw_hw = HEAT * HEAT;
+            acct(ACCT_GEMM, gemm_bytes(gh, 4));
             SUO_LAUNCH(launch_gemm1x1(gh, s));
         }
     }
@@ -890,6 +934,39 @@ int Net::range_exceeded() {
         fprintf(stderr, "libsuo_hip: an activation left the fp16 range (|x| >= %g); this network now runs the three-term bf16 form -- re-issue the call\n", (double)(S2_LIMIT / S2_XSCALE));
     }
     return 1;
+}
+
+// The launch schedule of ONE call of L crops cut from n_frames frames of H x W (with_priors: the 48-channel staging + full stem) walked as a dry run (nothing is
+// launched, nothing allocated): algorithmic HBM bytes per kind of launch -- out[0..5] = staging / stem, 3x3 (+ fused tails), 1x1 GEMMs, one-launch blocks,
+// pool / up-sample, decode + classifier -- and the number of launches.
+int Net::schedule_bytes(int L, int n_frames, int H, int W, int with_priors, double* out, int* n_launches) {
+    if (L <= 0 || L > max_crops_ || !out) { suo_set_error("suo_net_schedule_bytes: L=%d outside [1,%d] or null output", L, max_crops_); return SUO_ERR_ARG; }
+    const bool was_dry = dry_run_;
+    dry_run_ = true; acct_on_ = true; acct_launches_ = 0;
+    for (int k = 0; k < ACCT_KINDS; ++k) acct_[k] = 0.0;
+    int rc = SUO_OK;
+    try {
+        const double frame_bytes = (double)n_frames * H * W * 3;
+        const int in_c = with_priors ? IN_C : IMG_C;
+        const bool fstem = !with_priors && fused_stem();
+        if (fstem) {
+            acct(ACCT_STAGE, frame_bytes + 4.0 * L * 128 * 128 * 64 * (stem_computes_r1_conv1() ? 2 : 1) + 4.0 * 64 * 147);
+            ++acct_launches_;
+        } else {
+            acct(ACCT_STAGE, frame_bytes + 4.0 * L * CROP * CROP * in_c + (with_priors ? 8.0 * L * NUM_KP : 0.0));
+            ++acct_launches_;
+        }
+        rc = backbone(nullptr, in_c, nullptr, L, nullptr, fstem);
+        acct(ACCT_DECODE, 4.0 * L * NUM_KP * (HEAT * HEAT + 2 + 4 + 1) + 4.0 * L * NUM_KP * 3 + 4.0 * NUM_KP * (NUM_KP + 1));
+        acct_launches_ += 2;
+    } catch (const std::exception& e) {
+        suo_set_error("suo_net_schedule_bytes: %s", e.what());
+        rc = SUO_ERR_ARG;
+    }
+    dry_run_ = was_dry; acct_on_ = false;
+    for (int k = 0; k < ACCT_KINDS; ++k) out[k] = acct_[k];
+    if (n_launches) *n_launches = acct_launches_;
+    return rc;
 }
 
 // SUO_STEM_X3=0: the prior-less pass stages the crop (roi_align_concat_kernel) and runs the stem on the fp32 pipe inside the backbone, as rounds 1-3 did

@@ -94,6 +94,19 @@ class PkpNet:
     def workspace_bytes(self):
         return int(_lib.lib().suo_net_workspace_bytes(self._h))
 
+    SCHEDULE_KINDS = ("staging_stem", "conv3x3_and_fused_tails", "gemm_1x1", "one_launch_blocks", "pool_upsample", "decode_classifier")
+
+    def schedule_bytes(self, n_crops, n_frames=1, H=480, W=640, with_priors=False):
+        """Algorithmic HBM bytes of ONE call of n_crops crops (suo_net_schedule_bytes: a dry run of the launch schedule on the current pipe, nothing runs):
+        {kind: bytes, ..., "total": bytes, "launches": n}."""
+        import ctypes as C
+        b, n = (C.c_double * 6)(), C.c_int(0)
+        _lib.check(_lib.lib().suo_net_schedule_bytes(self._h, int(n_crops), int(n_frames), int(H), int(W), int(bool(with_priors)), b, C.byref(n)), "suo_net_schedule_bytes")
+        out = {k: float(v) for k, v in zip(self.SCHEDULE_KINDS, b)}
+        out["total"] = float(sum(b))
+        out["launches"] = int(n.value)
+        return out
+
     # -- matrix pipe and the fp16 form's range guard (include/suo_hip.h: SUO_PIPE_*, suo_net_range_exceeded) -------------------------
     def pipe(self):
         """0 = fp32 MFMA, 1 = three bf16 terms, 2 = two fp16 terms (the default; range-guarded)."""

@@ -57,10 +57,11 @@ def make_texture(rng, H=480, W=640):
     return np.ascontiguousarray((np.clip(img, 0, 1) * 255).astype(np.uint8))
 
 
-def make_frame(rng, n_obj=8, K=K_YCBV, H=480, W=640, noise=0.01, outlier_frac=0.0, with_image=True):
+def make_frame(rng, n_obj=8, K=K_YCBV, H=480, W=640, noise=0.01, outlier_frac=0.0, with_image=True, z_range=(600.0, 1200.0), class_rows=None, off_centre=(0.25, 0.18)):
     """One synthetic single-view frame.  Returns a dict with image, K, per-object class masks, model
     keypoints [L,41,3] (mm), GT poses T_OtoC [L,4,4], boxes [L,4] xyxy, K_bbox [L,3,3], measured uv
-    [L,41,2] (NDC, float32), cov [L,41,2,2] (float32), visibility/validity masks [L,41] and diameters."""
+    [L,41,2] (NDC, float32), cov [L,41,2,2] (float32), visibility/validity masks [L,41] and diameters.
+    z_range: object depth in mm (closer objects = larger boxes); class_rows: indices into YCBV_LIKE to draw the keypoint classes from."""
     model_kps = np.zeros((n_obj, NUM_KP, 3), np.float32)
     masks = np.zeros((n_obj, NUM_KP), bool)
     poses = np.zeros((n_obj, 4, 4))
@@ -70,15 +71,15 @@ def make_frame(rng, n_obj=8, K=K_YCBV, H=480, W=640, noise=0.01, outlier_frac=0.
     cov = np.zeros((n_obj, NUM_KP, 2, 2), np.float32)
     diam = np.zeros(n_obj)
     for o in range(n_obj):
-        masks[o] = class_mask(int(rng.integers(0, len(YCBV_LIKE))))
+        masks[o] = class_mask(int(rng.integers(0, len(YCBV_LIKE))) if class_rows is None else int(class_rows[int(rng.integers(0, len(class_rows)))]))
         ext = rng.uniform(40, 100, 3)
         model_kps[o] = (rng.uniform(-1, 1, (NUM_KP, 3)) * ext).astype(np.float32)
         diam[o] = 2 * np.linalg.norm(ext)
         for _ in range(100):
             T = np.eye(4)
             T[:3, :3] = random_rotation(rng)
-            z = rng.uniform(600, 1200)
-            T[:3, 3] = [rng.uniform(-0.25, 0.25) * z, rng.uniform(-0.18, 0.18) * z, z]
+            z = rng.uniform(z_range[0], z_range[1])
+            T[:3, 3] = [rng.uniform(-off_centre[0], off_centre[0]) * z, rng.uniform(-off_centre[1], off_centre[1]) * z, z]
             pts = model_kps[o].astype(np.float64)
             pc = pts @ T[:3, :3].T + T[:3, 3]
             px = pc @ K.T
@@ -104,6 +105,37 @@ def make_frame(rng, n_obj=8, K=K_YCBV, H=480, W=640, noise=0.01, outlier_frac=0.
     if with_image:
         frame["image"] = make_texture(rng, H, W)
     return frame
+
+
+# T-LESS (BASELINE configs[3]): 720 x 540 Primesense frames (bop.py reads K per image from scene_camera.json; this is the dataset's nominal test camera), objects
+# with 8 (box-like) or 10 (cylinder-like) keypoints and no texture groups (kp_configs/tless_kp_config.csv:2-31)
+K_TLESS = np.array([[1075.65091572, 0.0, 360.0], [0.0, 1073.90347929, 270.0], [0.0, 0.0, 1.0]])
+TLESS_ROWS = (12, 15)              # YCBV_LIKE rows with the bare class groups: cylinder_like (10 keypoints), box_like (8)
+
+
+def make_frame_tless(rng, n_small=5, n_mid=2, n_big=1, noise=0.01, outlier_frac=0.0, with_image=True):
+    """One T-LESS-shaped frame: 720 x 540, n_small objects at 600-1100 mm (boxes <= 256 px: one RoIAlign sample per bin), n_mid at 300-480 mm (256-512 px: two
+    samples per bin and axis, torchvision's adaptive ceil(roi / 256)) and n_big at 170-240 mm (> 512 px where the draw fits the frame: three) -- the box sizes
+    saved T-LESS detections produce (evaluate.py:104-125)."""
+    parts = []
+    for n, zr in ((n_small, (600.0, 1100.0)), (n_mid, (300.0, 480.0))):
+        if n > 0:
+            parts.append(make_frame(rng, n, K_TLESS, 540, 720, noise, outlier_frac, with_image and not parts, z_range=zr, class_rows=TLESS_ROWS))
+    for _ in range(n_big):                                   # one at a time: the depth is searched so that the box's longer side lands in (512, 538] inside the frame
+        z = 220.0
+        for _try in range(60):
+            p = make_frame(rng, 1, K_TLESS, 540, 720, noise, outlier_frac, with_image and not parts, z_range=(z, z), class_rows=TLESS_ROWS, off_centre=(0.01, 0.01))
+            b = p["boxes"][0]
+            side = max(b[2] - b[0], b[3] - b[1])
+            if 512 < side <= 538 and b[0] >= 0 and b[1] >= 0 and b[2] <= 719 and b[3] <= 539:
+                break
+            z *= float(side) / 526.0
+        parts.append(p)
+    out = dict(parts[0])
+    for k in ("model_kps", "model_kps_masks", "T_OtoC", "boxes", "K_bbox", "uv", "cov", "diameter"):
+        out[k] = np.concatenate([p[k] for p in parts])
+    out["obj_ids"] = list(range(1, len(out["boxes"]) + 1))
+    return out
 
 
 def frame_to_ba_problem(frame, init_poses, use_cov=True):

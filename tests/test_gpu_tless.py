@@ -100,3 +100,53 @@ def test_tless_slam_mode_starts_current_view_rounds_with_outliers(tmp_path):
         good += int(np.linalg.norm(np.array(t.split(), float) - gt[:3, 3]) < 0.03 * gt[2, 3])
     assert n >= 11 * 5 - 6 and good >= n - 4, (n, good)
     assert {len(kp_config.kp_list_of("tless", o)) for o in next(iter(desc["scenes"].values()))[1]} <= {8, 10}
+
+
+def test_tless_frame_shape_with_large_boxes_matches_the_oracle_end_to_end():
+    """BASELINE configs[3]'s frame shape through the whole network: a 720 x 540 frame whose eight detections are five boxes <= 256 px, two of 256-512 px and one
+    > 512 px (suo_slam_amd.synthetic.make_frame_tless: the sizes saved T-LESS detections produce) -- the fused RoIAlign + stem launch takes torchvision's adaptive
+    1, 2 and 3 samples per bin and axis (pkpnet.py:93) -- against the CPU oracle on the same inputs, at the network tolerance (1e-5)."""
+    import torch
+    from oracle import cnn_oracle as O
+    from suo_slam_amd import synthetic as S
+    from suo_slam_amd import weights
+    from suo_slam_amd.pkpnet import PkpNet
+    fr = S.make_frame_tless(np.random.default_rng(77))
+    boxes = fr["boxes"].astype(np.float32)
+    side = np.maximum(boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1])
+    assert fr["image"].shape == (540, 720, 3) and (side <= 256).any() and ((side > 256) & (side <= 512)).any() and (side > 512).any()
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    net = PkpNet(state_dict=sd, max_crops=8)
+    out = net(fr["image"], [torch.from_numpy(boxes)], None)
+    ref = O.pkpnet_forward(fr["image"], boxes, None, sd)
+    lg, lr = out["prob_logits"].cpu().numpy(), ref["prob_logits"].numpy()
+    assert np.abs(lg - lr).max() / np.abs(lr).max() < 1e-5
+    np.testing.assert_allclose(out["uv"].cpu().numpy(), ref["uv"].numpy(), atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out["cov"].cpu().numpy(), ref["cov"].numpy(), atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out["kp_mask"].cpu().numpy(), ref["kp_mask"].numpy(), atol=1e-5, rtol=0)
+
+
+def test_schedule_bytes_accounts_every_launch_of_a_call():
+    """suo_net_schedule_bytes (bench.py's roofline_all.whole_call): a dry run of the launch schedule -- nothing runs, the next forward is unaffected -- whose per-kind
+    sums behave like the schedule: decode reads every logit once, a call of 2L crops moves between 1x and 2x the bytes of one of L (the weights are counted once per
+    launch), the prior pass stages 48 channels where the prior-less pass stages none, and the launch count is that of the kernel trace (tools/profile_round.sh)."""
+    import torch
+    from suo_slam_amd import weights
+    from suo_slam_amd.pkpnet import PkpNet
+    sd = weights.make_random_state_dict(seed=0, logit_gain=8.0)
+    net = PkpNet(state_dict=sd, max_crops=32)
+    rng = np.random.default_rng(5)
+    img = (rng.uniform(0, 1, (480, 640, 3)) * 255).astype(np.uint8)
+    boxes = np.array([[100, 80, 300, 290], [350, 100, 600, 400]], np.float32)
+    before = net(img, [torch.from_numpy(boxes)], None)["prob_logits"].clone()
+    b8, b16, b32 = net.schedule_bytes(8), net.schedule_bytes(16, 2), net.schedule_bytes(32, 4)
+    assert torch.equal(net(img, [torch.from_numpy(boxes)], None)["prob_logits"], before)
+    for b in (b8, b16, b32):
+        assert all(b[k] > 0 for k in PkpNet.SCHEDULE_KINDS if k != "one_launch_blocks") and abs(sum(b[k] for k in PkpNet.SCHEDULE_KINDS) - b["total"]) < 1.0
+    assert b8["decode_classifier"] >= 4.0 * 8 * 41 * 4096
+    assert b8["total"] < b16["total"] < 2 * b8["total"] and b16["total"] < b32["total"] < 2 * b16["total"]
+    # a crop's compulsory traffic is at least its 59 Residual blocks' inputs and outputs at 64x64 alone ... and far below one fp32 pass per layer over 169 MB of slabs
+    assert 8 * 20e6 < b8["total"] < 8 * 400e6
+    assert 60 <= b32["launches"] <= 400
+    wp = net.schedule_bytes(8, 1, with_priors=True)
+    assert wp["staging_stem"] > b8["staging_stem"] and wp["total"] > b8["total"]
