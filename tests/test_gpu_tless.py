@@ -128,8 +128,8 @@ def test_tless_frame_shape_with_large_boxes_matches_the_oracle_end_to_end():
 
 def test_schedule_bytes_accounts_every_launch_of_a_call():
     """suo_net_schedule_bytes (bench.py's roofline_all.whole_call): a dry run of the launch schedule -- nothing runs, the next forward is unaffected -- whose per-kind
-    sums behave like the schedule: decode reads every logit once, a call of 2L crops moves between 1x and 2x the bytes of one of L (the weights are counted once per
-    launch), the prior pass stages 48 channels where the prior-less pass stages none, and the launch count is that of the kernel trace (tools/profile_round.sh)."""
+    sums behave like the schedule: decode reads every logit once, a call of 2L crops moves about twice the bytes of one of L (the weights are counted once per
+    launch; the kernels chosen change with the launch size), the prior pass stages 48 channels where the prior-less pass stages none, and the launch count is that of the kernel trace (tools/profile_round.sh)."""
     import torch
     from suo_slam_amd import weights
     from suo_slam_amd.pkpnet import PkpNet
@@ -144,7 +144,8 @@ def test_schedule_bytes_accounts_every_launch_of_a_call():
     for b in (b8, b16, b32):
         assert all(b[k] > 0 for k in PkpNet.SCHEDULE_KINDS if k != "one_launch_blocks") and abs(sum(b[k] for k in PkpNet.SCHEDULE_KINDS) - b["total"]) < 1.0
     assert b8["decode_classifier"] >= 4.0 * 8 * 41 * 4096
-    assert b8["total"] < b16["total"] < 2 * b8["total"] and b16["total"] < b32["total"] < 2 * b16["total"]
+    # (not exactly "< 2x": a larger call leaves the one-launch blocks for per-layer launches, whose intermediate tensors travel)
+    assert 1.5 * b8["total"] < b16["total"] < 2.3 * b8["total"] and 1.5 * b16["total"] < b32["total"] < 2.3 * b16["total"]
     # a crop's compulsory traffic is at least its 59 Residual blocks' inputs and outputs at 64x64 alone ... and far below one fp32 pass per layer over 169 MB of slabs
     assert 8 * 20e6 < b8["total"] < 8 * 400e6
     assert 60 <= b32["launches"] <= 400

@@ -180,3 +180,40 @@ def test_prior_stamp_equals_conv2d_of_an_impulse_with_opencvs_kernel():
     assert np.abs(got - ref).max() < 1e-6, np.abs(got - ref).max()
     # the reflection really is what doubles the outer ring (without it the corner would be a quarter of this)
     assert abs(ref[0, 0] / (4 * (k[0] / k[n // 2]) ** 2) - 1) < 1e-5
+
+
+# ---- round 6: the wide reference-generated goldens (tests/golden/make_golden_wide.py) ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def wide():
+    import os
+    from tests.conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "cnn_golden_wide.npz"))
+
+
+def test_oracle_backbone_on_five_crops_of_different_statistics(wide, state_dict):
+    """The oracle against the REFERENCE's logits / decode on five crops (texture with zero priors, with stamped priors, heavy-tailed, dark under dense priors,
+    saturated blocks): 2e-5 of each crop's own logit range, the decode on the reference's logits to float32 rounding."""
+    from tests.golden import cnn_inputs as I
+    P = O.to_torch(state_dict)
+    assert list(wide["kinds"]) == list(I.CROP_KINDS)
+    for i, kind in enumerate(I.CROP_KINDS):
+        with torch.no_grad():
+            raw = O.hourglass_net(torch.from_numpy(I.crop(kind)[None]), P).numpy()
+        ref = wide["logits"][i:i + 1]
+        assert np.abs(raw - ref).max() <= 2e-5 * np.abs(ref).max(), kind
+    d = O.decode(torch.from_numpy(wide["logits"]), P)
+    np.testing.assert_allclose(d["uv"].numpy(), wide["uv"], atol=2e-6)
+    np.testing.assert_allclose(d["cov"].numpy(), wide["cov"], atol=2e-6)
+    np.testing.assert_allclose(d["kp_mask"].numpy(), wide["kp_mask"], atol=1e-6)
+
+
+def test_oracle_residual_blocks_at_network_map_sizes(wide, state_dict):
+    """256 -> 256 at 64x64 / 32x32, r4 (128 -> 128) at 64x64 / 32x32, r5 (128 -> 256, conv4 skip) at 64x64 against the reference's Residual module."""
+    from tests.golden import cnn_inputs as I
+    P = O.to_torch(state_dict)
+    for i, (name, cin, cout, hw) in enumerate(I.BLOCKS):
+        with torch.no_grad():
+            y = O.residual(torch.from_numpy(I.block_input(i)), P, name).numpy()
+        ref = wide["block%d_rows" % i]
+        assert y.shape == (1, cout, hw, hw)
+        assert np.abs(y[:, :, I.block_rows(hw), :] - ref).max() <= 1e-5 * float(wide["block%d_absmax" % i]), (name, hw)
