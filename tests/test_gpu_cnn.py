@@ -837,7 +837,8 @@ def test_bench_launch_shape_frames_batched_per_call(ops, state_dict, reps):
             assert torch.equal(v[rep], v[0]), (key, rep)
     one = net(base[0], [torch.from_numpy(bx4[0])], None)
     lg = one["prob_logits"]
-    assert float((out["prob_logits"][:8] - lg).abs().max() / lg.abs().max()) < 1e-4
+    # (both calls are held to the reference at 1e-5 elsewhere -- at this launch shape directly in tests/test_gpu_golden_wide.py; observed here ~1e-6)
+    assert float((out["prob_logits"][:8] - lg).abs().max() / lg.abs().max()) < 1e-5
     net.close()
 
 
