@@ -12,6 +12,7 @@
 // vector additions per chunk), same epilogues -- the accumulator layout of the bf16 MFMA is that of the fp32 one, so the fused
 // Residual tail (conv3 1x1 + skip [+ up-sampled addend]) could be taken over unchanged (TX3 = false: conv3 on the fp32 pipe); the network uses
 // TX3 = true, conv3 on the bf16 pipe as well (two passes of 64 pixels: see the tail's comment).
+#include <stdlib.h>
 #include <string.h>
 
 #include "bf16x3.h"
@@ -126,8 +127,15 @@ void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float
 // NEXT (fp16 form of the fused tail only): the block's output never comes back for the NEXT block's conv1 -- relu(bn_next(out2)) of the tile is split into LDS
 // right where out2 is stored and multiplied by the next block's W1 (256 -> 128) here: the 256-channel tensor is written once and not re-read by a GEMM launch
 // (csrc/net.hip: residual(..., next)).  Same products in the same order as gemm_bf16x3_kernel<NP = 2> forms them: bit-identical to the separate launch.
-template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
+// PP (round 6): TWO tiles per workgroup of EIGHT waves, phase-shifted ("ping-pong").  Timing builds of round 6 showed that the kernel's parts ADD UP -- matrix pipe,
+// fold, transform, the LDS / load skeleton each cost what they cost alone (profiles/REJECTED.md: 691 us = 397 skeleton + 1/3 of the MFMAs, + 170 for the other 2/3, + 55
+// fold, + 63 transform): the two 4-wave workgroups a CU holds run in lock-step -- both transform, then both multiply -- and lock-step is stable, because contention
+// slows both alike.  Here the two tiles' wave groups (waves 0-3 = group 0, 4-7 = group 1; one wave of each per SIMD) execute the SAME instruction stream on their own
+// tile and their own half of LDS, group 1 one barrier interval behind group 0: every __syncthreads() below is workgroup-wide, group 1 passes one extra barrier before it
+// starts and group 0 one after it ends, so whatever segment group 0 runs between two barriers, group 1 runs the previous one beside it -- in the K loop the transform
+// of one tile (VALU, LDS writes) beside the products of the other (matrix pipe, LDS reads).  Same arithmetic in the same order per tile: bit-identical to PP = false.
+template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false, bool PP = false>
+__global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
     static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
     static_assert(!NEXT || (FUSE && TX3 && NP == 2), "the next block's conv1 rides on the fp16 tail");
     static_assert(NP == 3 || !FUSE || TX3, "the fp16 form's tail runs on the fp16 pipe");
@@ -137,14 +145,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                                                               // conflict-free A-fragment ds_read_b128, 2-way instead of 4-way on the transform's ds_write_b64
     constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
     constexpr int VFLOATS = NP * VPL / 2;
-    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
+    constexpr int GFLOATS = 2 * HSZ + VFLOATS;                // floats of LDS per tile
+    __shared__ __attribute__((aligned(16))) float S_all[(PP ? 2 : 1) * GFLOATS];
+    const int grp = PP ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;      // PP: which of the workgroup's two tiles this wave works on
+    float* S = &S_all[grp * GFLOATS];
     float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
     uint16_t* V = reinterpret_cast<uint16_t*>(&S[2 * HSZ]);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (a.OW + X_TW - 1) / X_TW, tiles_y = (a.OH + X_TH - 1) / X_TH;
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
+    if constexpr (PP) {
+        bid = 2 * bid + grp;                                  // (the launcher sends an even number of tiles)
+        if (grp == 1) __syncthreads();                        // group 1 runs one barrier interval behind group 0
+    }
     const int l = bid / (tiles_x * tiles_y);
     bid -= l * tiles_x * tiles_y;
     const int ty0 = bid / tiles_x, tx0 = bid - ty0 * tiles_x;
@@ -194,11 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     constexpr int NPAIR = NT == 4 ? 8 : 4;                      // component pairs per chunk and wave
     const int wsbase = wn * NP * 1024;
     auto bload = [&](int gc, x_u32x4 (&b)[NP]) {              // gc = chunk * 16 + comp
-#ifdef SUO_WX3_EXP_W0
-        const int g = gc & 1;                                 // timing experiment (wrong results): weights from two cache-resident groups
-#else
         const int g = gc;
-#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (NT * NP * 1024) + wsbase));
     };
@@ -212,27 +223,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if constexpr (NP == 2) {                                  // hi = rn16(v), lo = rn16(v - hi) (the residual is exact)
             const unsigned h0 = s2_pack_rn(v[0], v[1]), h1 = s2_pack_rn(v[2], v[3]);
             *(x_u32x2*)&V[comp * 32 * VROW + vbase] = x_u32x2{h0, h1};
-#ifdef SUO_WX3_EXP_NOSPLIT                                    // timing experiment (wrong results): no residual
-            const unsigned l0 = h0, l1 = h1;
-#else
             const unsigned l0 = s2_lo_pack(v[0], v[1], h0), l1 = s2_lo_pack(v[2], v[3], h1);
-#endif
             *(x_u32x2*)&V[VPL + comp * 32 * VROW + vbase] = x_u32x2{l0, l1};
             return;
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned q0 = s3_pack_rn(v[0], v[1]), q1 = s3_pack_rn(v[2], v[3]);       // round-to-nearest terms (csrc/bf16x3.h); p == 2: exact
-#ifdef SUO_WX3_EXP_NOCONFLICT                                 // timing experiment (wrong results): the V stores of a wave at consecutive 8-byte addresses -- no bank conflict
-            *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + (tid & 63) * 4 + (tid >> 6) * 256] = x_u32x2{q0, q1};
-#else
             *(x_u32x2*)&V[p * VPL + comp * 32 * VROW + vbase] = x_u32x2{q0, q1};
-#endif
-#ifndef SUO_WX3_EXP_NOSPLIT                                   // (timing experiment, wrong results: the three planes hold the same term)
             if (p < 2) {
                 v = x_sub4(v, x_f32x4{s3_lo(q0), s3_hi(q0), s3_lo(q1), s3_hi(q1)});        // exact residual
             }
-#endif
         }
     };
     // rows of B^T d:  half 0 (input rows 0,1,2): xi0 = r0 - r2, xi1 = r1 + r2;  half 1 (rows 1,2,3): xi3 = r1 - r3, xi2 = r2 - r1
@@ -249,19 +250,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             L2[c] = *(const x_f32x4*)(hs + (2 * X_IW + c) * X_PKH);
             Lx[c] = *(const x_f32x4*)(hs + hother + c * X_PKH);
         }
-#ifdef SUO_WX3_EXP_NOXFORM                                    // timing experiment (wrong results): the transform's LDS traffic without its arithmetic
-        {
-            const int xa = th ? 3 : 0, xb = th ? 2 : 1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    *(x_u32x2*)&V[p * VPL + (xa * 4 + c) * 32 * VROW + vbase] = x_u32x2{__float_as_uint(L0[c][p]), __float_as_uint(L2[c][p])};
-                    *(x_u32x2*)&V[p * VPL + (xb * 4 + c) * 32 * VROW + vbase] = x_u32x2{__float_as_uint(L1[c][p]), __float_as_uint(Lx[c][p])};
-                }
-            return;
-        }
-#endif
         x_f32x4 eA[4], eB[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -298,21 +286,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         if constexpr (NP == 2) {                                  // hi lo, lo hi, hi hi
             constexpr int UI[3] = {0, 1, 0}, UJ[3] = {1, 0, 0};
 #pragma unroll
-#ifdef SUO_WX3_EXP_MFMA1                                      // timing experiment (wrong results): one of the three cross terms
-            for (int t = 2; t < 3; ++t)
-#else
             for (int t = 0; t < 3; ++t)
-#endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x_f16x8, f[UI[t]]), __builtin_bit_cast(x_f16x8, bw[UJ[t]]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
             return;
         }
         constexpr int TI[6] = {0, 1, 2, 0, 1, 0}, TJ[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-#ifdef SUO_WX3_EXP_MFMA3                                      // timing experiment (wrong results): half of the cross terms
-        for (int t = 0; t < 3; ++t)
-#else
         for (int t = 0; t < 6; ++t)
-#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[TI[t] % NP], __builtin_bit_cast(x_bf16x8, bw[TJ[t] % NP]), (t == 0 && from_zero) ? zero16 : acc, 0, 0, 0);
     };
     // Consumption order of the components, in pairs: pairs 0-3 = (xi 0, xi 3) of nu = pair, accumulated straight into their Z; pairs 4-7 =
@@ -349,9 +329,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         XPROF(1);
         if (more) sstore(buf ^ 1);
         XPROF(2);
-#ifdef SUO_WX3_EXP_NOAREAD
-        x_u32x4 keepa[NP];
-#endif
 #pragma unroll
         for (int pair = 0; pair < NPAIR; ++pair) {
             const int slot = pair & 1;
@@ -364,14 +341,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             x_bf16x8 afa[NP], afb[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-#ifdef SUO_WX3_EXP_NOAREAD                                    // timing experiment (wrong results): A fragments read once per chunk
-                if (pair > 0) { afa[p] = __builtin_bit_cast(x_bf16x8, keepa[p]); afb[p] = __builtin_bit_cast(x_bf16x8, keepa[p]); continue; }
-#endif
                 afa[p] = *(const x_bf16x8*)&V[p * VPL + ca * 32 * VROW + afoff];
                 afb[p] = *(const x_bf16x8*)&V[p * VPL + cb * 32 * VROW + afoff];
-#ifdef SUO_WX3_EXP_NOAREAD
-                keepa[p] = __builtin_bit_cast(x_u32x4, afa[p]);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             if (NT == 2) {                                    // Z[local component]
@@ -384,11 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 x_f32x16 ta, tb;
                 mac6(ta, afa, bring[slot][0], true);
                 mac6(tb, afb, bring[slot][1], true);
-#ifdef SUO_WX3_EXP_NOFOLD                                     // (timing experiment, wrong results)
-                Z[pair - 4][0] += ta[0] + tb[0];
-#else
                 x_add16(Z[pair - 4], ta); x_add16(Z[pair - 4], tb); x_add16(Z[pair], ta); x_sub16(Z[pair], tb);      // Z[0][nu] += M1 + M2, Z[1][nu] += M1 - M2
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -609,6 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             if (h == 0 && !NEXT) __syncthreads();             // every wave is done with the A planes of pass 0 (NEXT: the K half's closing barrier)
         }
         if constexpr (NP == 2) s2_raise(a.range_flag, tmax);
+        if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
         return;
     }
 
@@ -663,9 +631,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             for (int i = 0; i < 2; ++i) af[i] = *(const x_f32x4*)(ms + i * 32 * MP + q * 8);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-#ifdef SUO_WX3_EXP_TAIL38                                     // timing experiment (wrong results): 3/8 of the tail's MFMA time = what the bf16x3 form would take
-                if ((q * 4 + t) % 8 < 3)
-#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -702,6 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
         return;
     }
 
@@ -749,6 +715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
         return;
     }
 
@@ -779,6 +746,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
+}
+
+// The two-tiles-per-workgroup form (PP) takes launches that still fill the chip with half as many workgroups -- from 1024 tiles: two workgroups of two tiles per CU --
+// and an even number of tiles; the fp16 form only.  SUO_WINO_PP=0: A/B against the one-tile form (same bits).
+static bool wino_pp(int tiles) {
+    const int on = getenv("SUO_WINO_PP") ? atoi(getenv("SUO_WINO_PP")) : 1;                       // (read per launch: the A/B test flips it inside one process)
+    const int from = getenv("SUO_WINO_PP_TILES") ? atoi(getenv("SUO_WINO_PP_TILES")) : 1024;
+    return on != 0 && tiles >= from && (tiles & 1) == 0;
 }
 
 // a.Wp = weights packed by pack_wino_weight_bf16x3 / _f16x2 (uint16 under a float pointer); 128 -> 128 or 64 -> 64 channels
@@ -787,7 +763,8 @@ static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
     if (NP == 2 && (!a.oscale || !a.range_flag)) { suo_set_error("conv3x3_wino_f16x2: oscale / range_flag missing"); return SUO_ERR_ARG; }
     if (a.OH == a.H && a.OW == a.W && a.N == 64 && a.C == 64) {
         const int tiles64 = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-        hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, NP>), dim3(tiles64), dim3(256), 0, s, a);
+        if (NP == 2 && wino_pp(tiles64)) hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, 2, false, true>), dim3(tiles64 / 2), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, NP>), dim3(tiles64), dim3(256), 0, s, a);
         SUO_HIP_CHECK(hipGetLastError());
         return SUO_OK;
     }
@@ -796,7 +773,8 @@ static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-    hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
+    if (NP == 2 && wino_pp(tiles)) hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, 2, false, true>), dim3(tiles / 2), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -815,9 +793,12 @@ int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s) {
         // (with an up-sampled addend the kernel would need 14-23 registers more than the 256 a two-workgroup-per-CU kernel has: it spilled and measured
         //  SLOWER than the two launches, profiles/REJECTED.md -- not built; csrc/net.hip does not ask for it)
         if (a.up) { suo_set_error("conv3x3_wino_f16x2_fused: the next block's conv1 cannot ride on a tail with an up-sampled addend"); return SUO_ERR_ARG; }
-        hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
-    } else
-    if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
+        if (wino_pp(tiles)) hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true, true>), dim3(tiles / 2), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
+    } else if (wino_pp(tiles)) {
+        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2, false, true>), dim3(tiles / 2), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, false, true>), dim3(tiles / 2), dim3(512), 0, s, a);
+    } else if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
