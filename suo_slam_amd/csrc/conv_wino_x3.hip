@@ -12,7 +12,6 @@
 // vector additions per chunk), same epilogues -- the accumulator layout of the bf16 MFMA is that of the fp32 one, so the fused
 // Residual tail (conv3 1x1 + skip [+ up-sampled addend]) could be taken over unchanged (TX3 = false: conv3 on the fp32 pipe); the network uses
 // TX3 = true, conv3 on the bf16 pipe as well (two passes of 64 pixels: see the tail's comment).
-#include <stdlib.h>
 #include <string.h>
 
 #include "bf16x3.h"
@@ -127,15 +126,8 @@ void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float
 // NEXT (fp16 form of the fused tail only): the block's output never comes back for the NEXT block's conv1 -- relu(bn_next(out2)) of the tile is split into LDS
 // right where out2 is stored and multiplied by the next block's W1 (256 -> 128) here: the 256-channel tensor is written once and not re-read by a GEMM launch
 // (csrc/net.hip: residual(..., next)).  Same products in the same order as gemm_bf16x3_kernel<NP = 2> forms them: bit-identical to the separate launch.
-// PP (round 6): TWO tiles per workgroup of EIGHT waves, phase-shifted ("ping-pong").  Timing builds of round 6 showed that the kernel's parts ADD UP -- matrix pipe,
-// fold, transform, the LDS / load skeleton each cost what they cost alone (profiles/REJECTED.md: 691 us = 397 skeleton + 1/3 of the MFMAs, + 170 for the other 2/3, + 55
-// fold, + 63 transform): the two 4-wave workgroups a CU holds run in lock-step -- both transform, then both multiply -- and lock-step is stable, because contention
-// slows both alike.  Here the two tiles' wave groups (waves 0-3 = group 0, 4-7 = group 1; one wave of each per SIMD) execute the SAME instruction stream on their own
-// tile and their own half of LDS, group 1 one barrier interval behind group 0: every __syncthreads() below is workgroup-wide, group 1 passes one extra barrier before it
-// starts and group 0 one after it ends, so whatever segment group 0 runs between two barriers, group 1 runs the previous one beside it -- in the K loop the transform
-// of one tile (VALU, LDS writes) beside the products of the other (matrix pipe, LDS reads).  Same arithmetic in the same order per tile: bit-identical to PP = false.
-template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false, bool PP = false>
-__global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
+template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
     static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
     static_assert(!NEXT || (FUSE && TX3 && NP == 2), "the next block's conv1 rides on the fp16 tail");
     static_assert(NP == 3 || !FUSE || TX3, "the fp16 form's tail runs on the fp16 pipe");
@@ -145,21 +137,14 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                                                               // conflict-free A-fragment ds_read_b128, 2-way instead of 4-way on the transform's ds_write_b64
     constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
     constexpr int VFLOATS = NP * VPL / 2;
-    constexpr int GFLOATS = 2 * HSZ + VFLOATS;                // floats of LDS per tile
-    __shared__ __attribute__((aligned(16))) float S_all[(PP ? 2 : 1) * GFLOATS];
-    const int grp = PP ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;      // PP: which of the workgroup's two tiles this wave works on
-    float* S = &S_all[grp * GFLOATS];
+    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
     float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
     uint16_t* V = reinterpret_cast<uint16_t*>(&S[2 * HSZ]);
-    const int tid = threadIdx.x & 255, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (a.OW + X_TW - 1) / X_TW, tiles_y = (a.OH + X_TH - 1) / X_TH;
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
-    if constexpr (PP) {
-        bid = 2 * bid + grp;                                  // (the launcher sends an even number of tiles)
-        if (grp == 1) __syncthreads();                        // group 1 runs one barrier interval behind group 0
-    }
     const int l = bid / (tiles_x * tiles_y);
     bid -= l * tiles_x * tiles_y;
     const int ty0 = bid / tiles_x, tx0 = bid - ty0 * tiles_x;
@@ -576,7 +561,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             if (h == 0 && !NEXT) __syncthreads();             // every wave is done with the A planes of pass 0 (NEXT: the K half's closing barrier)
         }
         if constexpr (NP == 2) s2_raise(a.range_flag, tmax);
-        if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
         return;
     }
 
@@ -667,7 +651,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-        if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
         return;
     }
 
@@ -715,7 +698,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
         return;
     }
 
@@ -746,15 +728,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (PP) { if (grp == 0) __syncthreads(); }       // group 0 waits out group 1's last interval: the barrier counts of the two groups match
-}
-
-// The two-tiles-per-workgroup form (PP) takes launches that still fill the chip with half as many workgroups -- from 1024 tiles: two workgroups of two tiles per CU --
-// and an even number of tiles; the fp16 form only.  SUO_WINO_PP=0: A/B against the one-tile form (same bits).
-static bool wino_pp(int tiles) {
-    const int on = getenv("SUO_WINO_PP") ? atoi(getenv("SUO_WINO_PP")) : 1;                       // (read per launch: the A/B test flips it inside one process)
-    const int from = getenv("SUO_WINO_PP_TILES") ? atoi(getenv("SUO_WINO_PP_TILES")) : 1024;
-    return on != 0 && tiles >= from && (tiles & 1) == 0;
 }
 
 // a.Wp = weights packed by pack_wino_weight_bf16x3 / _f16x2 (uint16 under a float pointer); 128 -> 128 or 64 -> 64 channels
@@ -763,8 +736,7 @@ static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
     if (NP == 2 && (!a.oscale || !a.range_flag)) { suo_set_error("conv3x3_wino_f16x2: oscale / range_flag missing"); return SUO_ERR_ARG; }
     if (a.OH == a.H && a.OW == a.W && a.N == 64 && a.C == 64) {
         const int tiles64 = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-        if (NP == 2 && wino_pp(tiles64)) hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, 2, false, true>), dim3(tiles64 / 2), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, NP>), dim3(tiles64), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 2, NP>), dim3(tiles64), dim3(256), 0, s, a);
         SUO_HIP_CHECK(hipGetLastError());
         return SUO_OK;
     }
@@ -773,8 +745,7 @@ static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-    if (NP == 2 && wino_pp(tiles)) hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, 2, false, true>), dim3(tiles / 2), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -793,11 +764,7 @@ int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s) {
         // (with an up-sampled addend the kernel would need 14-23 registers more than the 256 a two-workgroup-per-CU kernel has: it spilled and measured
         //  SLOWER than the two launches, profiles/REJECTED.md -- not built; csrc/net.hip does not ask for it)
         if (a.up) { suo_set_error("conv3x3_wino_f16x2_fused: the next block's conv1 cannot ride on a tail with an up-sampled addend"); return SUO_ERR_ARG; }
-        if (wino_pp(tiles)) hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true, true>), dim3(tiles / 2), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
-    } else if (wino_pp(tiles)) {
-        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2, false, true>), dim3(tiles / 2), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, false, true>), dim3(tiles / 2), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
     } else if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());

@@ -422,36 +422,3 @@ def test_chain_head_range_guard(ops):
     a2 = a.clone()
     a2[100, 3] = 5000.0
     assert ops.conv1x1_chain_head_f16x2(a2, w1, b, w2, np.zeros(64, np.float32), 41, hw)[1] == 1                          # the input
-
-
-@pytest.mark.parametrize("L,H,W", [(32, 64, 64), (64, 32, 32), (33, 64, 64)])
-def test_two_tiles_per_workgroup_form_is_bit_identical(ops, monkeypatch, L, H, W):
-    """Round 6: from 1024 tiles the fp16 Winograd kernels run TWO tiles per workgroup of eight waves, the second wave group one barrier interval behind the first
-    (csrc/conv_wino_x3.hip: PP) -- the same instruction stream per tile, so every output must equal the one-tile-per-workgroup form's bit for bit: fused tail, with the
-    up-sampled addend, with the next block's conv1, the 3x3 alone, the 64 -> 64 form.  (33 crops: an odd multiple of 32 tiles is still even.)"""
-    rng = np.random.default_rng(L + H)
-    x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
-    skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
-    low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda()
-    w2 = (rng.standard_normal((128, 128, 3, 3)) / 34).astype(np.float32)
-    b2 = (rng.standard_normal(128) * 0.2).astype(np.float32)
-    w3 = (rng.standard_normal((256, 128)) / 11).astype(np.float32)
-    b3 = rng.standard_normal(256).astype(np.float32)
-    n_pro = (rng.uniform(0.5, 1.5, 256).astype(np.float32), (rng.standard_normal(256) * 0.1).astype(np.float32))
-    n_w1 = (rng.standard_normal((128, 256)) / 16).astype(np.float32)
-    n_b1 = (rng.standard_normal(128) * 0.1).astype(np.float32)
-    x64 = torch.from_numpy(rng.standard_normal((max(L // 4, 8), 2 * H, 2 * W, 64)).astype(np.float32)).cuda()
-    w64 = (rng.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
-    b64 = (rng.standard_normal(64) * 0.2).astype(np.float32)
-
-    def run():
-        r = [ops.conv3x3_wino_f16x2_conv1x1_skip_up(x, w2, b2, w3, b3, skip)[0], ops.conv3x3_wino_f16x2_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low)[0],
-             ops.conv3x3_wino_f16x2(x, w2, b2, relu=True)[0], ops.conv3x3_wino_f16x2(x64, w64, b64, relu=True)[0]]
-        o, nx, _ = ops.conv3x3_wino_f16x2_tail_next(x, w2, b2, w3, b3, skip, None, n_pro, n_w1, n_b1)
-        return r + [o, nx]
-    monkeypatch.setenv("SUO_WINO_PP", "0")
-    one = run()
-    monkeypatch.setenv("SUO_WINO_PP", "1")
-    two = run()
-    for k, (p, q) in enumerate(zip(one, two)):
-        assert torch.isfinite(q).all() and torch.equal(p, q), k
