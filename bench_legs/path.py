@@ -179,7 +179,7 @@ def drop_in_leg(L, pool, n=40):
     return out
 
 
-def slam_leg(n_views=60, n_obj=8):
+def slam_leg(n_views=60, n_obj=8, on_device=True):
     """BASELINE configs[2]: one synthetic sequence through ObjectSLAM.process_view in SLAM mode, the reference's two meters
     (lib/object_slam.py:155-164, 421-427, 444-451): tracking = network pass without priors + camera-pose hypotheses + network pass with
     device-rendered priors for the symmetric objects + PnP + re-initialisation checks + current-view LM; global optimisation = the
@@ -192,7 +192,8 @@ def slam_leg(n_views=60, n_obj=8):
     sd = weights.make_random_state_dict(0, 8.0)
     out = None
     for rep in range(2):                        # the first pass pays graph captures / first launches
-        slam = ObjectSLAM(None, seq["mesh_db"], debug_gt_kp=True, manual_kp_std=0.01, state_dict=sd, max_crops=max(16, n_obj), run_network_in_debug=True)
+        slam = ObjectSLAM(None, seq["mesh_db"], debug_gt_kp=True, manual_kp_std=0.01, state_dict=sd, max_crops=max(16, n_obj), run_network_in_debug=True,
+                          debug_gt_on_device=on_device)
         t0 = time.perf_counter()
         for vw in seq["views"]:
             slam.process_view(vw["view_id"], vw["image"], vw["K"], vw["obj_ids"].copy(), vw["bboxes"].copy(), vw["model_kps"], vw["model_kps_masks"],
@@ -210,7 +211,16 @@ def slam_leg(n_views=60, n_obj=8):
                "global_opt_ms": round(1e3 * slam.opt_time_meter.average(), 3), "global_opts": slam.opt_time_meter.count,
                "wall_ms_per_view": round(1e3 * dt / n_views, 3), "camera_poses": len(slam.cam_poses), "poses": len(err),
                "median_rel_translation_err": round(float(np.median(err)), 5) if err else None,
-               "keypoints": "network run on the frame's pixels (both passes), output replaced by projected GT + N(0,0.01^2) (debug_gt_kp)"}
+               "keypoints": "network run on the frame's pixels (both passes), output replaced by projected GT + N(0,0.01^2) (debug_gt_kp)" +
+                            (" ON THE DEVICE (float32, what the network emits): the view continues on the product route -- masks / compaction / PnP as one device chain, "
+                             "one read-back per pass (ObjectSLAM._run_kp_model_chain)" if on_device else " on the host (rounds 1-5's leg: the reference's host-side debug route)")}
+    if on_device:
+        # rounds 1-5's figure beside it: the same sequence on the host-side debug route (three read-backs per pass, Python compaction, PnP on host arrays)
+        try:
+            host = slam_leg(n_views, n_obj, on_device=False)
+            out["host_debug_route"] = {k: host[k] for k in ("tracking_ms_per_view", "global_opt_ms", "wall_ms_per_view", "median_rel_translation_err")}
+        except Exception as e:
+            out["host_debug_route"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -191,7 +191,7 @@ class ObjectSLAM:
                  debug_gt_kp=False, sfm_mode=False, single_view_mode=False, viz_cov=False, do_viz_extra=False,
                  global_opt_every=10, kp_var_thresh=0.2, bbox_thresh=0.9, bbox_inflate=0.0, manual_kp_std=0.005,
                  opt_init_with_outliers=False, give_all_prior=False, state_dict=None, max_crops=16, seed=0, verbose=False,
-                 device_chain=True, run_network_in_debug=False):
+                 device_chain=True, run_network_in_debug=False, debug_gt_on_device=False):
         """Same keyword surface as the reference.  ``chkpt_path`` is a torch checkpoint whose ``['model']`` is the
         PkpNet state_dict (object_slam.py:92-97); ``state_dict`` may be given directly instead."""
         self.mesh_db = mesh_db
@@ -223,6 +223,9 @@ class ObjectSLAM:
         # frame's pixels and discard what it says in favour of the ground-truth keypoints -- random weights give meaningless
         # keypoints, a SLAM sequence needs meaningful ones, and the view's time must include the network
         self.run_network_in_debug = bool(run_network_in_debug and debug_gt_kp and state_dict is not None)
+        # ... and, with debug_gt_on_device, make that substitution WHERE THE NETWORK'S OUTPUT LIES: the ground-truth keypoints (+ the same noise draws) overwrite the
+        # device tensors in float32 -- the type the network emits -- and the view continues on the product route (_run_kp_model_chain), not on the host restatement
+        self.debug_gt_on_device = bool(debug_gt_on_device and self.run_network_in_debug and device_chain)
         if not debug_gt_kp or self.run_network_in_debug:
             from .pkpnet import PkpNet
             if state_dict is None:
@@ -671,6 +674,8 @@ class ObjectSLAM:
         objects of the frame (the reference loops lambdatwist.pnp per object)."""
         L = len(obj_ids)
         K_bbox = fix_K_for_bbox_ndc_many(K, bboxes).astype(np.float32)            # float32 container as in the reference (:1082)
+        if self.device_chain and self.model is not None and (not self.debug_gt_kp or self.debug_gt_on_device):
+            return self._run_kp_model_chain(img, K_bbox, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks_gt, uv_gt, prior_dets)
         cov_uv = None
         if not self.debug_gt_kp or self.run_network_in_debug:
             import torch
@@ -738,6 +743,60 @@ class ObjectSLAM:
             ret.append({"pose": pose, "inliers": inliers, "kp_mask": kp_masks[k], "model_kp": kp_model, "uv_gt": uv_gt,
                         "uv_pred": uv_pred, "cov_pred": cov_pred, "K": K_kp,
                         "score": 0.0 if inliers.size == 0 else float(inliers.astype(np.float32).mean())})
+        return ret
+
+    def _run_kp_model_chain(self, img, K_bbox, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks_gt, uv_gt, prior_dets):
+        """__run_kp_model (object_slam.py:1077-1167) of a SLAM pass with everything between the network and the PnP poses on the device: network -> masks ->
+        compaction -> normalisation -> batched PnP -> acceptance as ONE stream-ordered chain (suo_frame_geom_launch with do_lm = 0: the camera hypotheses of
+        :975-1072 continue on the host) and ONE read-back, where the host route makes three read-backs, compacts in Python and ships the points back for the PnP
+        launch.  Same kernels on the same numbers: PnP poses and statuses are those of the host route bit for bit (tests/test_gpu_frame_geom.py)."""
+        import torch
+        from .frame_geom import FrameGeometry, kbbox_terms
+        from .pkpnet import keypoint_masks
+        L = len(obj_ids)
+        prior_uv = prior_mask = None
+        if prior_dets:
+            prior_uv = np.zeros((L, NUM_KP, 2), dtype=np.float32)
+            prior_mask = np.zeros((L, NUM_KP), dtype=np.uint8)
+            for k, obj_id in enumerate(obj_ids):
+                if obj_id in prior_dets:
+                    prior_uv[k], prior_mask[k] = prior_dets[obj_id]
+        kinv, camk = kbbox_terms(K_bbox)
+        min_depth = np.array([0.5 * self.mesh_db[o]["diameter"] for o in obj_ids], dtype=np.float64)
+        if self._fg is None or self._fg.max_crops < L:
+            self._fg = FrameGeometry(max(16, L), 1)
+        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+        gt_uv = gt_mask = None
+        if self.debug_gt_kp:                                  # (debug_gt_on_device: the same draws, in the same order, as the host route's :1129-1131)
+            gt_mask = np.ascontiguousarray(kp_masks_gt, dtype=np.uint8)
+            gt_uv = np.zeros((L, NUM_KP, 2), dtype=np.float32)
+            for k in range(L):
+                m = gt_mask[k].astype(bool)
+                u = uv_gt[k][m].astype(np.float64)
+                gt_uv[k][m] = (u + self._rng.normal(scale=0.01, size=u.shape)).astype(np.float32)
+        kps_host = np.ascontiguousarray(model_kps, dtype=np.float32)
+        for _attempt in range(2):
+            pred = self.model(self._frame_on_device(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None, prior_uv=prior_uv, prior_mask=prior_mask, check=False)
+            dev = pred["uv"].device
+            if gt_uv is not None:
+                uv_dev, masks_dev = torch.from_numpy(gt_uv).to(dev), torch.from_numpy(gt_mask).to(dev)
+            else:
+                uv_dev, masks_dev = pred["uv"], keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, self.bbox_thresh, vt)
+            self._fg.launch([0, L], uv_dev, pred["cov"], masks_dev, torch.from_numpy(kps_host).to(dev), kinv, camk, min_depth, seed=self._pnp_seed,
+                            use_cov=not self.no_network_cov, do_lm=False)
+            r = self._fg.fetch(copy=True)
+            if not self.model.range_exceeded():               # (fp16 form only: the fetch synchronised; on True the network is on bf16x3 now, once more)
+                break
+        self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
+        ret = []
+        for k, obj_id in enumerate(obj_ids):
+            m = r["mask"][k]
+            n = int(r["n_kp"][k])
+            self.obj_num_dets[obj_id] += 1
+            self.obj_num_det_kps[obj_id] += n
+            ret.append({"pose": r["T_pnp"][k].copy() if r["accepted"][k] else None, "inliers": np.ones(n, dtype=bool), "kp_mask": m,
+                        "model_kp": model_kps[k][m].astype(np.float64), "uv_gt": uv_gt, "uv_pred": r["uv"][k][m].astype(np.float64),
+                        "cov_pred": None if self.no_network_cov else r["cov"][k][m], "K": K_bbox[k].astype(np.float64), "score": 0.0 if n == 0 else 1.0})
         return ret
 
     # ---------------------------------------------------------------------------------------------
