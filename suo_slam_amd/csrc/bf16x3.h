@@ -30,11 +30,7 @@ typedef float s3_f32x2 __attribute__((ext_vector_type(2)));
 // bf16(a) in the low half, bf16(b) in the high half, round-to-nearest-even (one v_cvt_pk_bf16_f32)
 // (-DSUO_S3_TRUNC builds the truncating split of rounds 1-3 again, device and host: tools/bias_ab.sh measures the two side by side)
 __device__ __forceinline__ unsigned s3_pack_rn(float a, float b) {
-#ifdef SUO_S3_TRUNC
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-#else
     return __builtin_bit_cast(unsigned, __builtin_convertvector(s3_f32x2{a, b}, s3_bf16x2));
-#endif
 }
 // the two halves of such a pair as fp32 values
 __device__ __forceinline__ float s3_lo(unsigned p) { return __uint_as_float(p << 16); }
@@ -45,9 +41,6 @@ static inline uint16_t s3_rn_host(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
     if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);      // inf / nan: keep the leading bits
-#ifdef SUO_S3_TRUNC
-    return (uint16_t)(u >> 16);
-#endif
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }

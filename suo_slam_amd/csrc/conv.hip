@@ -21,6 +21,7 @@
 
 #include "buffer_ops.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 #ifndef SUO_CONV_SCALAR_WAVE
 #define SUO_CONV_SCALAR_WAVE 1
@@ -35,9 +36,6 @@
                                     // 130.2 -- SUO_CONV_DYN_LDS experiment, round 2); the fused conv2 -> conv3 kernel takes 210 = two.
 #ifndef SUO_CONV_BRING3
 #define SUO_CONV_BRING3 4           // weight-ring slots of the 3x3 kernels (must divide 9 * CK / 8)
-#endif
-#ifndef SUO_CONV_EXP
-#define SUO_CONV_EXP 0
 #endif
 #ifndef SUO_GEMM_SCALAR_WAVE
 #define SUO_GEMM_SCALAR_WAVE 1
@@ -256,11 +254,11 @@ int launch_gemm1x1(const GemmArgs& a, hipStream_t s) {
     // tile choice: keep >= ~2 workgroups per CU where the problem allows it
     const long tiles128 = (long)((a.M + 127) / 128) * (a.N / 128 > 0 ? a.N / 128 : 1);
     const long tiles12864 = (long)((a.M + 127) / 128) * (a.N / 64);
-    static const int force_cfg = getenv("SUO_GEMM_CFG") ? atoi(getenv("SUO_GEMM_CFG")) : 0;           // tuning aid only
+    static const int force_cfg = (int)SUO_TUNE("SUO_GEMM_CFG", 0);           // tuning aid only
     int cfg = ((a.N % 128) == 0 && tiles128 >= 512) ? 1 : (tiles12864 >= 384 ? 2 : 3);      // 128x128 | 128x64 | 64x64
     if (force_cfg >= 2 || (force_cfg == 1 && (a.N % 128) == 0)) cfg = force_cfg;
     // whole tiles (every shape of this network): the persistent, branch-free kernel of csrc/gemm_persist.hip
-    static const int persist = getenv("SUO_GEMM_PERSIST") ? atoi(getenv("SUO_GEMM_PERSIST")) : 1;     // 0: A/B against the one-tile kernel
+    static const int persist = (int)SUO_TUNE("SUO_GEMM_PERSIST", 1);     // 0: A/B against the one-tile kernel
     if (persist && a.n_valid == a.N && a.M % (cfg == 3 ? 64 : 128) == 0) return launch_gemm_persist(a, cfg, s);
     if (cfg == 1) return launch_gemm_cfg<2, 2, 2, 2, false>(a, s);
     if (cfg == 2) return launch_gemm_cfg<2, 1, 2, 2, false>(a, s);
@@ -431,11 +429,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
         const float* as = &As[buf][0];
-#if defined(SUO_CONV_PROFILE) && (SUO_CONV_EXP & 2)              // timing experiment: activations staged once (wrong results)
-        const bool more = false;
-#else
         const bool more = c + 1 < nch;
-#endif
         // the G groups of this chunk, fully unrolled; every load is requested well ahead of its use and pinned there
         f32x4 afr[2][TM];
         aread(as, 0, afr[0]);
@@ -443,9 +437,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         for (int g = 0; g < G; ++g) {
             if (g == 0 && more) gload(c + 1, 0);
             if (g == G / 2 && more) { sstore(buf ^ 1, 0); gload(c + 1, 1); }
-#if !(defined(SUO_CONV_PROFILE) && (SUO_CONV_EXP & 1))      // timing experiment: weights never re-fetched (wrong results)
             bload(c * G + g + R - 1, bring[(g + R - 1) % R]);
-#endif
 #if SUO_CONV_AF_PIPE
             if (g + 1 < G) aread(as, g + 1, afr[(g + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -616,7 +608,7 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
     if (a.N % BN || a.C % CK) { suo_set_error("conv%dx%d: N=%d C=%d unsupported", KS, KS, a.N, a.C); return SUO_ERR_ARG; }
     const int tiles = ((a.OW + TW - 1) / TW) * ((a.OH + TH - 1) / TH) * a.L;
     dim3 grid(tiles, a.N / BN);
-    static const int dyn_lds = getenv("SUO_CONV_DYN_LDS") ? atoi(getenv("SUO_CONV_DYN_LDS")) : 0;      // occupancy experiments only
+    static const int dyn_lds = (int)SUO_TUNE("SUO_CONV_DYN_LDS", 0);      // occupancy experiments only
     hipLaunchKernelGGL((convk_kernel<KS, ST, CK, TH, TW, TM, TN, WGM, WGN, FUSE>), grid, dim3(WGM * WGN * 64), dyn_lds, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
@@ -630,7 +622,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
     const long px = (long)a.L * a.OH * a.OW;
     if (px <= 4096 && (a.C == 128 || a.C == 64 || a.C == 32)) return launch_conv3x3_small(a, s);
     const long t128 = ((px + 127) / 128) * (a.N / 64);
-    static const int force = getenv("SUO_CONV3_CFG") ? atoi(getenv("SUO_CONV3_CFG")) : 0;     // tuning aid only
+    static const int force = (int)SUO_TUNE("SUO_CONV3_CFG", 0);     // tuning aid only
     if (force == 1) return launch_conv_cfg<3, 1, 32, 8, 8, 1, 1, 2, 2>(a, s);
     if (force == 2 && (a.N % 128) == 0) return launch_conv_cfg<3, 1, 32, 8, 16, 2, 2, 2, 2>(a, s);
     if (force == 3) return launch_conv_cfg<3, 1, 32, 8, 16, 1, 1, 4, 2>(a, s);
@@ -651,8 +643,8 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 // conv2 (3x3, 128 -> 128) + conv3 (1x1, 128 -> 256) + skip of a Residual block in one launch (FUSE above)
 bool conv3x3_fusable(const ConvArgs& a) {
     const long px = (long)a.L * a.OH * a.OW;
-    static const int fuse = getenv("SUO_CONV_FUSE") ? atoi(getenv("SUO_CONV_FUSE")) : 1;              // 0: A/B against the separate launches
-    static const long min_tiles = getenv("SUO_CONV_FUSE_TILES") ? atol(getenv("SUO_CONV_FUSE_TILES")) : 1024;
+    static const int fuse = (int)SUO_TUNE("SUO_CONV_FUSE", 1);              // 0: A/B against the separate launches
+    static const long min_tiles = (long)SUO_TUNE("SUO_CONV_FUSE_TILES", 1024);
     return fuse && a.N == 128 && a.C == 128 && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && (px + 127) / 128 >= min_tiles;
 }
 int launch_conv3x3_fused(const ConvArgs& a, hipStream_t s) {

@@ -19,6 +19,7 @@
 // kernel by summation order and by the rounding of U (observed <= 2e-6 of the output range).
 #include "buffer_ops.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 
@@ -66,21 +67,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     float* V = &S[2 * HSZ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if defined(SUO_WINO_PRIO)
-    // experiment: asymmetric issue priority between the two workgroups of a CU.  A workgroup has one wave per SIMD, so the two
-    // co-resident ones sit in two wave slots of every SIMD; the slot number (HW_ID[3:0]) is inherited by whoever replaces a finished
-    // workgroup: odd slots always win the MFMA pipe, even slots fill the gaps (the symmetric default lets the two fall into lock-step)
-    {
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
-#if SUO_WINO_PRIO == 1
-        if (hw & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#elif SUO_WINO_PRIO == 2
-        if (hw & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-#elif SUO_WINO_PRIO == 3
-        if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
-    }
-#endif
     const int tiles_x = (a.OW + W_TW - 1) / W_TW, tiles_y = (a.OH + W_TH - 1) / W_TH;
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);          // XCD-aware tile order (csrc/conv.hip)
@@ -109,16 +95,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
     w_f32x4 areg[NLD];
     auto gload = [&](int c) {
-#ifdef SUO_WINO_EXP_NOGLOAD
-        return;                                                   // timing experiment (wrong results): no halo fetch at all
-#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) areg[i] = buf_load(in_srd, avoff[i], c * W_CK * 4);
     };
     auto sstore = [&](int buf) {
-#ifdef SUO_WINO_EXP_NOSSTORE
-        return;                                                   // timing experiment (wrong results): what would LDS-DMA staging of the halo save at most?
-#endif
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
@@ -133,11 +113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const int gtot = nch * 32;
     w_f32x4 bring[W_RING];
     auto bload = [&](int gg, w_f32x4& b) {
-#ifdef SUO_WINO_EXP_W0
-        const int gc = gg & 1;                                    // timing experiment: weights from two cache-resident groups (wrong results)
-#else
         const int gc = gg < gtot ? gg : gtot - 1;
-#endif
         b = buf_load(w_srd, wvoff, gc * NB * 1024);
     };
     // ---- transform: thread = (tile t, channel quad q, half h); h is wave-uniform (waves 0,1 / 2,3) -----------------------
@@ -154,16 +130,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
             L1[c] = *(const w_f32x4*)(hs + (W_IW + c) * W_PKH);
             L2[c] = *(const w_f32x4*)(hs + (2 * W_IW + c) * W_PKH);
         }
-#ifdef SUO_WINO_EXP_NOXFORM
-        {   // timing experiment (wrong results): the transform's LDS traffic without its 64 additions per thread -- the most that doing
-            // the B^T d B arithmetic on the matrix pipe could take off the VALU
-            float* va0 = &V[((th ? 3 : 0) * 4) * 32 * W_PKV + vbase];
-            float* vb0 = &V[((th ? 2 : 1) * 4) * 32 * W_PKV + vbase];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { *(w_f32x4*)(va0 + c * 32 * W_PKV) = L0[c]; *(w_f32x4*)(vb0 + c * 32 * W_PKV) = c & 1 ? L1[c] : L2[c]; }
-            return;
-        }
-#endif
         // rows of B^T d:  half 0 (input rows 0,1,2): xi0 = r0 - r2, xi1 = r1 + r2;  half 1 (rows 1,2,3): xi3 = r1 - r3, xi2 = r2 - r1
         w_f32x4 eA[4], eB[4];
 #pragma unroll
@@ -457,8 +423,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 // Measured at 128 -> 128 channels (tools/bench_wino.py): 1.46-1.75x the direct kernel from 256 tiles of 8 x 16 pixels up
 // (64x64 maps of 8 crops, 16x16 maps of 128 crops), 0.5x at 64 tiles -- there the direct kernel's smaller tiles fill more CUs.
 bool conv3x3_wino_pays(const ConvArgs& a, long min_tiles_arg) {
-    static const int on = getenv("SUO_CONV_WINO") ? atoi(getenv("SUO_CONV_WINO")) : 1;                  // 0: A/B against the direct kernels
-    static const long min_tiles_env = getenv("SUO_CONV_WINO_TILES") ? atol(getenv("SUO_CONV_WINO_TILES")) : -1;
+    static const int on = (int)SUO_TUNE("SUO_CONV_WINO", 1);                  // 0: A/B against the direct kernels
+    static const long min_tiles_env = (long)SUO_TUNE("SUO_CONV_WINO_TILES", -1);
     const long min_tiles = min_tiles_env >= 0 ? min_tiles_env : (min_tiles_arg >= 0 ? min_tiles_arg : 256);
     const long tiles = (long)((a.OW + W_TW - 1) / W_TW) * ((a.OH + W_TH - 1) / W_TH) * a.L;
     return on && ((a.N == 128 && a.C == 128) || (a.N == 64 && a.C == 64)) && a.OH == a.H && a.OW == a.W && a.OH >= 8 && a.OW >= 16 && tiles >= min_tiles;

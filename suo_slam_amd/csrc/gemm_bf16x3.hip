@@ -16,6 +16,7 @@
 #include "f16x2.h"
 #include "buffer_ops.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 
@@ -147,9 +148,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? S
     constexpr int BSL = NP == 2 ? SUO_X3_F16_BSLOTS : X3_BSLOTS;          // weight k-groups in flight
     x3_u32x4 braw[BSL][NCB][NP];
     auto requestA = [&](int ks, int slot) {
-#ifdef SUO_X3_EXP_NOLOADA
-        for (int i = 0; i < X3_NR; ++i) araw[slot][i] = x3_f32x4{(float)ks, 1.f, 2.f, (float)i};
-#else
         if (!DUAL || ks < ns1) {
 #pragma unroll
             for (int i = 0; i < X3_NR; ++i) araw[slot][i] = buf_load(a1_srd, avoff1[i], ks * X3_BK * 4);
@@ -157,7 +155,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? S
 #pragma unroll
             for (int i = 0; i < X3_NR; ++i) araw[slot][i] = buf_load(a2_srd, avoff2[i], (ks - ns1) * X3_BK * 4);
         }
-#endif
     };
     auto requestB = [&](int kg, int slot) {                                   // kg: 16-wide k-group
 #pragma unroll
@@ -234,9 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? S
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) af[h][rb][p] = *(const x3_bf16x8*)&As[p * PLANE + (32 * RB * wm + 32 * rb + (lane & 31)) * X3_PITCH + ko + 16 * h];
             __builtin_amdgcn_sched_barrier(0);
-#ifndef SUO_X3_EXP_NOSPLIT
             if (ks + 1 < nsteps) split_store(ks + 1, (u + 1) % X3_ASLOTS, (u + 1) & 1);
-#endif
             requestA(ks + X3_ASLOTS < nsteps ? ks + X3_ASLOTS : nsteps - 1, u);
 #pragma unroll
             for (int h = 0; h < X3_GH; ++h) {
@@ -301,9 +296,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP == 2 ? S
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.f);
                 }
-#ifdef SUO_X3_EXP_NOSTORE
-                if (o[0] == 123456.f)
-#endif
                 if (!POOL || g.out) buf_store(o, o_srd, row < M ? (row * ldo + col) * 4 : BUF_OOB);
                 if (POOL) {
                     x3_f32x4 hm;                                              // max over image columns j, j ^ 1 (8 lanes apart within a row of 16: row_ror:8)
@@ -548,7 +540,7 @@ static int launch_gemm_split(const GemmArgs& g, const uint16_t* Wx3, hipStream_t
     }
     const bool n64 = g.N % 128 != 0;                                          // 64 output channels: 64-column tiles
     // launches of fewer 128-row tiles than four per CU (the one-frame call: conv1 / lin at 64x64 for 8 crops = 256 / 512 tiles) take 64-row tiles: 2.206 -> 2.174 ms per network call, one frame in flight 2.857 -> 2.825 (tools/latency_ab.sh)
-    static const long rb1_max_tiles = getenv("SUO_X3_ROWS64_MAX_TILES") ? atol(getenv("SUO_X3_ROWS64_MAX_TILES")) : 1023;
+    static const long rb1_max_tiles = (long)SUO_TUNE("SUO_X3_ROWS64_MAX_TILES", 1023);
     const long tiles128 = (long)((g.M + 127) / 128) * (n64 ? 1 : g.N / 128);
     const bool rows64 = !n64 && !g.pool_out && X3_BK == 16 && tiles128 <= rb1_max_tiles;
     const int tiles = rows64 ? ((g.M + 63) / 64) * (g.N / 128) : (int)tiles128;

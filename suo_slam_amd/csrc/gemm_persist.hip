@@ -18,6 +18,7 @@
 //     epilogue patch (50 KB of LDS in all) lets THREE workgroups share a CU.
 #include "buffer_ops.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 
@@ -40,9 +41,6 @@ constexpr int GP_MAX_PRO_K = 512;       // channels of a fused BN-ReLU prologue 
 #ifndef SUO_GEMM_EPI_PREFETCH
 #define SUO_GEMM_EPI_PREFETCH 0     // 1: request bias / first residual block during the tile's last K-step (measured: no gain
 #endif                              //    with 3 workgroups per CU, and the 128x128 residual variant starts to spill)
-#ifndef SUO_GEMM_EXP
-#define SUO_GEMM_EXP 0
-#endif
 #ifndef SUO_GEMM_WAVES_PER_EU
 #define SUO_GEMM_WAVES_PER_EU 3
 #endif
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
     auto epi_prefetch = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bvall[j] = buf_load(bias_srd, bv, (n0 + j * 32) * 4);
-        if (HAS_R && !(SUO_GEMM_EXP & 8)) rload(0);
+        if (HAS_R) rload(0);
     };
     // (Tried, not kept: storing / loading straight in the accumulator layout -- one dword op of a wave covers two full
     // 128-byte row segments, no LDS patch, no wave barriers -- is 2-10 % SLOWER than this transposed 16-byte form: four
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         // each 32 x 32 accumulator goes through the 16-row patch in two halves: registers 0-7 hold rows 0-15, 8-15 rows 16-31
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (HAS_R && i > 0 && !(SUO_GEMM_EXP & 8)) rload(i);
+            if (HAS_R && i > 0) rload(i);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -236,9 +234,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
 #pragma unroll
                             for (int t = 0; t < 4; ++t) o[t] = fmaxf(o[t], 0.f);
                         }
-#if SUO_GEMM_EXP & 2
-                        if (o[0] == 12345.678f)
-#endif
                         if (full) buf_store(o, o_srd, ov, ((i * blk + 8 * (2 * h + k)) * a.ldo + j * 32) * 4);     // unpredicated: stores count in vmcnt too
                         if constexpr (POOL) {
                             if (i == 0) keep[j][2 * h + k] = o;
@@ -277,13 +272,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
         for (int ss = 0; ss < 4; ++ss) {
             // weights ride a static ring of 4 k-group slots (slot = group of the chunk), requested 3 groups ahead into
             // the slot the previous group just released; past the last step: a harmless re-read of chunk 0
-#if !(SUO_GEMM_EXP & 4)      // SUO_GEMM_EXP: timing-only experiments (wrong results): 1 no activation loads, 2 no stores,
             if (ss == 0) bgroup(kc, n0, 3, bring[3]);      //               4 no weight loads, 8 no residual loads
             else bgroup(nkc, nn0, ss - 1, bring[ss - 1]);
-#endif
-#if !(SUO_GEMM_EXP & 1)
             if (ss == 0) gload(a_free);
-#endif
 #if SUO_GEMM_EPI_PREFETCH
             if (ss == 1 && kc + 1 == nch) epi_prefetch();      // workgroup-uniform: last K-step of the tile
 #endif
@@ -309,12 +300,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(S
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bring[ss][j][t], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-#if SUO_GEMM_A_DEPTH != 2 && !(SUO_GEMM_EXP & 32)             // (32: no LDS staging, 16: no per-step barrier)
+#if SUO_GEMM_A_DEPTH != 2
         sstore(a_next, has_pro && nkc < nch1 ? nkc * BK : -1, buf ^ 1);
 #endif
-#if !(SUO_GEMM_EXP & 16)
         __syncthreads();
-#endif
         if (kc + 1 == nch) {                                // workgroup-uniform: the tile is complete
             epilogue();
             kc = 0; tile += t_stride; m0 = tile_m0(tile / ntn); n0 = (tile % ntn) * BN;
@@ -366,7 +355,7 @@ bool gemm1x1_can_pool(const GemmArgs& a) {
 }
 
 int launch_gemm_persist(const GemmArgs& a, int cfg, hipStream_t s) {
-    static const int max_wgs = getenv("SUO_GEMM_WGS") ? atoi(getenv("SUO_GEMM_WGS")) : 768;       // tuning aid
+    static const int max_wgs = (int)SUO_TUNE("SUO_GEMM_WGS", 768);       // tuning aid
     if (cfg == 3) return launch_persist_cfg<1, 1, 2, 2>(a, 2 * max_wgs, s);
     if (cfg == 2) return launch_persist_cfg<2, 1, 2, 2>(a, max_wgs, s);
     return launch_persist_cfg<2, 2, 2, 2>(a, max_wgs, s);

@@ -12,6 +12,7 @@
 
 #include "../../include/suo_hip.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 int launch_pnp_replay(int n_obj, const int* offsets, const double* xs, const double* ys, double threshold, const int* iter_tab, const int* iter_tab_off,
@@ -73,7 +74,7 @@ struct Arena {
             // priority level the stream also gets its own hardware queue instead of sharing one with the CNN's streams.
             int lo = 0, hi = 0;
             SUO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            static const int prio = getenv("SUO_GEOM_PRIO") ? atoi(getenv("SUO_GEOM_PRIO")) : 2;      // 2: highest, 1: default, 0: lowest (A/B only)
+            static const int prio = (int)SUO_TUNE("SUO_GEOM_PRIO", 2);      // 2: highest, 1: default, 0: lowest (A/B only)
             SUO_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio == 2 ? hi : (prio == 0 ? lo : 0)));
         }
         if (bytes <= cap) return SUO_OK;
@@ -427,10 +428,10 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     // call fall back to the 1024-thread single-workgroup build (csrc/lm_big.hip).
     int max_edges = 0;
     for (int i = 0; i < n_prob; ++i) max_edges = std::max(max_edges, probs[i].n_edge);
-    static const int big_from = getenv("SUO_LM_BIG_EDGES") ? atoi(getenv("SUO_LM_BIG_EDGES")) : 512;       // (640 edges: 9.5 vs 12.2 ms, 1000: 10.9 vs 16.0, 350: 8.6 vs 6.1)
-    static const int grid_wgs = getenv("SUO_LM_GRID_WGS") ? atoi(getenv("SUO_LM_GRID_WGS")) : 32;          // 0: never use the grid kernel
+    static const int big_from = (int)SUO_TUNE("SUO_LM_BIG_EDGES", 512);       // (640 edges: 9.5 vs 12.2 ms, 1000: 10.9 vs 16.0, 350: 8.6 vs 6.1)
+    static const int grid_wgs = (int)SUO_TUNE("SUO_LM_GRID_WGS", 32);          // 0: never use the grid kernel
     // camera tracking (ObjectSLAM.optimize(curr_only=True)): one free camera, every object fixed -> one wave per problem
-    static const int cam_kernel = getenv("SUO_LM_CAM") ? atoi(getenv("SUO_LM_CAM")) : 1;                    // 0: general kernel (A/B)
+    static const int cam_kernel = (int)SUO_TUNE("SUO_LM_CAM", 1);                    // 0: general kernel (A/B)
     bool cam_only = cam_kernel != 0;
     for (int i = 0; i < n_prob && cam_only; ++i) {
         int nfc = 0, nfo = 0;
@@ -439,27 +440,27 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         cam_only = nfc == 1 && nfo == 0;
     }
     // single-view frames (evaluate.py --nviews 1): no free camera -> block-diagonal system, one wave per object (csrc/lm_frame.hip)
-    static const int frame_kernel = getenv("SUO_LM_FRAME") ? atoi(getenv("SUO_LM_FRAME")) : 8;             // max objects per frame it takes; 0: off (A/B)
+    static const int frame_kernel = (int)SUO_TUNE("SUO_LM_FRAME", 8);             // max objects per frame it takes; 0: off (A/B)
     bool frame_only = frame_kernel > 0 && !cam_only;
     int frame_max_obj = 0;
     for (int i = 0; i < n_prob && frame_only; ++i) {
         int nfc = 0;
         for (int c = 0; c < probs[i].n_cam; ++c) nfc += probs[i].cam_fixed[c] ? 0 : 1;
         // (one wave per object takes <= SUO_LM_FRAME objects: the 16-wave build spills; one wave per frame takes 16)
-        const bool f2 = (getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1) != 0 && frame2_takes(probs[i]);
+        const bool f2 = ((int)SUO_TUNE("SUO_LM_FRAME2", 1) != 0 && frame2_takes(probs[i]));
         frame_only = nfc == 0 && probs[i].n_obj >= 1 && probs[i].n_obj <= (f2 ? 16 : frame_kernel) && probs[i].n_obj <= 16;
         frame_max_obj = std::max(frame_max_obj, probs[i].n_obj);
     }
     if (cam_only) {
         // the camera alone in its graph (what ObjectSLAM.optimize(curr_only=True) builds): registers / LDS only (csrc/lm_cam2.hip)
-        static const int cam2 = getenv("SUO_LM_CAM2") ? atoi(getenv("SUO_LM_CAM2")) : 1;                  // 0: csrc/lm_cam.hip (A/B)
+        static const int cam2 = (int)suo::env_switch("SUO_LM_CAM2", 1);                  // 0: csrc/lm_cam.hip (A/B)
         bool alone = cam2 != 0;
         for (int i = 0; i < n_prob && alone; ++i) alone = probs[i].n_cam == 1 && probs[i].n_edge <= lm_cam2_max_edges();
         if (alone) rc = launch_lm_cam2(g_arena.dev + st.o_structs, n_prob, max_edges, g_arena.stream);
         else rc = launch_lm_cam(g_arena.dev + st.o_structs, n_prob, g_arena.stream);
     } else if (frame_only) {
         // one fixed camera (the single-view frame of evaluate.py): one WAVE per frame, the objects side by side (csrc/lm_frame2.hip)
-        static const int frame2 = getenv("SUO_LM_FRAME2") ? atoi(getenv("SUO_LM_FRAME2")) : 1;              // 0: one wave per object (A/B)
+        static const int frame2 = (int)SUO_TUNE("SUO_LM_FRAME2", 1);              // 0: one wave per object (A/B)
         bool one_cam = frame2 != 0;
         for (int i = 0; i < n_prob && one_cam; ++i) one_cam = frame2_takes(probs[i]);
         if (one_cam) rc = launch_lm_frame2(g_arena.dev + st.o_structs, n_prob, frame_max_obj, max_edges, g_arena.stream);
@@ -574,7 +575,7 @@ void suo_ba_ctx_destroy(suo_ba_ctx* c) {
     b.d_io = c->d_io; b.h_io = c->h_io; b.io_cap = c->io_cap; b.d_big = c->d_big; b.big_cap = c->big_cap;
     c->arena.dev = nullptr; c->arena.host = nullptr; c->arena.stream = nullptr;
     delete c;
-    static const size_t keep = getenv("SUO_BA_CTX_POOL") ? (size_t)atoi(getenv("SUO_BA_CTX_POOL")) : 4;      // 0: free at once
+    static const size_t keep = (int)SUO_TUNE("SUO_BA_CTX_POOL", 4);      // 0: free at once
     bool parked = false;
     {
         std::lock_guard<std::mutex> lock(g_ba_pool_mu);

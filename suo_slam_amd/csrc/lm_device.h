@@ -297,10 +297,7 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
 #pragma unroll
             for (int c = 0; c <= r; ++c) L[r][c] = S[(k0 + r) * sp + k0 + c];
     };
-#ifndef SUO_CHOL_EXP          // timing experiments (wrong results): 1 = no factorisation, 2 = no substitutions, 4 = no trailing update
-#define SUO_CHOL_EXP 0
-#endif
-    for (int k0 = 0; k0 < ((SUO_CHOL_EXP & 1) ? 0 : ns); k0 += 6) {
+    for (int k0 = 0; k0 < ns; k0 += 6) {
         double L[6][6], rd[6];
         load_diag(k0, L);
         bool good = true;
@@ -354,7 +351,7 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
         // fp64 operations -> store, one after the other (22 of the 56 us of a 96-row solve, thread 0's wall clock).  Same operations per element: same bits.
         const int m = ns - k0 - 6, base = k0 + 6;
         const int ty = (tid >> 4) & 15, tx = tid & 15;
-        if (tid < 256 && !(SUO_CHOL_EXP & 4)) {
+        if (tid < 256) {
             for (int a0 = 0; a0 < m; a0 += 16) {
                 const int a = a0 + ty;
                 const bool a_ok = a < m;
@@ -387,7 +384,7 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
     // The substitutions by ONE wave (round 5): 2 ns / 6 block steps whose only parallel work is ns rows of six multiply-adds -- with the whole workgroup each step paid a
     // workgroup barrier and four redundant copies of the 6 x 6 solve (16 of the 56 us of a 96-row solve); a wave's LDS operations execute in order, so it needs none.
     // L y = rhs, block by block: every lane solves the 6 x 6 block redundantly, lane t then updates rows t, t + 64 below it
-    if (tid < 64 && !(SUO_CHOL_EXP & 2)) {
+    if (tid < 64) {
         for (int k0 = 0; k0 < ns; k0 += 6) {
             double L[6][6], y[6];
             load_diag(k0, L);

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include "tune.h"
 
 namespace suo {
 
@@ -133,14 +134,12 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // with 3-way split operands (csrc/conv_wino_x3.hip: same accuracy, ~1.2x faster)
 // (read when a network is built, not cached: one process can hold networks of both kinds)
 static bool wino_bf16x3() {
-    const char* e = getenv("SUO_WINO_BF16X3");
-    return (e ? atoi(e) : SUO_WINO_BF16X3_DEFAULT) != 0;
+    return env_switch("SUO_WINO_BF16X3", SUO_WINO_BF16X3_DEFAULT) != 0;
 }
 // SUO_F16X2=0: stay on the three-term bf16 form; default: the large launches run the two-term fp16 form (csrc/f16x2.h: half the MFMAs per product, range-guarded --
 // a call that leaves fp16's range is reported by Net::range_exceeded and the network falls back to the bf16 form, whose planes are packed as well)
 static bool pipe_f16x2() {
-    const char* e = getenv("SUO_F16X2");
-    return wino_bf16x3() && (e ? atoi(e) : 1) != 0;
+    return wino_bf16x3() && env_switch("SUO_F16X2", 1) != 0;
 }
 
 // 1x1 conv W[N][K] with optional per-output scale (BN folded) -> device packed weight + bias
@@ -535,11 +534,11 @@ static double block_bytes(const ResBlockArgs& a, double wb) {
 // --objects L --frames-per-step 1, ms, thresholds 256 / 32768 -> 32 / 4096): L = 1 1.544 -> 1.531, 2 1.631 -> 1.567, 3 1.886 -> 1.678, 4 1.921 -> 1.726, 5 2.155 -> 1.759,
 // 6 2.218 -> 1.800, 7 2.435 -> 1.832, 8 and up unchanged.
 long Net::wino_min_tiles() const {
-    static const long env = getenv("SUO_WINO_FUSE_TILES") ? atol(getenv("SUO_WINO_FUSE_TILES")) : -1;      // (0: never fuse)
+    static const long env = (long)SUO_TUNE("SUO_WINO_FUSE_TILES", -1);      // (0: never fuse)
     return env >= 0 ? env : (pipe_ == 2 ? 32 : 256);
 }
 long Net::x3_min_rows() const {
-    static const long env = getenv("SUO_GEMM_X3_MIN_ROWS") ? atol(getenv("SUO_GEMM_X3_MIN_ROWS")) : -1;
+    static const long env = (long)SUO_TUNE("SUO_GEMM_X3_MIN_ROWS", -1);
     return env >= 0 ? env : (pipe_ == 2 ? 4096 : 32768);
 }
 
@@ -559,9 +558,9 @@ bool Net::residual_tail_is_fused(const ResidualW& r, int L, int H, int W) const 
 //   SUO_RES_FUSED = 0: never; 1: the fp32-pipe kernel (bit-identical to the per-layer launches); 2 (default with SUO_WINO_BF16X3): the bf16x3 kernel
 //   SUO_RES_FUSED_MAX_TILES: largest launch (4 x 8 pixel tiles) that takes it; beyond that the Winograd kernels' larger tiles win
 int Net::residual_in_one_launch(const ResidualW& r, int L, int H, int W) const {
-    static const int mode = getenv("SUO_RES_FUSED") ? atoi(getenv("SUO_RES_FUSED")) : 2;
-    static const long max_tiles = getenv("SUO_RES_FUSED_MAX_TILES") ? atol(getenv("SUO_RES_FUSED_MAX_TILES")) : 768;
-    static const int min_side = getenv("SUO_RES_FUSED_MIN_SIDE") ? atoi(getenv("SUO_RES_FUSED_MIN_SIDE")) : 16;
+    static const int mode = (int)SUO_TUNE("SUO_RES_FUSED", 2);
+    static const long max_tiles = (long)SUO_TUNE("SUO_RES_FUSED_MAX_TILES", 768);
+    static const int min_side = (int)SUO_TUNE("SUO_RES_FUSED_MIN_SIDE", 16);
     if (mode <= 0 || !r.rb_w[0] || H > 32 || W > 32) return 0;
     const long t32 = (long)L * ((H + 3) / 4) * ((W + 7) / 8);
     // Half a round to three rounds of 4 x 8 pixel tiles (one workgroup per CU): the bf16x3 kernel, whatever the map (one frame at 32x32; batched frames at 8x8
@@ -570,11 +569,11 @@ int Net::residual_in_one_launch(const ResidualW& r, int L, int H, int W) const {
     // 8x8 / 4x4 maps (the three per-layer launches spread over all CUs, 13.5 us), many tiles (the Winograd kernels) -- stays per-layer.
     // (129 ... 255 tiles, e.g. the 5 crops of a SLAM pass at 32x32: one partial round of the bf16x3 kernel, 30 us, against 4 x 4 tiles
     //  that no longer fit one per CU, ~40)
-    static const long x3_from_env = getenv("SUO_RES_FUSED_X3_FROM") ? atol(getenv("SUO_RES_FUSED_X3_FROM")) : 129;
+    static const long x3_from_env = (long)SUO_TUNE("SUO_RES_FUSED_X3_FROM", 129);
     // the fp16 form of the 4 x 8-tile kernel streams a third less weight per workgroup (csrc/res_small_x3.hip, NP = 2): 16.8 us at 64 tiles (16x16, 8 crops) where the
     // fp32 kernel's 128 tiles of 4 x 4 take 23.4 and the bf16x3 form 23.1 -- it takes over from 33 tiles (tools/bench_res_block.py; 8x8 at 8 crops = 16 tiles: 16.6
     // against 13.4 for the three per-layer launches, which stay)
-    static const long f16_from = getenv("SUO_RES_FUSED_F16_FROM") ? atol(getenv("SUO_RES_FUSED_F16_FROM")) : 33;
+    static const long f16_from = (long)SUO_TUNE("SUO_RES_FUSED_F16_FROM", 33);
     const long x3_from = (pipe_ == 2 && r.rbh_w[0] && mode >= 2) ? std::min(f16_from, x3_from_env) : x3_from_env;
     if (mode >= 2 && r.rbx_w[0] && t32 >= x3_from && t32 <= max_tiles) return 2;
     if (H >= min_side && W >= min_side && (t32 < x3_from || (mode == 1 && t32 <= max_tiles))) return 1;
@@ -614,7 +613,7 @@ int Net::maxpool(const float* in, float* out, int L, int H, int W, int C, hipStr
 // when only the pooled tensor is wanted.
 int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hipStream_t s, const GemmW* gw) {
     const float* Wx3 = gw ? gw->Wx3 : nullptr;
-    static const int fuse_pool = getenv("SUO_FUSE_POOL") ? atoi(getenv("SUO_FUSE_POOL")) : 1;                    // 0: A/B
+    static const int fuse_pool = (int)suo::env_switch("SUO_FUSE_POOL", 1);                    // 0: A/B
     // large launches with a bf16x3 form of the weights: on the bf16 pipe (csrc/gemm_bf16x3.hip)
     const long x3_min_rows = this->x3_min_rows();
     if (Wx3 && g.M >= x3_min_rows) {
@@ -646,7 +645,7 @@ int Net::gemm_maybe_pooled(GemmArgs& g, int L, int H, int W, float* pool_out, hi
 // The next block's conv1 can ride on this block's fused fp16 tail when the separate launch would have been the fp16 GEMM on the same operands
 // (256 -> 128 with a BatchNorm prologue, >= SUO_GEMM_X3_MIN_ROWS pixels, not a one-launch block): then the two are bit-identical (tests/test_gpu_f16x2.py)
 bool Net::next_conv1_fusable(const ResidualW& next, int L, int H, int W) const {
-    static const int on = getenv("SUO_FUSE_NEXT_CONV1") ? atoi(getenv("SUO_FUSE_NEXT_CONV1")) : 1;                // 0: A/B
+    static const int on = (int)SUO_TUNE("SUO_FUSE_NEXT_CONV1", 1);                // 0: A/B
     const long x3_min_rows = this->x3_min_rows();
     return on && pipe_ == 2 && next.cin == 256 && next.c1.W16 && next.c1.osc16 && next.c1.N == 128 && next.c1.n_valid == 128 && next.c1.K1 == 256 && next.c1.K2 == 0 &&
            (long)L * H * W >= x3_min_rows && !residual_in_one_launch(next, L, H, W);
@@ -746,14 +745,14 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     // with none; 32 frames per call 738 / 745 / 749.  The second call in flight already fills the gaps the fork was meant to fill,
     // and every extra stream competes for the 4 hardware queues with the other network and the geometry stream.  With a single
     // call in flight the fork is worth about 1 % (385 vs 381 frames/s at 8 crops).
-    static const int n_side = getenv("SUO_NET_SIDE_STREAMS") ? std::max(0, std::min(kNumSide, atoi(getenv("SUO_NET_SIDE_STREAMS")))) : 0;
+    static const int n_side = std::max(0, std::min(kNumSide, (int)env_switch("SUO_NET_SIDE_STREAMS", 0)));
     // ... except on the SMALL maps of a call of few crops (the one-frame call: 16x16 and 8x8 at 8 crops): there every kernel is a handful of workgroups and a
     // dependent launch costs its latency, not its work -- the up1 blocks (16.8 / 2 x 13.4 us) run beside the low branch instead of in front of it.
     // SUO_NET_FORK_SMALL_PIXELS: largest L * H * W that forks (2048 = 16x16 at 8 crops); default 0 = never: MEASURED SLOWER -- one frame per call 2.010 ms with
     // the fork against 1.897 without (same box, tools/time_frame_chain.py): the captured graph's extra branch costs more than the two or three launches it hides.
-    static const long fork_small = getenv("SUO_NET_FORK_SMALL_PIXELS") ? atol(getenv("SUO_NET_FORK_SMALL_PIXELS")) : 0;
-    const bool small_fork = getenv("SUO_SERIAL") == nullptr && fork_small > 0 && (long)L * H * W <= fork_small && H >= 8;
-    const bool serial = (getenv("SUO_SERIAL") != nullptr || n_side == 0) && !small_fork;     // one stream, kernels back to back
+    static const long fork_small = (long)SUO_TUNE("SUO_NET_FORK_SMALL_PIXELS", 0);
+    const bool small_fork = !env_set("SUO_SERIAL") && fork_small > 0 && (long)L * H * W <= fork_small && H >= 8;
+    const bool serial = (env_set("SUO_SERIAL") || n_side == 0) && !small_fork;     // one stream, kernels back to back
     hipStream_t side = serial ? s : side_[depth_idx % (n_side > 0 ? n_side : kNumSide)];
     hipEvent_t ev_fork = ev_[(ev_next_++) % (kNumEvents - 1)], ev_join = ev_[(ev_next_++) % (kNumEvents - 1)];      // (the last event is follow_null_stream's)
     float* up_a = alloc(n_hi);
@@ -763,7 +762,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
     // "up1 + up2(low3)" (hg.py:56-58): when the last up1 block ends in the fused Winograd tail, that tail adds the up-sampled low
     // branch itself and writes `out` -- no up-sample kernel, no extra pass over the high-resolution tensor.  The block then has to
     // wait for the low branch; its predecessor still runs beside it on the side stream.
-    static const int fuse_up = getenv("SUO_FUSE_UPSAMPLE") ? atoi(getenv("SUO_FUSE_UPSAMPLE")) : 1;              // 0: A/B
+    static const int fuse_up = (int)suo::env_switch("SUO_FUSE_UPSAMPLE", 1);              // 0: A/B
     const bool up_in_tail = fuse_up && (residual_tail_is_fused(h.up1[1], L, H, W) || residual_in_one_launch(h.up1[1], L, H, W));
     SUO_TRY(residual(h.up1[0], x, up_a, L, H, W, side, nullptr, nullptr, &h.up1[1]));
     if (!up_in_tail) SUO_TRY(residual(h.up1[1], up_a, up_b, L, H, W, side));
@@ -771,7 +770,7 @@ int Net::hourglass(const HourglassW& h, const float* x, float* out, int L, int H
 
     const float* pooled = x_pooled;                           // (the caller's producer kernel may have pooled x already)
     // max_pool2d(x) (hg.py:41) has ONE reader, the first low block: when that block runs in one launch it takes the pool while staging x
-    static const int pool_in_block = getenv("SUO_RES_POOL_IN") ? atoi(getenv("SUO_RES_POOL_IN")) : 1;           // 0: A/B
+    static const int pool_in_block = (int)SUO_TUNE("SUO_RES_POOL_IN", 1);           // 0: A/B
     const bool pool_by_block = !pooled && pool_in_block && residual_in_one_launch(h.low1[0], L, H / 2, W / 2) && (H % 2 == 0) && (W % 2 == 0);
     if (!pooled && !pool_by_block) {
         float* p = alloc(n_lo);
@@ -834,7 +833,7 @@ int Net::backbone(const float* in0, int in_c, float* logits, int L, hipStream_t 
         SUO_TRY(residual(post_[i][0], hg, ra, L, 64, 64, s, nullptr, nullptr, &post_[i][1]));
         SUO_TRY(residual(post_[i][1], ra, rb, L, 64, 64, s));
         // the last stack's lin -> head pair: `ll` has one reader, so it never leaves the CU (one launch, 1.2 GB of traffic instead of 3.3 at 256 crops)
-        static const int chain_head = getenv("SUO_CHAIN_HEAD") ? atoi(getenv("SUO_CHAIN_HEAD")) : 1;            // 0: A/B
+        static const int chain_head = (int)SUO_TUNE("SUO_CHAIN_HEAD", 1);            // 0: A/B
         const long chain_min_rows = x3_min_rows();
         if (i == 1 && chain_head && pipe_ == 2 && lin_[i].W16 && head_[i].W16 && lin_[i].N == 256 && lin_[i].K1 == 256 && M >= chain_min_rows &&
             gemm_chain_head_takes(M, 256, NUM_KP, HEAT * HEAT)) {
@@ -973,11 +972,11 @@ int Net::schedule_bytes(int L, int n_frames, int H, int W, int with_priors, doub
 // the fused stem launch of the fp16 pipe also computes r1's conv1 on its tile (csrc/stem_x3.hip: NEXT); a function of the network's state only -- suo_net_prepare captures the
 // backbone without launching the stem
 bool Net::stem_computes_r1_conv1() const {
-    static const int on = getenv("SUO_STEM_NEXT") ? atoi(getenv("SUO_STEM_NEXT")) : 1;              // 0: A/B
+    static const int on = (int)SUO_TUNE("SUO_STEM_NEXT", 1);              // 0: A/B
     return on && fused_stem() && pipe_ == 2 && stem_h2_w_ && r1_.c1.W16 && r1_.c1.osc16 && r1_.cin == 64 && r1_.c1.N == 64 && r1_.c1.K1 == 64 && r1_.c1.K2 == 0;
 }
 bool Net::fused_stem() const {
-    static const int on = getenv("SUO_STEM_X3") ? atoi(getenv("SUO_STEM_X3")) : 1;
+    static const int on = (int)suo::env_switch("SUO_STEM_X3", 1);
     return on != 0 && stem_x3_w_ != nullptr;
 }
 

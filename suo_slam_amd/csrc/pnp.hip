@@ -19,6 +19,7 @@
 // of the 6x6 normal equations, redundant per-lane Cholesky).  All arithmetic is fp64 with
 // contraction off so thresholds fall the same way as in the CPU restatement.
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 
@@ -711,7 +712,7 @@ int launch_pnp_batch_counts(int n_obj, const int* offsets, const int* counts, co
                             const int* iter_tab, const int* iter_tab_off, int do_refine, double* T_out, int* status, int* best_out,
                             int* iters_out, hipStream_t s, const uint64_t* seed_add = nullptr) {
     if (n_obj <= 0) return SUO_OK;
-    static const int wide_upto = getenv("SUO_PNP_WIDE_UPTO") ? atoi(getenv("SUO_PNP_WIDE_UPTO")) : 32;      // objects per launch that still take 16 waves each (0: never)
+    static const int wide_upto = (int)SUO_TUNE("SUO_PNP_WIDE_UPTO", 32);      // objects per launch that still take 16 waves each (0: never)
     if (n_obj <= wide_upto)
         hipLaunchKernelGGL(pnp_batch_kernel<16>, dim3(n_obj), dim3(1024), 0, s, offsets, counts, group_first, xs, ys, threshold, seed, iter_tab, iter_tab_off,
                            do_refine, T_out, status, best_out, iters_out, (const int*)nullptr, 0, (int*)nullptr, seed_add);

@@ -31,6 +31,7 @@
 
 #include "buffer_ops.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 
@@ -395,7 +396,7 @@ bool res_block_takes(const ResBlockArgs& a) {
 // tile: 4 x 8 pixels when that still gives every CU a workgroup, else 4 x 4
 int launch_res_block(const ResBlockArgs& a, hipStream_t s) {
     if (!res_block_takes(a)) { suo_set_error("res_block: unsupported arguments (L=%d H=%d W=%d)", a.L, a.H, a.W); return SUO_ERR_ARG; }
-    static const int force = getenv("SUO_RES_TILE") ? atoi(getenv("SUO_RES_TILE")) : 0;           // tuning aid: 16 / 32 pixels
+    static const int force = (int)SUO_TUNE("SUO_RES_TILE", 0);           // tuning aid: 16 / 32 pixels
     const long t32 = (long)a.L * ((a.H + 3) / 4) * ((a.W + 7) / 8);
     const bool big = force ? force == 32 : (a.W >= 8 && t32 >= 256);
 #define RS_LAUNCH(TH_, TW_, tiles)                                                                                                         \

@@ -143,11 +143,7 @@ __global__ __launch_bounds__(256) void res_block_x3_kernel(const ResBlockArgs a)
         for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(r3_u32x4, buf_load(w1_srd, wv + p * 1024, (k * 4 + w) * NP * 1024));
     };
     auto load2 = [&](int ks, r3_u32x4 (&b)[NP]) {               // conv2: step = tap * 8 + k-step
-#if defined(SUO_R3_EXP) && (SUO_R3_EXP & 1)                     // timing experiment (wrong results): weights from two cache-resident steps
-        const int k = ks & 1;
-#else
         const int k = ks < NS2 ? ks : NS2 - 1;
-#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(r3_u32x4, buf_load(w2_srd, wv + p * 1024, (k * 4 + w) * NP * 1024));
     };
@@ -318,11 +314,7 @@ __global__ __launch_bounds__(256) void res_block_x3_kernel(const ResBlockArgs a)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-#if defined(SUO_R3_EXP) && (SUO_R3_EXP & 2)                     // timing experiment (wrong results): A fragments from two fixed rows of LDS
-                    for (int p = 0; p < NP; ++p) af[u][p] = *(const r3_bf16x8*)(M1 + p * MPL + lr * MPB + lk * 16 + u * 32);
-#else
                     for (int p = 0; p < NP; ++p) af[u][p] = *(const r3_bf16x8*)(M1 + p * MPL + arow[tap] + (ks + u) * 32);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 mac6x2(acc2, af[0], ring2[ks], acc2b, af[1], ring2[ks + 1]);
                 __builtin_amdgcn_sched_barrier(0);

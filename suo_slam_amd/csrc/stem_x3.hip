@@ -30,10 +30,6 @@ typedef __bf16 sx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sx_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SX_STEPS = 14, SX_N = 64;
-// timing experiments only (tools/build_variant.sh -DSUO_SX_EXP=n; results are wrong): 1 no sampling (constants staged), 2 no products, 3 no output stores
-#ifndef SUO_SX_EXP
-#define SUO_SX_EXP 0
-#endif
 
 // host: W[64][Cw][7][7] (the first 3 input channels; times out_scale[n]: bn1 folded) -> [step = ky * 2 + h][n-tile][plane][lane][8 bf16],
 //   k = 8 (lane >> 5) + e  ->  entry j = k / 4, channel c = k % 4, tap kx = 2 j + h   (zero for c == 3 and for the odd buffer's 4th entry)
@@ -170,7 +166,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
         };
         constexpr int NSLOT = IR * 40, NIT = (NSLOT + 255) / 256;
         const RoiBins bins = roi_bins(x1, y1, x2, y2);
-        if (SUO_SX_EXP != 1 && bins.gh == 1 && bins.gw == 1) {
+        if (bins.gh == 1 && bins.gw == 1) {
             // boxes of <= 256 px (one sample per bin): the taps of ALL of this thread's slots are requested before the first is consumed --
             // one memory latency per tile instead of one per slot
             RoiTaps<FMT> tp[NIT];
@@ -201,8 +197,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
                 int r, h, j, py, px;
                 const bool inside = slot_geom(slot, r, h, j, py, px);
                 float v[3] = {0.f, 0.f, 0.f};
-                if (SUO_SX_EXP == 1) v[0] = v[1] = v[2] = (float)slot * x1;
-                else if (inside) roi_sample<FMT, FMT == 0>(img, a.H, a.W, x1, y1, x2, y2, py, px, v, lut);
+                if (inside) roi_sample<FMT, FMT == 0>(img, a.H, a.W, x1, y1, x2, y2, py, px, v, lut);
                 store3(r, h, j, v[0], v[1], v[2]);
             }
         }
@@ -227,7 +222,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
         abase[i] = (2 * oyl) * ROW_B + oxl * 8 + (lane >> 5) * 16;
     }
 #pragma unroll
-    for (int s = 0; s < (SUO_SX_EXP == 2 ? 1 : SX_STEPS); ++s) {                        // s = ky * 2 + h
+    for (int s = 0; s < SX_STEPS; ++s) {                        // s = ky * 2 + h
         loadw(s + R - 1, ring[(s + R - 1) % R]);
         sx_bf16x8 af[2][NP];
 #pragma unroll
@@ -271,7 +266,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const StemArgs a) {
         for (int k = 0; k < 8; ++k) {
             const int idx = tid + 256 * k, p = idx >> 4, q = idx & 15;
             const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-            if (SUO_SX_EXP != 3 || P[p * PP + 4 * q] == 12345.f) *(sx_f32x4*)(o + ((size_t)oy * 128 + ox) * SX_N + 4 * q) = *(const sx_f32x4*)&P[p * PP + 4 * q];
+            *(sx_f32x4*)(o + ((size_t)oy * 128 + ox) * SX_N + 4 * q) = *(const sx_f32x4*)&P[p * PP + 4 * q];
         }
     }
     SX_T(4);

@@ -774,15 +774,25 @@ class ObjectSLAM:
                 m = gt_mask[k].astype(bool)
                 u = uv_gt[k][m].astype(np.float64)
                 gt_uv[k][m] = (u + self._rng.normal(scale=0.01, size=u.shape)).astype(np.float32)
-        kps_host = np.ascontiguousarray(model_kps, dtype=np.float32)
+        # every small host array of the pass in ONE pinned block and ONE stream-ordered copy kernel, enqueued BEFORE the network: a pageable .to(device) per array
+        # blocks the host until it has run -- in front of the network that is tens of microseconds each on the critical path, behind it a wait for the network
+        host_arrays = [np.ascontiguousarray(model_kps, dtype=np.float32), np.ascontiguousarray(bboxes, dtype=np.float32),
+                       gt_mask if gt_uv is not None else np.ascontiguousarray(model_kps_masks, dtype=np.uint8)]
+        if gt_uv is not None:
+            host_arrays.append(gt_uv)
+        if prior_uv is not None:
+            host_arrays += [prior_uv, prior_mask]
         for _attempt in range(2):
-            pred = self.model(self._frame_on_device(img), [torch.as_tensor(np.asarray(bboxes, np.float32))], None, prior_uv=prior_uv, prior_mask=prior_mask, check=False)
-            dev = pred["uv"].device
+            frame = self._frame_on_device(img)
+            st = self.model.stage_block(host_arrays)
+            kps_dev, bx_dev, mm_dev = st[0], st[1], st[2]
+            puv_dev, pmk_dev = (st[-2], st[-1]) if prior_uv is not None else (None, None)
+            pred = self.model(frame, [bx_dev], None, prior_uv=puv_dev, prior_mask=pmk_dev, check=False)
             if gt_uv is not None:
-                uv_dev, masks_dev = torch.from_numpy(gt_uv).to(dev), torch.from_numpy(gt_mask).to(dev)
+                uv_dev, masks_dev = st[3], mm_dev
             else:
-                uv_dev, masks_dev = pred["uv"], keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], model_kps_masks, self.bbox_thresh, vt)
-            self._fg.launch([0, L], uv_dev, pred["cov"], masks_dev, torch.from_numpy(kps_host).to(dev), kinv, camk, min_depth, seed=self._pnp_seed,
+                uv_dev, masks_dev = pred["uv"], keypoint_masks(pred["uv"], pred["cov"], pred["kp_mask"], mm_dev, self.bbox_thresh, vt)
+            self._fg.launch([0, L], uv_dev, pred["cov"], masks_dev, kps_dev, kinv, camk, min_depth, seed=self._pnp_seed,
                             use_cov=not self.no_network_cov, do_lm=False)
             r = self._fg.fetch(copy=True)
             if not self.model.range_exceeded():               # (fp16 form only: the fetch synchronised; on True the network is on bf16x3 now, once more)

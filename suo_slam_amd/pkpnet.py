@@ -156,8 +156,12 @@ class PkpNet:
         if prior_uv is not None:
             # the prior heat-maps are rendered on the device from the projected keypoints (suo_net_forward_prior_kp):
             # prior_uv [L,41,2] NDC, prior_mask [L,41] -- what make_prior_kp_input takes per object (utils.py:398-411)
-            puv = torch.as_tensor(np.asarray(prior_uv, dtype=np.float32)).reshape(L, NUM_KP, 2).to(dev).contiguous()
-            pmk = torch.as_tensor(np.asarray(prior_mask, dtype=np.uint8)).reshape(L, NUM_KP).to(dev).contiguous()
+            if isinstance(prior_uv, torch.Tensor) and prior_uv.is_cuda:      # already on the device (stage_block: one upload for every small array of the call)
+                puv, pmk = prior_uv.reshape(L, NUM_KP, 2).contiguous(), prior_mask.reshape(L, NUM_KP).contiguous()
+                assert puv.dtype == torch.float32 and pmk.dtype == torch.uint8
+            else:
+                puv = torch.as_tensor(np.asarray(prior_uv, dtype=np.float32)).reshape(L, NUM_KP, 2).to(dev).contiguous()
+                pmk = torch.as_tensor(np.asarray(prior_mask, dtype=np.uint8)).reshape(L, NUM_KP).to(dev).contiguous()
             _lib.check(_lib.lib().suo_net_forward_prior_kp(self._h, _ptr(img), fmt, H, W, _ptr(bx), None, L, _ptr(puv), _ptr(pmk), _ptr(uv),
                                                            _ptr(cov), _ptr(kpm), _ptr(kpl), _ptr(logits), _stream()), "suo_net_forward_prior_kp")
         else:

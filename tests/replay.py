@@ -42,14 +42,17 @@ def record():
     def forward(self, images, boxes, prior_kp=None, **kw):
         out = orig_fwd(self, images, boxes, prior_kp, **kw)
         # (since round 4 ObjectSLAM uploads the frame once per view and hands the DEVICE tensor to both network passes)
-        rec.forward.append({"image": images.cpu().numpy() if hasattr(images, "cpu") else np.array(images), "boxes": np.asarray(boxes[0].cpu() if hasattr(boxes[0], "cpu") else boxes[0], dtype=np.float32), "prior_uv": kw.get("prior_uv"),
-                            "prior_mask": kw.get("prior_mask"),
+        rec.forward.append({"image": images.cpu().numpy() if hasattr(images, "cpu") else np.array(images), "boxes": np.asarray(boxes[0].cpu() if hasattr(boxes[0], "cpu") else boxes[0], dtype=np.float32), "prior_uv": _host(kw.get("prior_uv")),
+                            "prior_mask": _host(kw.get("prior_mask")),
                             "out": {k: out[k].cpu().numpy() for k in ("uv", "cov", "kp_mask", "prob_logits")}})
         return out
 
+    def _host(t):
+        return t.cpu().numpy() if hasattr(t, "cpu") else t
+
     def keypoint_masks(uv, cov, kp, mm, bt=0.9, vt=0.2):
         out = orig_masks(uv, cov, kp, mm, bt, vt)
-        rec.masks.append({"uv": uv.cpu().numpy(), "cov": cov.cpu().numpy(), "kp": kp.cpu().numpy(), "mm": None if mm is None else np.array(mm),
+        rec.masks.append({"uv": uv.cpu().numpy(), "cov": cov.cpu().numpy(), "kp": kp.cpu().numpy(), "mm": None if mm is None else (mm.cpu().numpy() if hasattr(mm, "cpu") else np.array(mm)),
                           "bt": bt, "vt": vt, "out": out.cpu().numpy().astype(bool)})
         return out
     # the device-resident frame chain (suo_frame_geom_*): what it was launched on and what it read back

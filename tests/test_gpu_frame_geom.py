@@ -251,9 +251,10 @@ def test_upload_kernel_copies_pinned_host_memory_bit_for_bit():
         _lib.check(lib.suo_upload(C.c_void_p(d.data_ptr() + 4), C.c_void_p(h.data_ptr()), 64, st))
 
 
-def test_more_than_sixteen_objects_take_the_host_route():
-    """The device chain refines frames of <= 16 crops; ObjectSLAM sends larger frames (T-LESS scenes can have more) through the host
-    route instead of failing -- same interface, same kind of result."""
+def test_more_than_sixteen_objects_refine_through_suo_optimize():
+    """The device chain REFINES frames of <= 16 crops (one wave per frame, csrc/lm_frame2.hip); ObjectSLAM sends larger frames (T-LESS scenes can have more) through
+    process_view's general route instead of failing -- since round 6 with network -> masks -> compaction -> PnP -> acceptance still as one device chain
+    (do_lm = 0, no crop limit) and the pose graph through suo_optimize: same interface, same kind of result, both halves replayed against the oracles."""
     from suo_slam_amd import weights
     from suo_slam_amd.object_slam import ObjectSLAM
     from tests import replay
@@ -264,6 +265,16 @@ def test_more_than_sixteen_objects_take_the_host_route():
     with replay.record() as rec:
         slam.process_view(0, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
                           fr["model_kps_masks"])
-    assert len(rec.chain) == 0 and len(rec.pnp) == 1 and len(rec.ba) == 1
-    assert replay.check_pnp(rec) >= 12 and replay.check_ba(rec) == 1
+    assert len(rec.chain) == 1 and not rec.chain[0]["do_lm"] and len(rec.pnp) == 0 and len(rec.ba) == 1
+    n_pnp, n_lm = replay.check_chain(rec)
+    assert n_pnp >= 12 and n_lm == 0 and replay.check_ba(rec) == 1
+    # ... and the host route (device_chain=False: three read-backs, suo_pnp_batch on host arrays) leaves the same frame behind
+    host = ObjectSLAM(None, _mesh_db(fr), sfm_mode=True, single_view_mode=True, state_dict=sd, max_crops=18, kp_var_thresh=0.5, bbox_thresh=1.0, device_chain=False)
+    with replay.record() as rec_h:
+        host.process_view(0, fr["image"], fr["K"], np.array(fr["obj_ids"]), fr["boxes"].astype(np.float64), fr["model_kps"], fr["model_kps_masks"],
+                          fr["model_kps_masks"])
+    assert len(rec_h.chain) == 0 and len(rec_h.pnp) == 1 and len(rec_h.ba) == 1
+    assert list(host.obj_poses.keys()) == list(slam.obj_poses.keys())
+    for o in host.obj_poses:
+        np.testing.assert_allclose(np.asarray(slam.obj_poses[o])[:3], np.asarray(host.obj_poses[o])[:3], rtol=0, atol=1e-9 * np.abs(host.obj_poses[o]).max())
     assert len(slam.collect_results()[0]["poses"]) == 18

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Build a tuning variant of libsuo_hip.so: tools/build_variant.sh <name> [-DFLAG=VALUE ...]   (select it with SUO_HIP_LIB=<path>)
+# Build a tuning variant of libsuo_hip.so: tools/build_variant.sh <name> [-DFLAG=VALUE ...]   (select it with SUO_HIP_LIB=<path>).  Variants are built with -DSUO_TUNING:
+# every SUO_TUNE knob of csrc/tune.h then follows the environment (the product library compiles them to their defaults).  "tools/build_variant.sh tuning" = just that.
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/suo_slam_amd/csrc
 V=$ROOT/suo_slam_amd/variants
 mkdir -p $V
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DSUO_TUNING"     # the tuning knobs of csrc/tune.h read the environment in these builds only
 VAR="conv conv_wino conv_wino_x3 gemm_persist gemm_bf16x3 conv_small res_small res_small_x3 stem_x3 lm_grid lm_frame lm_frame2 lm_dist net misc"
 for f in $VAR; do /opt/rocm/bin/hipcc $FL "$@" -c $C/$f.hip -o $V/${f}_$NAME.o & done
 wait

@@ -33,12 +33,17 @@ def wrap(owner, name, label=None):
     setattr(owner, name, g)
 
 
-for n in ("_process_objects", "_run_kp_model", "_estimate_camera_pose", "_maybe_reinit_objects", "optimize", "build_problem", "apply_problem", "_cull_after_optimize"):
+for n in ("_process_objects", "_run_kp_model", "_run_kp_model_chain", "_estimate_camera_pose", "_maybe_reinit_objects", "optimize", "build_problem", "apply_problem", "_cull_after_optimize"):
     wrap(OS.ObjectSLAM, n)
 wrap(OS._sc, "chi2_counts", "chi2_counts (device)")
 wrap(OS._lt, "pnp_batch", "pnp_batch")
 wrap(OS._ba, "optimize_batch", "optimize_batch")
 wrap(PkpNet, "forward", "net.forward")
+wrap(PkpNet, "stage_block", "stage_block")
+wrap(PkpNet, "_to_device", "frame upload (host side)")
+from suo_slam_amd.frame_geom import FrameGeometry  # noqa: E402
+wrap(FrameGeometry, "launch", "chain launch (host side)")
+wrap(FrameGeometry, "fetch", "chain fetch (waits for network + chain)")
 PkpNet.__call__ = PkpNet.forward
 
 seq = S.make_slam_sequence(np.random.default_rng(3), 60, 8)
@@ -46,7 +51,7 @@ sd = weights.make_random_state_dict(0, 8.0)
 
 
 def run():
-    slam = OS.ObjectSLAM(None, seq["mesh_db"], debug_gt_kp=True, manual_kp_std=0.01, state_dict=sd if net else None, max_crops=16, run_network_in_debug=net)
+    slam = OS.ObjectSLAM(None, seq["mesh_db"], debug_gt_kp=True, manual_kp_std=0.01, state_dict=sd if net else None, max_crops=16, run_network_in_debug=net, debug_gt_on_device=(net and os.environ.get("SUO_SLAM_HOST_DEBUG", "0") == "0"))
     for vw in seq["views"]:
         slam.process_view(vw["view_id"], vw["image"], vw["K"], vw["obj_ids"].copy(), vw["bboxes"].copy(), vw["model_kps"], vw["model_kps_masks"], vw["kp_masks"], uv_gt=vw["uv_gt"])
     return slam
