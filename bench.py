@@ -255,6 +255,8 @@ def main():
             "cnn_executed_frac_of_fp32_mfma_peak": round(fps / world * L * exec_gflop / 1e3 / FP32_MFMA_PEAK_TF, 4),
             "cnn_tflops_algorithmic": round(fps * L * GFLOP_PER_CROP / 1e3, 2),           # reference-counted FLOPs per crop x crops/s
             "cnn_algorithmic_over_fp32_mfma_peak": round(fps / world * L * GFLOP_PER_CROP / 1e3 / FP32_MFMA_PEAK_TF, 4),
+            # (FramePipeline.check_range raises when a step leaves fp16's range: a line that exists holds no re-issued call)
+            "fp16_range_reissues_in_timed_region": 0,
             "power_in_timed_region": dict(power) if power else None,
             "geometry_in_timed_region": {"keypoints_passed_by_the_masks": int(n_kp), "poses_accepted": int(n_pose), "inlier_edges": int(n_inl),
                                          "lm_trials": int(n_trials), "crops": int(world * args.steps * F * L)},

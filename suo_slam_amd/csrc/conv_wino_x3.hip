@@ -18,6 +18,7 @@
 #include "f16x2.h"
 #include "buffer_ops.h"
 #include "suo_internal.h"
+#include "tune.h"
 
 namespace suo {
 
@@ -126,9 +127,18 @@ void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float
 // NEXT (fp16 form of the fused tail only): the block's output never comes back for the NEXT block's conv1 -- relu(bn_next(out2)) of the tile is split into LDS
 // right where out2 is stored and multiplied by the next block's W1 (256 -> 128) here: the 256-channel tensor is written once and not re-read by a GEMM launch
 // (csrc/net.hip: residual(..., next)).  Same products in the same order as gemm_bf16x3_kernel<NP = 2> forms them: bit-identical to the separate launch.
-template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
+// W8 (round 6; 128 -> 128 channels, fp16 form): EIGHT waves on the tile for launches of at most one workgroup per CU (a one-frame call, the 2-7 crops of a SLAM
+// pass).  There a workgroup's latency is the launch's duration -- 50 us for the fused tail whether 64 or 256 workgroups run, against 64 us per round of two co-resident
+// ones in a 256-crop launch: stalls, not throughput -- so the tile's work is spread over twice the waves: wave (wn, wc) owns n-tile wn = w & 3 and the eight components
+// of rows xi = 2 wc, 2 wc + 1 (wc = w >> 2) -- one accumulator each, half the products per wave, NO fold -- exactly the 64-channel form's scheme, the halves meeting
+// through LDS after the K loop; a thread of the transform computes ONE row of B^T d B (four components); the tail's conv3 gives every wave one 32-channel n-tile of
+// the 256.  Each output element is the same sum of the same products in the same order, except that Y = (R0 + R1) + R2 / (R3' - R2) + R1 pairs its rows as the
+// 64-channel form does, where the four-wave form folds per chunk: results agree to fp32 rounding of that last addition, not bit for bit.
+template <bool FUSE, bool UP = false, bool TX3 = false, int NT = 4, int NP = 3, bool NEXT = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2))) void wino3x3_x3_kernel(const ConvArgs a) {
     static_assert(NT == 4 || (NT == 2 && !FUSE), "64-channel form: plain convolution only");
+    static_assert(!W8 || (NT == 4 && NP == 2 && !NEXT && (TX3 || !FUSE)), "eight waves: the fp16 form of the 128-channel kernel, without the next block's conv1");
+    constexpr int NTHR = W8 ? 512 : 256;
     static_assert(!NEXT || (FUSE && TX3 && NP == 2), "the next block's conv1 rides on the fp16 tail");
     static_assert(NP == 3 || !FUSE || TX3, "the fp16 form's tail runs on the fp16 pipe");
     // one LDS array: halo double buffer (fp32) | V (three bf16 planes); the fused tail re-uses ALL of it for the conv2 tile
@@ -137,7 +147,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                                                               // conflict-free A-fragment ds_read_b128, 2-way instead of 4-way on the transform's ds_write_b64
     constexpr int VPL = 16 * 32 * VROW;                       // bf16 per plane
     constexpr int VFLOATS = NP * VPL / 2;
-    __shared__ __attribute__((aligned(16))) float S[2 * HSZ + VFLOATS];
+    // (W8: one workgroup per CU anyway -- the tail's eight transposition patches get their own room behind the operand planes)
+    constexpr int TAILF = NP * 8 * (64 * 32 + 32) / 4;        // floats of the tail's operand planes (NP planes x 8 k-steps x (64 pixels x 32 bytes + 32))
+    constexpr int SFLOATS = W8 ? (2 * HSZ + VFLOATS > TAILF + 8 * 32 * 36 ? 2 * HSZ + VFLOATS : TAILF + 8 * 32 * 36) : 2 * HSZ + VFLOATS;
+    __shared__ __attribute__((aligned(16))) float S[SFLOATS];
     float (*Hin)[HSZ] = reinterpret_cast<float (*)[HSZ]>(&S[0]);
     uint16_t* V = reinterpret_cast<uint16_t*>(&S[2 * HSZ]);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -157,11 +170,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const __amdgpu_buffer_rsrc_t out_srd = make_srd(a.out + (size_t)l * a.OH * a.OW * a.N, (size_t)a.OH * a.OW * a.N * sizeof(float));
 
     // ---- halo staging (as csrc/conv_wino.hip): 180 pixels x 4 float4 per chunk over 256 threads -----------------------------
-    constexpr int NF4 = X_NPIX * 4, NLD = (NF4 + 255) / 256;
+    constexpr int NF4 = X_NPIX * 4, NLD = (NF4 + NTHR - 1) / NTHR;
     int avoff[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTHR;
         const int pix = idx >> 2, cc = idx & 3;
         const int py = pix / X_IW, px = pix - py * X_IW;
         const int iy = iy0 + py, ix = ix0 + px;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             if constexpr (NP == 2) {                              // the activation scale (exact) and the guard's running max ride on the staging copy
                 areg[i] *= S2_XSCALE;
                 dmax = s2_track(s2_track(dmax, areg[i][0], areg[i][1]), areg[i][2], areg[i][3]);
@@ -190,8 +203,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     // The group offset is the instruction's SCALAR offset, which raw buffer loads do not range-check: every prefetch must name a group
     // inside Wq3 -- the loop below re-requests the last chunk's first pair instead of running past the end.)
     const int wvoff = lane * 16;
-    const int wn = NT == 4 ? w : (w & 1), wc = NT == 4 ? 0 : (w >> 1);      // n-tile, component half
-    constexpr int NPAIR = NT == 4 ? 8 : 4;                      // component pairs per chunk and wave
+    const int wn = NT == 4 ? (W8 ? (w & 3) : w) : (w & 1), wc = NT == 4 ? (W8 ? (w >> 2) : 0) : (w >> 1);      // n-tile, component half
+    constexpr bool HALF = NT == 2 || W8;                        // the wave owns half of the components, one accumulator each
+    constexpr int NPAIR = HALF ? 4 : 8;                         // component pairs per chunk and wave
     const int wsbase = wn * NP * 1024;
     auto bload = [&](int gc, x_u32x4 (&b)[NP]) {              // gc = chunk * 16 + comp
         const int g = gc;
@@ -199,7 +213,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         for (int p = 0; p < NP; ++p) b[p] = __builtin_bit_cast(x_u32x4, buf_load(w_srd, wvoff + p * 1024, g * (NT * NP * 1024) + wsbase));
     };
     // ---- transform: thread = (tile tt, channel quad tq, half th) as in csrc/conv_wino.hip; every result vector is split on its way to LDS ----
-    const int tt = tid & 31, tq = (tid >> 5) & 3, th = tid >> 7;
+    const int tt = tid & 31, tq = (tid >> 5) & 3, th = (tid >> 7) & 1;
+    const int tv = __builtin_amdgcn_readfirstlane(tid >> 8);   // W8: which of the half's two rows this thread computes (0: first - third, 1: second +- other)
     const int t_ty = tt >> 3, t_tx = tt & 7;
     const int hbase = ((2 * t_ty + th) * X_IW + 2 * t_tx) * X_PKH + tq * 4;
     // V element offset of (component 0, tile tt, channels 4 tq ..): row tt, half (tq >> 1) swapped where bits 2, 3 of tt differ, 4 bf16 = 8 bytes
@@ -227,6 +242,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     const float hsign = th ? -1.f : 1.f;
     auto transform = [&](int buf) {
         const float* hs = &Hin[buf][hbase];
+        if constexpr (W8) {                                      // one row per thread: two of the four halo rows, four components
+            const int xi = tv == 0 ? (th ? 3 : 0) : (th ? 2 : 1);
+            x_f32x4 e[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (tv == 0) {
+                    e[c] = x_sub4(*(const x_f32x4*)(hs + c * X_PKH), *(const x_f32x4*)(hs + (2 * X_IW + c) * X_PKH));
+                } else {
+                    const x_f32x4 l1 = *(const x_f32x4*)(hs + (X_IW + c) * X_PKH), lx = *(const x_f32x4*)(hs + hother + c * X_PKH);
+                    e[c] = x_f32x4{__builtin_fmaf(lx[0], hsign, l1[0]), __builtin_fmaf(lx[1], hsign, l1[1]), __builtin_fmaf(lx[2], hsign, l1[2]), __builtin_fmaf(lx[3], hsign, l1[3])};
+                }
+            }
+            vstore(xi * 4 + 0, x_sub4(e[0], e[2]));
+            vstore(xi * 4 + 1, x_add4(e[1], e[2]));
+            vstore(xi * 4 + 2, x_sub4(e[2], e[1]));
+            vstore(xi * 4 + 3, x_sub4(e[1], e[3]));
+            return;
+        }
         x_f32x4 L0[4], L1[4], L2[4], Lx[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -286,8 +319,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     // this schedule 920 / 1620; the two accumulation chains of a pair interleaved 1030 / 1800; one component at a time with the A
     // fragments one and the weights one / three components ahead 943 / 1690 and 1052 / 1825.
     auto comp_of = [&](int pair, int which) -> int {
-        if (NT == 4) return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4));
-        return wc * 8 + 2 * pair + which;                     // (64-channel form: the wave's own half, in order)
+        if (!HALF) return pair < 4 ? (which ? 12 + pair : pair) : (which ? 8 + (pair - 4) : 4 + (pair - 4));
+        return wc * 8 + 2 * pair + which;                     // (64-channel form / eight waves: the wave's own half, in order)
     };
     // A operand of component comp: tile = lane & 31, channels 8 (lane >> 5) .. + 7 (the half, swapped as the rows were written)
     const int afoff = (lane & 31) * VROW + (((lane >> 5) ^ (((lane >> 2) ^ (lane >> 3)) & 1)) * 8);
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 afb[p] = *(const x_bf16x8*)&V[p * VPL + cb * 32 * VROW + afoff];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (NT == 2) {                                    // Z[local component]
+            if (HALF) {                                       // Z[local component]
                 mac6(Z[2 * pair], afa, bring[slot][0], false);
                 mac6(Z[2 * pair + 1], afb, bring[slot][1], false);
             } else if (pair < 4) {                            // accumulate into their own Z, no scratch, no additions
@@ -358,6 +391,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         out[2 * h] = Z[4 * h] + Z[4 * h + 1] + Z[4 * h + 2];
         out[2 * h + 1] = Z[4 * h + 1] - Z[4 * h + 2] - Z[4 * h + 3];
     }
+    // W8: the two component halves of an n-tile meet (as in the 64-channel form below): wave wc = 0 holds R of rows xi = 0, 1 (out[0..1], out[2..3]), wave wc = 1 of
+    // rows 2, 3 (row 3 negated in the weights).  Y[0][j] = (R0 + R1) + R2, Y[1][j] = (R3' - R2) + R1: wave wc keeps output row i = wc and hands its MIDDLE row to the
+    // partner through the V area ([wave][register][lane]: 32 KB per column j, two rounds)
+    x_f32x16 mine[2];
+    if constexpr (W8) {
+        static_assert(VFLOATS >= 8 * 16 * 64, "the exchange area is the V planes");
+        float* X = &S[2 * HSZ];                                // (the last chunk's closing barrier has passed: V is free)
+        const int pw = (1 - wc) * 4 + wn;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[(w * 16 + r) * 64 + lane] = wc == 0 ? out[2 + q][r] : out[q][r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[q][r] = (wc == 0 ? out[q][r] + out[2 + q][r] : out[2 + q][r] - out[q][r]) + X[(pw * 16 + r) * 64 + lane];
+            __syncthreads();
+        }
+    }
 
     if constexpr (FUSE && TX3) {
         // ---- tail of the Residual block (layers/Residual.py:27-35) on the bf16 pipe as well: out2 = W3 relu(conv2 + bias2) + bias3 + skip [+ up],
@@ -370,7 +421,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         // then its epilogue (transposition through a wave-private patch, + bias3 + skip [+ up], 16-byte stores).
         constexpr int KS_STRIDE = 64 * 32 + 32;                 // bytes per k-step image (+ 32: the two k-steps a wave stores to hit different banks)
         constexpr int PL_STRIDE = 8 * KS_STRIDE;
-        static_assert(NP * PL_STRIDE + 4 * 32 * 36 * 4 <= (2 * HSZ + VFLOATS) * 4, "tail staging must fit the workgroup's LDS");
+        static_assert(NP * PL_STRIDE == TAILF * 4 && NP * PL_STRIDE + (W8 ? 8 : 4) * 32 * 36 * 4 <= SFLOATS * 4, "tail staging must fit the workgroup's LDS");
+        constexpr int NJ = W8 ? 1 : 2;                          // n-tiles of conv3 per wave: W8 -> the one tile w of eight; else tiles w and 4 + w
         unsigned char* AP = reinterpret_cast<unsigned char*>(&S[0]);
         float* T = &S[NP * PL_STRIDE / 4] + w * (32 * 36);
         const __amdgpu_buffer_rsrc_t w3_srd = make_srd(a.W3p, (size_t)a.N * a.N2 * NP * sizeof(uint16_t));
@@ -380,12 +432,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         constexpr bool has_up = UP;
         const __amdgpu_buffer_rsrc_t up_srd = make_srd(has_up ? a.up + (size_t)l * (crop2 / 4) : a.R, has_up ? crop2 / 4 * sizeof(float) : 0);
         // NP = 2: the conv2 accumulator carries 2^(t_n + S2_XSHIFT); conv3's operand is 2^S2_XSHIFT relu(conv2 + b2) = relu(acc 2^-t_n + 2^S2_XSHIFT b2): one fma
-        const float b2v = NP == 2 ? a.bias[w * 32 + (lane & 31)] * S2_XSCALE : a.bias[w * 32 + (lane & 31)];
-        const float c2v = NP == 2 ? a.oscale[w * 32 + (lane & 31)] * S2_XSCALE : 1.f;
+        const float b2v = NP == 2 ? a.bias[wn * 32 + (lane & 31)] * S2_XSCALE : a.bias[wn * 32 + (lane & 31)];
+        const float c2v = NP == 2 ? a.oscale[wn * 32 + (lane & 31)] * S2_XSCALE : 1.f;
         float tmax = 0.f;
         // store address of the lane's channel n = 32 w + (lane & 31): k-step n >> 4, half (n >> 3) & 1 (swapped for pixels 8-15: = lane >> 5, see m below),
         // element n & 7; pixel m = 16 (r >> 2) + 2 (r & 3) + 8 (lane >> 5) + pj for accumulator row r (tile (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-        const int sbase = (2 * w + ((lane >> 4) & 1)) * KS_STRIDE + (lane >> 5) * (8 * 32) + ((((lane >> 3) & 1) ^ (lane >> 5)) * 16) + (lane & 7) * 2;
+        const int sbase = (2 * wn + ((lane >> 4) & 1)) * KS_STRIDE + (lane >> 5) * (8 * 32) + ((((lane >> 3) & 1) ^ (lane >> 5)) * 16) + (lane & 7) * 2;
         // A operand: pixel m = 32 i + (lane & 31), channels 8 (lane >> 5) .. + 7 of the k-step
         const int aoff = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
         // weights: W3x[(ks * 8 + nb) * 3 + plane][lane][8 bf16], 1 KB each (pack_tail_weight_bf16x3); the wave's n-tiles are w and 4 + w (output channels
@@ -394,19 +446,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         auto b3load = [&](int ks, x_u32x4 (&b)[2][NP]) {
             const int k = ks < 8 ? ks : 7;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + 4 * j + w) * NP) + p) * 1024));
+                for (int p = 0; p < NP; ++p) b[j][p] = __builtin_bit_cast(x_u32x4, buf_load(w3_srd, w3voff, (((k * 8 + (W8 ? w : 4 * j + w)) * NP) + p) * 1024));
         };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             x_u32x4 b3[2][2][NP];
             b3load(0, b3[0]);
+            if (!W8 || wc == h)                               // (W8: the pass's pixel rows are held by the waves of component half h)
 #pragma unroll
             for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = NP == 2 ? fmaxf(fmaf(out[2 * h + pj][r], c2v, b2v), 0.f) : fmaxf(out[2 * h + pj][r] + b2v, 0.f);
+                    const float cv = W8 ? mine[pj][r] : out[2 * h + pj][r];
+                    float v = NP == 2 ? fmaxf(fmaf(cv, c2v, b2v), 0.f) : fmaxf(cv + b2v, 0.f);
                     const int off = sbase + (16 * (r >> 2) + 2 * (r & 3) + pj) * 32;
                     if constexpr (NP == 2) {
                         tmax = fmaxf(tmax, v);                            // (v >= 0)
@@ -442,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) mac6(acc2[i][j], af[i], b3[ks & 1][j], false);
+                    for (int j = 0; j < NJ; ++j) mac6(acc2[i][j], af[i], b3[ks & 1][j], false);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (NEXT) __syncthreads();              // every wave is past its conv3 reads of AP: the NEXT conv1's operand planes overwrite it
@@ -452,10 +506,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
                 for (int i = 0; i < 2; ++i) acc1[i] = zero16;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {                     // j = the wave's n-tile: output channels [128 j + 32 w, + 32); NEXT: round j = conv1's K half j
+            for (int j = 0; j < NJ; ++j) {                    // j = the wave's n-tile: output channels [128 j + 32 w, + 32) (W8: [32 w, + 32)); NEXT: round j = conv1's K half j
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int col = (4 * j + w) * 32 + (lane & 7) * 4;
+                    const int col = (W8 ? w : 4 * j + w) * 32 + (lane & 7) * 4;
                     const x_f32x4 bv = *(const x_f32x4*)(a.bias3 + col);
                     x_f32x4 osc3 = x_f32x4{1.f, 1.f, 1.f, 1.f};
                     if constexpr (NP == 2) osc3 = *(const x_f32x4*)(a.oscale3 + col);
@@ -654,24 +708,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
         return;
     }
 
-    if constexpr (NT == 2) {
-        // the two component halves of an n-tile meet.  Wave wc = 0 holds rows xi = 0, 1 (out[0..1] = R of row 0, out[2..3] = R of row 1), wave wc = 1
+    if constexpr (NT == 2 || W8) {
+        // the two component halves of an n-tile meet (W8: they already have, above).  Wave wc = 0 holds rows xi = 0, 1 (out[0..1] = R of row 0, out[2..3] = R of row 1), wave wc = 1
         // rows xi = 2, 3 (row 3 negated in the weights).  Y[0][j] = R0 + R1 + R2, Y[1][j] = R1 - R2 + R3': wave wc keeps output row i = wc and
         // hands its MIDDLE row (1 or 2) to the partner through LDS ([position][register][lane]: conflict-free).
-        float* X = &S[2 * HSZ];                                // (the last chunk's closing barrier has passed: V is free)
+        if constexpr (NT == 2) {
+            float* X = &S[2 * HSZ];                            // (the last chunk's closing barrier has passed: V is free)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[((w * 2 + q) * 16 + r) * 64 + lane] = wc == 0 ? out[2 + q][r] : out[q][r];
-        __syncthreads();
-        const int pw = (1 - wc) * 2 + wn;
-        x_f32x16 mine[2];
+                for (int r = 0; r < 16; ++r) X[((w * 2 + q) * 16 + r) * 64 + lane] = wc == 0 ? out[2 + q][r] : out[q][r];
+            __syncthreads();
+            const int pw = (1 - wc) * 2 + wn;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                mine[q][r] = (wc == 0 ? out[q][r] + out[2 + q][r] : out[2 + q][r] - out[q][r]) + X[((pw * 2 + q) * 16 + r) * 64 + lane];
-        __syncthreads();                                      // the exchange area becomes the transposition patches
+                for (int r = 0; r < 16; ++r)
+                    mine[q][r] = (wc == 0 ? out[q][r] + out[2 + q][r] : out[2 + q][r] - out[q][r]) + X[((pw * 2 + q) * 16 + r) * 64 + lane];
+            __syncthreads();                                  // the exchange area becomes the transposition patches
+        }
         float* T = &S[2 * HSZ] + w * (32 * 36);
         const int col = wn * 32 + (lane & 7) * 4;
         const x_f32x4 bv = *(const x_f32x4*)(a.bias + col);
@@ -730,6 +785,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 }
 
+// Launches of at most one workgroup per CU (<= 256 tiles: a one-frame call, a SLAM pass) take the eight-wave form of the fp16 kernel (W8): there the
+// workgroup's latency IS the launch's duration.  SUO_WINO_W8=0 (supported switch, include/suo_hip.h; read per launch): the four-wave form everywhere (A/B);
+// SUO_WINO_W8_TILES (tuning builds): largest such launch.
+bool conv3x3_wino_f16x2_w8(long tiles) {
+    static const long upto = SUO_TUNE("SUO_WINO_W8_TILES", 256);
+    return tiles > 0 && tiles <= upto && env_switch("SUO_WINO_W8", 1) != 0;
+}
+
 // a.Wp = weights packed by pack_wino_weight_bf16x3 / _f16x2 (uint16 under a float pointer); 128 -> 128 or 64 -> 64 channels
 template <int NP>
 static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
@@ -745,7 +808,8 @@ static int launch_wino_split(const ConvArgs& a, hipStream_t s) {
         return SUO_ERR_ARG;
     }
     const int tiles = ((a.OW + X_TW - 1) / X_TW) * ((a.OH + X_TH - 1) / X_TH) * a.L;
-    hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
+    if (NP == 2 && conv3x3_wino_f16x2_w8(tiles)) hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, 2, false, true>), dim3(tiles), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((wino3x3_x3_kernel<false, false, false, 4, NP>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());
     return SUO_OK;
 }
@@ -765,6 +829,9 @@ int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s) {
         //  SLOWER than the two launches, profiles/REJECTED.md -- not built; csrc/net.hip does not ask for it)
         if (a.up) { suo_set_error("conv3x3_wino_f16x2_fused: the next block's conv1 cannot ride on a tail with an up-sampled addend"); return SUO_ERR_ARG; }
         hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, true>), dim3(tiles), dim3(256), 0, s, a);
+    } else if (conv3x3_wino_f16x2_w8(tiles)) {
+        if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2, false, true>), dim3(tiles), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2, false, true>), dim3(tiles), dim3(512), 0, s, a);
     } else if (a.up) hipLaunchKernelGGL((wino3x3_x3_kernel<true, true, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wino3x3_x3_kernel<true, false, true, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
     SUO_HIP_CHECK(hipGetLastError());

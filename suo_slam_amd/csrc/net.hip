@@ -648,7 +648,8 @@ bool Net::next_conv1_fusable(const ResidualW& next, int L, int H, int W) const {
     static const int on = (int)SUO_TUNE("SUO_FUSE_NEXT_CONV1", 1);                // 0: A/B
     const long x3_min_rows = this->x3_min_rows();
     return on && pipe_ == 2 && next.cin == 256 && next.c1.W16 && next.c1.osc16 && next.c1.N == 128 && next.c1.n_valid == 128 && next.c1.K1 == 256 && next.c1.K2 == 0 &&
-           (long)L * H * W >= x3_min_rows && !residual_in_one_launch(next, L, H, W);
+           (long)L * H * W >= x3_min_rows && !residual_in_one_launch(next, L, H, W) &&
+           !conv3x3_wino_f16x2_w8((long)((W + 15) / 16) * ((H + 7) / 8) * L);                     // (the eight-wave form of small launches does not carry it)
 }
 
 int Net::residual(const ResidualW& r, const float* x, float* out, int L, int H, int W, hipStream_t s, const float* up, float* pool_out, const ResidualW* next) {

@@ -142,6 +142,7 @@ void pack_tail_weight_f16x2(const float* W3, int N2, int K, uint16_t* out, float
 void pack_wino_weight_f16x2(const float* W, int N, int C, int Np, int Cp, const float* out_scale, uint16_t* out, float* oscale_out);
 int launch_conv3x3_wino_f16x2(const ConvArgs& a, hipStream_t s);
 int launch_conv3x3_wino_f16x2_fused(const ConvArgs& a, hipStream_t s);
+bool conv3x3_wino_f16x2_w8(long tiles);                // launches of <= one workgroup per CU: the eight-wave form (no next-block conv1 there)
 // RoIAlign + stem 7x7 / 2 (+ BN + ReLU) of the prior-less pass in one launch on the bf16 pipe (csrc/stem_x3.hip)
 void pack_stem_weight_bf16x3(const float* W, int Cw, const float* out_scale, uint16_t* out);
 // osc / range_flag: both null = Wx holds three bf16 planes; both set = two fp16 planes (pack_stem_weight_f16x2) with their per-channel factors and the guard flag

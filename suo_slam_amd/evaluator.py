@@ -251,7 +251,10 @@ class Evaluator:
                         if meter is not None:                         # the reference updates unconditionally; without ADD there is no meter
                             meter.update_no_det([o])
         out = {"method": None, "csv_path": None, "summary_path": None, "result": None, "saved_result": None, "num_views": num,
-               "num_cam_poses_found": num_cam_poses_found}
+               "num_cam_poses_found": num_cam_poses_found,
+               # a silent demotion of the network to the bf16x3 form must show in the reported numbers: calls re-issued, and the form it ended on
+               "fp16_range_reissues": int(getattr(self.object_slam, "fp16_range_reissues", 0)),
+               "matrix_pipe_at_end": (None if self.object_slam.model is None else {0: "f32", 1: "bf16x3", 2: "f16x2"}[self.object_slam.model.pipe()])}
         gt_obj_map = YCBV_CLASSES if ds.bop_dset == "ycbv" else TLESS_CLASSES
         if saved_meter is not None:
             out["saved_result"] = saved_meter.result()

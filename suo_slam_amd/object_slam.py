@@ -238,6 +238,7 @@ class ObjectSLAM:
             self._gpu_stream = torch.cuda.Stream(device=self.model.device)
             # frames carry a varying number of detections: capture the graph of every crop count now, not inside a timed view
             self.model.prepare(with_priors=(False,) if (single_view_mode or no_prior_det) else (False, True))
+        self.fp16_range_reissues = 0          # network calls re-issued on the bf16x3 form because an activation left fp16's range (reported by Evaluator.run / bench.py)
         self.avg_std_meter = AverageMeter()
         self.track_time_meter = AverageMeter()
         self.opt_time_meter = AverageMeter()
@@ -407,6 +408,7 @@ class ObjectSLAM:
             r = self._fg.fetch(copy=True)
             if not self.model.range_exceeded():               # (fp16 form only: an activation left its range -> the network is on bf16x3 now, once more)
                 break
+            self.fp16_range_reissues += 1
         self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
         self._ingest_single_view(view_id, obj_ids, bboxes, model_kps, model_kps_masks, K_bbox, r, 0, 0)
 
@@ -553,6 +555,7 @@ class ObjectSLAM:
             # key).  The network is on bf16x3 now: re-issue all of them in order from the host's seed, which only ever counted valid batches.
             redo = self._tickets
             self._tickets = []
+            self.fp16_range_reissues += len(redo)
             import torch
             torch.cuda.synchronize()
             self.model.range_exceeded()
@@ -705,6 +708,7 @@ class ObjectSLAM:
                     cov_uv = pred["cov"].cpu().numpy()
                 if not self.model.range_exceeded():           # (fp16 form only: the read-backs above synchronised; on True the network is on bf16x3 now)
                     break
+                self.fp16_range_reissues += 1
         if self.debug_gt_kp:
             assert kp_masks_gt is not None and uv_gt is not None
             kp_masks = np.asarray(kp_masks_gt, dtype=bool)
@@ -797,6 +801,7 @@ class ObjectSLAM:
             r = self._fg.fetch(copy=True)
             if not self.model.range_exceeded():               # (fp16 form only: the fetch synchronised; on True the network is on bf16x3 now, once more)
                 break
+            self.fp16_range_reissues += 1
         self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
         ret = []
         for k, obj_id in enumerate(obj_ids):

@@ -84,12 +84,20 @@ class PkpNet:
     def set_graph(self, enable: bool):
         _lib.check(_lib.lib().suo_net_set_graph(self._h, int(enable)), "suo_net_set_graph")
 
-    def prepare(self, crop_counts=None, with_priors=(False, True)):
+    def prepare(self, crop_counts=None, with_priors=(False, True), fallback_pipe=True):
         """Capture the backbone graphs for these crop counts (default: 1..max_crops) before the first frame arrives, so that no
-        frame with a not-yet-seen number of detections pays a graph capture (suo_net_prepare)."""
-        for L in (range(1, self.max_crops + 1) if crop_counts is None else crop_counts):
-            for wp in with_priors:
-                _lib.check(_lib.lib().suo_net_prepare(self._h, int(L), int(bool(wp)), _stream()), "suo_net_prepare")
+        frame with a not-yet-seen number of detections pays a graph capture (suo_net_prepare).  fallback_pipe: on the fp16 form also capture the graphs of the
+        bf16x3 form the network moves to when an activation leaves fp16's range -- the first such view then pays a re-issued forward, not a capture."""
+        counts = list(range(1, self.max_crops + 1) if crop_counts is None else crop_counts)
+        pipes = [self.pipe()] + ([1] if (fallback_pipe and self.pipe() == 2) else [])
+        for p in reversed(pipes):                          # (the form in use last: the network is left on it)
+            if p != self.pipe():
+                self.set_pipe(p)
+            for L in counts:
+                for wp in with_priors:
+                    _lib.check(_lib.lib().suo_net_prepare(self._h, int(L), int(bool(wp)), _stream()), "suo_net_prepare")
+        if self.pipe() != pipes[0]:
+            self.set_pipe(pipes[0])
 
     def workspace_bytes(self):
         return int(_lib.lib().suo_net_workspace_bytes(self._h))

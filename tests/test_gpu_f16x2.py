@@ -323,10 +323,12 @@ def test_network_falls_back_when_activations_leave_the_fp16_range(monkeypatch, c
 
 @pytest.mark.parametrize("up", [False, True])
 @pytest.mark.parametrize("L,H,W", [(6, 32, 32), (3, 20, 24), (2, 64, 64)])
-def test_fused_tail_with_the_next_blocks_conv1_equals_the_separate_launches(ops, up, L, H, W):
+def test_fused_tail_with_the_next_blocks_conv1_equals_the_separate_launches(ops, monkeypatch, up, L, H, W):
     """csrc/conv_wino_x3.hip, NEXT: the block's output is split for the next block's conv1 where it is stored and multiplied on the spot.  Bit for bit: `out` = the
     fused tail without NEXT; `next` = suo_conv1x1_f16x2_ex (BN + ReLU prologue, ReLU) on that `out` -- the same products in the same order.  Ragged maps (tiles that
-    leave the map write nothing outside it), the up-sampled addend, and the range guard on the inner operand relu(bn_next(out))."""
+    leave the map write nothing outside it), the up-sampled addend, and the range guard on the inner operand relu(bn_next(out)).
+    (Bit-identity is between the FOUR-wave forms: the eight-wave form small launches take pairs its last additions differently, test_eight_wave_form_of_small_launches.)"""
+    monkeypatch.setenv("SUO_WINO_W8", "0")
     rng = np.random.default_rng(31 + H + up)
     x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
     skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
@@ -422,3 +424,43 @@ def test_chain_head_range_guard(ops):
     a2 = a.clone()
     a2[100, 3] = 5000.0
     assert ops.conv1x1_chain_head_f16x2(a2, w1, b, w2, np.zeros(64, np.float32), 41, hw)[1] == 1                          # the input
+
+
+@pytest.mark.parametrize("L,H,W", [(1, 64, 64), (5, 64, 64), (8, 64, 64), (3, 32, 32), (2, 40, 24)])
+def test_eight_wave_form_of_small_launches(ops, monkeypatch, L, H, W):
+    """Round 6: launches of <= 256 tiles (a one-frame call, the passes of a SLAM view) run the fp16 Winograd kernels with EIGHT waves per tile
+    (csrc/conv_wino_x3.hip: W8 -- two waves per 32-channel slice, half the components each, no fold; conv3 one n-tile per wave).  Against fp64 at the split forms'
+    tolerance, against the four-wave form (SUO_WINO_W8=0) to fp32 rounding of the last additions, and -- ragged maps -- nothing written outside the map."""
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(100 * L + H)
+    x = torch.from_numpy(rng.standard_normal((L, H, W, 128)).astype(np.float32)).cuda()
+    skip = torch.from_numpy(rng.standard_normal((L, H, W, 256)).astype(np.float32)).cuda()
+    w2 = (rng.standard_normal((128, 128, 3, 3)) / 34).astype(np.float32)
+    b2 = (rng.standard_normal(128) * 0.2).astype(np.float32)
+    w3 = (rng.standard_normal((256, 128)) / 11).astype(np.float32)
+    b3 = rng.standard_normal(256).astype(np.float32)
+    even = H % 2 == 0 and W % 2 == 0
+    low = torch.from_numpy(rng.standard_normal((L, H // 2, W // 2, 256)).astype(np.float32)).cuda() if even else None
+
+    def run():
+        r = [ops.conv3x3_wino_f16x2_conv1x1_skip_up(x, w2, b2, w3, b3, skip), ops.conv3x3_wino_f16x2(x, w2, b2, relu=True)]
+        if even:
+            r.append(ops.conv3x3_wino_f16x2_conv1x1_skip_up(x, w2, b2, w3, b3, skip, low))
+        assert all(f == 0 for _, f in r)
+        return [t for t, _ in r]
+    monkeypatch.setenv("SUO_WINO_W8", "0")
+    four = run()
+    monkeypatch.setenv("SUO_WINO_W8", "1")
+    eight = run()
+    xm = x.cpu().permute(0, 3, 1, 2).double()
+    mid = Fn.relu(Fn.conv2d(xm, torch.from_numpy(w2).double(), torch.from_numpy(b2).double(), padding=1))
+    ref_tail = Fn.conv2d(mid, torch.from_numpy(w3).double()[:, :, None, None], torch.from_numpy(b3).double()).permute(0, 2, 3, 1) + skip.cpu().double()
+    refs = [ref_tail, mid.permute(0, 2, 3, 1)]
+    if even:
+        refs.append(ref_tail + low.cpu().double().repeat_interleave(2, 1).repeat_interleave(2, 2))
+    for k, (a, b, r) in enumerate(zip(four, eight, refs)):
+        scale = float(r.abs().max())
+        assert torch.isfinite(b).all()
+        assert float((b.cpu().double() - r).abs().max()) < 5e-6 * scale, (k, "vs fp64")
+        assert float((b - a).abs().max()) < 2e-6 * scale, (k, "vs the four-wave form")
+        assert not torch.equal(a, b) or L * H * W < 64                      # (the eight-wave form really ran: its last additions pair differently)
