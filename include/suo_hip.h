@@ -11,6 +11,22 @@
  * or a SUO_ERR_* code (suo_last_error() gives the message).  Pointers named *_dev are device (HBM)
  * pointers; `stream` is a hipStream_t passed as void* (NULL = internal stream + blocking).
  * All work is stream-ordered; the library never reads or writes host memory behind *_dev names.
+ *
+ * Runtime switches.  The library reads NINE environment variables, all of them selections between forms whose results the test suite holds against each other
+ * (csrc/tune.h: env_switch); nothing else in the environment changes what it does:
+ *     SUO_WINO_BF16X3=0      networks are built on the fp32 matrix pipe (SUO_PIPE_F32)                      read when a network is created
+ *     SUO_F16X2=0            networks are built on three bf16 terms per operand (SUO_PIPE_BF16X3)             read when a network is created
+ *     SUO_STEM_X3=0          prior-less pass: RoIAlign and the stem as two launches instead of the fused one  first use, per process
+ *     SUO_FUSE_UPSAMPLE=0    Hourglass up-sample add as its own launch instead of the fused tail's epilogue   first use, per process
+ *     SUO_FUSE_POOL=0        2x2 max-pool as its own launch instead of the producing GEMM's epilogue          first use, per process
+ *     SUO_NET_SIDE_STREAMS=n the Hourglass up1 branches on n side streams (default 0)                          first use, per process
+ *     SUO_SERIAL             (set) one stream, kernels back to back: per-kernel profiling                      per call
+ *     SUO_LM_CAM2=0          camera tracking on lm_cam_kernel instead of lm_cam2_kernel                        first use, per process
+ *     SUO_WINO_W8=0          small launches keep the four-wave Winograd kernels (see suo_conv3x3_wino_f16x2*)  per launch
+ * The thresholds and A/B knobs behind the measurements of DESIGN.md / profiles/REJECTED.md (SUO_TUNE in csrc/tune.h: launch-size thresholds, tile choices, kernel
+ * selections) are compiled to their defaults; only the variant builds of tools/build_variant.sh (-DSUO_TUNING) read them from the environment.  The host side above
+ * the ABI has its own, in suo_slam_amd/: SUO_HIP_LIB (path of the library), SUO_BA_GRAPH / SUO_BA_HOST_SCHEDULE / SUO_FORCE_COLLECTIVES (ba_dist.py),
+ * SUO_SLAM_STORE_SLOTS (slam_score.py).
  */
 #ifndef SUO_HIP_H
 #define SUO_HIP_H
@@ -205,7 +221,10 @@ int suo_conv3x3_wino_x3_conv1x1_skip_up(const float* in_dev, int L, int H, int W
                                         const void* wp3_dev, int tail_bf16x3, const float* bias3_dev, const float* skip_dev,
                                         const float* up_dev, float* out_dev, void* stream);
 /* csrc/conv_wino_x3.hip on two fp16 terms per operand (csrc/f16x2.h; the network's default for the Residual blocks' 3x3 + tail): packers return the planes
- * (2 * 16 * N * C / 2 * N2 * K uint16) and the per-output-channel factors; range_flag_dev as suo_conv1x1_f16x2_ex. */
+ * (2 * 16 * N * C / 2 * N2 * K uint16) and the per-output-channel factors; range_flag_dev as suo_conv1x1_f16x2_ex.
+ * Launches of at most 256 tiles of 8 x 16 pixels (one workgroup per CU: a one-frame call, the passes of a SLAM view) run the 128-channel kernels with EIGHT waves
+ * per tile (two per 32-channel slice, half the Winograd components each, no per-chunk fold; conv3 one 32-channel tile per wave): the same products, the last
+ * additions of the output transform paired differently -- results within fp32 rounding of the four-wave form's, which SUO_WINO_W8=0 keeps everywhere. */
 int suo_pack_wino_weight_f16x2(const float* w, int N, int C, uint16_t* out, float* oscale_out);
 int suo_conv3x3_wino_f16x2_n(const float* in_dev, int L, int H, int W, int channels, const uint16_t* wq16_dev, const float* oscale_dev, const float* bias_dev,
                              float* out_dev, int relu, unsigned* range_flag_dev, void* stream);
@@ -216,7 +235,8 @@ int suo_conv3x3_wino_f16x2_conv1x1_skip_up(const float* in_dev, int L, int H, in
 /* ... and with the NEXT Residual block's conv1 in the same launch (layers/Residual.py:22-24 of the block that consumes out_dev): next_out_dev [L,H,W,128] =
  * relu(W1' relu(out * next_scale + next_shift) + next_b1) with W1' [128][256] (bn1 folded) as suo_pack_gemm_weight_f16x2 planes + factors.  out_dev is written as
  * before; the 256-channel tensor is not re-read by a separate 1x1 launch.  Bit-identical to suo_conv3x3_wino_f16x2_conv1x1_skip_up followed by
- * suo_conv1x1_f16x2_ex (same products, same order).  What suo_net_forward launches wherever a 256 -> 256 block on a large launch feeds another. */
+ * suo_conv1x1_f16x2_ex (same products, same order).  What suo_net_forward launches wherever a 256 -> 256 block on a launch of more than 256 tiles feeds another
+ * (always the four-wave kernel: the eight-wave form of small launches does not carry the next block's conv1). */
 int suo_conv3x3_wino_f16x2_conv1x1_skip_up_next(const float* in_dev, int L, int H, int W, const uint16_t* wq16_dev, const float* oscale2_dev, const float* bias2_dev,
                                                 const uint16_t* w3p16_dev, const float* oscale3_dev, const float* bias3_dev, const float* skip_dev, const float* up_dev,
                                                 float* out_dev, const float* next_scale_dev, const float* next_shift_dev, const uint16_t* next_w1h_dev,

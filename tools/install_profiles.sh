@@ -3,7 +3,7 @@
 # installed file starts with the command that produced it, taken from the cmd_*.txt the profiling script wrote (not retyped here).
 #   bash tools/install_profiles.sh <tag> [round-prefix, default r03]
 set -eu
-TAG=$1; P=${2:-r05}
+TAG=$1; P=${2:-r06}
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/round_$TAG
 for extra in "" _driver_flags _objects16; do

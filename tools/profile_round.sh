@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (one gpurun call): bench lines, kernel traces, dominant-kernel stats, PMC passes.
 #   bash tools/profile_round.sh <round-tag>      -> gpurun_out/round_<tag>/...   (then: bash tools/install_profiles.sh <tag> <prefix>)
 # Every rocprofv3 command is written next to its output (cmd_*.txt) so that the installed files carry the command that made them.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
 [ -z "${SUO_PROFILE_ONLY_PMC:-}" ] && rm -rf $OUT
@@ -67,7 +67,7 @@ python3 $R/tools/bench_chain_head.py 256 2>&1 | grep -v amdgpu.ids > $OUT/chain_
 python3 $R/tools/bench_chain_head.py 8 2>&1 | grep -v amdgpu.ids >> $OUT/chain_head.txt
 ms() { python3 $R/bench.py --no-legs --only cnn --depth 1 --objects $1 --frames-per-step 1 --steps 200 --warmup 20 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
 for L in 1 2 3 4 5 6 7 8 9; do
-  echo "crops per call $L: $(ms $L) ms | thresholds of rounds 1-4 (SUO_CONV_WINO_TILES=256 SUO_WINO_FUSE_TILES=256 SUO_GEMM_X3_MIN_ROWS=32768): $(SUO_CONV_WINO_TILES=256 SUO_WINO_FUSE_TILES=256 SUO_GEMM_X3_MIN_ROWS=32768 ms $L) ms"
+  echo "crops per call $L: $(ms $L) ms | four-wave Winograd kernels on small launches too (SUO_WINO_W8=0, rounds 1-5): $(SUO_WINO_W8=0 ms $L) ms"
 done > $OUT/network_by_crops.txt
 python3 $R/tools/bench_global_ba.py 60 8 2>&1 | grep -v amdgpu.ids > $OUT/global_ba_tool.txt
 fi
