@@ -364,6 +364,25 @@ int suo_frame_geom_launch(suo_frame_geom* g, int n_frames, const int* frame_firs
                           const suo_frame_geom_params* params, void* stream);
 int suo_frame_geom_fetch(suo_frame_geom* g, suo_frame_geom_result* out);
 int suo_frame_geom_ready(suo_frame_geom* g);      /* 1 when the last launch has completed (or nothing is in flight), 0 otherwise; never blocks */
+/* The result block's DEVICE pointers (same fields): valid, stream-ordered, for work enqueued on the launch's stream behind it, until the context's next launch. */
+int suo_frame_geom_device_result(suo_frame_geom* g, suo_frame_geom_result* out);
+
+/* ---- SLAM tracking between the two network passes of a view (round 6): camera-hypothesis vote + prior projection on the device -------------
+ * Replaces, on the caller's stream and without a host round trip, ObjectSLAM.__estimate_camera_pose (lib/object_slam.py:975-1072) on the detections of the view's
+ * FIRST pass and the projection of the prior keypoints of the SECOND pass's objects (:486-514).  Inputs on the device: pass A's chain results
+ * (suo_frame_geom_device_result: T_pnp [n_a][16], accepted [n_a], n_kp [n_a]), pass A's network outputs uv / cov, its masks and model keypoints ([n_a,41,...]), pass B's
+ * model keypoints [n_b,41,3] float32 and class masks [n_b,41]; block_dev = SUO_SLAM_VOTE_BLOCK doubles staged by the caller (e.g. with its other small arrays):
+ *   a_in_map [16] | a_T_OtoG [16][12] | a_K_bbox [16][9] (the float32 container widened, :1082) | b_in_map [16] | b_T_OtoG [16][12] | b_K_bbox [16][9] (fix_K_for_bbox_ndc, double)
+ * (rows of objects that are not in the map: in_map 0, the rest ignored).  has_cov / kp_std2 / chi2_max as suo_slam_score; min_inliers = 4 (:975).
+ * Outputs on the device: prior_uv_dev [n_b][41][2] float32 + prior_mask_dev [n_b][41] -- what suo_net_forward_prior_kp takes (rows of objects without a prior: zeros) --
+ * and out_dev [SUO_SLAM_VOTE_OUT] doubles: T_GtoC [3][4] | best crop (-1: no hypothesis reached min_inliers -- the caller falls back to
+ * __backup_estimate_camera_pose and issues pass B again) | number of hypotheses | best count | counts [16] (-1: not a hypothesis) | NaN flag. */
+#define SUO_SLAM_VOTE_BLOCK 704
+#define SUO_SLAM_VOTE_OUT 32
+int suo_slam_vote(int n_a, const double* T_pnp_dev, const uint8_t* accepted_dev, const int* n_kp_dev, const float* uv_dev, const float* cov_dev,
+                  const uint8_t* mask_dev, const float* model_kps_a_dev, const double* block_dev, int n_b, const float* model_kps_b_dev,
+                  const uint8_t* model_mask_b_dev, int has_cov, double kp_std2, double chi2_max, int min_inliers, float* prior_uv_dev,
+                  uint8_t* prior_mask_dev, double* out_dev, void* stream);
 
 /* ---- pose refinement / bundle adjustment: replaces the g2o calls of ObjectSLAM.optimize -------------
  * (lib/object_slam.py:703-903; g2o surface listed in SURVEY.md 8b).  A problem is the flat SoA of the graph

@@ -119,6 +119,8 @@ SIGNATURES = {
     "suo_frame_geom_launch": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "suo_frame_geom_fetch": (C.c_int, [VP, VP]),
     "suo_frame_geom_ready": (C.c_int, [VP]),
+    "suo_frame_geom_device_result": (C.c_int, [VP, VP]),
+    "suo_slam_vote": (C.c_int, [C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, VP, VP, C.c_int, C.c_double, C.c_double, C.c_int, VP, VP, VP, VP]),
     "suo_mesh_db_create": (C.c_int, [C.c_int, VP, VP, C.POINTER(VP)]),
     "suo_mesh_db_destroy": (None, [VP]),
     "suo_pose_errors": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),

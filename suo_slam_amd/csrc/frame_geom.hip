@@ -305,6 +305,18 @@ int suo_frame_geom_fetch(suo_frame_geom* c, suo_frame_geom_result* r) {
     return SUO_OK;
 }
 
+// The same block where it lies on the DEVICE after the launch's kernels (stream-ordered: valid for work enqueued on the launch's stream behind it, until the
+// context's next launch): what a kernel that continues the chain reads -- csrc/slam_vote.hip takes T_pnp / accepted / n_kp of a SLAM view's first pass from here.
+int suo_frame_geom_device_result(suo_frame_geom* c, suo_frame_geom_result* r) {
+    if (!c || !r) { suo_set_error("suo_frame_geom_device_result: null argument"); return SUO_ERR_ARG; }
+    if (!c->launched) { suo_set_error("suo_frame_geom_device_result: nothing launched"); return SUO_ERR_ARG; }
+    r->n_frames = c->n_frames; r->n_crops = c->L;
+    r->T_pnp = c->A.T_pnp; r->T_opt = c->A.T_opt; r->chi2 = c->A.chi2; r->pnp_status = c->A.status; r->pnp_best_inliers = c->A.best;
+    r->pnp_iterations = c->A.iters; r->n_kp = c->A.counts_out; r->lm_stats = c->A.stats; r->accepted = c->A.accepted; r->inlier = c->A.inlier;
+    r->uv = c->A.uv_out; r->cov = c->A.cov_out; r->mask = c->A.mask_out;
+    return SUO_OK;
+}
+
 int suo_frame_geom_ready(suo_frame_geom* c) {
     if (!c || !c->launched) return 1;
     return hipEventQuery(c->done) == hipSuccess ? 1 : 0;

@@ -72,6 +72,13 @@ class FrameGeometry:
                                                    kinv.ctypes.data, camk.ctypes.data, md.ctypes.data, C.byref(p), C.c_void_p(int(stream))),
                    "suo_frame_geom_launch")
 
+    def device_result(self):
+        """The last launch's result block where it lies on the DEVICE (raw pointers in a FrameGeomResult; stream-ordered behind the launch, valid until this
+        context's next launch): what a kernel continuing the chain reads (suo_slam_vote)."""
+        r = _lib.FrameGeomResult()
+        _lib.check(self._lib.suo_frame_geom_device_result(self._h, C.byref(r)), "suo_frame_geom_device_result")
+        return r
+
     def ready(self):
         return bool(self._lib.suo_frame_geom_ready(self._h))
 

@@ -18,6 +18,8 @@ from __future__ import annotations
 from collections import defaultdict
 from time import time
 
+import os
+
 import numpy as np
 
 from . import ba as _ba
@@ -359,7 +361,10 @@ class ObjectSLAM:
         def sub(mask):
             return (obj_ids[mask], bboxes[mask], model_kps[mask], model_kps_masks[mask], kp_masks[mask],
                     uv_gt[mask] if uv_gt is not None else None)
-        if n_non_sym > 0:
+        chained = False
+        if self._slam_view_takes_the_vote_chain(view_id, cam_pose, n_non_sym, n_sym):
+            chained = self._process_view_slam_chain(view_id, img, K, sub(is_non_sym), sub(is_sym))
+        elif n_non_sym > 0:
             self._process_objects(False, view_id, img, K, *sub(is_non_sym))
         if view_id not in self.cam_poses:
             if len(self.view_ids) == 0:
@@ -367,7 +372,7 @@ class ObjectSLAM:
                 self.cam_poses[view_id] = np.eye(4)[:3, :]
             else:
                 self._backup_estimate_camera_pose(view_id, obj_ids, bboxes)
-        if n_sym > 0 and ((view_id in self.cam_poses) or self.no_prior_det):
+        if n_sym > 0 and not chained and ((view_id in self.cam_poses) or self.no_prior_det):
             self._process_objects(True, view_id, img, K, *sub(is_sym))
         if not self.single_view_mode:
             self._maybe_reinit_objects(view_id, len(self.view_ids) if self.sfm_mode else 15)
@@ -626,6 +631,13 @@ class ObjectSLAM:
                     prior_det_uv[obj_id] = full
                     prior_dets[obj_id] = (full, m.astype(np.uint8))        # rendered on the device (pkpnet.PkpNet.forward)
         kp_det = self._run_kp_model(view_id, img, K, obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt, prior_dets)
+        self._install_kp_detections(view_id, obj_ids, bboxes, model_kps_masks, kp_det, prior_det_uv)
+
+    _VOTE_ON_HOST = object()
+
+    def _install_kp_detections(self, view_id, obj_ids, bboxes, model_kps_masks, kp_det, prior_det_uv, cam_vote=_VOTE_ON_HOST):
+        """Second half of __process_objects (object_slam.py:527-593): the detections of a pass into the state, the view's camera pose from the hypothesis vote when it
+        has none yet, new objects into the map.  cam_vote: the vote's outcome when it was taken on the device (csrc/slam_vote.hip: the pose or None), else the host votes."""
         if not self.no_network_cov:
             for det in kp_det:
                 if det["cov_pred"] is not None and det["cov_pred"].size > 0:
@@ -651,7 +663,7 @@ class ObjectSLAM:
             if self.num_views_processed() == 0:
                 self.cam_poses[view_id] = np.eye(4)[:3, :]
             else:
-                cam_pose = self._estimate_camera_pose(view_id)
+                cam_pose = self._estimate_camera_pose(view_id) if cam_vote is self._VOTE_ON_HOST else cam_vote
                 if cam_pose is None:
                     return
                 self.cam_poses[view_id] = cam_pose
@@ -803,6 +815,10 @@ class ObjectSLAM:
                 break
             self.fp16_range_reissues += 1
         self._pnp_seed += int(np.count_nonzero(r["n_kp"] >= 4))
+        return self._kp_det_from_chain(r, obj_ids, model_kps, K_bbox, uv_gt)
+
+    def _kp_det_from_chain(self, r, obj_ids, model_kps, K_bbox, uv_gt):
+        """What __run_kp_model returns per object (:1150-1165), from a chain read-back."""
         ret = []
         for k, obj_id in enumerate(obj_ids):
             m = r["mask"][k]
@@ -813,6 +829,141 @@ class ObjectSLAM:
                         "model_kp": model_kps[k][m].astype(np.float64), "uv_gt": uv_gt, "uv_pred": r["uv"][k][m].astype(np.float64),
                         "cov_pred": None if self.no_network_cov else r["cov"][k][m], "K": K_bbox[k].astype(np.float64), "score": 0.0 if n == 0 else 1.0})
         return ret
+
+    def _slam_view_takes_the_vote_chain(self, view_id, cam_pose, n_non_sym, n_sym):
+        """Both passes of a SLAM view as ONE device chain (pass A -> PnP -> hypothesis vote -> prior projection -> pass B): a tracking view of a running map with
+        objects of both kinds, on the routes that keep their keypoints on the device.  SUO_SLAM_VOTE_CHAIN=0: the host votes between the passes (A/B)."""
+        return (self.device_chain and self.model is not None and (not self.debug_gt_kp or self.debug_gt_on_device) and not self.single_view_mode and cam_pose is None
+                and not self.no_prior_det and 0 < n_non_sym <= 16 and 0 < n_sym <= 16 and self.num_views_processed() > 0 and view_id not in self.cam_poses
+                and os.environ.get("SUO_SLAM_VOTE_CHAIN", "1") not in ("", "0"))
+
+    def _process_view_slam_chain(self, view_id, img, K, A, B):
+        """A SLAM view's two network passes with NOTHING on the host between them (round 6; lib/object_slam.py:464-593 twice, :975-1072 between): pass A (the
+        non-symmetric objects) -> masks -> compaction -> PnP -> acceptance (csrc/frame_geom.hip) -> camera-hypothesis vote + projection of the symmetric objects' prior
+        keypoints (csrc/slam_vote.hip) -> pass B with device-rendered priors -> its PnP, enqueued back to back; the host reads pass A's block and the vote while pass B
+        runs and does pass A's bookkeeping under it.  A / B = (obj_ids, bboxes, model_kps, model_kps_masks, kp_masks, uv_gt) of the two passes.  Leaves the state the
+        two _process_objects calls leave; when no hypothesis reaches four inliers (:1067) it returns False with pass A installed, and the caller continues as the
+        reference does (__backup_estimate_camera_pose, then pass B again with that pose)."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        from .frame_geom import FrameGeometry, kbbox_terms
+        from .pkpnet import keypoint_masks
+        lib = _lib.lib()
+        ids_a, bb_a, kps_a, mm_a, gtm_a, gtu_a = A
+        ids_b, bb_b, kps_b, mm_b, gtm_b, gtu_b = B
+        La, Lb = len(ids_a), len(ids_b)
+        Kb_a = fix_K_for_bbox_ndc_many(K, bb_a).astype(np.float32)            # float32 containers (:1082)
+        Kb_b = fix_K_for_bbox_ndc_many(K, bb_b).astype(np.float32)
+        kinv_a, camk_a = kbbox_terms(Kb_a)
+        kinv_b, camk_b = kbbox_terms(Kb_b)
+        md_a = np.array([0.5 * self.mesh_db[o]["diameter"] for o in ids_a], dtype=np.float64)
+        md_b = np.array([0.5 * self.mesh_db[o]["diameter"] for o in ids_b], dtype=np.float64)
+        if self._fg is None or self._fg.max_crops < max(La, Lb):
+            self._fg = FrameGeometry(max(16, La, Lb), 1)
+        if getattr(self, "_fg2", None) is None or self._fg2.max_crops < max(La, Lb):
+            self._fg2 = FrameGeometry(max(16, La, Lb), 1)
+        vt = 1e30 if self.no_network_cov else self.kp_var_thresh
+        # the vote's host block (include/suo_hip.h: SUO_SLAM_VOTE_BLOCK): map poses and intrinsics of both passes' objects
+        blk = np.zeros(704)
+        for k, o in enumerate(ids_a):
+            if o in self.obj_poses:
+                blk[k] = 1.0
+                blk[16 + 12 * k:28 + 12 * k] = np.asarray(self.obj_poses[o], dtype=np.float64)[:3, :4].reshape(-1)
+            blk[208 + 9 * k:217 + 9 * k] = Kb_a[k].astype(np.float64).reshape(-1)
+        for k, o in enumerate(ids_b):
+            if o in self.obj_poses:
+                blk[352 + k] = 1.0
+                blk[368 + 12 * k:380 + 12 * k] = np.asarray(self.obj_poses[o], dtype=np.float64)[:3, :4].reshape(-1)
+            blk[560 + 9 * k:569 + 9 * k] = fix_K_for_bbox_ndc(K, bb_b[k]).reshape(-1)               # (double, as the reference projects with it: :505)
+
+        def gt_arrays(L, gtm, gtu):                           # (debug_gt_on_device: the host route's draws, in its order -- pass A's objects, then pass B's)
+            mask = np.ascontiguousarray(gtm, dtype=np.uint8)
+            uv = np.zeros((L, NUM_KP, 2), dtype=np.float32)
+            for k in range(L):
+                m = mask[k].astype(bool)
+                u = gtu[k][m].astype(np.float64)
+                uv[k][m] = (u + self._rng.normal(scale=0.01, size=u.shape)).astype(np.float32)
+            return mask, uv
+        debug = self.debug_gt_kp
+        rng_state = self._rng.bit_generator.state if debug else None
+        host = [np.ascontiguousarray(kps_a, dtype=np.float32), np.ascontiguousarray(bb_a, dtype=np.float32), np.ascontiguousarray(mm_a, dtype=np.uint8),
+                np.ascontiguousarray(kps_b, dtype=np.float32), np.ascontiguousarray(bb_b, dtype=np.float32), np.ascontiguousarray(mm_b, dtype=np.uint8), blk]
+        if debug:
+            ga, ua = gt_arrays(La, gtm_a, gtu_a)
+            gb, ub = gt_arrays(Lb, gtm_b, gtu_b)
+            host += [ga, ua, gb, ub]
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        for _attempt in range(2):
+            frame = self._frame_on_device(img)
+            st = self.model.stage_block(host)
+            dev = st[0].device
+            seed_run = torch.zeros(1, dtype=torch.int64, device=dev)
+            puv = torch.empty((Lb, NUM_KP, 2), dtype=torch.float32, device=dev)
+            pmk = torch.empty((Lb, NUM_KP), dtype=torch.uint8, device=dev)
+            vout = torch.empty(32, dtype=torch.float64, device=dev)
+            # ---- pass A
+            pa = self.model(frame, [st[1]], None, check=False, out_slot="slam A")
+            uv_a, mk_a = (st[8], st[7]) if debug else (pa["uv"], keypoint_masks(pa["uv"], pa["cov"], pa["kp_mask"], st[2], self.bbox_thresh, vt))
+            self._fg.launch([0, La], uv_a, pa["cov"], mk_a, st[0], kinv_a, camk_a, md_a, seed=self._pnp_seed, use_cov=not self.no_network_cov, do_lm=False,
+                            seed_dev=seed_run)
+            ra_dev = self._fg.device_result()
+            # ---- vote + priors, on the stream, behind pass A's PnP
+            _lib.check(lib.suo_slam_vote(La, ra_dev.T_pnp, ra_dev.accepted, ra_dev.n_kp, P(uv_a), P(pa["cov"]), P(mk_a), P(st[0]), P(st[6]), Lb, P(st[3]), P(st[5]),
+                                         int(not self.no_network_cov), float(self.manual_kp_std) ** 2, CHI2_2DOF_95, 4, P(puv), P(pmk), P(vout),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "suo_slam_vote")
+            if getattr(self, "_vote_pin", None) is None:
+                self._vote_pin = (torch.empty(32, dtype=torch.float64).pin_memory(), torch.empty((16, NUM_KP, 2), dtype=torch.float32).pin_memory(),
+                                  torch.empty((16, NUM_KP), dtype=torch.uint8).pin_memory(), torch.cuda.Event())
+            v_pin, puv_pin, pmk_pin, v_ev = self._vote_pin
+            v_pin.copy_(vout, non_blocking=True)
+            puv_pin[:Lb].copy_(puv, non_blocking=True)
+            pmk_pin[:Lb].copy_(pmk, non_blocking=True)
+            v_ev.record()
+            # ---- pass B: priors rendered on the device from what the vote kernel wrote; nothing above has waited
+            pb = self.model(frame, [st[4]], None, prior_uv=puv, prior_mask=pmk, check=False, out_slot="slam B")
+            uv_b, mk_b = (st[10], st[9]) if debug else (pb["uv"], keypoint_masks(pb["uv"], pb["cov"], pb["kp_mask"], st[5], self.bbox_thresh, vt))
+            self._fg2.launch([0, Lb], uv_b, pb["cov"], mk_b, st[3], kinv_b, camk_b, md_b, seed=self._pnp_seed, use_cov=not self.no_network_cov, do_lm=False,
+                             seed_dev=seed_run)
+            # ---- the host, under pass B: pass A's block and the vote
+            ra = self._fg.fetch(copy=True)
+            v_ev.synchronize()
+            vote = v_pin.numpy().copy()
+            prior_uv_h, prior_mask_h = puv_pin[:Lb].numpy().copy(), pmk_pin[:Lb].numpy().copy()
+            rb = self._fg2.fetch(copy=True)
+            if not self.model.range_exceeded():
+                break
+            self.fp16_range_reissues += 1                     # (fp16 form only: both passes again on bf16x3)
+        assert vote[31] == 0.0, "NaN in information matrix"
+        n_solv_a = int(np.count_nonzero(ra["n_kp"] >= 4))
+        best = int(vote[12])
+        hyp_ids = [o for k, o in enumerate(ids_a) if vote[15 + k] >= 0]
+        # ---- pass A into the state, with the device's vote
+        self._pnp_seed += n_solv_a
+        det_a = self._kp_det_from_chain(ra, ids_a, kps_a, Kb_a, gtu_a)
+        cam = None
+        if best >= 0:
+            cam = np.eye(4)
+            cam[:3, :4] = vote[:12].reshape(3, 4)
+        self.last_cam_hypotheses = ({"obj_ids": hyp_ids, "counts": [int(vote[15 + k]) for k in range(La) if vote[15 + k] >= 0], "best_num_inliers": int(vote[14])}
+                                    if hyp_ids else None)
+        self._install_kp_detections(view_id, ids_a, bb_a, mm_a, det_a, None, cam_vote=cam)
+        if cam is None:
+            # no hypothesis reached four inliers: the reference falls back to the bbox-centroid pose and THEN runs pass B -- with priors this chain did not have.
+            # Pass B's speculative results are dropped (its PnP consumed sampler keys past the host's seed, which never counted them); the noise draws of its
+            # ground-truth keypoints are taken back so that the pass the caller now issues draws them again.
+            if debug:
+                st_ = self._rng.bit_generator.state
+                self._rng.bit_generator.state = rng_state
+                gt_arrays(La, gtm_a, gtu_a)                   # (re-consume pass A's share)
+                del st_
+            return False
+        # ---- pass B into the state
+        self._pnp_seed += int(np.count_nonzero(rb["n_kp"] >= 4))
+        det_b = self._kp_det_from_chain(rb, ids_b, kps_b, Kb_b, gtu_b)
+        prior_det_uv = {o: prior_uv_h[k] for k, o in enumerate(ids_b) if prior_mask_h[k].any()}
+        self._install_kp_detections(view_id, ids_b, bb_b, mm_b, det_b, prior_det_uv)
+        return True
 
     # ---------------------------------------------------------------------------------------------
     def _estimate_camera_pose(self, view_id, min_num_inliers=4):

@@ -129,13 +129,15 @@ class PkpNet:
         forward(..., check=True) -- the default -- does all of this itself."""
         return bool(_lib.lib().suo_net_range_exceeded(self._h))
 
-    def forward(self, images, boxes, prior_kp=None, want_prob=False, prior_uv=None, prior_mask=None, check=True):
+    def forward(self, images, boxes, prior_kp=None, want_prob=False, prior_uv=None, prior_mask=None, check=True, out_slot=None):
         """images: uint8 [H,W,3] (cv2 layout) or float32 [1,3,H,W] device/host tensor; boxes: list with
         one Tensor[L,4] (xyxy); prior_kp: list with one Tensor[L,41,256,256] or None.
         Returns the reference's dict: uv, cov, prob_logits, kp_mask_logits, kp_mask (+ prob if asked).
         check: on the fp16 form, wait for the call and re-issue it on bf16x3 if an activation left the range (the reference's callers read the
         outputs back right away, lib/object_slam.py:1100-1111, so the wait costs them nothing); check=False returns at once -- the caller then
-        asks range_exceeded() after its own synchronisation and re-issues (what ObjectSLAM's device chains do)."""
+        asks range_exceeded() after its own synchronisation and re-issues (what ObjectSLAM's device chains do).
+        out_slot: any hashable -- the output tensors of (crop count, slot) are allocated once and handed out again by later calls naming the same slot (a caller that
+        has consumed the previous call's outputs: five allocations per call saved on a path whose host time is on the critical path)."""
         assert self._h is not None, "load_state_dict first"
         assert isinstance(boxes, (list, tuple)) and len(boxes) == 1, "one image per call (lib/object_slam.py:1092-1099)"
         dev = self.device
@@ -156,11 +158,20 @@ class PkpNet:
             assert prior_uv is None, "give the dense prior heat-maps OR the prior keypoints, not both"
             pr = torch.cat([torch.as_tensor(p, dtype=torch.float32) for p in prior_kp]).to(dev).contiguous()
             assert tuple(pr.shape) == (L, NUM_KP, 256, 256)
-        uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
-        cov = torch.empty((L, NUM_KP, 2, 2), dtype=torch.float32, device=dev)
-        kpm = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
-        kpl = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
-        logits = torch.empty((L, NUM_KP, HEAT, HEAT), dtype=torch.float32, device=dev)
+        cached = None
+        if out_slot is not None:
+            cache = self.__dict__.setdefault("_out_cache", {})
+            cached = cache.get((L, out_slot))
+        if cached is None:
+            uv = torch.empty((L, NUM_KP, 2), dtype=torch.float32, device=dev)
+            cov = torch.empty((L, NUM_KP, 2, 2), dtype=torch.float32, device=dev)
+            kpm = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+            kpl = torch.empty((L, NUM_KP), dtype=torch.float32, device=dev)
+            logits = torch.empty((L, NUM_KP, HEAT, HEAT), dtype=torch.float32, device=dev)
+            if out_slot is not None:
+                cache[(L, out_slot)] = (uv, cov, kpm, kpl, logits)
+        else:
+            uv, cov, kpm, kpl, logits = cached
         if prior_uv is not None:
             # the prior heat-maps are rendered on the device from the projected keypoints (suo_net_forward_prior_kp):
             # prior_uv [L,41,2] NDC, prior_mask [L,41] -- what make_prior_kp_input takes per object (utils.py:398-411)
@@ -178,7 +189,7 @@ class PkpNet:
         if check and self.pipe() == 2:
             torch.cuda.current_stream().synchronize()
             if self.range_exceeded():
-                return self.forward(images, boxes, prior_kp, want_prob, prior_uv, prior_mask, check=False)     # (now on bf16x3: fp32's range)
+                return self.forward(images, boxes, prior_kp, want_prob, prior_uv, prior_mask, check=False, out_slot=out_slot)     # (now on bf16x3: fp32's range)
         ret = {"uv": uv, "cov": cov, "prob_logits": logits, "kp_mask_logits": kpl, "kp_mask": kpm}
         if want_prob:
             ret.update(decode_extras(logits))

@@ -60,13 +60,16 @@ def record():
     orig_launch, orig_fetch = FG.FrameGeometry.launch, FG.FrameGeometry.fetch
 
     def launch(self, frame_first, uv_dev, cov_dev, mask_dev, model_kps_dev, kinv, camk, min_depth, seed=0, use_cov=True, do_lm=True,
-               its=(10, 10, 40, 40), pnp_threshold=1e-3, stream=None):
+               its=(10, 10, 40, 40), pnp_threshold=1e-3, stream=None, seed_dev=None):
+        # (seed_dev: the device-resident running key of chains that enqueue several launches before reading any back -- its value when this launch's PnP
+        #  runs is what everything enqueued before it left there: read it now, the stream is in order)
+        run = int(seed_dev.cpu().item()) if seed_dev is not None else 0
         self._rec = {"frame_first": np.array(frame_first), "uv": uv_dev.cpu().numpy(), "cov": cov_dev.cpu().numpy(),
                      "mask": mask_dev.cpu().numpy().astype(bool), "model_kps": model_kps_dev.cpu().numpy(), "kinv": np.array(kinv),
-                     "camk": np.array(camk), "min_depth": np.array(min_depth), "seed": int(seed), "use_cov": bool(use_cov), "do_lm": bool(do_lm),
+                     "camk": np.array(camk), "min_depth": np.array(min_depth), "seed": int(seed) + run, "use_cov": bool(use_cov), "do_lm": bool(do_lm),
                      "its": tuple(its), "thr": pnp_threshold}
         return orig_launch(self, frame_first, uv_dev, cov_dev, mask_dev, model_kps_dev, kinv, camk, min_depth, seed=seed, use_cov=use_cov,
-                           do_lm=do_lm, its=its, pnp_threshold=pnp_threshold, stream=stream)
+                           do_lm=do_lm, its=its, pnp_threshold=pnp_threshold, stream=stream, seed_dev=seed_dev)
 
     def fetch(self, copy=True):
         out = orig_fetch(self, True)

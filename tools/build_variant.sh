@@ -12,7 +12,7 @@ VAR="conv conv_wino conv_wino_x3 gemm_persist gemm_bf16x3 conv_small res_small r
 for f in $VAR; do /opt/rocm/bin/hipcc $FL "$@" -c $C/$f.hip -o $V/${f}_$NAME.o & done
 wait
 OBJS=""
-for f in capi pnp lm lm_big lm_cam lm_cam2 geom_api frame_geom eval slam_score; do OBJS="$OBJS $C/$f.o"; done
+for f in capi pnp lm lm_big lm_cam lm_cam2 geom_api frame_geom eval slam_score slam_vote; do OBJS="$OBJS $C/$f.o"; done
 for f in $VAR; do OBJS="$OBJS $V/${f}_$NAME.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libsuo_hip_$NAME.so $OBJS
 rm -f $V/*_$NAME.o
