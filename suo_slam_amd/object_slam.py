@@ -853,29 +853,13 @@ class ObjectSLAM:
         ids_a, bb_a, kps_a, mm_a, gtm_a, gtu_a = A
         ids_b, bb_b, kps_b, mm_b, gtm_b, gtu_b = B
         La, Lb = len(ids_a), len(ids_b)
-        Kb_a = fix_K_for_bbox_ndc_many(K, bb_a).astype(np.float32)            # float32 containers (:1082)
-        Kb_b = fix_K_for_bbox_ndc_many(K, bb_b).astype(np.float32)
-        kinv_a, camk_a = kbbox_terms(Kb_a)
-        kinv_b, camk_b = kbbox_terms(Kb_b)
-        md_a = np.array([0.5 * self.mesh_db[o]["diameter"] for o in ids_a], dtype=np.float64)
-        md_b = np.array([0.5 * self.mesh_db[o]["diameter"] for o in ids_b], dtype=np.float64)
         if self._fg is None or self._fg.max_crops < max(La, Lb):
             self._fg = FrameGeometry(max(16, La, Lb), 1)
         if getattr(self, "_fg2", None) is None or self._fg2.max_crops < max(La, Lb):
             self._fg2 = FrameGeometry(max(16, La, Lb), 1)
         vt = 1e30 if self.no_network_cov else self.kp_var_thresh
-        # the vote's host block (include/suo_hip.h: SUO_SLAM_VOTE_BLOCK): map poses and intrinsics of both passes' objects
-        blk = np.zeros(704)
-        for k, o in enumerate(ids_a):
-            if o in self.obj_poses:
-                blk[k] = 1.0
-                blk[16 + 12 * k:28 + 12 * k] = np.asarray(self.obj_poses[o], dtype=np.float64)[:3, :4].reshape(-1)
-            blk[208 + 9 * k:217 + 9 * k] = Kb_a[k].astype(np.float64).reshape(-1)
-        for k, o in enumerate(ids_b):
-            if o in self.obj_poses:
-                blk[352 + k] = 1.0
-                blk[368 + 12 * k:380 + 12 * k] = np.asarray(self.obj_poses[o], dtype=np.float64)[:3, :4].reshape(-1)
-            blk[560 + 9 * k:569 + 9 * k] = fix_K_for_bbox_ndc(K, bb_b[k]).reshape(-1)               # (double, as the reference projects with it: :505)
+        debug = self.debug_gt_kp
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
         def gt_arrays(L, gtm, gtu):                           # (debug_gt_on_device: the host route's draws, in its order -- pass A's objects, then pass B's)
             mask = np.ascontiguousarray(gtm, dtype=np.uint8)
@@ -885,31 +869,51 @@ class ObjectSLAM:
                 u = gtu[k][m].astype(np.float64)
                 uv[k][m] = (u + self._rng.normal(scale=0.01, size=u.shape)).astype(np.float32)
             return mask, uv
-        debug = self.debug_gt_kp
-        rng_state = self._rng.bit_generator.state if debug else None
-        host = [np.ascontiguousarray(kps_a, dtype=np.float32), np.ascontiguousarray(bb_a, dtype=np.float32), np.ascontiguousarray(mm_a, dtype=np.uint8),
-                np.ascontiguousarray(kps_b, dtype=np.float32), np.ascontiguousarray(bb_b, dtype=np.float32), np.ascontiguousarray(mm_b, dtype=np.uint8), blk]
+        # pass A's host arrays now; pass B's and the vote's block are prepared AFTER pass A is enqueued, under its GPU time
+        Kb_a = fix_K_for_bbox_ndc_many(K, bb_a).astype(np.float32)            # float32 container (:1082)
+        kinv_a, camk_a = kbbox_terms(Kb_a)
+        md_a = np.array([0.5 * self.mesh_db[o]["diameter"] for o in ids_a], dtype=np.float64)
+        host_a = [np.ascontiguousarray(kps_a, dtype=np.float32), np.ascontiguousarray(bb_a, dtype=np.float32), np.ascontiguousarray(mm_a, dtype=np.uint8)]
         if debug:
-            ga, ua = gt_arrays(La, gtm_a, gtu_a)
-            gb, ub = gt_arrays(Lb, gtm_b, gtu_b)
-            host += [ga, ua, gb, ub]
-        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+            host_a += list(gt_arrays(La, gtm_a, gtu_a))
+        rng_after_a = self._rng.bit_generator.state if debug else None      # (a pass B that has to be issued again draws its noise again: from here)
+        host_b = None
         for _attempt in range(2):
             frame = self._frame_on_device(img)
-            st = self.model.stage_block(host)
-            dev = st[0].device
+            sa = self.model.stage_block(host_a)
+            dev = sa[0].device
             seed_run = torch.zeros(1, dtype=torch.int64, device=dev)
+            # ---- pass A
+            pa = self.model(frame, [sa[1]], None, check=False, out_slot="slam A")
+            uv_a, mk_a = (sa[4], sa[3]) if debug else (pa["uv"], keypoint_masks(pa["uv"], pa["cov"], pa["kp_mask"], sa[2], self.bbox_thresh, vt))
+            self._fg.launch([0, La], uv_a, pa["cov"], mk_a, sa[0], kinv_a, camk_a, md_a, seed=self._pnp_seed, use_cov=not self.no_network_cov, do_lm=False,
+                            seed_dev=seed_run)
+            ra_dev = self._fg.device_result()
+            if host_b is None:
+                Kb_b = fix_K_for_bbox_ndc_many(K, bb_b).astype(np.float32)
+                kinv_b, camk_b = kbbox_terms(Kb_b)
+                md_b = np.array([0.5 * self.mesh_db[o]["diameter"] for o in ids_b], dtype=np.float64)
+                # the vote's host block (include/suo_hip.h: SUO_SLAM_VOTE_BLOCK): map poses and intrinsics of both passes' objects
+                blk = np.zeros(704)
+                for k, o in enumerate(ids_a):
+                    if o in self.obj_poses:
+                        blk[k] = 1.0
+                        blk[16 + 12 * k:28 + 12 * k] = np.asarray(self.obj_poses[o], dtype=np.float64)[:3, :4].reshape(-1)
+                    blk[208 + 9 * k:217 + 9 * k] = Kb_a[k].astype(np.float64).reshape(-1)
+                for k, o in enumerate(ids_b):
+                    if o in self.obj_poses:
+                        blk[352 + k] = 1.0
+                        blk[368 + 12 * k:380 + 12 * k] = np.asarray(self.obj_poses[o], dtype=np.float64)[:3, :4].reshape(-1)
+                    blk[560 + 9 * k:569 + 9 * k] = fix_K_for_bbox_ndc(K, bb_b[k]).reshape(-1)       # (double, as the reference projects with it: :505)
+                host_b = [np.ascontiguousarray(kps_b, dtype=np.float32), np.ascontiguousarray(bb_b, dtype=np.float32), np.ascontiguousarray(mm_b, dtype=np.uint8), blk]
+                if debug:
+                    host_b += list(gt_arrays(Lb, gtm_b, gtu_b))
+            sb = self.model.stage_block(host_b)
             puv = torch.empty((Lb, NUM_KP, 2), dtype=torch.float32, device=dev)
             pmk = torch.empty((Lb, NUM_KP), dtype=torch.uint8, device=dev)
             vout = torch.empty(32, dtype=torch.float64, device=dev)
-            # ---- pass A
-            pa = self.model(frame, [st[1]], None, check=False, out_slot="slam A")
-            uv_a, mk_a = (st[8], st[7]) if debug else (pa["uv"], keypoint_masks(pa["uv"], pa["cov"], pa["kp_mask"], st[2], self.bbox_thresh, vt))
-            self._fg.launch([0, La], uv_a, pa["cov"], mk_a, st[0], kinv_a, camk_a, md_a, seed=self._pnp_seed, use_cov=not self.no_network_cov, do_lm=False,
-                            seed_dev=seed_run)
-            ra_dev = self._fg.device_result()
             # ---- vote + priors, on the stream, behind pass A's PnP
-            _lib.check(lib.suo_slam_vote(La, ra_dev.T_pnp, ra_dev.accepted, ra_dev.n_kp, P(uv_a), P(pa["cov"]), P(mk_a), P(st[0]), P(st[6]), Lb, P(st[3]), P(st[5]),
+            _lib.check(lib.suo_slam_vote(La, ra_dev.T_pnp, ra_dev.accepted, ra_dev.n_kp, P(uv_a), P(pa["cov"]), P(mk_a), P(sa[0]), P(sb[3]), Lb, P(sb[0]), P(sb[2]),
                                          int(not self.no_network_cov), float(self.manual_kp_std) ** 2, CHI2_2DOF_95, 4, P(puv), P(pmk), P(vout),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "suo_slam_vote")
             if getattr(self, "_vote_pin", None) is None:
@@ -921,24 +925,26 @@ class ObjectSLAM:
             pmk_pin[:Lb].copy_(pmk, non_blocking=True)
             v_ev.record()
             # ---- pass B: priors rendered on the device from what the vote kernel wrote; nothing above has waited
-            pb = self.model(frame, [st[4]], None, prior_uv=puv, prior_mask=pmk, check=False, out_slot="slam B")
-            uv_b, mk_b = (st[10], st[9]) if debug else (pb["uv"], keypoint_masks(pb["uv"], pb["cov"], pb["kp_mask"], st[5], self.bbox_thresh, vt))
-            self._fg2.launch([0, Lb], uv_b, pb["cov"], mk_b, st[3], kinv_b, camk_b, md_b, seed=self._pnp_seed, use_cov=not self.no_network_cov, do_lm=False,
+            pb = self.model(frame, [sb[1]], None, prior_uv=puv, prior_mask=pmk, check=False, out_slot="slam B")
+            uv_b, mk_b = (sb[5], sb[4]) if debug else (pb["uv"], keypoint_masks(pb["uv"], pb["cov"], pb["kp_mask"], sb[2], self.bbox_thresh, vt))
+            self._fg2.launch([0, Lb], uv_b, pb["cov"], mk_b, sb[0], kinv_b, camk_b, md_b, seed=self._pnp_seed, use_cov=not self.no_network_cov, do_lm=False,
                              seed_dev=seed_run)
             # ---- the host, under pass B: pass A's block and the vote
             ra = self._fg.fetch(copy=True)
             v_ev.synchronize()
             vote = v_pin.numpy().copy()
             prior_uv_h, prior_mask_h = puv_pin[:Lb].numpy().copy(), pmk_pin[:Lb].numpy().copy()
-            rb = self._fg2.fetch(copy=True)
             if not self.model.range_exceeded():
                 break
-            self.fp16_range_reissues += 1                     # (fp16 form only: both passes again on bf16x3)
+            # (fp16 form only) pass A left the range: its results -- and the priors pass B is running on -- are invalid.  Let pass B drain, then both again on bf16x3
+            self._fg2.fetch(copy=False)
+            self.model.range_exceeded()
+            self.fp16_range_reissues += 1
         assert vote[31] == 0.0, "NaN in information matrix"
         n_solv_a = int(np.count_nonzero(ra["n_kp"] >= 4))
         best = int(vote[12])
         hyp_ids = [o for k, o in enumerate(ids_a) if vote[15 + k] >= 0]
-        # ---- pass A into the state, with the device's vote
+        # ---- pass A into the state, with the device's vote -- while pass B runs
         self._pnp_seed += n_solv_a
         det_a = self._kp_det_from_chain(ra, ids_a, kps_a, Kb_a, gtu_a)
         cam = None
@@ -948,15 +954,16 @@ class ObjectSLAM:
         self.last_cam_hypotheses = ({"obj_ids": hyp_ids, "counts": [int(vote[15 + k]) for k in range(La) if vote[15 + k] >= 0], "best_num_inliers": int(vote[14])}
                                     if hyp_ids else None)
         self._install_kp_detections(view_id, ids_a, bb_a, mm_a, det_a, None, cam_vote=cam)
-        if cam is None:
+        rb = self._fg2.fetch(copy=True)
+        b_invalid = self.model.range_exceeded()               # (fp16 form only: pass B alone left the range)
+        if b_invalid:
+            self.fp16_range_reissues += 1
+        if cam is None or b_invalid:
             # no hypothesis reached four inliers: the reference falls back to the bbox-centroid pose and THEN runs pass B -- with priors this chain did not have.
-            # Pass B's speculative results are dropped (its PnP consumed sampler keys past the host's seed, which never counted them); the noise draws of its
-            # ground-truth keypoints are taken back so that the pass the caller now issues draws them again.
-            if debug:
-                st_ = self._rng.bit_generator.state
-                self._rng.bit_generator.state = rng_state
-                gt_arrays(La, gtm_a, gtu_a)                   # (re-consume pass A's share)
-                del st_
+            # Pass B's speculative results are dropped (its PnP consumed sampler keys past the host's seed, which never counted them) and the caller issues the
+            # pass again, one at a time; the noise draws of its ground-truth keypoints are taken back so that it draws them again.
+            if rng_after_a is not None:
+                self._rng.bit_generator.state = rng_after_a
             return False
         # ---- pass B into the state
         self._pnp_seed += int(np.count_nonzero(rb["n_kp"] >= 4))

@@ -47,7 +47,12 @@ for rep in range(3):
         f = [m for m in marks if m[0] == "fetch"]
         ln = [m for m in marks if m[0] == "launched"]
         if len(f) == 2 and len(ln) == 2 and slam.all_time_num_views > 5 and not (len(slam.view_ids) > 1 and len(slam.view_ids) % slam.global_opt_every == 0):
-            rows.append((ln[0][1] - t0, f[0][2] - ln[0][1], ln[1][1] - f[0][2], f[1][2] - ln[1][1], t1 - f[1][2], t1 - t0))
+            chained = ln[1][1] < f[0][1]                      # pass B enqueued before pass A's results were waited for (the two-pass device chain)
+            if chained:   # host until A enqueued | host until B enqueued (under A's GPU time) | wait for A's block | host under B (A's bookkeeping) | wait for B | host after B
+                rows.append((ln[0][1] - t0, ln[1][1] - ln[0][1], f[0][2] - ln[1][1], f[1][1] - f[0][2], f[1][2] - f[1][1], t1 - f[1][2], t1 - t0))
+            else:         # host until A enqueued | 0 | wait for A | host between the passes | wait for B | host after B
+                rows.append((ln[0][1] - t0, 0.0, f[0][2] - ln[0][1], ln[1][1] - f[0][2], f[1][2] - ln[1][1], t1 - f[1][2], t1 - t0))
 r = 1e3 * np.median(np.array(rows), axis=0)
 print("views with two passes and no global adjustment: %d   (median per view, ms)" % len(rows))
-print("host before pass A is enqueued %.3f | wait for pass A %.3f | host between the passes %.3f | wait for pass B %.3f | host after pass B %.3f | view %.3f" % tuple(r))
+print("host until pass A is enqueued %.3f | host until pass B is enqueued (two-pass chain: under pass A's GPU time) %.3f | wait for pass A's results %.3f | "
+      "host between / under the passes %.3f | wait for pass B %.3f | host after pass B %.3f | view %.3f" % tuple(r))
