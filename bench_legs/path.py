@@ -212,8 +212,9 @@ def slam_leg(n_views=60, n_obj=8, on_device=True):
                "wall_ms_per_view": round(1e3 * dt / n_views, 3), "camera_poses": len(slam.cam_poses), "poses": len(err),
                "median_rel_translation_err": round(float(np.median(err)), 5) if err else None,
                "keypoints": "network run on the frame's pixels (both passes), output replaced by projected GT + N(0,0.01^2) (debug_gt_kp)" +
-                            (" ON THE DEVICE (float32, what the network emits): the view continues on the product route -- masks / compaction / PnP as one device chain, "
-                             "one read-back per pass (ObjectSLAM._run_kp_model_chain)" if on_device else " on the host (rounds 1-5's leg: the reference's host-side debug route)")}
+                            (" ON THE DEVICE (float32, what the network emits): the view continues on the product route -- both passes as ONE device chain: pass A, PnP, "
+                             "camera-hypothesis vote + prior projection (suo_slam_vote), pass B, PnP, the host reading pass A's block while pass B runs "
+                             "(ObjectSLAM._process_view_slam_chain)" if on_device else " on the host (rounds 1-5's leg: the reference's host-side debug route)")}
     if on_device:
         # rounds 1-5's figure beside it: the same sequence on the host-side debug route (three read-backs per pass, Python compaction, PnP on host arrays)
         try:

@@ -26,7 +26,7 @@
  * The thresholds and A/B knobs behind the measurements of DESIGN.md / profiles/REJECTED.md (SUO_TUNE in csrc/tune.h: launch-size thresholds, tile choices, kernel
  * selections) are compiled to their defaults; only the variant builds of tools/build_variant.sh (-DSUO_TUNING) read them from the environment.  The host side above
  * the ABI has its own, in suo_slam_amd/: SUO_HIP_LIB (path of the library), SUO_BA_GRAPH / SUO_BA_HOST_SCHEDULE / SUO_FORCE_COLLECTIVES (ba_dist.py),
- * SUO_SLAM_STORE_SLOTS (slam_score.py).
+ * SUO_SLAM_STORE_SLOTS (slam_score.py), SUO_SLAM_VOTE_CHAIN (object_slam.py: 0 = the host votes between the passes of a SLAM view).
  */
 #ifndef SUO_HIP_H
 #define SUO_HIP_H
