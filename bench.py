@@ -342,13 +342,15 @@ def main():
                         if "frames_per_s" in extra.get("frames_from_pinned_host", {}):
                             base["value_pcie_inclusive"] = extra["frames_from_pinned_host"]["frames_per_s"]
                 leg("pose_check", pose_check_leg, L, pool, not args.no_graph)
-                if not args.no_tless_leg:
-                    leg("tless", tless_leg, not args.no_graph, args.depth)
                 if not args.no_latency_leg:
                     leg("latency", latency_leg, L, pool, not args.no_graph)
                     leg("drop_in", drop_in_leg, L, pool)
                 if not args.no_slam_leg:
                     leg("slam", slam_leg)
+                if not args.no_tless_leg:
+                    # (after the one-frame-per-call legs: measured, a SLAM leg that follows this one runs 0.5-1 ms per view slower than one that does not --
+                    #  four 256-crop networks' worth of workspace allocated and freed in between; the legs that time host latency go first)
+                    leg("tless", tless_leg, not args.no_graph, args.depth)
                 if not args.no_cpu_baseline:
                     leg("cpu_baseline", cpu_baseline, pool, L)
                     with lock:                      # the host figures beside the legs they belong to (VERDICT r4 missing #5)

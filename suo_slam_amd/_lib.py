@@ -191,3 +191,13 @@ def require_gpu():
     if n <= 0:
         raise SuoError("no HIP device visible: the suo_slam_amd product path needs an MI355X (no CPU fallback)")
     return n
+
+
+def current_stream_ptr():
+    """torch's current HIP stream of the current device as an integer handle.  torch.cuda.current_stream() builds a Stream object behind three device-index
+    look-ups (13 us on the GPU boxes, eight to ten times per SLAM view on the host's critical path); the raw query underneath it is a microsecond."""
+    import torch
+    try:
+        return int(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:                                  # (a torch without the private entry points: the public route)
+        return int(torch.cuda.current_stream().cuda_stream)

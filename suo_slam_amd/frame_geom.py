@@ -66,8 +66,7 @@ class FrameGeometry:
         def ptr(t):
             return C.c_void_p(t.data_ptr()) if hasattr(t, "data_ptr") else C.c_void_p(int(t))
         if stream is None:
-            import torch
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _lib.current_stream_ptr()
         _lib.check(self._lib.suo_frame_geom_launch(self._h, len(ff) - 1, ff.ctypes.data, ptr(uv_dev), ptr(cov_dev), ptr(mask_dev), ptr(model_kps_dev),
                                                    kinv.ctypes.data, camk.ctypes.data, md.ctypes.data, C.byref(p), C.c_void_p(int(stream))),
                    "suo_frame_geom_launch")

@@ -53,8 +53,9 @@ def to4x4(T):
     T = np.asarray(T, dtype=np.float64)
     if T.shape == (4, 4):
         return T
-    out = np.eye(4)
-    out[:3, :4] = T[:3, :4]
+    out = np.empty((4, 4))
+    out[:3] = T[:3, :4]
+    out[3] = (0.0, 0.0, 0.0, 1.0)
     return out
 
 

@@ -22,7 +22,7 @@ def _ptr(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_lib.current_stream_ptr())
 
 
 class PkpNet:

@@ -32,10 +32,11 @@ def _usage(src, tmp_path):
     return kernels
 
 
-@pytest.mark.parametrize("src,fused_tag,n_fused", [("conv_wino.hip", "wino3x3_kernelILb1E", 2), ("conv_wino_x3.hip", "wino3x3_x3_kernelILb1E", 7)])
+@pytest.mark.parametrize("src,fused_tag,n_fused", [("conv_wino.hip", "wino3x3_kernelILb1E", 2), ("conv_wino_x3.hip", "wino3x3_x3_kernelILb1E", 9)])
 def test_fused_winograd_tail_does_not_spill(tmp_path, src, fused_tag, n_fused):
     """All forms: fp32 pipe (2) / split operands: bf16x3 with the tail on either pipe (4, at 252-254 of their 256 registers), fp16x2 (2, 246) and fp16x2 with the
-    next block's conv1 on the tile (1, 245)."""
+    next block's conv1 on the tile (1, 245); round 6: the eight-wave forms of small launches (fused tail with / without the up-sampled addend, and the plain
+    3x3: 208-210 registers, 70 KB of LDS -- one workgroup of eight waves per CU by design)."""
     k = _usage(src, tmp_path)
     fused = {n: v for n, v in k.items() if fused_tag in n}
     assert len(fused) == n_fused, list(k)
@@ -45,8 +46,9 @@ def test_fused_winograd_tail_does_not_spill(tmp_path, src, fused_tag, n_fused):
             assert v["VGPRs Spill"] <= 1 and v["ScratchSize"] <= 8, (name, v)
         else:
             assert v["VGPRs Spill"] == 0 and v["ScratchSize"] == 0, (name, v)
-        assert v["Occupancy"] >= 2, (name, v)          # two workgroups per CU
-        assert 2 * v["LDS Size"] <= 160 * 1024, (name, v)
+        assert v["Occupancy"] >= 2, (name, v)          # two waves per SIMD: two four-wave workgroups per CU, or one of eight waves
+        eight_waves = src == "conv_wino_x3.hip" and name.endswith("Lb1EEEvNS_8ConvArgsE")                  # <..., W8 = true>
+        assert (1 if eight_waves else 2) * v["LDS Size"] <= 160 * 1024, (name, v)
 
 
 def test_frame_lm_kernel_keeps_its_small_systems_in_registers(tmp_path):
