@@ -115,7 +115,8 @@ DTYPE_NOTE = {
 
 
 def dominant_kernel_name():
-    return {"f16x2": "wino3x3_x3_kernel<true,false,true,4,2,false>", "bf16x3": "wino3x3_x3_kernel<true,false,true,4,3,false>", "f32": "wino3x3_kernel<true"}[matrix_pipe()]
+    # (template arguments FUSE, UP, TX3, NT, NP, NEXT, W8: the four-wave fused tail of a batched launch)
+    return {"f16x2": "wino3x3_x3_kernel<true,false,true,4,2,false,false>", "bf16x3": "wino3x3_x3_kernel<true,false,true,4,3,false,false>", "f32": "wino3x3_kernel<true"}[matrix_pipe()]
 
 
 def dominant_kernel_traffic(L):

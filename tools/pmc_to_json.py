@@ -9,7 +9,7 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 # the fused Residual tail in Winograd form as the network launches it: bf16 pipe with 3-way split operands (default), or the fp32 pipe
 X3 = os.environ.get("SUO_WINO_BF16X3", "1") not in ("0", "")
 F16 = X3 and os.environ.get("SUO_F16X2", "1") not in ("0", "")          # two fp16 planes (csrc/f16x2.h), the default
-KERNEL = ("wino3x3_x3_kernel<true,false,true,4,2,false>" if F16 else "wino3x3_x3_kernel<true,false,true,4,3,false>") if X3 else "wino3x3_kernel<true,4,false>"
+KERNEL = ("wino3x3_x3_kernel<true,false,true,4,2,false,false>" if F16 else "wino3x3_x3_kernel<true,false,true,4,3,false,false>") if X3 else "wino3x3_kernel<true,4,false>"
 vals = {}
 dur_ns = {}                                     # counter -> average duration of the kernel in the pass that collected it
 for f in os.listdir(os.path.join(ROOT, "gpurun_out", "pmc")):
