@@ -190,8 +190,9 @@ def slam_leg(n_views=60, n_obj=8, on_device=True):
     from suo_slam_amd.object_slam import ObjectSLAM
     seq = S.make_slam_sequence(np.random.default_rng(3), n_views, n_obj)
     sd = weights.make_random_state_dict(0, 8.0)
-    out = None
-    for rep in range(2):                        # the first pass pays graph captures / first launches
+    out, reps = None, []
+    for rep in range(4):                        # the first pass pays graph captures / first launches; then three measured passes: the MEDIAN is reported (these
+        #                                         boxes are shared -- a pass that coincides with a neighbour's burst reads 0.5-1 ms per view high, see tracking_ms_reps)
         slam = ObjectSLAM(None, seq["mesh_db"], debug_gt_kp=True, manual_kp_std=0.01, state_dict=sd, max_crops=max(16, n_obj), run_network_in_debug=True,
                           debug_gt_on_device=on_device)
         t0 = time.perf_counter()
@@ -200,6 +201,8 @@ def slam_leg(n_views=60, n_obj=8, on_device=True):
                               vw["kp_masks"], uv_gt=vw["uv_gt"])
         res = slam.collect_results(no_viz=True, final=True)
         dt = time.perf_counter() - t0
+        if rep == 0:
+            continue
         err = []
         for vw in seq["views"]:
             for o in vw["obj_ids"]:
@@ -207,14 +210,17 @@ def slam_leg(n_views=60, n_obj=8, on_device=True):
                 if T is not None:
                     gt = vw["T_GtoC_gt"] @ seq["T_OtoG_gt"][int(o)]
                     err.append(np.linalg.norm(T[:3, 3] - gt[:3, 3]) / gt[2, 3])
-        out = {"views": n_views, "objects": n_obj, "tracking_ms_per_view": round(1e3 * slam.track_time_meter.average(), 3),
-               "global_opt_ms": round(1e3 * slam.opt_time_meter.average(), 3), "global_opts": slam.opt_time_meter.count,
-               "wall_ms_per_view": round(1e3 * dt / n_views, 3), "camera_poses": len(slam.cam_poses), "poses": len(err),
-               "median_rel_translation_err": round(float(np.median(err)), 5) if err else None,
-               "keypoints": "network run on the frame's pixels (both passes), output replaced by projected GT + N(0,0.01^2) (debug_gt_kp)" +
-                            (" ON THE DEVICE (float32, what the network emits): the view continues on the product route -- both passes as ONE device chain: pass A, PnP, "
-                             "camera-hypothesis vote + prior projection (suo_slam_vote), pass B, PnP, the host reading pass A's block while pass B runs "
-                             "(ObjectSLAM._process_view_slam_chain)" if on_device else " on the host (rounds 1-5's leg: the reference's host-side debug route)")}
+        reps.append({"views": n_views, "objects": n_obj, "tracking_ms_per_view": round(1e3 * slam.track_time_meter.average(), 3),
+                     "global_opt_ms": round(1e3 * slam.opt_time_meter.average(), 3), "global_opts": slam.opt_time_meter.count,
+                     "wall_ms_per_view": round(1e3 * dt / n_views, 3), "camera_poses": len(slam.cam_poses), "poses": len(err),
+                     "median_rel_translation_err": round(float(np.median(err)), 5) if err else None})
+        del slam
+    reps.sort(key=lambda r: r["tracking_ms_per_view"])
+    out = dict(reps[len(reps) // 2], tracking_ms_reps=[r["tracking_ms_per_view"] for r in reps], global_opt_ms_reps=[r["global_opt_ms"] for r in reps],
+               keypoints="network run on the frame's pixels (both passes), output replaced by projected GT + N(0,0.01^2) (debug_gt_kp)" +
+               (" ON THE DEVICE (float32, what the network emits): the view continues on the product route -- both passes as ONE device chain: pass A, PnP, "
+                "camera-hypothesis vote + prior projection (suo_slam_vote), pass B, PnP, the host reading pass A's block while pass B runs "
+                "(ObjectSLAM._process_view_slam_chain)" if on_device else " on the host (rounds 1-5's leg: the reference's host-side debug route)"))
     if on_device:
         # rounds 1-5's figure beside it: the same sequence on the host-side debug route (three read-backs per pass, Python compaction, PnP on host arrays)
         try:

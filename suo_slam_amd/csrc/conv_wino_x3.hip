@@ -347,21 +347,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
         XPROF(1);
         if (more) sstore(buf ^ 1);
         XPROF(2);
-#ifndef SUO_WX3_FOLD_ILV
-#define SUO_WX3_FOLD_ILV 0
-#endif
-        // SUO_WX3_FOLD_ILV = 1 (four-wave 128-channel form): the scratch pairs and the direct pairs alternate -- (xi 1, xi 2) of nu, then (xi 0, xi 3) of nu + 1 -- and a
-        // scratch pair's fold is issued in the NEXT step's scheduling region, beside products that touch other accumulators (nu + 1), instead of behind its own MFMAs
-        constexpr bool ILV = SUO_WX3_FOLD_ILV != 0 && !HALF;
-        constexpr int ORD[8] = {4, 1, 5, 2, 6, 3, 7, 0};
-        x_f32x16 ta, tb;
 #pragma unroll
-        for (int step = 0; step < NPAIR; ++step) {
-            const int pair = ILV ? ORD[step] : step;
-            const int slot = step & 1;
-            {   // next pair (of this chunk, or the first one of the next chunk; after the last chunk the first pair of that chunk again -- never consumed, but in range)
-                const int ns = step + 1 < NPAIR ? step + 1 : 0, nc = step + 1 < NPAIR ? c : (more ? c + 1 : c);
-                const int np = ILV ? ORD[ns] : ns;
+        for (int pair = 0; pair < NPAIR; ++pair) {
+            const int slot = pair & 1;
+            {   // next pair (of this chunk, or pair 0 of the next one; after the last chunk pair 0 of that chunk again -- never consumed, but in range)
+                const int np = pair + 1 < NPAIR ? pair + 1 : 0, nc = pair + 1 < NPAIR ? c : (more ? c + 1 : c);
                 bload(nc * 16 + comp_of(np, 0), bring[slot ^ 1][0]);
                 bload(nc * 16 + comp_of(np, 1), bring[slot ^ 1][1]);
             }
@@ -379,16 +369,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
             } else if (pair < 4) {                            // accumulate into their own Z, no scratch, no additions
                 mac6(Z[pair], afa, bring[slot][0], false);
                 mac6(Z[4 + pair], afb, bring[slot][1], false);
-                if constexpr (ILV) {                          // ... and the fold of the scratch pair before it (nu = ORD[step - 1] - 4, other accumulators than this pair's)
-                    const int fp = ORD[step - 1];
-                    x_add16(Z[fp - 4], ta); x_add16(Z[fp - 4], tb); x_add16(Z[fp], ta); x_sub16(Z[fp], tb);
-                }
             } else {
+                x_f32x16 ta, tb;
                 mac6(ta, afa, bring[slot][0], true);
                 mac6(tb, afb, bring[slot][1], true);
-                if constexpr (!ILV) {
-                    x_add16(Z[pair - 4], ta); x_add16(Z[pair - 4], tb); x_add16(Z[pair], ta); x_sub16(Z[pair], tb);      // Z[0][nu] += M1 + M2, Z[1][nu] += M1 - M2
-                }
+                x_add16(Z[pair - 4], ta); x_add16(Z[pair - 4], tb); x_add16(Z[pair], ta); x_sub16(Z[pair], tb);      // Z[0][nu] += M1 + M2, Z[1][nu] += M1 - M2
             }
             __builtin_amdgcn_sched_barrier(0);
         }
