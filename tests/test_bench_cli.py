@@ -77,3 +77,19 @@ def test_gpus_flag_starts_the_ranks_itself():
 def test_one_gpu_stays_one_process():
     bench, args = _bench(["--gpus", "1", "--dry-run"])
     assert args.dry_run and args.gpus == 1
+
+
+def test_line_bookkeeping_of_round_6():
+    """The legs live in bench_legs/ and bench.py re-exports what the tools import; `dtype` names the arithmetic; the whole-call roofline is bytes over time
+    against a copy's rate; the committed PMC summary is the one of the kernel the line names (its template signature gained a parameter this round)."""
+    bench, args = _bench(["--no-tless-leg"])
+    assert args.no_tless_leg
+    from bench_legs import common, path, roofline
+    assert bench.conv_roofline is roofline.conv_roofline and bench.slam_leg is path.slam_leg and bench.tless_leg is path.tless_leg
+    assert set(common.DTYPE) == {"f16x2", "bf16x3", "f32"} and common.DTYPE[bench.matrix_pipe()].startswith("f32")
+    w = roofline.whole_call({"total": 63e9, "launches": 84, "gemm_1x1": 23e9, "conv3x3_and_fused_tails": 40e9}, 10.0, 4)
+    assert w["bound"] == "hbm" and abs(w["achieved"] - 6300.0) < 1e-6 and abs(w["frac_of_achievable_6300"] - 1.0) < 1e-9 and abs(w["frac"] - 6300 / 8000) < 1e-4
+    assert set(w["by_kind"]) == {"gemm_1x1", "conv3x3_and_fused_tails"} and w["launches_per_call"] == 84
+    import json
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_dominant_conv.json")))
+    assert rec["kernel"].replace(" ", "").startswith(bench.dominant_kernel_name())
