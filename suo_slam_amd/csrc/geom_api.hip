@@ -381,6 +381,7 @@ static int fetch_results(suo_ba_problem* probs, int n_prob, Arena& A, Staged& st
 }
 
 static int optimize_phasewise(suo_ba_problem* q);
+static int optimize_phases_one_rank(suo_ba_problem* q);
 
 // csrc/lm_frame2.hip takes one fixed camera, <= 16 objects, the edges that fit its LDS allotment, and -- its lanes keep their own edges'
 // outlier flags in a 32-bit mask -- at most 32 edges per lane: 32 * G per object, G = 8 lanes (<= 8 objects) or 4 (9-16)
@@ -417,6 +418,20 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
                 else { int rc = optimize_phasewise(&probs[i]); if (rc != SUO_OK) return rc; }
             }
             return SUO_OK;
+        }
+    }
+    // ONE large graph with free cameras and free objects (the global SLAM adjustment): the phase kernels of csrc/lm_dist.hip under the device-resident LM schedule,
+    // driven from here (round 6).  Measured at 60 cameras x 8 objects: 106 us per LM trial against 129 for lm_grid_kernel's grid barriers; the Python-driven form of
+    // this very schedule (suo_slam_amd/ba_dist.py, one rank) was already the faster route and ObjectSLAM.optimize could not reach it through one C call.
+    // SUO_LM_PHASES (tuning builds): 0 = lm_grid_kernel as in rounds 2-5.
+    {
+        static const int phases = (int)SUO_TUNE("SUO_LM_PHASES", 1);
+        static const int big_from_ph = (int)SUO_TUNE("SUO_LM_BIG_EDGES", 512);
+        if (phases && n_prob == 1 && probs[0].n_edge >= big_from_ph) {
+            int nfo = 0, nfc = 0;
+            for (int o = 0; o < probs[0].n_obj; ++o) nfo += probs[0].obj_fixed[o] ? 0 : 1;
+            for (int c = 0; c < probs[0].n_cam; ++c) nfc += probs[0].cam_fixed[c] ? 0 : 1;
+            if (nfo > 0 && nfc > 1) return optimize_phases_one_rank(&probs[0]);
         }
     }
     std::lock_guard<std::mutex> lock(g_arena.mu);
@@ -689,6 +704,74 @@ static int optimize_phasewise(suo_ba_problem* q) {
         rc = suo_ba_classify(c, 0, &good); if (rc) return rc;
         num_good = (int)(good + 0.5);
         if (rnd == drop) robust_on = false;
+    }
+    rc = suo_ba_ctx_download(c, q);
+    q->stats[0] = rounds; q->stats[1] = lm_its; q->stats[2] = lm_trials; q->stats[3] = num_good;
+    return rc;
+}
+
+// One rank, device-resident schedule, driven from C: what suo_slam_amd/ba_dist.py: optimize_distributed does at world = 1 (units enqueued blindly, g2o's accept / reject
+// arithmetic in the control block, the host looks at 16 doubles once per <= 12 units) without Python between the launches.  Exchange buffers: one grow-only device
+// block + 16 pinned doubles, process-wide under their own lock.
+static int optimize_phases_one_rank(suo_ba_problem* q) {
+    static std::mutex mu;
+    static double* d_buf = nullptr; static size_t d_cap = 0; static double* h_pin = nullptr; static int buf_dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    suo_ba_ctx* c = nullptr;
+    int rc = suo_ba_ctx_create(q, &c);
+    if (rc != SUO_OK) return rc;
+    struct Guard { suo_ba_ctx* c; ~Guard() { suo_ba_ctx_destroy(c); } } guard{c};
+    const int O = q->n_obj, ns = c->ns;
+    const size_t n_lin = 2 + 27 * (size_t)O, n_sch = (size_t)ns * ns + ns + 1;
+    const size_t need = 2 * n_lin + n_sch + 4 + 1 + 16;
+    if (need > d_cap || buf_dev != c->device) {
+        if (d_buf) (void)hipFree(d_buf);
+        d_buf = nullptr; d_cap = 0;
+        SUO_HIP_CHECK(hipMalloc((void**)&d_buf, need * sizeof(double)));
+        d_cap = need; buf_dev = c->device;
+    }
+    if (!h_pin) SUO_HIP_CHECK(hipHostMalloc((void**)&h_pin, 16 * sizeof(double), hipHostMallocDefault));
+    hipStream_t s = c->arena.stream;
+    SUO_HIP_CHECK(hipMemsetAsync(d_buf, 0, need * sizeof(double), s));
+    double* lin_loc = d_buf; double* lin = lin_loc + n_lin; double* sch = lin + n_lin; double* red = sch + n_sch; double* good = red + 4; double* ctl = good + 1;
+    auto look = [&](const double* dev, int n) -> int {
+        SUO_HIP_CHECK(hipMemcpyAsync(h_pin, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+        SUO_HIP_CHECK(hipStreamSynchronize(s));
+        return SUO_OK;
+    };
+    auto classify = [&](int keep_all, int* n_good) -> int {
+        int r = launch_ba_classify(c->dev_problem(), keep_all, good, c->scratch(), s);
+        if (r != SUO_OK) return r;
+        r = look(good, 1);
+        *n_good = (int)(h_pin[0] + 0.5);
+        return r;
+    };
+    int rounds = 0, lm_its = 0, lm_trials = 0, num_good = q->n_edge, tmp = 0;
+    if (q->init_with_outliers) { rc = classify(1, &tmp); if (rc) return rc; }
+    else { rc = classify(0, &num_good); if (rc) return rc; }
+    int robust_on = 1;
+    const int drop = std::max(1, q->n_rounds / 2);
+    static const int batch = (int)SUO_TUNE("SUO_BA_UNITS_PER_LOOK", 12);
+    for (int rnd = 0; rnd < q->n_rounds; ++rnd) {
+        if (q->n_edge < 4 || num_good < 4) break;
+        ++rounds;
+        const int its = q->its[rnd];
+        rc = launch_ba_ctl_begin(ctl, its, 1, s); if (rc) return rc;
+        int budget = std::min(its, batch);
+        bool done = its <= 0;
+        while (!done) {
+            for (int u = 0; u < budget; ++u) {                // one unit = 12 launches, the control steps riding in the tail kernels (suo_ba_lm_unit_one_rank_dev)
+                rc = launch_ba_linearize(c->dev_problem(), robust_on, lin_loc, c->scratch(), 0, 1, s, ctl, lin, 1 + 27 * O + 1, ctl); if (rc) return rc;
+                rc = launch_ba_schur(c->dev_problem(), 0.0, ns, sch, c->scratch(), s, ctl); if (rc) return rc;
+                rc = launch_ba_solve_update(c->dev_problem(), 0.0, ns, robust_on, lin + 1, sch, 1, red, c->scratch(), c->d_big, s, ctl, ctl); if (rc) return rc;
+            }
+            rc = look(ctl, 16); if (rc) return rc;
+            done = (int)h_pin[3] == 2;
+            budget = std::min(std::max(1, its - (int)h_pin[4]) + 1, batch);
+        }
+        lm_its = (int)h_pin[7]; lm_trials = (int)h_pin[8];
+        rc = classify(0, &num_good); if (rc) return rc;
+        if (rnd == drop) robust_on = 0;
     }
     rc = suo_ba_ctx_download(c, q);
     q->stats[0] = rounds; q->stats[1] = lm_its; q->stats[2] = lm_trials; q->stats[3] = num_good;
