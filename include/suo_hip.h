@@ -472,6 +472,11 @@ int suo_ba_lm_unit_one_rank_dev(suo_ba_ctx* ctx, int robust_on, double* ctl_dev,
  * the caller's order jac_out[e][29] = [J_cam 2x6 | J_obj 2x6 | w*info (xx,xy,yy) | -w*info*err (2)] (EdgeSE3ProjectFromObject::
  * linearizeOplus, types_object_slam.cpp:70-123, columns = [omega, upsilon]) and err_out[e][2] (computeError, :45-60). */
 int suo_debug_ba_jacobians(suo_ba_ctx* ctx, int n_edge, double* jac_out, double* err_out);
+/* Test entry: the reduced (object) system's solve as the LM kernels run it -- block-6 Cholesky of one workgroup, trailing updates on v_mfma_f64_16x16x4_f64 tiles, the
+ * right-hand side eliminated inside the factorisation (csrc/lm_device.h: wg_cholesky_solve; g2o solves the same system with a sparse LL^T, block_solver.hpp:464-566 /
+ * linear_solver_cholmod.h) -- on a dense symmetric A [ns][ns] (HOST, row-major, lower triangle read; ns a multiple of 6, at most 96) and b [ns]: x_out [ns] solves
+ * A x = b; *ok_out = 0 when a pivot was not positive (the LM kernels then reject the trial). */
+int suo_debug_cholesky_solve(const double* A, const double* b, int ns, double* x_out, int* ok_out);
 
 /* ---- evaluation meter: ADD / ADD-S pose errors ------------------------------------
  * Replaces the distance part of EvalMeter.update (lib/utils/eval_meter.py:126-155,233-242):

@@ -114,6 +114,7 @@ SIGNATURES = {
     "suo_ba_lm_unit_one_rank_dev": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP, VP]),
     "suo_ba_lm_decide_dev": (C.c_int, [VP, VP, VP, VP]),
     "suo_debug_ba_jacobians": (C.c_int, [VP, C.c_int, VP, VP]),
+    "suo_debug_cholesky_solve": (C.c_int, [VP, VP, C.c_int, VP, VP]),
     "suo_frame_geom_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(VP)]),
     "suo_frame_geom_destroy": (None, [VP]),
     "suo_frame_geom_launch": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),

@@ -31,6 +31,7 @@ int launch_lm_frame2(const void* problems_dev, int n_problems, int max_obj, int 
 int lm_frame2_max_edges();
 size_t lm_grid_scratch_bytes();
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
+int launch_debug_cholesky(const double* A, const double* b, int ns, double* x, int* ok, hipStream_t s);
 size_t lm_problem_struct_size();
 int launch_ba_init(const void* P, hipStream_t s);
 size_t ba_scratch_doubles();
@@ -834,6 +835,24 @@ int suo_ba_lm_unit_one_rank_dev(suo_ba_ctx* c, int robust_on, double* ctl_dev, d
 int suo_ba_lm_decide_dev(suo_ba_ctx* c, double* ctl_dev, const double* red_dev, void* stream) {
     if (!c || !ctl_dev || !red_dev) { suo_set_error("suo_ba_lm_decide_dev: null argument"); return SUO_ERR_ARG; }
     return launch_ba_ctl_decide(c->dev_problem(), ctl_dev, red_dev, c->on(stream));
+}
+
+// Test entry: the workgroup Cholesky solve of the reduced system (csrc/lm_device.h: wg_cholesky_solve) on a dense symmetric ns x ns matrix (host, row-major; ns a multiple
+// of 6, at most 96) -- x solves A x = b; *ok_out = 0 when a pivot was not positive (x is then meaningless).
+int suo_debug_cholesky_solve(const double* A, const double* b, int ns, double* x_out, int* ok_out) {
+    if (!A || !b || !x_out || !ok_out || ns <= 0) { suo_set_error("suo_debug_cholesky_solve: bad argument"); return SUO_ERR_ARG; }
+    double* d = nullptr;
+    const size_t n = (size_t)ns * ns + 2 * (size_t)ns + 1;
+    SUO_HIP_CHECK(hipMalloc((void**)&d, n * sizeof(double)));
+    struct Free { double* d; ~Free() { (void)hipFree(d); } } guard{d};
+    SUO_HIP_CHECK(hipMemcpy(d, A, (size_t)ns * ns * sizeof(double), hipMemcpyHostToDevice));
+    SUO_HIP_CHECK(hipMemcpy(d + (size_t)ns * ns, b, (size_t)ns * sizeof(double), hipMemcpyHostToDevice));
+    int rc = launch_debug_cholesky(d, d + (size_t)ns * ns, ns, d + (size_t)ns * ns + ns, (int*)(d + (size_t)ns * ns + 2 * (size_t)ns), nullptr);
+    if (rc != SUO_OK) return rc;
+    SUO_HIP_CHECK(hipDeviceSynchronize());
+    SUO_HIP_CHECK(hipMemcpy(x_out, d + (size_t)ns * ns + ns, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost));
+    SUO_HIP_CHECK(hipMemcpy(ok_out, d + (size_t)ns * ns + 2 * (size_t)ns, sizeof(int), hipMemcpyDeviceToHost));
+    return SUO_OK;
 }
 
 // Test entry: what the LM kernels linearise.  After suo_ba_linearize (edge_pass_partial of csrc/lm_device.h, shared by every LM

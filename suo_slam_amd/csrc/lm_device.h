@@ -435,6 +435,204 @@ DEV void wg_cholesky_solve(double* S, int sp, double* rhs, int ns_, int tid, int
     }
 }
 
+// The same solve for a kernel that does nothing else (csrc/lm_dist.hip: ba_solve_kernel -- the global adjustment's reduced system, up to 96 rows): Cholesky
+// factorisation, forward and backward substitution by the WHOLE workgroup (NTHREADS threads, all of them calling), blocked by 6 (one object's pose block; ns is a multiple of 6): right-looking Cholesky of the lower triangle in LDS (row-major, pitch `sp` doubles, only
+// the lower triangle is referenced -- use an ODD pitch: with sp = ns = 48 a column access lands on one LDS bank).  S must hold ns + 1 rows: the right-hand side rides
+// as row ns of the system, so the forward substitution happens inside the factorisation (its panel row is y's block, its trailing update the elimination) and only
+// L^T x = y is left for afterwards.
+//
+// The trailing matrix lives in REGISTERS (round 6): the (ns + 1) x ns lower triangle is cut into 16 x 16 tiles on a fixed grid, dealt round-robin
+// to the waves once (27 tiles at ns = 96: seven per wave of a 256-thread workgroup, 56 registers), each the accumulator of v_mfma_f64_16x16x4_f64 and kept NEGATED,
+// so a block step's update  C -= L21 L21^T  is  -C += A B  with A = B = the panel's fragments straight from LDS: two MFMAs (K = 6 as 4 + 2), four LDS reads and no
+// write per tile and step.  Per block step: every thread factors the 6 x 6 diagonal block redundantly in registers (broadcast LDS reads, no hand-off), thread t
+// solves panel row t against it, one barrier, the tiles that still have a live element are updated, the six columns the NEXT step factors are written back to
+// LDS, one barrier.  History of this update, 96 rows, thread 0's clock: one element per thread on the vector pipe with 13 LDS reads each (rounds 2-5) 43 k cycles;
+// MFMA tiles read from and written to LDS each step 52 k -- one wave per SIMD pays ~5 cycles per instruction, and the index arithmetic of a tile walk plus 12 LDS
+// accesses per tile cost what the vector form cost; tiles in registers: see profiles/r06_cholesky.txt.  fp64 MFMA on gfx950 has the vector pipe's rate (64 cycles per
+// 16 x 16 x 4): what it buys here is operand reuse, not FLOPs.
+// *ok is cleared on a non-positive / non-finite pivot; the factorisation then continues with a unit pivot and the caller rejects the trial.  `rhs` holds the
+// solution after the caller's next barrier.
+typedef double lm_f64x4 __attribute__((ext_vector_type(4)));
+#ifdef SUO_CHOL_PROF
+#define CHOL_T(i) do { if (pt) { const long long now_ = clock64(); pt[i] += now_ - tprev_; tprev_ = now_; } } while (0)
+#define CHOL_PT , long long* pt
+#define CHOL_NOPT , nullptr
+#else
+#define CHOL_T(i) do { } while (0)
+#define CHOL_PT
+#define CHOL_NOPT
+#endif
+template <int NTHREADS>
+DEV void wg_cholesky_solve_mfma(double* S, int sp, double* rhs, int ns_, int tid, int* ok CHOL_PT) {
+#ifdef SUO_CHOL_PROF
+    long long tprev_ = clock64();
+#endif
+    constexpr int NW = NTHREADS / 64;
+    constexpr int MAXTC = (LM_NS + 15) / 16, MAXT = MAXTC * (MAXTC + 1) / 2 + MAXTC;      // tile rows 0 .. LM_NS / 16 (the last holds the right-hand side)
+    constexpr int NTW = (MAXT + NW - 1) / NW;
+    const int ns = __builtin_amdgcn_readfirstlane(ns_);
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    auto load_diag = [&](int k0, double (&L)[6][6]) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) L[r][c] = S[(k0 + r) * sp + k0 + c];
+    };
+    for (int i = tid; i < ns; i += NTHREADS) S[ns * sp + i] = rhs[i];
+    __syncthreads();
+    // this wave's tiles: t = wv + NW u -> (tile row ta, tile column tb <= ta); lane l of a tile holds -C[16 ta + (l >> 4) + 4 q][16 tb + (l & 15)], q < 4, and
+    // supplies A[l & 15][l >> 4] = L21[16 ta + (l & 15)][k + (l >> 4)], B likewise from tile column tb's rows.  Rows past ns / columns past ns - 1 are clamped
+    // on the way in (their products land in elements that are never written back).
+    const int ntc = (ns + 15) >> 4, ntri = ntc * (ntc + 1) / 2, ntiles = ntri + ((ns & 15) == 0 ? ntc : 0);
+    int tta[NTW], ttb[NTW], offA[NTW], offB[NTW], wb[NTW][4];
+    lm_f64x4 c[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        int t = wv + NW * u, r = 0;
+        if (t >= ntiles) {                                                     // (never live)
+            tta[u] = ttb[u] = -64; offA[u] = offB[u] = 0; c[u] = lm_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wb[u][q] = 2;
+            continue;
+        }
+        if (t >= ntri) { r = ntc; t -= ntri; }
+        else { while ((r + 1) * (r + 2) / 2 <= t) ++r; t -= r * (r + 1) / 2; }
+        tta[u] = r; ttb[u] = t;
+        offA[u] = min(16 * r + li, ns) * sp + lk;
+        offB[u] = min(16 * t + li, ns - 1) * sp + lk;
+        const int col = min(16 * t + li, ns - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * r + lk + 4 * q, cc = 16 * t + li;
+            c[u][q] = -S[min(row, ns) * sp + col];
+            wb[u][q] = (row >= cc && row <= ns && cc < ns) ? row * sp + cc : 2;       // (element (0, 2): above the diagonal and not a 1 / L_rr slot -- never read)
+        }
+    }
+    CHOL_T(0);
+    for (int k0 = 0; k0 < ns; k0 += 6) {
+        double L[6][6], rd[6];
+        load_diag(k0, L);
+        bool good = true;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double piv = L[c][c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) piv -= L[c][q] * L[c][q];
+            if (!(piv > 0) || !isfinite(piv)) good = false;
+            const double pp = piv > 0 ? piv : 1.0;
+            rd[c] = rsqrt(pp);
+            L[c][c] = pp * rd[c];
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                double v = L[r][c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= L[r][q] * L[c][q];
+                L[r][c] = v * rd[c];
+            }
+        }
+        if (!good && tid == 0) *ok = 0;
+        CHOL_T(1);
+        // panel row i = k0 + 6 + t (row ns: the right-hand side):  L21[i][.] = A21[i][.] L11^-T
+        for (int i = k0 + 6 + tid; i <= ns; i += NTHREADS) {
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = S[i * sp + k0 + c];
+#pragma unroll
+                for (int q = 0; q < c; ++q) v -= x[q] * L[c][q];
+                x[c] = v * rd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[i * sp + k0 + c] = x[c];
+        }
+        CHOL_T(2);
+        __syncthreads();                                   // panel complete; every thread has read the diagonal block
+        CHOL_T(3);
+        if (lane == 0 && wv < 4) {
+            // the factored diagonal block (and 1 / L_rr for the back substitution, kept in the never-referenced element right of the diagonal -- sp > ns: the last
+            // row's is the pad column -- six fp64 divisions per block step otherwise) back to LDS: lane 0 of waves 0 .. 3, seven stores each with compile-time
+            // register indices.  (Six lanes each selecting "its" row with a runtime index: 72 conditional moves in six divergent blocks; one lane alone: 33 stores on
+            // the way of its wave into the update below, ~450 cycles that the other waves then waited for at the barrier.)
+#define LM_PUT_ROW(r) do { _Pragma("unroll") for (int c_ = 0; c_ <= (r); ++c_) S[(k0 + (r)) * sp + k0 + c_] = L[(r)][c_]; S[(k0 + (r)) * sp + k0 + (r) + 1] = rd[(r)]; } while (0)
+            if (wv == 0) { LM_PUT_ROW(5); }
+            else if (wv == 1) { LM_PUT_ROW(4); }
+            else if (wv == 2) { LM_PUT_ROW(3); LM_PUT_ROW(0); }
+            else { LM_PUT_ROW(2); LM_PUT_ROW(1); }
+#undef LM_PUT_ROW
+        }
+        const int base = k0 + 6;
+        if (base < ns) {
+            // every live tile's fragments first (one LDS round trip for the wave), then the first MFMA of every tile, then the second: no MFMA waits for the one before it
+            double a0[NTW], b0[NTW], a1[NTW], b1[NTW];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                if (16 * ttb[u] + 15 < base) continue;                        // (scalar) every element of the tile is final -- or the tile does not exist
+                const double* pa = S + offA[u] + k0;
+                const double* pb = S + offB[u] + k0;
+                a0[u] = pa[0]; b0[u] = pb[0]; a1[u] = pa[4]; b1[u] = pb[4];   // (lanes lk >= 2 read two columns of the trailing block there: both zeroed)
+            }
+#ifdef SUO_CHOL_PROF
+            __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); CHOL_T(8); __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+                if (16 * ttb[u] + 15 >= base) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < NTW; ++u)
+                if (16 * ttb[u] + 15 >= base) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(lk < 2 ? a1[u] : 0.0, lk < 2 ? b1[u] : 0.0, c[u], 0, 0, 0);
+#ifdef SUO_CHOL_PROF
+            { double sink = 0; _Pragma("unroll") for (int u = 0; u < NTW; ++u) sink += c[u][0]; asm volatile("" :: "v"(sink)); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            CHOL_T(4);
+            // the columns of the next block step, base .. base + 5, from the registers back to LDS (rows >= column, <= ns): its diagonal block and panel.  The LDS
+            // address of every element a lane holds is fixed (wb[] below; elements above the diagonal or below row ns point at element (0, 2), which nothing reads), so a tile costs one lane test and four stores
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                if (16 * ttb[u] + 15 < base || 16 * ttb[u] > base + 5) continue;      // (scalar)
+                if ((unsigned)(16 * ttb[u] + li - base) < 6u) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) S[wb[u][q]] = -c[u][q];
+                }
+            }
+        }
+        CHOL_T(5);
+        __syncthreads();
+        CHOL_T(6);
+    }
+    // L^T x = y by ONE wave (round 5), from the last block up: 2 ns / 6 block steps whose only parallel work is ns rows of six multiply-adds -- with the whole
+    // workgroup each step paid a workgroup barrier and four redundant copies of the 6 x 6 solve; a wave's LDS operations execute in order, so it needs none.
+    // Every lane solves the 6 x 6 block redundantly, lane t then updates entries t, t + 64 above it.
+    if (tid < 64) {
+        for (int i = tid; i < ns; i += 64) rhs[i] = S[ns * sp + i];
+        __builtin_amdgcn_wave_barrier();
+        for (int k0 = ns - 6; k0 >= 0; k0 -= 6) {
+            double L[6][6], x[6];
+            load_diag(k0, L);
+#pragma unroll
+            for (int c = 5; c >= 0; --c) {
+                double v = rhs[k0 + c];
+#pragma unroll
+                for (int q = c + 1; q < 6; ++q) v -= L[q][c] * x[q];
+                x[c] = v * S[(k0 + c) * sp + k0 + c + 1];
+            }
+            for (int i = tid; i < k0; i += 64) {
+                double v = rhs[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v -= S[(k0 + c) * sp + i] * x[c];
+                rhs[i] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) rhs[k0 + c] = x[c];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    CHOL_T(7);
+}
+
 DEV bool edge_active(const LmProblem& P, int e) {
     const int p = P.edge_pair[e];
     return P.level[e] == 0 && !(P.cam_fixed[P.pair_cam[p]] && P.obj_fixed[P.pair_obj[p]]);

@@ -293,13 +293,18 @@ __global__ __launch_bounds__(LM_THREADS) void ba_schur_s_kernel(const LmProblem*
 
 // ---- solve the reduced system (identical on every rank) | back-substitute + update | chi2 | tail -----------------
 // HB = [Hoo_total(21)+bo_total(6) per object], St = [S_total (ns x ns) | r_total (ns) | number of ranks whose Schur phase was ok]
-__global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
+// (two waves per SIMD at least = at most 256 registers per lane: the compiler then keeps the fp64 MFMA accumulators of wg_cholesky_solve in VGPRs; with 512 allowed it put
+//  them in AGPRs and copied each tile out after every MFMA, behind an 18-cycle s_nop -- every MFMA completed before the next instruction issued)
+__global__ __launch_bounds__(LM_THREADS, 2) void ba_solve_kernel(const LmProblem* __restrict__ Pp, double lambda, int ns,
                                                                const double* __restrict__ HB, const double* __restrict__ St, int expect_ok,
                                                                int* __restrict__ bad, const double* __restrict__ ctl, int want) {
     BA_GUARD(ctl, want);
+#ifdef SUO_CHOL_PROF
+    const long long t0c = clock64();
+#endif
     if (ctl) lambda = ctl[CTL_LAMBDA];
     const LmProblem& P = *Pp;
-    __shared__ double S[LM_NS * (LM_NS + 1) + 8];      // odd pitch (+ slack)
+    __shared__ double S[(LM_NS + 1) * (LM_NS + 1) + 8];      // odd pitch, ns + 1 rows: the right-hand side is the last (wg_cholesky_solve)
     __shared__ double rhs[LM_NS];
     __shared__ int sh_ok;
     const int tid = threadIdx.x;
@@ -307,17 +312,27 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
     const double* rt = St + ns * ns;
     if (tid == 0) sh_ok = 1;
     if (tid == 0 && expect_ok > 0 && (int)(rt[ns] + 0.5) != expect_ok) atomicAdd(bad, 1);      // some rank's camera block was singular
-    // the reduced system into LDS (lower triangle): eight independent loads in flight per thread (a wave per row, one row after the other, was 24 dependent
-    // round trips to L2 -- a third of this kernel)
-    for (int base = 0; base < ns * ns; base += 8 * LM_THREADS) {
-        double v[8];
+    // the reduced system into LDS (lower triangle only): 32 lanes per row, every load of a thread issued before its first LDS store -- ONE round trip to L2 (the buffer
+    // was written by another kernel, possibly behind another XCD's L2: ~2 us a trip).  Round 5 went in batches of eight loads over the full square: five trips, 13 % of
+    // this kernel.
+    {
+        constexpr int RG = LM_THREADS / 32, NR = (LM_NS + RG - 1) / RG, NC = (LM_NS + 31) / 32;
+        const int r0 = tid >> 5, c0 = tid & 31;
+        double v[NR][NC];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int idx = base + u * LM_THREADS + tid; v[u] = idx < ns * ns ? St[idx] : 0.0; }
+        for (int i = 0; i < NR; ++i)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * LM_THREADS + tid, row = idx / ns, col = idx - row * ns;
-            if (idx < ns * ns && col <= row) S[row * sp + col] = -v[u];
-        }
+            for (int j = 0; j < NC; ++j) {
+                const int row = r0 + i * RG, col = c0 + 32 * j;
+                v[i][j] = St[(row < ns && col <= row) ? row * ns + col : 0];      // (an address whatever the lane: no predicated loads, no branches between them)
+            }
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int row = r0 + i * RG, col = c0 + 32 * j;
+                if (row < ns && col <= row) S[row * sp + col] = -v[i][j];
+            }
     }
     __syncthreads();
     for (int idx = tid; idx < P.n_obj * 36; idx += LM_THREADS) {
@@ -333,8 +348,16 @@ __global__ __launch_bounds__(LM_THREADS) void ba_solve_kernel(const LmProblem* _
         if (P.obj_slot[o] >= 0) rhs[6 * P.obj_slot[o] + r] = HB[27 * o + 21 + r] - rt[6 * P.obj_slot[o] + r];
     }
     __syncthreads();
-    wg_cholesky_solve(S, sp, rhs, ns, tid, LM_THREADS, &sh_ok);                  // blocked by 6, the whole workgroup (lm_device.h)
+#ifdef SUO_CHOL_PROF
+    long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t1 = clock64();
+    wg_cholesky_solve_mfma<LM_THREADS>(S, sp, rhs, ns, tid, &sh_ok, pt);
     __syncthreads();
+    { static __device__ int calls = 0; if (tid == 0) { int c = atomicAdd(&calls, 1); if (c % 50 == 20) printf("ba_solve ns=%d: load %lld | rhs copy + tiles into registers %lld  diag %lld  panel %lld  barrier %lld  store diag + fragment loads %lld  mfma %lld  column write-back %lld  barrier %lld  backward %lld  (thread 0)\n", ns, t1 - t0c, pt[0], pt[1], pt[2], pt[3], pt[8], pt[4], pt[5], pt[6], pt[7]); } }
+#else
+    wg_cholesky_solve_mfma<LM_THREADS>(S, sp, rhs, ns, tid, &sh_ok);                  // blocked by 6, the whole workgroup (lm_device.h)
+    __syncthreads();
+#endif
     for (int idx = tid; idx < P.n_obj * 6; idx += LM_THREADS) {
         const int o = idx / 6;
         P.xo[idx] = P.obj_slot[o] >= 0 ? rhs[6 * P.obj_slot[o] + (idx - o * 6)] : 0.0;
@@ -615,6 +638,32 @@ int launch_ba_solve_update(const void* P, double lambda, int ns, int robust_on, 
     BA_GRID(ba_edge_pass_kernel, robust_on, 0, scratch, ctl, ST_TRIAL);
     BA_ONE(ba_update_tail_kernel, lambda, (const double*)scratch, BA_WGS, HB, (const int*)bad, out, ctl, ST_TRIAL, fold_ctl);
     BA_DONE
+}
+// test entry (suo_debug_cholesky_solve): wg_cholesky_solve on a dense symmetric system, as ba_solve_kernel calls it
+__global__ __launch_bounds__(LM_THREADS, 2) void debug_cholesky_kernel(const double* __restrict__ A, const double* __restrict__ b, int ns, double* __restrict__ x, int* __restrict__ ok_out) {
+    __shared__ double S[(LM_NS + 1) * (LM_NS + 1) + 8];
+    __shared__ double rhs[LM_NS];
+    __shared__ int sh_ok;
+    const int tid = threadIdx.x, sp = ns | 1;
+    if (tid == 0) sh_ok = 1;
+    for (int idx = tid; idx < ns * ns; idx += LM_THREADS) { const int row = idx / ns, col = idx - row * ns; if (col <= row) S[row * sp + col] = A[idx]; }
+    for (int i = tid; i < ns; i += LM_THREADS) rhs[i] = b[i];
+    __syncthreads();
+#ifdef SUO_CHOL_PROF
+    long long ptd[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    wg_cholesky_solve_mfma<LM_THREADS>(S, sp, rhs, ns, tid, &sh_ok, ptd);
+#else
+    wg_cholesky_solve_mfma<LM_THREADS>(S, sp, rhs, ns, tid, &sh_ok);
+#endif
+    __syncthreads();
+    for (int i = tid; i < ns; i += LM_THREADS) x[i] = rhs[i];
+    if (tid == 0) *ok_out = sh_ok;
+}
+int launch_debug_cholesky(const double* A, const double* b, int ns, double* x, int* ok, hipStream_t s) {
+    if (ns <= 0 || ns > LM_NS || ns % 6) { suo_set_error("suo_debug_cholesky_solve: ns = %d (a multiple of 6, at most %d)", ns, LM_NS); return SUO_ERR_ARG; }
+    hipLaunchKernelGGL(debug_cholesky_kernel, dim3(1), dim3(LM_THREADS), 0, s, A, b, ns, x, ok);
+    SUO_HIP_CHECK(hipGetLastError());
+    return SUO_OK;
 }
 int launch_ba_ctl_begin(double* ctl, int its, int world, hipStream_t s) {
     hipLaunchKernelGGL(ba_ctl_begin_kernel, dim3(1), dim3(64), 0, s, ctl, its, world);
