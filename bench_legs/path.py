@@ -264,6 +264,20 @@ def global_ba_leg(world, L, n_cam_per_rank=32, reps=3):
     else:
         full, t = run()
     ts = [t]
+    if world == 1:
+        # the same adjustment through the ONE C call ObjectSLAM.optimize makes (suo_optimize: the phase kernels under the device-resident schedule, driven from C --
+        # no Python between the launches, no collective)
+        tc = []
+        for _ in range(reps):
+            one = ba.Problem(*[P[k].copy() for k in keys])
+            t0 = time.perf_counter()
+            ba.optimize_batch([one])
+            tc.append(time.perf_counter() - t0)
+        extra["suo_optimize_ms"] = round(1e3 * min(tc), 2)
+        # (the LM trial count follows the last bits of the reduced system's solve -- +-25 % per problem between two correct builds, profiles/r06_global_ba_ab.txt --
+        #  so the per-trial figure is the one to compare across builds)
+        extra["suo_optimize_us_per_lm_trial"] = round(1e6 * min(tc) / max(int(one.stats[2]), 1), 1)
+        extra["suo_optimize_identical"] = bool(np.array_equal(one.cam_T, full.cam_T) and np.array_equal(one.obj_T, full.obj_T) and np.array_equal(one.inlier, full.inlier))
     err = float(max(np.linalg.norm(full.obj_T.reshape(-1, 3, 4)[o][:, 3] - P["obj_gt"][o][:, 3]) for o in range(L)))
     return {**extra, "ranks": world, "cameras": n_cam, "objects": L, "edges": int(len(P["edge_cam"])), "ms": round(1e3 * min(ts), 2),
             "lm_trials": int(full.stats[2]), "collectives_per_trial": ba_dist.COLLECTIVES_PER_TRIAL,

@@ -412,7 +412,13 @@ typedef struct suo_ba_problem {
     int stats[4];                  /* out: rounds, LM iterations, LM trials, final num_good */
 } suo_ba_problem;
 int suo_optimize(suo_ba_problem* problem);
-/* many independent problems (frames) in one launch, one workgroup each */
+/* many independent problems (frames) in one launch, one workgroup each.
+ * Which kernels run (all of them g2o's Levenberg-Marquardt on the same graph, optimization_algorithm_levenberg.cpp:58-150; they differ in summation order only):
+ *   frame-sized graphs (the per-view refinements)                       one 256-thread workgroup per problem (csrc/lm.hip)
+ *   ONE graph of >= 512 edges with free cameras and free objects        the phase kernels of the multi-GPU adjustment below on one rank under the device-resident
+ *   (ObjectSLAM.optimize's global adjustment, lib/object_slam.py:746)   schedule, driven from C: ~12 launches per LM trial, the host reads 16 doubles once per <= 12 trials
+ *                                                                       (round 6; 60 cameras x 8 objects: 6.8 ms, 10.5 through the grid-barrier kernel of rounds 4-5)
+ *   more than 16 free objects next to free cameras                      the same phases under the host-driven schedule (the reduced system then lives in HBM) */
 int suo_optimize_batch(suo_ba_problem* problems, int n_problems);
 
 /* ---- phase-wise bundle adjustment for the multi-GPU global pose graph ------------------------

@@ -731,7 +731,7 @@ static int optimize_phases_one_rank(suo_ba_problem* q) {
         SUO_HIP_CHECK(hipMalloc((void**)&d_buf, need * sizeof(double)));
         d_cap = need; buf_dev = c->device;
     }
-    if (!h_pin) SUO_HIP_CHECK(hipHostMalloc((void**)&h_pin, 16 * sizeof(double), hipHostMallocDefault));
+    if (!h_pin) SUO_HIP_CHECK(hipHostMalloc((void**)&h_pin, 16 * sizeof(double), hipHostMallocPortable));
     hipStream_t s = c->arena.stream;
     SUO_HIP_CHECK(hipMemsetAsync(d_buf, 0, need * sizeof(double), s));
     double* lin_loc = d_buf; double* lin = lin_loc + n_lin; double* sch = lin + n_lin; double* red = sch + n_sch; double* good = red + 4; double* ctl = good + 1;
