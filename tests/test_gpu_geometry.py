@@ -280,8 +280,9 @@ def _multi_view_scene(rng, n_cam, n_obj, noise_px=0.5):
 def test_global_bundle_adjustment_matches_oracle(ba, n_cam, n_obj):
     """Global mode: first camera fixed, all other cameras and all objects free (object_slam.py:746-778).
     HIP eliminates cameras by Schur complement; the oracle solves the full dense system.  Below 512 edges one
-    workgroup runs the whole adjustment (csrc/lm.hip); the larger graphs (612 - 5400 edges) take the
-    multi-workgroup kernel with grid barriers (csrc/lm_grid.hip)."""
+    workgroup runs the whole adjustment (csrc/lm.hip); the larger graphs (612 - 5400 edges) take the phase kernels
+    of csrc/lm_dist.hip under the device-resident schedule, driven from C (geom_api.hip: optimize_phases_one_rank;
+    rounds 4-5: the grid-barrier kernel of csrc/lm_grid.hip)."""
     rng = np.random.default_rng(n_cam * 7 + n_obj)
     P, obj_gt = _multi_view_scene(rng, n_cam, n_obj)
     got, ref = _compare_ba(ba, P)
@@ -386,6 +387,24 @@ def test_device_resident_lm_schedule_equals_the_host_schedule(ba, monkeypatch, n
     assert a.stats[2] >= a.stats[1] > 4
     assert np.array_equal(a.cam_T, b.cam_T) and np.array_equal(a.obj_T, b.obj_T)
     assert np.array_equal(a.inlier, b.inlier) and np.array_equal(a.chi2, b.chi2)
+
+
+@pytest.mark.parametrize("n_cam,n_obj", [(12, 6), (32, 16), (60, 8), (25, 13)])
+def test_the_one_c_call_runs_the_schedule_of_the_python_driver(ba, n_cam, n_obj):
+    """suo_optimize on ONE large graph with free cameras and objects (what ObjectSLAM.optimize hands over for the global adjustment, lib/object_slam.py:746-778)
+    enqueues the phase kernels itself (csrc/geom_api.hip: optimize_phases_one_rank) -- the units, the looks at the control block and the robust rounds of
+    suo_slam_amd/ba_dist.py at one rank, without Python between the launches: poses, inlier flags, chi2 and the round / iteration / trial counters are
+    bit-identical to the Python-driven run."""
+    from suo_slam_amd import ba_dist
+    rng = np.random.default_rng(n_cam * 17 + n_obj)
+    P, _ = _multi_view_scene(rng, n_cam, n_obj)
+    assert len(P["edge_cam"]) >= 512
+    keys = ("cam_T", "cam_fixed", "obj_T", "obj_fixed", "edge_cam", "edge_obj", "edge_camk", "edge_p", "edge_uv", "edge_info", "edge_inlier")
+    a = ba.optimize_batch([ba.Problem(*[P[k].copy() for k in keys])])[0]
+    b = ba_dist.optimize_distributed(ba.Problem(*[P[k].copy() for k in keys]))
+    assert np.array_equal(a.stats, b.stats) and a.stats[2] > 4, (a.stats, b.stats)
+    assert np.array_equal(a.cam_T, b.cam_T) and np.array_equal(a.obj_T, b.obj_T)
+    assert np.array_equal(a.inlier, b.inlier) and np.array_equal(a.chi2[:len(b.chi2)], b.chi2)
 
 
 def test_one_rank_unit_with_folded_control_steps_equals_the_four_calls(ba, monkeypatch):

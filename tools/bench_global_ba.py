@@ -1,5 +1,6 @@
-"""Time one global bundle adjustment (first camera fixed, everything else free) through suo_optimize:
-python tools/bench_global_ba.py [n_cam] [n_obj]   (SUO_LM_GRID_WGS=0/4/8/16/32 selects the kernel, one process each)"""
+"""Time one global bundle adjustment (first camera fixed, everything else free) through suo_optimize (one C call: since round 6 the phase kernels under the
+device-resident schedule, driven from C) and through suo_slam_amd/ba_dist.py on one rank (the same kernels, Python between the launches):
+python tools/bench_global_ba.py [n_cam] [n_obj]   (tuning builds: SUO_LM_PHASES=0 = rounds 4-5's grid-barrier kernel, SUO_LM_GRID_WGS=0/4/8/16/32 its width)"""
 import os
 import sys
 import time
@@ -20,8 +21,8 @@ for rep in range(4):
     t0 = time.perf_counter()
     out = BA.optimize(*a)
     ts.append(time.perf_counter() - t0)
-print(f"SUO_LM_GRID_WGS={os.environ.get('SUO_LM_GRID_WGS', 'default')}: {n_cam} cams x {n_obj} objs, {len(P['edge_cam'])} edges: "
-      f"{1e3 * min(ts):.2f} ms (stats rounds/its/trials/good = {list(out[4])})")
+print(f"suo_optimize (SUO_LM_PHASES={os.environ.get('SUO_LM_PHASES', 'default')}, SUO_LM_GRID_WGS={os.environ.get('SUO_LM_GRID_WGS', 'default')}): {n_cam} cams x {n_obj} objs, "
+      f"{len(P['edge_cam'])} edges: {1e3 * min(ts):.2f} ms, {1e6 * min(ts) / max(int(out[4][2]), 1):.1f} us per LM trial (rounds/its/trials/good = {[int(v) for v in out[4]]})")
 
 from suo_slam_amd import _lib  # noqa: E402
 if hasattr(_lib.lib(), "suo_debug_lg_prof"):          # -DSUO_LG_PROFILE build (tools/build_variant.sh lgprof -DSUO_LG_PROFILE)
@@ -45,4 +46,4 @@ for rep in range(4):
     t0 = time.perf_counter()
     ba_dist.optimize_distributed(prob)
     ts.append(time.perf_counter() - t0)
-print(f"phase-wise (1 rank): {1e3 * min(ts):.2f} ms (stats = {list(prob.stats)})")
+print(f"ba_dist.py, one rank (Python-driven): {1e3 * min(ts):.2f} ms, {1e6 * min(ts) / max(int(prob.stats[2]), 1):.1f} us per LM trial (rounds/its/trials/good = {[int(v) for v in prob.stats]})")

@@ -31,4 +31,4 @@ if [ -s $SRC/views_single_host.txt ]; then { echo "# python3 tools/time_views_si
 if [ -s $SRC/frame_chain.txt ]; then { echo "# python3 tools/time_frame_chain.py   (1x MI355X; tools/profile_round.sh $TAG; one frame per call, one in flight)"; cat $SRC/frame_chain.txt; } > profiles/${P}_frame_chain.txt; fi
 if [ -s $SRC/chain_head.txt ]; then { echo "# python3 tools/bench_chain_head.py 256; python3 tools/bench_chain_head.py 8   (1x MI355X; tools/profile_round.sh $TAG; HIP events, 20 launches each)"; cat $SRC/chain_head.txt; } > profiles/${P}_chain_head.txt; fi
 if [ -s $SRC/network_by_crops.txt ]; then { echo "# python3 bench.py --no-legs --only cnn --depth 1 --objects L --frames-per-step 1 --steps 200 --warmup 20   (1x MI355X; tools/profile_round.sh $TAG; one network call of L crops at a time: H2D of boxes + network + decode + masks)"; cat $SRC/network_by_crops.txt; } > profiles/${P}_network_by_crops.txt; fi
-if [ -s $SRC/global_ba_tool.txt ]; then { echo "# python3 tools/bench_global_ba.py 60 8   (1x MI355X; tools/profile_round.sh $TAG; the global SLAM adjustment through suo_optimize = lm_grid_kernel, and the phase kernels at one rank)"; cat $SRC/global_ba_tool.txt; } > profiles/${P}_global_ba_tool.txt; fi
+if [ -s $SRC/global_ba_tool.txt ]; then { echo "# python3 tools/bench_global_ba.py 60 8 | 32 16 | 120 8   (1x MI355X; tools/profile_round.sh $TAG; a global adjustment through suo_optimize = the phase kernels driven from C, and through ba_dist.py on one rank)"; cat $SRC/global_ba_tool.txt; } > profiles/${P}_global_ba_tool.txt; fi

@@ -70,6 +70,8 @@ for L in 1 2 3 4 5 6 7 8 9; do
   echo "crops per call $L: $(ms $L) ms | four-wave Winograd kernels on small launches too (SUO_WINO_W8=0, rounds 1-5): $(SUO_WINO_W8=0 ms $L) ms"
 done > $OUT/network_by_crops.txt
 python3 $R/tools/bench_global_ba.py 60 8 2>&1 | grep -v amdgpu.ids > $OUT/global_ba_tool.txt
+python3 $R/tools/bench_global_ba.py 32 16 2>&1 | grep -v amdgpu.ids >> $OUT/global_ba_tool.txt
+python3 $R/tools/bench_global_ba.py 120 8 2>&1 | grep -v amdgpu.ids >> $OUT/global_ba_tool.txt
 fi
 # gpurun merges gpurun_out/ back only when it is <= 64 MiB: the raw counter databases stay on the box (their summaries are in $OUT and profiles/*.json)
 rm -rf $R/gpurun_out/pmc
