@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsuo_hip.so")
-SOURCES = ["capi.hip", "net.hip", "conv.hip", "conv_wino.hip", "conv_wino_x3.hip", "conv_small.hip", "stem_x3.hip", "res_small.hip", "res_small_x3.hip", "gemm_persist.hip", "gemm_bf16x3.hip", "misc.hip", "pnp.hip", "lm.hip", "lm_big.hip", "lm_grid.hip", "lm_cam.hip", "lm_cam2.hip", "lm_frame.hip", "lm_frame2.hip", "lm_dist.hip", "geom_api.hip", "frame_geom.hip", "eval.hip", "slam_score.hip", "slam_vote.hip"]
+SOURCES = ["capi.hip", "net.hip", "conv.hip", "conv_wino.hip", "conv_wino_x3.hip", "conv_small.hip", "stem_x3.hip", "res_small.hip", "res_small_x3.hip", "gemm_persist.hip", "gemm_bf16x3.hip", "misc.hip", "pnp.hip", "lm.hip", "lm_big.hip", "lm_cam.hip", "lm_cam2.hip", "lm_frame.hip", "lm_frame2.hip", "lm_dist.hip", "geom_api.hip", "frame_geom.hip", "eval.hip", "slam_score.hip", "slam_vote.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # -ffp-contract=off: the fp64 geometry kernels (pnp.hip / lm.hip) must round like the gcc-built

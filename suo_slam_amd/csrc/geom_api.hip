@@ -22,14 +22,18 @@ int launch_pnp_batch(int n_obj, const int* offsets, const double* xs, const doub
                      int* iters_out, hipStream_t s);
 int launch_lm(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
 int launch_lm_big(const void* problems_dev, int n_problems, int lds_bytes, hipStream_t s);
-int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);
+#ifdef SUO_TUNING
+int launch_lm_grid(const void* problem_dev, void* scratch_dev, int n_wgs, hipStream_t s);       // (csrc/lm_grid.hip: rounds 4-5's route for one large graph; tuning builds only)
+#endif
 int launch_lm_cam(const void* problems_dev, int n_problems, hipStream_t s);
 int launch_lm_cam2(const void* problems_dev, int n_problems, int max_edges, hipStream_t s);
 int lm_cam2_max_edges();
 int launch_lm_frame(const void* problems_dev, int n_problems, int max_obj, hipStream_t s);
 int launch_lm_frame2(const void* problems_dev, int n_problems, int max_obj, int max_edges, hipStream_t s);
 int lm_frame2_max_edges();
+#ifdef SUO_TUNING
 size_t lm_grid_scratch_bytes();
+#endif
 int lm_lds_bytes(int C, int O, int E, int NP, int n_free_obj_schur);
 int launch_debug_cholesky(const double* A, const double* b, int ns, double* x, int* ok, hipStream_t s);
 size_t lm_problem_struct_size();
@@ -424,7 +428,7 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
     // ONE large graph with free cameras and free objects (the global SLAM adjustment): the phase kernels of csrc/lm_dist.hip under the device-resident LM schedule,
     // driven from here (round 6).  Measured at 60 cameras x 8 objects: 106 us per LM trial against 129 for lm_grid_kernel's grid barriers; the Python-driven form of
     // this very schedule (suo_slam_amd/ba_dist.py, one rank) was already the faster route and ObjectSLAM.optimize could not reach it through one C call.
-    // SUO_LM_PHASES (tuning builds): 0 = lm_grid_kernel as in rounds 2-5.
+    // SUO_LM_PHASES (tuning builds, which also link csrc/lm_grid.hip): 0 = lm_grid_kernel as in rounds 4-5.
     {
         static const int phases = (int)SUO_TUNE("SUO_LM_PHASES", 1);
         static const int big_from_ph = (int)SUO_TUNE("SUO_LM_BIG_EDGES", 512);
@@ -432,20 +436,22 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
             int nfo = 0, nfc = 0;
             for (int o = 0; o < probs[0].n_obj; ++o) nfo += probs[0].obj_fixed[o] ? 0 : 1;
             for (int c = 0; c < probs[0].n_cam; ++c) nfc += probs[0].cam_fixed[c] ? 0 : 1;
-            if (nfo > 0 && nfc > 1) return optimize_phases_one_rank(&probs[0]);
+            if (nfo > 0 && nfc > 0) return optimize_phases_one_rank(&probs[0]);
         }
     }
     std::lock_guard<std::mutex> lock(g_arena.mu);
     Staged st;
     int rc = stage_problems(probs, n_prob, g_arena, st);
     if (rc != SUO_OK) return rc;
-    // frame-sized graphs: one 256-thread workgroup each (csrc/lm.hip).  A large graph (the global SLAM adjustment):
-    // ONE problem spread over up to 32 workgroups with grid barriers (csrc/lm_grid.hip); several large graphs in one
-    // call fall back to the 1024-thread single-workgroup build (csrc/lm_big.hip).
+    // frame-sized graphs: one 256-thread workgroup each (csrc/lm.hip); large graphs that the phase route above does not take (several in one call, or no free
+    // object / no free camera): the 1024-thread single-workgroup build (csrc/lm_big.hip).  Tuning builds with SUO_LM_PHASES=0: ONE large graph spread over up
+    // to 32 workgroups with grid barriers (csrc/lm_grid.hip), rounds 4-5's route.
     int max_edges = 0;
     for (int i = 0; i < n_prob; ++i) max_edges = std::max(max_edges, probs[i].n_edge);
     static const int big_from = (int)SUO_TUNE("SUO_LM_BIG_EDGES", 512);       // (640 edges: 9.5 vs 12.2 ms, 1000: 10.9 vs 16.0, 350: 8.6 vs 6.1)
+#ifdef SUO_TUNING
     static const int grid_wgs = (int)SUO_TUNE("SUO_LM_GRID_WGS", 32);          // 0: never use the grid kernel
+#endif
     // camera tracking (ObjectSLAM.optimize(curr_only=True)): one free camera, every object fixed -> one wave per problem
     static const int cam_kernel = (int)SUO_TUNE("SUO_LM_CAM", 1);                    // 0: general kernel (A/B)
     bool cam_only = cam_kernel != 0;
@@ -481,12 +487,14 @@ int suo_optimize_batch(suo_ba_problem* probs, int n_prob) {
         for (int i = 0; i < n_prob && one_cam; ++i) one_cam = frame2_takes(probs[i]);
         if (one_cam) rc = launch_lm_frame2(g_arena.dev + st.o_structs, n_prob, frame_max_obj, max_edges, g_arena.stream);
         else rc = launch_lm_frame(g_arena.dev + st.o_structs, n_prob, frame_max_obj, g_arena.stream);
+#ifdef SUO_TUNING
     } else if (max_edges >= big_from && n_prob == 1 && grid_wgs > 0) {
         static void* grid_scratch = nullptr;
         if (!grid_scratch) SUO_HIP_CHECK(hipMalloc(&grid_scratch, lm_grid_scratch_bytes()));
         SUO_HIP_CHECK(hipMemsetAsync(grid_scratch, 0, 64, g_arena.stream));
         const int wgs = std::max(1, std::min(grid_wgs, (max_edges + 255) / 256));
         rc = launch_lm_grid(g_arena.dev + st.o_structs, grid_scratch, wgs, g_arena.stream);
+#endif
     } else if (max_edges >= big_from) {
         rc = launch_lm_big(g_arena.dev + st.o_structs, n_prob, st.lds_need, g_arena.stream);
     } else {
